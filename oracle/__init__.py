@@ -1,0 +1,36 @@
+"""CPU oracle for the MPC random-shooting / CEM hot path.  TEST INFRASTRUCTURE ONLY.
+
+This package is a NumPy restatement of the reference algorithm
+(``learning_to_adapt/policies/mpc_controller.py:59-129`` and the model /
+reward code it calls).  It exists so that the HIP path can be checked against
+something that follows the reference line by line.
+
+Rules (enforced by ``tests/test_layout.py``):
+
+* only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+  ``cpu_baseline`` leg may import anything from here;
+* nothing under ``learning_to_adapt_amd/`` imports it - the product path has
+  no CPU fallback and fails loudly when the HIP extension is missing.
+
+Parity status
+-------------
+* planner (``oracle/planner.py``): PINNED.  Checked in this container against
+  the *real* reference ``MPCController`` (imported from ``/root/reference``
+  with a stub ``tensorflow`` module, see ``tools/gen_golden.py``) and against
+  the committed golden vectors under ``tests/golden/``.
+* rewards (``oracle/rewards.py``): restated from the reference env files; the
+  reference envs need the proprietary MuJoCo 1.31 binary at import time and
+  cannot be executed here.  The formulas are three lines each and are cited.
+* MLP arithmetic (``oracle/dynamics.py``): **parity unpinned at the
+  TensorFlow boundary**.  The arithmetic lives in third-party
+  ``tensorflow==1.13.1`` (``docker/environment.yml:57``), which is not under
+  ``/root/reference`` and not installed; the reference has no test pinning
+  it.  The restatement follows the call sites
+  (``dynamics/core/utils.py:111-142``, ``:264-296``) - dense = ``x @ W + b``,
+  kernels ``[in, out]`` - and is cross-checked against float64 NumPy and
+  torch CPU fp32 in ``tests/test_oracle.py``.
+"""
+
+from .dynamics import OracleMLPDynamics, mlp_forward_f32  # noqa: F401
+from .rewards import make_reward  # noqa: F401
+from .planner import rs_plan, cem_plan  # noqa: F401
