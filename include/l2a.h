@@ -1,0 +1,162 @@
+/*
+ * l2a.h - C ABI of libl2a_hip.so: the MI355X (gfx950) MPC random-shooting rollout.
+ *
+ * The reference (iclavera/learning_to_adapt) has no FFI: its planner is Python that calls
+ * `dynamics_model.predict` (-> TensorFlow `sess.run`) once per horizon step.  This header is
+ * the boundary a maintainer would bind instead; every entry point names the reference code
+ * it replaces.  All pointers marked "device" are HIP device pointers (in practice
+ * `tensor.data_ptr()` of PyTorch-ROCm tensors - torch only stores the bytes); everything else
+ * is host memory.  No torch types, no C++ types and no exceptions cross this boundary.
+ *
+ * Error model: functions return 0 on success and a negative L2A_E* code on failure;
+ * `l2a_last_error` returns a human-readable message for the last failure on that context.
+ * Threading: one context per (process, device); calls on one context are not re-entrant.
+ * All device work is enqueued on the caller's stream; the library never synchronises except
+ * inside l2a_init / l2a_model_create / l2a_model_destroy / l2a_destroy.
+ */
+#ifndef L2A_H_
+#define L2A_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct l2a_ctx l2a_ctx;
+typedef struct l2a_model l2a_model;
+
+/* ---- error codes --------------------------------------------------------------------- */
+#define L2A_OK 0
+#define L2A_EINVAL (-1)      /* bad argument / unsupported shape                           */
+#define L2A_EHIP (-2)        /* a HIP runtime call failed (message has hipGetErrorString)  */
+#define L2A_ENODEV (-3)      /* no usable gfx950 device                                    */
+#define L2A_ESTATE (-4)      /* call order violated (e.g. plan before weights were set)    */
+
+/* ---- enums ---------------------------------------------------------------------------- */
+/* hidden / output nonlinearity: dynamics/mlp_dynamics.py:16-23 (`_activations`).           */
+#define L2A_ACT_IDENTITY 0
+#define L2A_ACT_RELU 1
+#define L2A_ACT_TANH 2
+#define L2A_ACT_SIGMOID 3
+#define L2A_ACT_SWISH 4
+
+/* how the E weight sets of a model are used                                                 */
+#define L2A_MODE_SINGLE 0     /* E == 1: MLPDynamicsModel.predict (mlp_dynamics.py:204-222)   */
+#define L2A_MODE_PER_BLOCK 1  /* row block i (env i) <-> set i: MetaMLPDynamicsModel._predict
+                                 with adapted weights (meta_mlp_dynamics.py:296-306,143-163)  */
+#define L2A_MODE_MEAN 2       /* delta = mean_e denorm_e(MLP_e(norm_e(.))) - build-defined
+                                 ensemble of BASELINE.json (not in the reference)            */
+
+/* which rollout kernel l2a_plan_rs / l2a_predict dispatch to                                */
+#define L2A_KERNEL_AUTO 0     /* MFMA kernel when the shape allows it, else the VALU kernel  */
+#define L2A_KERNEL_MFMA 1     /* fail with L2A_EINVAL when the shape is not MFMA-eligible    */
+#define L2A_KERNEL_VALU 2     /* generic fp32 VALU kernel (any layer sizes)                  */
+
+/*
+ * Closed-form reward, evaluated in-kernel once per (candidate, horizon step).  Replaces the
+ * host call `self.unwrapped_env.reward(observation, a[t], next_observation)`
+ * (policies/mpc_controller.py:125) for the reference's env rewards:
+ *   envs/half_cheetah_env.py:58-65, envs/ant_env.py:56-66, envs/arm_7dof_env.py:91-99.
+ *
+ *   r = w_vel * (next[vel_index] - obs[vel_index]) * inv_dt + alive
+ *       - ctrl_coef * sum_k act[k]^2 - dist_coef * || next[dist_index .. dist_index+2] ||
+ */
+typedef struct l2a_reward {
+    float w_vel;
+    float inv_dt;
+    float alive;
+    float ctrl_coef;
+    float dist_coef;
+    int vel_index;
+    int dist_index;
+    int reserved;
+} l2a_reward;
+
+/* ---- context -------------------------------------------------------------------------- */
+/* Create a context on HIP device `device`.  Lazy by design: the reference forks its env
+ * workers (samplers/sampler.py:37) before it creates the TF session
+ * (trainers/mb_trainer.py:46-48); callers must likewise call this after forking.            */
+int l2a_init(int device, l2a_ctx** out);
+void l2a_destroy(l2a_ctx* ctx);
+/* Message of the last failed call on `ctx` (or of a failed l2a_init when ctx == NULL).      */
+const char* l2a_last_error(const l2a_ctx* ctx);
+/* Library / device facts: writes up to `cap` bytes of a JSON object (arch, CU count, ...).  */
+int l2a_device_info(const l2a_ctx* ctx, char* buf, int cap);
+/* Select the kernel (L2A_KERNEL_*) used by subsequent launches on this context.             */
+int l2a_set_kernel(l2a_ctx* ctx, int kind);
+
+/* ---- model ----------------------------------------------------------------------------- */
+/* Describe the MLP dynamics model: replaces the graph construction of
+ * MLPDynamicsModel.__init__ (dynamics/mlp_dynamics.py:61-89) / the post-update graph of
+ * MetaMLPDynamicsModel (meta_mlp_dynamics.py:143-163) and dynamics/core/utils.py:111-142.
+ * `hidden` has `n_hidden` entries; `n_sets` weight sets are allocated (E).                  */
+int l2a_model_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_hidden, const int* hidden,
+                     int hidden_act, int output_act, int n_sets, int mode, l2a_model** out);
+void l2a_model_destroy(l2a_model* model);
+
+/* Load weight set `e` from fp32 DEVICE arrays in the reference's parameter order
+ * (dynamics/core/layers.py:160-163; forward_mlp, dynamics/core/utils.py:250,273-274):
+ *   ptrs = { hidden_0/kernel [in,h0], hidden_0/bias [h0], ..., output/kernel [hL,obs],
+ *            output/bias [obs] },  kernels row-major [in, out].
+ * Replaces feeding `network_params_feed_dict` on every sess.run (meta_mlp_dynamics.py:429-432).
+ * The library re-packs into its own HBM layout (MFMA fragment order) on `stream`; the caller
+ * keeps ownership of the source arrays and may free them once `stream` has passed this call. */
+int l2a_model_set_weights(l2a_model* model, int e, const void* const* device_ptrs,
+                          void* stream);
+
+/* Normalisation statistics of set `e` (float64 HOST vectors, as `compute_normalization`
+ * stores them, mlp_dynamics.py:253-262).  The +1e-10 of normalize/denormalize
+ * (mlp_dynamics.py:265-270) is applied inside.  Passing NULL for all six = identity
+ * (normalize_input=False).                                                                  */
+int l2a_model_set_norm(l2a_model* model, int e, const double* mean_obs, const double* std_obs,
+                       const double* mean_act, const double* std_act,
+                       const double* mean_delta, const double* std_delta, void* stream);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* One random-shooting plan step: replaces the whole horizon loop of
+ * MPCController.get_rs_action (policies/mpc_controller.py:116-129) and of one CEM iteration
+ * (:92-100) - normalise, MLP (all sets), denormalise, state update, reward, discounted
+ * return, arg-max - in one kernel launch.
+ *
+ *   obs0      device fp32 [m, obs_dim]        current observation of each env
+ *   actions   device fp32 [h, m*n, act_dim]   candidate action sequences, row r = i*n + j
+ *                                             (env i, candidate j) - the layout of
+ *                                             `a.reshape(h, n*m, -1)` (mpc_controller.py:114)
+ *   returns_out  device fp32 [m, n] or NULL   discounted return of every candidate
+ *   best_key  device u64 [m]                  packed arg-max, see l2a_key_decode.  The library
+ *                                             zeroes it on `stream` before the launch.
+ *   cand_offset                               global index of local candidate 0 (multi-GPU
+ *                                             sharding: indices in best_key are global)
+ * Rows whose env index is i use weight set i in L2A_MODE_PER_BLOCK (needs n_sets >= m).      */
+int l2a_plan_rs(l2a_model* model, const float* obs0, const float* actions, int m, int n, int h,
+                float discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                unsigned long long* best_key, void* stream);
+
+/* One-step batched prediction: MLPDynamicsModel.predict / MetaMLPDynamicsModel.predict
+ * (mlp_dynamics.py:204-222, meta_mlp_dynamics.py:276-294).
+ *   obs device fp32 [R, obs_dim], act device fp32 [R, act_dim] -> next_obs device fp32 [R, obs_dim]
+ * In L2A_MODE_PER_BLOCK the rows are split into `n_blocks` equal blocks (block i <-> set i);
+ * pass n_blocks = 1 otherwise.                                                               */
+int l2a_predict(l2a_model* model, const float* obs, const float* act, int rows, int n_blocks,
+                float* next_obs_out, void* stream);
+
+/* best_key packing (host helpers, pure functions):
+ *   key = (orderable_u32(return) << 31) | (0x7fffffff - global_index), top bit always 0, so
+ *   unsigned max == signed max == "largest return, ties -> lowest index" = np.argmax
+ *   (mpc_controller.py:129).  A max all-reduce of the keys over ranks (RCCL, int64 MAX) is the
+ *   only collective of a plan step.                                                          */
+unsigned long long l2a_key_encode(float ret, int index);
+void l2a_key_decode(unsigned long long key, float* ret, int* index);
+
+/* ---- introspection used by tests (no GPU needed) ------------------------------------------ */
+/* 1 when (obs_dim, act_dim, hidden[]) is eligible for the MFMA kernel, else 0.               */
+int l2a_mfma_eligible(int obs_dim, int act_dim, int n_hidden, const int* hidden);
+/* Host implementation of the weight re-packing used by the device pack kernel (same index
+ * function).  Packs kernel W [k_in, n_out] (row-major) into `out`, which must hold
+ * l2a_packed_layer_floats(k_in, n_out) floats.                                               */
+long long l2a_packed_layer_floats(int k_in, int n_out);
+int l2a_pack_layer_host(const float* w, int k_in, int n_out, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2A_H_ */

@@ -1,0 +1,134 @@
+"""ctypes binding of ``libl2a_hip.so`` (C ABI: ``include/l2a.h``).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, an
+exception is raised.  The CPU oracle under ``oracle/`` is test infrastructure and is never
+imported from here.
+"""
+
+import ctypes
+import json
+import os
+
+from .envs.reward_spec import RewardSpec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libl2a_hip.so")
+
+# include/l2a.h
+L2A_OK = 0
+ACT_CODES = {None: 0, "identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4}
+MODE_CODES = {"single": 0, "per_block": 1, "mean": 2}
+KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
+
+EXPORTED_SYMBOLS = (
+    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel",
+    "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_norm",
+    "l2a_plan_rs", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
+    "l2a_packed_layer_floats", "l2a_pack_layer_host",
+)
+
+
+class L2AError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype of include/l2a.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise L2AError(
+            "%s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i32, f32 = c.c_void_p, c.c_int, c.c_float
+    lib.l2a_init.argtypes = [i32, c.POINTER(vp)]
+    lib.l2a_init.restype = i32
+    lib.l2a_destroy.argtypes = [vp]
+    lib.l2a_destroy.restype = None
+    lib.l2a_last_error.argtypes = [vp]
+    lib.l2a_last_error.restype = c.c_char_p
+    lib.l2a_device_info.argtypes = [vp, c.c_char_p, i32]
+    lib.l2a_device_info.restype = i32
+    lib.l2a_set_kernel.argtypes = [vp, i32]
+    lib.l2a_set_kernel.restype = i32
+    lib.l2a_model_create.argtypes = [vp, i32, i32, i32, c.POINTER(i32), i32, i32, i32, i32, c.POINTER(vp)]
+    lib.l2a_model_create.restype = i32
+    lib.l2a_model_destroy.argtypes = [vp]
+    lib.l2a_model_destroy.restype = None
+    lib.l2a_model_set_weights.argtypes = [vp, i32, c.POINTER(vp), vp]
+    lib.l2a_model_set_weights.restype = i32
+    dp = c.POINTER(c.c_double)
+    lib.l2a_model_set_norm.argtypes = [vp, i32, dp, dp, dp, dp, dp, dp, vp]
+    lib.l2a_model_set_norm.restype = i32
+    lib.l2a_plan_rs.argtypes = [vp, vp, vp, i32, i32, i32, f32, c.POINTER(RewardSpec), i32, vp, vp, vp]
+    lib.l2a_plan_rs.restype = i32
+    lib.l2a_predict.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.l2a_predict.restype = i32
+    lib.l2a_key_encode.argtypes = [f32, i32]
+    lib.l2a_key_encode.restype = c.c_ulonglong
+    lib.l2a_key_decode.argtypes = [c.c_ulonglong, c.POINTER(f32), c.POINTER(i32)]
+    lib.l2a_key_decode.restype = None
+    lib.l2a_mfma_eligible.argtypes = [i32, i32, i32, c.POINTER(i32)]
+    lib.l2a_mfma_eligible.restype = i32
+    lib.l2a_packed_layer_floats.argtypes = [i32, i32]
+    lib.l2a_packed_layer_floats.restype = c.c_longlong
+    lib.l2a_pack_layer_host.argtypes = [c.POINTER(f32), i32, i32, c.POINTER(f32)]
+    lib.l2a_pack_layer_host.restype = i32
+    _lib = lib
+    return lib
+
+
+def key_decode(key):
+    """``best_key`` -> (return as float, global candidate index)."""
+    lib = load()
+    ret, idx = ctypes.c_float(), ctypes.c_int()
+    lib.l2a_key_decode(ctypes.c_ulonglong(int(key) & 0xFFFFFFFFFFFFFFFF), ctypes.byref(ret), ctypes.byref(idx))
+    return ret.value, idx.value
+
+
+class Context(object):
+    """One ``l2a_ctx`` per (process, device).  Created lazily by the models (never at import
+    or construction time: the reference forks env workers before touching the accelerator,
+    ``samplers/sampler.py:37`` vs ``trainers/mb_trainer.py:46-48``)."""
+
+    _by_device = {}
+
+    def __init__(self, device=0):
+        self.lib = load()
+        handle = ctypes.c_void_p()
+        rc = self.lib.l2a_init(int(device), ctypes.byref(handle))
+        if rc != L2A_OK:
+            raise L2AError("l2a_init(device=%d) failed (%d): %s" % (
+                device, rc, self.lib.l2a_last_error(None).decode()))
+        self.handle = handle
+        self.device = int(device)
+        self.pid = os.getpid()
+
+    @classmethod
+    def get(cls, device=0):
+        ctx = cls._by_device.get(device)
+        if ctx is None or ctx.pid != os.getpid():
+            ctx = cls(device)
+            cls._by_device[device] = ctx
+            kind = os.environ.get("L2A_KERNEL")
+            if kind:
+                ctx.set_kernel(kind)
+        return ctx
+
+    def check(self, rc, what):
+        if rc != L2A_OK:
+            raise L2AError("%s failed (%d): %s" % (what, rc, self.lib.l2a_last_error(self.handle).decode()))
+
+    def info(self):
+        buf = ctypes.create_string_buffer(512)
+        self.check(self.lib.l2a_device_info(self.handle, buf, 512), "l2a_device_info")
+        return json.loads(buf.value.decode())
+
+    def set_kernel(self, kind):
+        self.check(self.lib.l2a_set_kernel(self.handle, KERNEL_CODES[kind]), "l2a_set_kernel")

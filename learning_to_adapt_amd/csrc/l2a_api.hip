@@ -1,0 +1,491 @@
+// l2a_api.hip - host side of libl2a_hip.so: the C ABI declared in include/l2a.h.
+//
+// Owns: the context (device facts, kernel selection), the model (one HBM block per weight set
+// holding raw + MFMA-packed weights and the padded normalisation vectors) and the launch logic
+// of the fused rollout kernels in l2a_kernels.h.  Everything is enqueued on the caller's stream.
+
+#include "l2a_kernels.h"
+#include "l2a_mfma.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_init_error;
+
+struct HipFail {
+    hipError_t code;
+    const char* what;
+};
+
+}  // namespace
+
+struct l2a_ctx {
+    int device = 0;
+    int kernel_kind = L2A_KERNEL_AUTO;
+    int num_cu = 0;
+    int lds_per_block = 0;
+    int clock_khz = 0;
+    std::string arch;
+    std::string name;
+    mutable std::string err;
+};
+
+struct l2a_model {
+    l2a_ctx* ctx = nullptr;
+    int obs_dim = 0, act_dim = 0, in_dim = 0;
+    int n_hidden = 0;
+    int hidden[L2A_MAX_LAYERS] = {0};
+    int hidden_act = L2A_ACT_RELU, output_act = L2A_ACT_IDENTITY;
+    int n_sets = 1, mode = L2A_MODE_SINGLE;
+    bool mfma_ok = false;
+    int H = 0, TPW = 0, KG0 = 0, OT = 0, hmax = 0;
+    float* wblk = nullptr;
+    long long set_stride = 0;
+    long long raw_w[L2A_MAX_LAYERS] = {0};
+    long long raw_b[L2A_MAX_LAYERS] = {0};
+    long long pk_w0 = 0, pk_wmid = 0, pk_wmid_stride = 0, pk_wout = 0, pk_bout = 0, nm_off = 0;
+    std::vector<char> weights_set, norm_set;
+    std::vector<std::vector<float>> norm_stage;   // host staging, kept alive for async H2D
+};
+
+namespace {
+
+int fail(const l2a_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_init_error = msg;
+    return code;
+}
+
+#define L2A_HIP(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((ctx), L2A_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+bool mfma_eligible(int obs_dim, int act_dim, int n_hidden, const int* hidden) {
+    if (n_hidden < 1 || n_hidden > L2A_MAX_LAYERS - 1) return false;
+    const int H = hidden[0];
+    if (H != 128 && H != 256 && H != 512) return false;
+    for (int i = 1; i < n_hidden; ++i)
+        if (hidden[i] != H) return false;
+    if (obs_dim < 1 || obs_dim > 16 * L2A_OTMAX) return false;
+    if (act_dim < 1 || act_dim > 16) return false;
+    if (obs_dim + act_dim > 16 * L2A_KG0MAX) return false;
+    return true;
+}
+
+long long packed_floats(int k_in, int n_out) {
+    return (long long)ceil_div(n_out, 16) * ceil_div(k_in, 16) * 256;
+}
+
+template <typename K>
+int allow_big_lds(const l2a_ctx* ctx, K kernel, int bytes) {
+    L2A_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return L2A_OK;
+}
+
+// Launch geometry of the MFMA kernel for (m, n): NT candidate tiles per workgroup.
+int choose_nt(const l2a_model* md, int m, int n, int sa_bytes_nt2) {
+    const int cus = md->ctx->num_cu > 0 ? md->ctx->num_cu : 256;
+    if (2 * sa_bytes_nt2 + 8192 > md->ctx->lds_per_block) return 1;
+    const long long wg1 = (long long)m * ceil_div(n, 16);
+    const long long wg2 = (long long)m * ceil_div(n, 32);
+    const double cost1 = (double)((wg1 + cus - 1) / cus) * 1.0;
+    const double cost2 = (double)((wg2 + cus - 1) / cus) * 1.9;
+    return (cost2 < cost1) ? 2 : 1;
+}
+
+int sa_elems_for(const l2a_model* md, int nt) {
+    const int ht = md->H / 16;
+    const int a = nt * ht;
+    const int b = 8 * nt * md->OT;
+    return (a > b ? a : b) * 64;
+}
+
+template <int NT, int TPW, int OT, int KG0>
+int launch_mfma_inst(const l2a_model* md, const L2AKParams& p, dim3 grid, dim3 block, int smem,
+                     hipStream_t stream) {
+    int rc = allow_big_lds(md->ctx, l2a_rollout_mfma_k<NT, TPW, OT, KG0>, smem);
+    if (rc != L2A_OK) return rc;
+    hipLaunchKernelGGL((l2a_rollout_mfma_k<NT, TPW, OT, KG0>), grid, block, smem, stream, p);
+    return L2A_OK;
+}
+
+// (OT, KG0) = (ceil(obs/16), ceil((obs+act)/16)); act_dim <= 16 makes KG0 either OT or OT + 1.
+template <int NT, int TPW>
+int launch_mfma_shape(const l2a_model* md, const L2AKParams& p, dim3 grid, dim3 block, int smem,
+                      hipStream_t stream) {
+    switch (md->OT * 8 + md->KG0) {
+        case 1 * 8 + 1: return launch_mfma_inst<NT, TPW, 1, 1>(md, p, grid, block, smem, stream);
+        case 1 * 8 + 2: return launch_mfma_inst<NT, TPW, 1, 2>(md, p, grid, block, smem, stream);
+        case 2 * 8 + 2: return launch_mfma_inst<NT, TPW, 2, 2>(md, p, grid, block, smem, stream);
+        case 2 * 8 + 3: return launch_mfma_inst<NT, TPW, 2, 3>(md, p, grid, block, smem, stream);
+        case 3 * 8 + 3: return launch_mfma_inst<NT, TPW, 3, 3>(md, p, grid, block, smem, stream);
+        case 3 * 8 + 4: return launch_mfma_inst<NT, TPW, 3, 4>(md, p, grid, block, smem, stream);
+        case 4 * 8 + 4: return launch_mfma_inst<NT, TPW, 4, 4>(md, p, grid, block, smem, stream);
+        case 4 * 8 + 5: return launch_mfma_inst<NT, TPW, 4, 5>(md, p, grid, block, smem, stream);
+        default: return fail(md->ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim)");
+    }
+}
+
+int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
+    l2a_ctx* ctx = md->ctx;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const int sets_needed = (p.mode == L2A_MODE_PER_BLOCK) ? (p.m < md->n_sets ? p.m : md->n_sets) : md->n_sets;
+    for (int e = 0; e < sets_needed; ++e) {
+        if (!md->weights_set[e]) return fail(ctx, L2A_ESTATE, "weight set " + std::to_string(e) + " was never set");
+        if (!md->norm_set[e]) return fail(ctx, L2A_ESTATE, "normalisation of set " + std::to_string(e) + " was never set");
+    }
+    if (p.mode == L2A_MODE_PER_BLOCK && p.m > md->n_sets)
+        return fail(ctx, L2A_EINVAL, "per-block mode needs one weight set per env/block");
+
+    int kind = ctx->kernel_kind;
+    if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
+    if (kind == L2A_KERNEL_MFMA && !md->mfma_ok)
+        return fail(ctx, L2A_EINVAL, "model shape is not eligible for the MFMA kernel "
+                                     "(needs equal hidden widths of 128/256/512, obs_dim<=64, act_dim<=16)");
+
+    if (kind == L2A_KERNEL_MFMA) {
+        const int nt = choose_nt(md, p.m, p.n, sa_elems_for(md, 2) * 16);
+        p.sa_elems = sa_elems_for(md, nt);
+        p.tiles_per_env = ceil_div(p.n, 16 * nt);
+        const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
+        const int smem = 2 * p.sa_elems * 16 + e_loop * (32 * md->KG0 + 32 * md->OT) * 4;
+        if (smem > ctx->lds_per_block)
+            return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
+        const dim3 grid((unsigned)(p.m * p.tiles_per_env)), block(512);
+        int rc = L2A_EINVAL;
+        if (nt == 1) {
+            if (md->TPW == 4) rc = launch_mfma_shape<1, 4>(md, p, grid, block, smem, stream);
+            else if (md->TPW == 2) rc = launch_mfma_shape<1, 2>(md, p, grid, block, smem, stream);
+            else rc = launch_mfma_shape<1, 1>(md, p, grid, block, smem, stream);
+        } else {
+            if (md->TPW == 4) rc = launch_mfma_shape<2, 4>(md, p, grid, block, smem, stream);
+            else if (md->TPW == 2) rc = launch_mfma_shape<2, 2>(md, p, grid, block, smem, stream);
+            else rc = launch_mfma_shape<2, 1>(md, p, grid, block, smem, stream);
+        }
+        if (rc != L2A_OK) return rc;
+    } else {
+        p.tiles_per_env = ceil_div(p.n, L2A_VT);
+        const int smem = (md->in_dim + 2 * md->hmax + 3 * md->obs_dim + md->act_dim + 1) * L2A_VT * 4;
+        if (smem > ctx->lds_per_block)
+            return fail(ctx, L2A_EINVAL, "LDS budget exceeded by the VALU kernel (" + std::to_string(smem) + " B)");
+        int rc = allow_big_lds(ctx, l2a_rollout_valu_k, smem);
+        if (rc != L2A_OK) return rc;
+        const dim3 grid((unsigned)(p.m * p.tiles_per_env)), block(256);
+        hipLaunchKernelGGL(l2a_rollout_valu_k, grid, block, smem, stream, p);
+    }
+    L2A_HIP(ctx, hipGetLastError());
+    return L2A_OK;
+}
+
+void fill_model_params(const l2a_model* md, L2AKParams& p) {
+    std::memset(&p, 0, sizeof(p));
+    p.wblk = md->wblk;
+    p.set_stride = md->set_stride;
+    for (int i = 0; i < L2A_MAX_LAYERS; ++i) {
+        p.raw_w[i] = md->raw_w[i];
+        p.raw_b[i] = md->raw_b[i];
+        p.hidden[i] = md->hidden[i];
+    }
+    p.pk_w0 = md->pk_w0; p.pk_wmid = md->pk_wmid; p.pk_wmid_stride = md->pk_wmid_stride;
+    p.pk_wout = md->pk_wout; p.pk_bout = md->pk_bout; p.nm_off = md->nm_off;
+    p.n_hidden = md->n_hidden;
+    p.obs_dim = md->obs_dim; p.act_dim = md->act_dim; p.in_dim = md->in_dim;
+    p.hidden_act = md->hidden_act; p.output_act = md->output_act;
+    p.mode = md->mode; p.n_sets = md->n_sets;
+    p.KG0 = md->KG0; p.OT = md->OT; p.hmax = md->hmax;
+}
+
+}  // namespace
+
+extern "C" {
+
+int l2a_init(int device, l2a_ctx** out) {
+    if (!out) return fail(nullptr, L2A_EINVAL, "l2a_init: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, L2A_ENODEV, std::string("no HIP device visible: ") +
+                                             (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= count)
+        return fail(nullptr, L2A_EINVAL, "device index " + std::to_string(device) + " out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, L2A_EHIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    std::string arch(prop.gcnArchName);
+    if (arch.rfind("gfx950", 0) != 0)
+        return fail(nullptr, L2A_ENODEV, "libl2a_hip.so is built for gfx950 only; device reports " + arch);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, L2A_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    l2a_ctx* ctx = new l2a_ctx();
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->lds_per_block = (int)prop.sharedMemPerBlock;
+    // gfx950 lets one workgroup take the whole 160 KiB of a CU (MI355X_MICROARCH.md, LDS).
+    if (ctx->lds_per_block < 160 * 1024) ctx->lds_per_block = 160 * 1024;
+    ctx->clock_khz = prop.clockRate;
+    ctx->arch = arch;
+    ctx->name = prop.name;
+    *out = ctx;
+    return L2A_OK;
+}
+
+void l2a_destroy(l2a_ctx* ctx) { delete ctx; }
+
+const char* l2a_last_error(const l2a_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int l2a_device_info(const l2a_ctx* ctx, char* buf, int cap) {
+    if (!ctx || !buf || cap <= 0) return L2A_EINVAL;
+    std::snprintf(buf, (size_t)cap,
+                  "{\"device\": %d, \"name\": \"%s\", \"arch\": \"%s\", \"compute_units\": %d, "
+                  "\"clock_khz\": %d, \"lds_per_block\": %d}",
+                  ctx->device, ctx->name.c_str(), ctx->arch.c_str(), ctx->num_cu, ctx->clock_khz,
+                  ctx->lds_per_block);
+    return L2A_OK;
+}
+
+int l2a_set_kernel(l2a_ctx* ctx, int kind) {
+    if (!ctx) return L2A_EINVAL;
+    if (kind != L2A_KERNEL_AUTO && kind != L2A_KERNEL_MFMA && kind != L2A_KERNEL_VALU)
+        return fail(ctx, L2A_EINVAL, "unknown kernel kind");
+    ctx->kernel_kind = kind;
+    return L2A_OK;
+}
+
+int l2a_mfma_eligible(int obs_dim, int act_dim, int n_hidden, const int* hidden) {
+    return (hidden && mfma_eligible(obs_dim, act_dim, n_hidden, hidden)) ? 1 : 0;
+}
+
+long long l2a_packed_layer_floats(int k_in, int n_out) { return packed_floats(k_in, n_out); }
+
+int l2a_pack_layer_host(const float* w, int k_in, int n_out, float* out) {
+    if (!w || !out || k_in < 1 || n_out < 1) return L2A_EINVAL;
+    const int KG = ceil_div(k_in, 16);
+    const long long total = packed_floats(k_in, n_out);
+    for (long long idx = 0; idx < total; ++idx) {
+        int k, u;
+        l2a_pack_decode(idx, KG, &k, &u);
+        out[idx] = (k < k_in && u < n_out) ? w[(long long)k * n_out + u] : 0.0f;
+    }
+    return L2A_OK;
+}
+
+unsigned long long l2a_key_encode(float ret, int index) { return l2a_key_pack(ret, index); }
+
+void l2a_key_decode(unsigned long long key, float* ret, int* index) {
+    const unsigned int ord = (unsigned int)(key >> 31);
+    const unsigned int idx = 0x7fffffffu - (unsigned int)(key & 0x7fffffffull);
+    const unsigned int u = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+    union { float f; unsigned int u; } cv;
+    cv.u = u;
+    if (ret) *ret = cv.f;
+    if (index) *index = (int)idx;
+}
+
+int l2a_model_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_hidden, const int* hidden,
+                     int hidden_act, int output_act, int n_sets, int mode, l2a_model** out) {
+    if (!ctx) return L2A_EINVAL;
+    if (!out || !hidden) return fail(ctx, L2A_EINVAL, "l2a_model_create: null argument");
+    *out = nullptr;
+    if (obs_dim < 1 || act_dim < 1) return fail(ctx, L2A_EINVAL, "obs_dim and act_dim must be >= 1");
+    if (n_hidden < 1 || n_hidden > L2A_MAX_LAYERS - 1)
+        return fail(ctx, L2A_EINVAL, "n_hidden must be in [1, 8]");
+    for (int i = 0; i < n_hidden; ++i)
+        if (hidden[i] < 1 || hidden[i] > 1024) return fail(ctx, L2A_EINVAL, "hidden sizes must be in [1, 1024]");
+    if (hidden_act < 0 || hidden_act > L2A_ACT_SWISH || output_act < 0 || output_act > L2A_ACT_SWISH)
+        return fail(ctx, L2A_EINVAL, "unsupported nonlinearity");
+    if (mode != L2A_MODE_SINGLE && mode != L2A_MODE_PER_BLOCK && mode != L2A_MODE_MEAN)
+        return fail(ctx, L2A_EINVAL, "unknown mode");
+    if (n_sets < 1 || (mode == L2A_MODE_SINGLE && n_sets != 1))
+        return fail(ctx, L2A_EINVAL, "n_sets must be >= 1 (and exactly 1 in single mode)");
+
+    l2a_model* md = new l2a_model();
+    md->ctx = ctx;
+    md->obs_dim = obs_dim; md->act_dim = act_dim; md->in_dim = obs_dim + act_dim;
+    md->n_hidden = n_hidden;
+    md->hmax = 0;
+    for (int i = 0; i < n_hidden; ++i) {
+        md->hidden[i] = hidden[i];
+        if (hidden[i] > md->hmax) md->hmax = hidden[i];
+    }
+    md->hidden_act = hidden_act; md->output_act = output_act;
+    md->n_sets = n_sets; md->mode = mode;
+    md->KG0 = ceil_div(md->in_dim, 16);
+    md->OT = ceil_div(obs_dim, 16);
+    md->mfma_ok = mfma_eligible(obs_dim, act_dim, n_hidden, hidden);
+    md->H = md->mfma_ok ? hidden[0] : 0;
+    md->TPW = md->mfma_ok ? hidden[0] / 128 : 0;
+
+    // ---- lay out one weight-set block (offsets in floats, every region 64-B aligned) ------
+    long long off = 0;
+    auto take = [&off](long long n) { long long o = off; off += (n + 15) / 16 * 16; return o; };
+    int k_in = md->in_dim;
+    for (int l = 0; l <= n_hidden; ++l) {
+        const int n_out = (l < n_hidden) ? hidden[l] : obs_dim;
+        md->raw_w[l] = take((long long)k_in * n_out);
+        md->raw_b[l] = take(n_out);
+        k_in = n_out;
+    }
+    if (md->mfma_ok) {
+        md->pk_w0 = take(packed_floats(md->in_dim, md->H));
+        md->pk_wmid_stride = packed_floats(md->H, md->H);
+        md->pk_wmid = take(md->pk_wmid_stride * (n_hidden - 1));
+        md->pk_wout = take(packed_floats(md->H, obs_dim));
+    }
+    md->pk_bout = take(16 * md->OT);
+    md->nm_off = take(32 * md->KG0 + 32 * md->OT);
+    md->set_stride = off;
+
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&md->wblk), (size_t)off * n_sets * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(md->wblk, 0, (size_t)off * n_sets * sizeof(float));
+    if (e != hipSuccess) {
+        std::string msg = std::string("allocating model storage: ") + hipGetErrorString(e);
+        delete md;
+        return fail(ctx, L2A_EHIP, msg);
+    }
+    md->weights_set.assign(n_sets, 0);
+    md->norm_set.assign(n_sets, 0);
+    md->norm_stage.resize(n_sets);
+    *out = md;
+    return L2A_OK;
+}
+
+void l2a_model_destroy(l2a_model* md) {
+    if (!md) return;
+    if (md->wblk) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(md->wblk);
+    }
+    delete md;
+}
+
+int l2a_model_set_weights(l2a_model* md, int e, const void* const* device_ptrs, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (e < 0 || e >= md->n_sets) return fail(ctx, L2A_EINVAL, "weight set index out of range");
+    if (!device_ptrs) return fail(ctx, L2A_EINVAL, "device_ptrs is null");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    float* blk = md->wblk + (long long)e * md->set_stride;
+    int k_in = md->in_dim;
+    for (int l = 0; l <= md->n_hidden; ++l) {
+        const int n_out = (l < md->n_hidden) ? md->hidden[l] : md->obs_dim;
+        const float* w = static_cast<const float*>(device_ptrs[2 * l]);
+        const float* b = static_cast<const float*>(device_ptrs[2 * l + 1]);
+        if (!w || !b) return fail(ctx, L2A_EINVAL, "null parameter pointer for layer " + std::to_string(l));
+        L2A_HIP(ctx, hipMemcpyAsync(blk + md->raw_w[l], w, sizeof(float) * (size_t)k_in * n_out,
+                                    hipMemcpyDeviceToDevice, stream));
+        L2A_HIP(ctx, hipMemcpyAsync(blk + md->raw_b[l], b, sizeof(float) * (size_t)n_out,
+                                    hipMemcpyDeviceToDevice, stream));
+        if (md->mfma_ok) {
+            float* dst;
+            if (l == 0) dst = blk + md->pk_w0;
+            else if (l < md->n_hidden) dst = blk + md->pk_wmid + (long long)(l - 1) * md->pk_wmid_stride;
+            else dst = blk + md->pk_wout;
+            const long long total = packed_floats(k_in, n_out);
+            const int KG = ceil_div(k_in, 16);
+            const unsigned blocks = (unsigned)((total + 255) / 256);
+            hipLaunchKernelGGL(l2a_pack_layer_k, dim3(blocks), dim3(256), 0, stream, w, k_in, n_out, KG, total, dst);
+            L2A_HIP(ctx, hipGetLastError());
+        }
+        if (l == md->n_hidden) {
+            // padded copy of the output bias (the tail beyond obs_dim stays zero from model_create)
+            L2A_HIP(ctx, hipMemcpyAsync(blk + md->pk_bout, b, sizeof(float) * (size_t)n_out,
+                                        hipMemcpyDeviceToDevice, stream));
+        }
+        k_in = n_out;
+    }
+    md->weights_set[e] = 1;
+    return L2A_OK;
+}
+
+int l2a_model_set_norm(l2a_model* md, int e, const double* mean_obs, const double* std_obs,
+                       const double* mean_act, const double* std_act, const double* mean_delta,
+                       const double* std_delta, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (e < 0 || e >= md->n_sets) return fail(ctx, L2A_EINVAL, "weight set index out of range");
+    const int n_null = !mean_obs + !std_obs + !mean_act + !std_act + !mean_delta + !std_delta;
+    if (n_null != 0 && n_null != 6)
+        return fail(ctx, L2A_EINVAL, "pass all six normalisation vectors, or none for identity");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const int KG0 = md->KG0, OT = md->OT;
+    std::vector<float>& st = md->norm_stage[e];
+    // a previous async copy from this staging buffer must have drained before we overwrite it
+    if (!st.empty()) L2A_HIP(ctx, hipStreamSynchronize(stream));
+    st.assign((size_t)(32 * KG0 + 32 * OT), 0.0f);
+    float* in_mu = st.data();
+    float* in_iv = in_mu + 16 * KG0;
+    float* out_mu = in_iv + 16 * KG0;
+    float* out_sd = out_mu + 16 * OT;
+    const double eps = 1e-10;   // mlp_dynamics.py:265-270
+    for (int k = 0; k < md->in_dim; ++k) {
+        if (n_null) { in_mu[k] = 0.0f; in_iv[k] = 1.0f; continue; }
+        const double mu = (k < md->obs_dim) ? mean_obs[k] : mean_act[k - md->obs_dim];
+        const double sd = (k < md->obs_dim) ? std_obs[k] : std_act[k - md->obs_dim];
+        in_mu[k] = (float)mu;
+        in_iv[k] = (float)(1.0 / (sd + eps));
+    }
+    for (int d = 0; d < md->obs_dim; ++d) {
+        out_mu[d] = n_null ? 0.0f : (float)mean_delta[d];
+        out_sd[d] = n_null ? 1.0f : (float)(std_delta[d] + eps);
+    }
+    float* dst = md->wblk + (long long)e * md->set_stride + md->nm_off;
+    L2A_HIP(ctx, hipMemcpyAsync(dst, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    md->norm_set[e] = 1;
+    return L2A_OK;
+}
+
+int l2a_plan_rs(l2a_model* md, const float* obs0, const float* actions, int m, int n, int h,
+                float discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                unsigned long long* best_key, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!obs0 || !actions || !reward) return fail(ctx, L2A_EINVAL, "l2a_plan_rs: null obs0/actions/reward");
+    if (!best_key && !returns_out) return fail(ctx, L2A_EINVAL, "l2a_plan_rs: nothing to write (best_key and returns_out are null)");
+    if (m < 1 || n < 1 || h < 1) return fail(ctx, L2A_EINVAL, "l2a_plan_rs: m, n and h must be >= 1");
+    if ((long long)m * n > 0x3fffffffLL || cand_offset < 0 || (long long)cand_offset + n > 0x7fffffffLL)
+        return fail(ctx, L2A_EINVAL, "l2a_plan_rs: too many candidates");
+    if (reward->w_vel != 0.0f && (reward->vel_index < 0 || reward->vel_index >= md->obs_dim))
+        return fail(ctx, L2A_EINVAL, "reward.vel_index out of range");
+    if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
+        return fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (best_key) L2A_HIP(ctx, hipMemsetAsync(best_key, 0, sizeof(unsigned long long) * (size_t)m, stream));
+    L2AKParams p;
+    fill_model_params(md, p);
+    p.obs0 = obs0; p.actions = actions; p.returns_out = returns_out; p.best_key = best_key;
+    p.state_out = nullptr; p.obs_per_row = 0;
+    p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
+    return launch_rollout(md, p, stream_v);
+}
+
+int l2a_predict(l2a_model* md, const float* obs, const float* act, int rows, int n_blocks,
+                float* next_obs_out, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!obs || !act || !next_obs_out) return fail(ctx, L2A_EINVAL, "l2a_predict: null pointer");
+    if (rows < 1 || n_blocks < 1 || rows % n_blocks != 0)
+        return fail(ctx, L2A_EINVAL, "l2a_predict: rows must be a positive multiple of n_blocks");
+    if (md->mode != L2A_MODE_PER_BLOCK && n_blocks != 1)
+        return fail(ctx, L2A_EINVAL, "l2a_predict: n_blocks > 1 needs per-block mode");
+    L2AKParams p;
+    fill_model_params(md, p);
+    p.obs0 = obs; p.actions = act; p.returns_out = nullptr; p.best_key = nullptr;
+    p.state_out = next_obs_out; p.obs_per_row = 1;
+    p.m = n_blocks; p.n = rows / n_blocks; p.h = 1; p.cand_offset = 0; p.discount = 1.0f;
+    std::memset(&p.rw, 0, sizeof(p.rw));
+    return launch_rollout(md, p, stream_v);
+}
+
+}  // extern "C"

@@ -1,0 +1,398 @@
+// l2a_mfma.h - the fp32 MFMA rollout kernel (gfx950 / CDNA4 only).  Included by l2a_api.hip.
+//
+// Workgroup = 8 waves (512 threads) owning NT tiles of 16 candidates of one env for the whole
+// horizon and all weight sets; workgroups never talk to each other (one atomicMax at the end).
+//
+// Data distribution: lane (j = l & 15, qq = l >> 4) holds, for candidate j of a tile,
+// features 16c + 4qq + 0..3 of every 16-feature tile c - for the state, the deltas and the
+// hidden activations alike.  That is at once the D-fragment layout of
+// v_mfma_f32_16x16x4_f32 (computed as D = W^T-tile x activations) and, thanks to the k
+// permutation baked into the packed weights (l2a_kernels.h), the B-fragment layout of the
+// next layer: layers chain through LDS with one 16-byte write and one 16-byte read per lane
+// and tile, no transposes, no bank conflicts (every access is lane-linear).
+//
+// Per (step, weight set):
+//   layer 0      : wave w computes hidden tiles [w*TPW, (w+1)*TPW); B = normalised [obs|act]
+//                  built in registers from the state fragment; K = in_dim (KG0 k-groups)
+//   hidden layers: same tile ownership; B fragments (activations) come from LDS; A fragments
+//                  (weights, 1 KiB per wave-level load) stream from L2 straight into VGPRs
+//                  with two k-groups in flight ahead of the MFMAs
+//   output layer : K split over the 8 waves (TPW k-groups each), partial sums exchanged
+//                  through the idle LDS region, every wave reduces them in the same order,
+//                  so all 8 waves hold bit-identical copies of state / return
+// LDS: two activation regions of sa_elems f32x4 each + the normalisation vectors.
+//
+// Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave
+// (hidden width = 128 * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16).
+#pragma once
+
+#include "l2a_kernels.h"
+
+// Make `v` opaque to the optimiser at this point (no instructions emitted).  Used on the
+// pre-loop fills of the software-pipeline registers: without it InstCombine folds the
+// loop-carried phi(load, load) into load(phi(addr)) and the prefetch distance collapses to 0.
+#define L2A_OPAQUE(v) asm volatile("" : "+v"(v))
+
+// One hidden->hidden layer for this wave's TPW output tiles.
+//
+// Software pipeline over the HT k-groups, prefetch distance 2 groups, 4 register buffers in
+// rotation (A, B, C, D <-> group index mod 4) so that a buffer is refilled only after its
+// last use: no loop-carried register copies.  `sched_barrier(0)` pins each refill at the
+// start of its stage (hipcc otherwise sinks the loads next to their consumers), and the
+// pre-loop fills are made opaque so InstCombine cannot fold phi(load, load) into
+// load(phi(addr)) and collapse the prefetch distance.
+#define L2A_STAGE(CA, CB, FA, FB, GF)                                                      \
+    {                                                                                      \
+        const int gf_ = ((GF) < HT) ? (GF) : HT - 1;                                       \
+        _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                                 \
+            FA[tt] = wl[((c0 + tt) * HT + gf_) * 64];                                      \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
+            FB[nt] = hin[(nt * HT + gf_) * 64 + lane];                                     \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                   \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                              \
+                _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                         \
+                    acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);           \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+
+template <int NT, int TPW>
+__device__ __forceinline__ void l2a_hidden_layer(const f32x4* __restrict__ wl,   // lane applied
+                                                 const float* __restrict__ bl,
+                                                 const f32x4* hin, f32x4* hout,
+                                                 int wave, int lane, int qq, int act) {
+    constexpr int HT = 8 * TPW;
+    static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
+    const int c0 = wave * TPW;
+    f32x4 acc[NT][TPW];
+    f32x4 aA[TPW], aB[TPW], aC[TPW], aD[TPW], bA[NT], bB[NT], bC[NT], bD[NT], bias[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        aA[tt] = wl[((c0 + tt) * HT + 0) * 64];
+        aB[tt] = wl[((c0 + tt) * HT + 1) * 64];
+        bias[tt] = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bA[nt] = hin[(nt * HT + 0) * 64 + lane];
+        bB[nt] = hin[(nt * HT + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) { L2A_OPAQUE(aA[tt]); L2A_OPAQUE(aB[tt]); }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { L2A_OPAQUE(bA[nt]); L2A_OPAQUE(bB[nt]); }
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+    for (int g = 0; g < HT; g += 4) {
+        L2A_STAGE(aA, bA, aC, bC, g + 2)
+        L2A_STAGE(aB, bB, aD, bD, g + 3)
+        L2A_STAGE(aC, bC, aA, bA, g + 4)
+        L2A_STAGE(aD, bD, aB, bB, g + 5)
+    }
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            hout[(nt * HT + c0 + tt) * 64 + lane] = l2a_act4(acc[nt][tt] + bias[tt], act);
+}
+
+template <int NT, int TPW, int OT, int KG0>
+__global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
+    constexpr int HT = 8 * TPW;
+    constexpr int NRM_SET = 32 * KG0 + 32 * OT;
+    extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
+    f32x4* buf0 = reinterpret_cast<f32x4*>(l2a_smem);
+    f32x4* buf1 = buf0 + p.sa_elems;
+    float* nrm = reinterpret_cast<float*>(buf1 + p.sa_elems);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jc = lane & 15;
+    const int qq = lane >> 4;
+
+    const int bid = l2a_logical_wg(blockIdx.x, gridDim.x);
+    const int env = bid / p.tiles_per_env;
+    const int tb = bid - env * p.tiles_per_env;
+    const int R = p.m * p.n;
+    const int obs_dim = p.obs_dim, act_dim = p.act_dim;
+
+    int cand[NT], row[NT];
+    bool valid[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        cand[nt] = tb * (16 * NT) + nt * 16 + jc;
+        valid[nt] = cand[nt] < p.n;
+        row[nt] = env * p.n + (valid[nt] ? cand[nt] : p.n - 1);
+    }
+
+    // ---- normalisation vectors of every set this workgroup uses -> LDS --------------------
+    const bool per_block = (p.mode == L2A_MODE_PER_BLOCK);
+    const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
+    for (int i = tid; i < e_loop * NRM_SET; i += 512) {
+        const int s = i / NRM_SET;
+        const int o = i - s * NRM_SET;
+        const int ws = per_block ? env : s;
+        nrm[i] = p.wblk[(long long)ws * p.set_stride + p.nm_off + o];
+    }
+
+    // ---- state fragment -------------------------------------------------------------------
+    f32x4 st[NT][OT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float* orow = p.obs0 + (p.obs_per_row ? (long long)row[nt] : (long long)env) * obs_dim;
+#pragma unroll
+        for (int c = 0; c < OT; ++c)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int dim = 16 * c + 4 * qq + ii;
+                const float v = orow[dim < obs_dim ? dim : obs_dim - 1];   // branch-free, in bounds
+                st[nt][c][ii] = (dim < obs_dim) ? v : 0.0f;
+            }
+    }
+    __syncthreads();
+
+    // ---- actions occupy input k-groups ga0 and ga0 + 1 (act_dim <= 16) ----------------------
+    const int ga0 = obs_dim >> 4;
+    f32x4 av_next[NT][2];
+    auto load_actions = [&](int t, f32x4 (&dst)[NT][2]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float* arow = p.actions + ((long long)t * R + row[nt]) * act_dim;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+                    const bool in = (ka >= 0) && (ka < act_dim);
+                    const float v = arow[in ? ka : 0];
+                    dst[nt][s][ii] = in ? v : 0.0f;
+                }
+        }
+    };
+    load_actions(0, av_next);
+
+    float ret[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ret[nt] = 0.0f;
+
+    f32x4* hcur = buf0;
+    f32x4* hoth = buf1;
+    const float e_count = (float)e_loop;
+    double disc_pow = 1.0;      // discount ** t, carried in float64 like the reference (:126)
+
+    for (int t = 0; t < p.h; ++t) {
+        f32x4 av[NT][2];
+        float asq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            av[nt][0] = av_next[nt][0];
+            av[nt][1] = av_next[nt][1];
+            float s = 0.0f;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                s = fmaf(av[nt][0][ii], av[nt][0][ii], s);
+                s = fmaf(av[nt][1][ii], av[nt][1][ii], s);
+            }
+            asq[nt] = s;
+        }
+        load_actions((t + 1 < p.h) ? t + 1 : t, av_next);   // prefetch the next step's actions
+
+        f32x4 dsum[NT][OT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < OT; ++c) dsum[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int e = 0; e < e_loop; ++e) {
+            const int ws = per_block ? env : e;
+            const float* wb = p.wblk + (long long)ws * p.set_stride;
+            const float* nr = nrm + e * NRM_SET;    // per_block / single: e == 0
+
+            // ---- layer 0 -------------------------------------------------------------------
+            {
+                const f32x4* w0 = reinterpret_cast<const f32x4*>(wb + p.pk_w0) + lane;
+                const float* b0p = wb + p.raw_b[0];
+                const int c0 = wave * TPW;
+                f32x4 a[KG0][TPW];
+#pragma unroll
+                for (int g = 0; g < KG0; ++g)
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt) a[g][tt] = w0[((c0 + tt) * KG0 + g) * 64];
+                f32x4 bias[TPW];
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+                    bias[tt] = *reinterpret_cast<const f32x4*>(b0p + 16 * (c0 + tt) + 4 * qq);
+                f32x4 acc[NT][TPW];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < KG0; ++g) {
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
+                    const f32x4 iv = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
+                    f32x4 x[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (g < OT) sv = st[nt][g < OT ? g : 0];
+                        f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (g == ga0) aa = av[nt][0];
+                        if (g == ga0 + 1) aa = av[nt][1];
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const int k = 16 * g + 4 * qq + ii;
+                            const float v = (k < obs_dim) ? sv[ii] : aa[ii];
+                            x[nt][ii] = (v - mu[ii]) * iv[ii];
+                        }
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int tt = 0; tt < TPW; ++tt)
+                                acc[nt][tt] = L2A_MFMA(a[g][tt][ii], x[nt][ii], acc[nt][tt]);
+                }
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        hcur[(nt * HT + c0 + tt) * 64 + lane] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
+            }
+            __syncthreads();
+
+            // ---- hidden -> hidden layers ---------------------------------------------------
+            for (int l = 1; l < p.n_hidden; ++l) {
+                const f32x4* wl = reinterpret_cast<const f32x4*>(
+                                      wb + p.pk_wmid + (long long)(l - 1) * p.pk_wmid_stride) + lane;
+                l2a_hidden_layer<NT, TPW>(wl, wb + p.raw_b[l], hcur, hoth, wave, lane, qq, p.hidden_act);
+                __syncthreads();
+                f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
+            }
+
+            // ---- output layer: K split over the 8 waves, partials through LDS --------------
+            {
+                const f32x4* wo = reinterpret_cast<const f32x4*>(wb + p.pk_wout) + lane;
+                f32x4 a[TPW][OT], b[TPW][NT];
+#pragma unroll
+                for (int gi = 0; gi < TPW; ++gi) {
+                    const int g = wave * TPW + gi;
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) a[gi][c] = wo[(c * HT + g) * 64];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[gi][nt] = hcur[(nt * HT + g) * 64 + lane];
+                }
+                f32x4 acc[NT][OT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) acc[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int gi = 0; gi < TPW; ++gi)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+                                acc[nt][c] = L2A_MFMA(a[gi][c][ii], b[gi][nt][ii], acc[nt][c]);
+                // partial of wave w, tile (nt, c) -> hoth[((w * NT + nt) * OT + c) * 64 + lane]
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c)
+                        hoth[((wave * NT + nt) * OT + c) * 64 + lane] = acc[nt][c];
+            }
+            __syncthreads();
+            {
+                const float* bo = wb + p.pk_bout;
+#pragma unroll
+                for (int c = 0; c < OT; ++c) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(bo + 16 * c + 4 * qq);
+                    const f32x4 omu = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * c + 4 * qq);
+                    const f32x4 osd = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 s = hoth[((0 * NT + nt) * OT + c) * 64 + lane];
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) s += hoth[((w * NT + nt) * OT + c) * 64 + lane];
+                        s = l2a_act4(s + bias, p.output_act);
+                        dsum[nt][c] += s * osd + omu;
+                    }
+                }
+            }
+            // No barrier here: the next writes to `hoth` (a hidden layer, or the next output
+            // partials) come after the layer-0 barrier below, which every wave reaches only
+            // after finishing these reads; the next layer 0 writes `hcur`, which nobody reads
+            // any more (its last readers were the output-layer MFMAs before the barrier above).
+        }
+
+        // ---- ensemble mean, reward, state update -------------------------------------------
+        const float disc_t = (float)disc_pow;
+        disc_pow *= (double)p.discount;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[nt];
+            float psq = 0.0f;
+#pragma unroll
+            for (int c = 0; c < OT; ++c) {
+                f32x4 d = dsum[nt][c];
+                if (e_loop > 1) d = d / e_count;
+                const f32x4 nx = st[nt][c] + d;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int dim = 16 * c + 4 * qq + ii;
+                    if (dim == p.rw.vel_index) plin += p.rw.w_vel * d[ii] * p.rw.inv_dt;
+                    const bool in_dist = (p.rw.dist_coef != 0.0f) && (dim >= p.rw.dist_index) &&
+                                         (dim < p.rw.dist_index + 3) && (dim < obs_dim);
+                    psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
+                }
+                st[nt][c] = nx;
+            }
+            plin += __shfl_xor(plin, 16);
+            plin += __shfl_xor(plin, 32);
+            psq += __shfl_xor(psq, 16);
+            psq += __shfl_xor(psq, 32);
+            float r = plin;
+            if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
+            ret[nt] = fmaf(disc_t, r, ret[nt]);
+        }
+    }
+
+    // ---- results: wave 0 writes returns, arg-max key and (for predict) the final state -----
+    if (wave == 0) {
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (valid[nt] && qq == 0) {
+                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[nt]] = ret[nt];
+                const unsigned long long k = l2a_key_pack(ret[nt], p.cand_offset + cand[nt]);
+                key = (k > key) ? k : key;
+            }
+            if (p.state_out && valid[nt]) {
+                float* srow = p.state_out + ((long long)env * p.n + cand[nt]) * obs_dim;
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int dim = 16 * c + 4 * qq + ii;
+                        if (dim < obs_dim) srow[dim] = st[nt][c][ii];
+                    }
+            }
+        }
+        if (p.best_key) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const unsigned int hi = __shfl_xor((unsigned int)(key >> 32), off);
+                const unsigned int lo = __shfl_xor((unsigned int)(key & 0xffffffffu), off);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key = (other > key) ? other : key;
+            }
+            if (lane == 0 && key != 0ull) atomicMax(p.best_key + env, key);
+        }
+    }
+}
