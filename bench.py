@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py - controller-steps/s of the fused MPC random-shooting plan step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 2, the configuration `metric` is quoted on): HalfCheetah-shaped
+synthetic inputs, n_candidates = 2000 per GPU, horizon 30, mean-ensemble of 5 MLPs
+26->512->512->20 (fp32), discount 1, random-init weights from the seeded recipe
+(learning_to_adapt_amd/utils/synthetic.py).  A "step" is one plan step: best-key memset +
+fused rollout kernel (+ one int64 MAX all-reduce when N > 1) over candidate actions that are
+already resident in HBM.  At N > 1 every rank owns its own 2000 candidates (weak scaling:
+config 4 = 16000 candidates over 8 GPUs) and `value` counts 2000-candidate controller steps:
+value = N * K / time.
+
+One JSON line on stdout (rank 0).  Extra objects: `roofline` (fp32 MFMA roofline of the rollout
+kernel, measured live with HIP events on the launch stream) and `cpu_baseline` (the NumPy
+oracle = CPU restatement of the reference path, timed on this box's host cores, N = 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_CAND, HORIZON, ENSEMBLE, HIDDEN = 2000, 30, 5, (512, 512)
+OBS_DIM, ACT_DIM = 20, 6
+MAC_PER_ROW = (OBS_DIM + ACT_DIM) * 512 + 512 * 512 + 512 * OBS_DIM          # 285 696
+FLOP_PER_LAUNCH = 2.0 * MAC_PER_ROW * ENSEMBLE * N_CAND * HORIZON             # 171.4 GFLOP
+PARAMS_PER_SET = (OBS_DIM + ACT_DIM) * 512 + 512 + 512 * 512 + 512 + 512 * OBS_DIM + OBS_DIM
+HBM_BYTES_PER_LAUNCH = 4.0 * (N_CAND * HORIZON * ACT_DIM + ENSEMBLE * PARAMS_PER_SET + OBS_DIM) + 8
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps to time (0 = auto, ~10-30 s)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the rollout path is HIP-only)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from learning_to_adapt_amd import _lib
+    from learning_to_adapt_amd.dynamics.native_model import NativeModel
+    import cases
+
+    case = cases.CASES["c2_hc_rs_n2000_h30_e5"]
+    env, model = cases.product_model(case)       # host-side model (used by the end-to-end modes at N = 1)
+    native = NativeModel(OBS_DIM, ACT_DIM, HIDDEN, "relu", None, ENSEMBLE, "mean", device=local_rank)
+    _, sets, norms = cases.recipe(case)
+    for e in range(ENSEMBLE):
+        native.set_weights(e, sets[e])
+        native.set_norm(e, norms[e])
+    dev = native.device
+    spec = env.reward_spec
+    gold = cases.load_golden("c2_hc_rs_n2000_h30_e5_s0")
+    obs0 = torch.from_numpy(gold["obs0"].astype(np.float32)).to(dev)
+
+    # candidate actions resident in HBM: buffer 0 = the reference's seed-0 draw of THIS rank's
+    # shard (index check), buffers 1..3 = device-generated uniform candidates
+    n_glob = N_CAND * world
+    from oracle.planner import sample_rs_actions
+    np.random.seed(0)
+    a0 = sample_rs_actions(env.action_space.low, env.action_space.high, n_glob, 1, HORIZON)
+    lo = rank * N_CAND
+    bufs = [torch.from_numpy(np.ascontiguousarray(a0[:, lo:lo + N_CAND, :], dtype=np.float32)).to(dev)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    for _ in range(3):
+        bufs.append(torch.rand((HORIZON, N_CAND, ACT_DIM), generator=gen, device=dev) * 2.0 - 1.0)
+    best = torch.zeros((1,), dtype=torch.int64, device=dev)
+
+    def step(i):
+        native.plan_rs(obs0, bufs[i % len(bufs)], 1, N_CAND, HORIZON, 1.0, spec, cand_offset=lo, best_key=best)
+        if world > 1:
+            dist.all_reduce(best, op=dist.ReduceOp.MAX)
+
+    # ---- correctness gate: the first plan must pick the reference planner's candidate ---------
+    step(0)
+    torch.cuda.synchronize()
+    ret0, idx0 = _lib.key_decode(int(best.cpu()[0]))
+    index_match = None
+    if world == 1:
+        index_match = bool(idx0 == int(gold["best"][0]))
+        assert index_match, "plan picked candidate %d, reference picked %d" % (idx0, int(gold["best"][0]))
+
+    for i in range(args.warmup):
+        step(i)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.cpu()[0])
+
+    # ---- kernel-only duration: HIP events around each launch on the launch stream -------------
+    kern_ms = None
+    if rank == 0:
+        k2 = min(args.steps, 100)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k2)]
+        torch.cuda.synchronize()
+        for i in range(k2):
+            evs[i][0].record()
+            native.plan_rs(obs0, bufs[i % len(bufs)], 1, N_CAND, HORIZON, 1.0, spec, cand_offset=lo, best_key=best)
+            evs[i][1].record()
+        torch.cuda.synchronize()
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if world > 1:
+        dist.barrier()
+
+    # ---- end-to-end modes through the drop-in MPCController (informational) --------------------
+    modes = {}
+    if rank == 0 and world == 1:
+        for mode in ("numpy", "device"):
+            ctrl = cases.product_controller(case, model=model, env=env, rng=mode)
+            np.random.seed(0)
+            ctrl.get_actions(gold["obs0"])
+            torch.cuda.synchronize()
+            k3 = 20
+            t1 = time.perf_counter()
+            for _ in range(k3):
+                ctrl.get_actions(gold["obs0"])
+            torch.cuda.synchronize()
+            modes["get_actions_rng_" + mode + "_steps_per_s"] = round(k3 / (time.perf_counter() - t1), 2)
+
+    # ---- CPU baseline: the NumPy oracle on this box's host cores (N = 1, rank 0) ---------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import make_reward
+        from oracle.planner import rollout_returns
+        dyn = cases.oracle_dynamics(case)
+        reward = make_reward("half_cheetah", env.dt)
+        a64 = a0.astype(np.float64)
+        t1 = time.perf_counter()
+        rollout_returns(dyn, reward, gold["obs0"], a64, N_CAND, 1.0)        # warm-up, also sizes the sample
+        one = time.perf_counter() - t1
+        k4 = args.cpu_steps or int(max(3, min(20, round(15.0 / max(one, 1e-3)))))
+        t1 = time.perf_counter()
+        for _ in range(k4):
+            r = rollout_returns(dyn, reward, gold["obs0"], a64, N_CAND, 1.0)
+        cpu_t = (time.perf_counter() - t1) / k4
+        assert int(np.argmax(r)) == int(gold["best"][0])
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count() or 1
+        cpu = {"value": round(1.0 / cpu_t, 4), "unit": "controller-steps/s", "cores": int(threads),
+               "kind": "port",
+               "sample": "%d plan steps of the same workload (n=2000, h=30, ens=5) through oracle/ "
+                         "(NumPy/OpenBLAS fp32 MLP, float64 host state), %.2f s each" % (k4, cpu_t),
+               "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "controller-steps/sec (n_cand=2000, H=30, ens=5)",
+            "value": round(value, 3),
+            "unit": "controller-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "HalfCheetah mb_mpc random shooting, n_candidates=2000 per GPU "
+                                   "(global %d), horizon=30, mean-ensemble=5 x MLP 26-512-512-20, m=1 env; "
+                                   "candidate actions resident in HBM" % n_glob,
+                       "global_candidates": n_glob, "plan_steps_per_s": round(args.steps / elapsed, 3),
+                       "mlp_steps_per_ms": round(world * N_CAND * HORIZON * ENSEMBLE / ms_per_step, 1),
+                       "collective": "int64 MAX all-reduce of 1 key per plan step" if world > 1 else "none",
+                       "action_index_match_vs_reference": index_match,
+                       "best_index": idx0, "best_return": round(ret0, 4)},
+        }
+        if kern_ms is not None:
+            ach = FLOP_PER_LAUNCH / (kern_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "l2a_rollout_mfma_k<1,4,2,2>",
+                "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                "kernel_ms": round(kern_ms, 4),
+                "flop_per_launch": FLOP_PER_LAUNCH,
+                "hbm_algorithmic_bytes_per_launch": HBM_BYTES_PER_LAUNCH,
+                "hbm_achieved_GBps": round(HBM_BYTES_PER_LAUNCH / (kern_ms * 1e-3) / 1e9, 3),
+                "hbm_frac": round(HBM_BYTES_PER_LAUNCH / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
+                "note": "dense contraction (24 kFLOP per compulsory HBM byte): bound by the fp32 matrix "
+                        "rate, not HBM; hbm_* reported because BASELINE.json names the HBM roofline",
+            }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if modes:
+            out["config"].update(modes)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

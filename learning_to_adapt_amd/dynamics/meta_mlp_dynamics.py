@@ -1,0 +1,280 @@
+"""``MetaMLPDynamicsModel`` - drop-in for ``learning_to_adapt/dynamics/meta_mlp_dynamics.py`` (GrBAL).
+
+Hot-path part: after ``adapt`` the batch handed to ``predict`` is
+split into equal row blocks and block *i* runs through adapted weight set *i*
+(``meta_mlp_dynamics.py:296-306,143-163``).  The fused planner does the same with
+``L2A_MODE_PER_BLOCK``: env *i* <-> weight set *i*; the adapted sets are uploaded ONCE per
+``adapt`` call instead of being fed through ``feed_dict`` on every horizon step
+(``:429-432``).
+
+"Next" part (section 8(f) rank 1): ``adapt`` itself - one SGD step per env on its last
+``adapt_batch_size`` transitions, ``theta_i = theta - alpha * grad MSE_i``
+(``:321-345,409-421,106-120``) - is stock PyTorch autograd on the device, so the adapted
+weights never visit the host.  Meta-training (``fit``, ``:165-275``) is first-order stock
+PyTorch as well and is not part of the fused path.
+"""
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from ..utils.serializable import Serializable
+from . import core
+
+
+class MetaMLPDynamicsModel(Serializable):
+    _activations = core.ACTIVATION_NAMES
+
+    def __init__(self,
+                 name,
+                 env,
+                 hidden_sizes=(512, 512),
+                 meta_batch_size=10,
+                 hidden_nonlinearity="relu",
+                 output_nonlinearity=None,
+                 batch_size=500,
+                 learning_rate=0.001,
+                 inner_learning_rate=0.1,
+                 normalize_input=True,
+                 optimizer=None,
+                 valid_split_ratio=0.2,
+                 rolling_average_persitency=0.99,
+                 init_seed=None,
+                 ):
+        Serializable.quick_init(self, locals())
+
+        self.normalization = None
+        self.normalize_input = normalize_input
+        self.meta_batch_size = meta_batch_size
+        self.valid_split_ratio = valid_split_ratio
+        self.rolling_average_persitency = rolling_average_persitency
+        self.batch_size = batch_size
+        self.learning_rate = learning_rate
+        self.inner_learning_rate = inner_learning_rate
+        self.name = name
+        self._dataset_train = None
+        self._dataset_test = None
+        self._prev_params = None
+        self._adapted_param_values = None
+        self._num_adapted_models = 0
+
+        self.obs_space_dims = int(env.observation_space.shape[0])
+        self.action_space_dims = int(env.action_space.shape[0])
+        if hidden_nonlinearity not in self._activations or output_nonlinearity not in self._activations:
+            raise ValueError("unsupported nonlinearity %r / %r" % (hidden_nonlinearity, output_nonlinearity))
+        self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
+        self.hidden_nonlinearity = hidden_nonlinearity
+        self.output_nonlinearity = output_nonlinearity
+
+        sizes = (self.obs_space_dims + self.action_space_dims,) + self.hidden_sizes + (self.obs_space_dims,)
+        self._params = core.xavier_params(sizes, np.random.RandomState(init_seed))
+        self._native_base = None        # single-set handle (pre-adapt predictions)
+        self._native_adapted = None     # per-block handle (post-adapt)
+        self._base_dirty = True
+        self._adapted_dirty = True
+
+    # ------------------------------------------------------------------ parameters
+    def get_param_values(self):
+        names = core.param_names(len(self.hidden_sizes))
+        return OrderedDict((k, p.detach().cpu().numpy().copy()) for k, p in zip(names, self._params))
+
+    def set_params(self, params):
+        self._params = core.as_param_list(params, len(self.hidden_sizes))
+        self._base_dirty = True
+
+    def set_normalization(self, normalization):
+        self.normalization = normalization
+        self._base_dirty = True
+        self._adapted_dirty = True
+
+    def set_adapted_params(self, param_sets):
+        """Install externally computed adapted weight sets (list of OrderedDict / flat lists)."""
+        self._adapted_param_values = [core.as_param_list(p, len(self.hidden_sizes)) for p in param_sets]
+        self._num_adapted_models = len(param_sets)
+        self._adapted_dirty = True
+
+    def _norm(self):
+        if not self.normalize_input:
+            return None
+        assert self.normalization is not None, "model has no normalization yet (call fit first)"
+        return self.normalization
+
+    @property
+    def mode(self):
+        return "per_block" if self._adapted_param_values is not None else "single"
+
+    def planner_blocks(self, m):
+        return self._num_adapted_models if self._adapted_param_values is not None else 1
+
+    def planner_model(self):
+        from .native_model import NativeModel
+        if self._adapted_param_values is not None:
+            k = self._num_adapted_models
+            if self._native_adapted is None or self._native_adapted.n_sets != k:
+                if self._native_adapted is not None:
+                    self._native_adapted.close()
+                self._native_adapted = NativeModel(self.obs_space_dims, self.action_space_dims,
+                                                   self.hidden_sizes, self.hidden_nonlinearity,
+                                                   self.output_nonlinearity, k, "per_block")
+                self._adapted_dirty = True
+            if self._adapted_dirty:
+                for i in range(k):
+                    self._native_adapted.set_weights(i, self._adapted_param_values[i])
+                    self._native_adapted.set_norm(i, self._norm())
+                self._adapted_dirty = False
+            return self._native_adapted
+        if self._native_base is None:
+            self._native_base = NativeModel(self.obs_space_dims, self.action_space_dims, self.hidden_sizes,
+                                            self.hidden_nonlinearity, self.output_nonlinearity, 1, "single")
+            self._base_dirty = True
+        if self._base_dirty:
+            self._native_base.set_weights(0, self._params)
+            self._native_base.set_norm(0, self._norm())
+            self._base_dirty = False
+        return self._native_base
+
+    # ------------------------------------------------------------------ predict (reference :276-306)
+    def predict(self, obs, act):
+        assert obs.shape[0] == act.shape[0]
+        assert obs.ndim == 2 and obs.shape[1] == self.obs_space_dims
+        assert act.ndim == 2 and act.shape[1] == self.action_space_dims
+        native = self.planner_model()
+        n_blocks = self.planner_blocks(None)
+        assert obs.shape[0] % n_blocks == 0, "rows must split evenly over the adapted models"
+        o = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)).to(native.device)
+        a = torch.from_numpy(np.ascontiguousarray(act, dtype=np.float32)).to(native.device)
+        nxt = native.predict(o, a, n_blocks=n_blocks)
+        return nxt.cpu().numpy().astype(np.float64)
+
+    # ------------------------------------------------------------------ adapt (reference :321-351)
+    def adapt(self, obs, act, obs_next):
+        """One inner SGD step per env.  ``obs`` / ``act`` / ``obs_next``: lists of m arrays
+        ``[adapt_batch_size, dim]`` (``samplers/sampler.py:81-90``)."""
+        self._num_adapted_models = len(obs)
+        assert len(obs) == len(act) == len(obs_next)
+        dev = core.training_device()
+        base = [p.to(dev) for p in self._params]
+        adapted = []
+        for ob, ac, ob_next in zip(obs, act, obs_next):
+            ob = np.asarray(ob, dtype=np.float64)
+            ac = np.asarray(ac, dtype=np.float64)
+            ob_next = np.asarray(ob_next, dtype=np.float64)
+            assert ob.ndim == 2 and ob.shape[1] == self.obs_space_dims
+            assert ac.ndim == 2 and ac.shape[1] == self.action_space_dims
+            assert ob_next.shape == ob.shape and ac.shape[0] == ob.shape[0]
+            if self.normalize_input:
+                nm = self._norm()
+                o_n = core.normalize(ob, nm["obs"][0], nm["obs"][1])
+                a_n = core.normalize(ac, nm["act"][0], nm["act"][1])
+                d_n = core.normalize(ob_next - ob, nm["delta"][0], nm["delta"][1])
+            else:
+                o_n, a_n, d_n = ob, ac, ob_next - ob
+            # Only the real rows enter the pre-update loss: the reference pads each task with an
+            # equal number of zero rows and then splits the task batch in two, pre = real half
+            # (:324-326, :99-103).
+            x = torch.as_tensor(np.concatenate([o_n, a_n], axis=1), dtype=torch.float32, device=dev)
+            y = torch.as_tensor(d_n, dtype=torch.float32, device=dev)
+            params = [p.detach().clone().requires_grad_(True) for p in base]
+            pred = core.mlp_forward(x, params, self.hidden_nonlinearity, self.output_nonlinearity)
+            loss = torch.mean((y - pred) ** 2)                                      # :118
+            grads = torch.autograd.grad(loss, params)
+            adapted.append([(p - self.inner_learning_rate * g).detach() for p, g in zip(params, grads)])  # :415-417
+        self._prev_params = [p.clone() for p in self._params]
+        self._adapted_param_values = adapted
+        self._adapted_dirty = True
+
+    def switch_to_pre_adapt(self):
+        if self._prev_params is not None:
+            self._params = self._prev_params
+            self._prev_params = None
+            self._adapted_param_values = None
+            self._base_dirty = True
+
+    # ------------------------------------------------------------------ normalisation / fit
+    def compute_normalization(self, obs, act, obs_next):
+        """``obs`` etc. are ``[paths, path_len, dim]`` as in the reference (``:392-407``)."""
+        assert obs.shape[:2] == obs_next.shape[:2] == act.shape[:2]
+        delta = obs_next - obs
+        norm = OrderedDict()
+        norm["obs"] = (np.mean(obs, axis=(0, 1)), np.std(obs, axis=(0, 1)))
+        norm["delta"] = (np.mean(delta, axis=(0, 1)), np.std(delta, axis=(0, 1)))
+        norm["act"] = (np.mean(act, axis=(0, 1)), np.std(act, axis=(0, 1)))
+        self.set_normalization(norm)
+
+    def fit(self, obs, act, obs_next, epochs=1000, compute_normalization=True,
+            valid_split_ratio=None, rolling_average_persitency=None, verbose=False, log_tabular=False):
+        """First-order meta-training (stock PyTorch): sample ``meta_batch_size`` windows of
+        ``2 * batch_size`` consecutive transitions, adapt on the first half, minimise the
+        post-update loss on the second half (reference ``:165-275``, ``:353-390``)."""
+        assert obs.ndim == 3 and obs.shape[2] == self.obs_space_dims
+        assert act.ndim == 3 and act.shape[2] == self.action_space_dims
+        if rolling_average_persitency is None:
+            rolling_average_persitency = self.rolling_average_persitency
+        if (self.normalization is None or compute_normalization) and self.normalize_input:
+            self.compute_normalization(obs, act, obs_next)
+        if self.normalize_input:
+            nm = self.normalization
+            o_n = core.normalize(obs, nm["obs"][0], nm["obs"][1])
+            a_n = core.normalize(act, nm["act"][0], nm["act"][1])
+            d_n = core.normalize(obs_next - obs, nm["delta"][0], nm["delta"][1])
+        else:
+            o_n, a_n, d_n = obs, act, obs_next - obs
+        dev = core.training_device()
+        X = torch.as_tensor(np.concatenate([o_n, a_n], axis=2), dtype=torch.float32, device=dev)
+        Y = torch.as_tensor(d_n, dtype=torch.float32, device=dev)
+        num_paths, len_path = X.shape[:2]
+        bs = self.batch_size
+        assert len_path > 2 * bs, "paths must be longer than 2 * batch_size"
+        params = [p.to(dev).requires_grad_(True) for p in self._params]
+        opt = torch.optim.Adam(params, lr=self.learning_rate)
+        steps_per_epoch = max(int(num_paths * len_path / (self.meta_batch_size * bs * 2)), 1)
+        rolling, rolling_prev, last_epoch = None, None, 0
+        for epoch in range(epochs):
+            post_losses = []
+            for _ in range(steps_per_epoch):
+                ip = np.random.randint(0, num_paths, size=self.meta_batch_size)
+                ib = np.random.randint(bs, len_path - bs, size=self.meta_batch_size)
+                total = 0.0
+                for p_i, b_i in zip(ip, ib):
+                    xa, ya = X[p_i, b_i - bs:b_i], Y[p_i, b_i - bs:b_i]
+                    xb, yb = X[p_i, b_i:b_i + bs], Y[p_i, b_i:b_i + bs]
+                    pre = torch.mean((ya - core.mlp_forward(xa, params, self.hidden_nonlinearity,
+                                                            self.output_nonlinearity)) ** 2)
+                    grads = torch.autograd.grad(pre, params, create_graph=True)
+                    fast = [p - self.inner_learning_rate * g for p, g in zip(params, grads)]
+                    total = total + torch.mean((yb - core.mlp_forward(xb, fast, self.hidden_nonlinearity,
+                                                                      self.output_nonlinearity)) ** 2)
+                loss = total / self.meta_batch_size
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                post_losses.append(float(loss.detach()))
+            valid_loss = float(np.mean(post_losses))
+            if rolling is None:
+                rolling, rolling_prev = 1.5 * valid_loss, 2 * valid_loss
+            rolling = rolling_average_persitency * rolling + (1.0 - rolling_average_persitency) * valid_loss
+            last_epoch = epoch
+            if verbose:
+                print("Training MetaDynamicsModel - epoch %i -- post loss: %.4f  mov_avg: %.4f"
+                      % (epoch, valid_loss, rolling))
+            if rolling_prev < rolling or epoch == epochs - 1:
+                break
+            rolling_prev = rolling
+        self._params = [p.detach().to("cpu").contiguous() for p in params]
+        self._base_dirty = True
+        self.fit_stats = dict(Epochs=last_epoch)
+        return self.fit_stats
+
+    # ------------------------------------------------------------------ pickling (reference :434-445)
+    def __getstate__(self):
+        state = dict()
+        state["init_args"] = Serializable.__getstate__(self)
+        state["normalization"] = self.normalization
+        state["networks"] = [dict(network_params=self.get_param_values())]
+        return state
+
+    def __setstate__(self, state):
+        Serializable.__setstate__(self, state["init_args"])
+        self.normalization = state["normalization"]
+        self.set_params(state["networks"][0]["network_params"])

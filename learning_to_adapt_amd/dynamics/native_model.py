@@ -1,0 +1,126 @@
+"""Python handle on an ``l2a_model`` (C ABI: ``include/l2a.h``).
+
+Holds no numerics of its own: it hands device pointers of PyTorch-ROCm tensors (storage only)
+to ``libl2a_hip.so`` and launches the fused rollout / predict kernels on torch's current HIP
+stream.  Raises ``L2AError`` on any failure - there is no CPU fallback.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..envs.reward_spec import RewardSpec
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _dvec(x):
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    return x, x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class NativeModel(object):
+    def __init__(self, obs_dim, act_dim, hidden_sizes, hidden_act, output_act, n_sets, mode, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.L2AError("no MI355X visible to PyTorch-ROCm: the rollout path is HIP-only "
+                                "(there is no CPU fallback)")
+        self.ctx = _lib.Context.get(device)
+        self.lib = self.ctx.lib
+        self.device = torch.device("cuda", device)
+        self.obs_dim, self.act_dim = int(obs_dim), int(act_dim)
+        self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
+        self.n_sets, self.mode = int(n_sets), mode
+        if hidden_act not in _lib.ACT_CODES or output_act not in _lib.ACT_CODES:
+            raise _lib.L2AError("nonlinearity %r / %r is not supported by the HIP kernels"
+                                % (hidden_act, output_act))
+        hid = (ctypes.c_int * len(self.hidden_sizes))(*self.hidden_sizes)
+        handle = ctypes.c_void_p()
+        rc = self.lib.l2a_model_create(self.ctx.handle, self.obs_dim, self.act_dim, len(self.hidden_sizes),
+                                       hid, _lib.ACT_CODES[hidden_act], _lib.ACT_CODES[output_act],
+                                       self.n_sets, _lib.MODE_CODES[mode], ctypes.byref(handle))
+        self.ctx.check(rc, "l2a_model_create")
+        self.handle = handle
+        self._keep = {}     # source tensors kept alive until the stream has consumed them
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.l2a_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------
+    def set_weights(self, e, params):
+        """``params``: [W0, b0, ..., Wout, bout] (torch tensors or arrays, kernels ``[in, out]``)."""
+        dev = []
+        for p in params:
+            t = torch.as_tensor(p) if not torch.is_tensor(p) else p
+            dev.append(t.detach().to(device=self.device, dtype=torch.float32).contiguous())
+        sizes = (self.obs_dim + self.act_dim,) + self.hidden_sizes + (self.obs_dim,)
+        assert len(dev) == 2 * (len(sizes) - 1), "expected %d parameter arrays" % (2 * (len(sizes) - 1))
+        for li in range(len(sizes) - 1):
+            assert tuple(dev[2 * li].shape) == (sizes[li], sizes[li + 1]), \
+                "kernel %d has shape %s, expected %s" % (li, tuple(dev[2 * li].shape), (sizes[li], sizes[li + 1]))
+            assert tuple(dev[2 * li + 1].shape) == (sizes[li + 1],)
+        ptrs = (ctypes.c_void_p * len(dev))(*[t.data_ptr() for t in dev])
+        rc = self.lib.l2a_model_set_weights(self.handle, int(e), ptrs, _stream_ptr())
+        self.ctx.check(rc, "l2a_model_set_weights")
+        self._keep[("w", e)] = dev
+
+    def set_norm(self, e, norm):
+        """``norm``: the reference's ``normalization`` dict (``'obs'/'act'/'delta' -> (mean, std)``)
+        or ``None`` for identity."""
+        if norm is None:
+            null = ctypes.POINTER(ctypes.c_double)()
+            rc = self.lib.l2a_model_set_norm(self.handle, int(e), null, null, null, null, null, null,
+                                             _stream_ptr())
+        else:
+            keep, args = [], []
+            for key in ("obs", "act", "delta"):
+                for j in (0, 1):
+                    arr, p = _dvec(norm[key][j])
+                    expect = self.act_dim if key == "act" else self.obs_dim
+                    assert arr.shape == (expect,), "normalization[%r] has shape %s" % (key, arr.shape)
+                    keep.append(arr)
+                    args.append(p)
+            rc = self.lib.l2a_model_set_norm(self.handle, int(e), *args, _stream_ptr())
+        self.ctx.check(rc, "l2a_model_set_norm")
+
+    # ---- launches -----------------------------------------------------------------------
+    def plan_rs(self, obs0, actions, m, n, h, discount, reward, cand_offset=0, returns_out=None,
+                best_key=None):
+        """All tensor arguments are fp32 / int64 CUDA tensors; see ``l2a_plan_rs`` in include/l2a.h."""
+        assert obs0.is_cuda and actions.is_cuda and obs0.dtype == torch.float32 and actions.dtype == torch.float32
+        assert obs0.is_contiguous() and actions.is_contiguous()
+        assert obs0.numel() == m * self.obs_dim and actions.numel() == h * m * n * self.act_dim
+        if returns_out is not None:
+            assert returns_out.is_cuda and returns_out.dtype == torch.float32 and returns_out.numel() == m * n
+        if best_key is not None:
+            assert best_key.is_cuda and best_key.dtype == torch.int64 and best_key.numel() == m
+        assert isinstance(reward, RewardSpec)
+        rc = self.lib.l2a_plan_rs(self.handle, _ptr(obs0), _ptr(actions), int(m), int(n), int(h),
+                                  float(discount), ctypes.byref(reward), int(cand_offset),
+                                  _ptr(returns_out), _ptr(best_key), _stream_ptr())
+        self.ctx.check(rc, "l2a_plan_rs")
+
+    def predict(self, obs, act, n_blocks=1, out=None):
+        assert obs.is_cuda and act.is_cuda and obs.dtype == torch.float32 and act.dtype == torch.float32
+        rows = obs.shape[0]
+        if out is None:
+            out = torch.empty((rows, self.obs_dim), dtype=torch.float32, device=self.device)
+        rc = self.lib.l2a_predict(self.handle, _ptr(obs.contiguous()), _ptr(act.contiguous()), int(rows),
+                                  int(n_blocks), _ptr(out), _stream_ptr())
+        self.ctx.check(rc, "l2a_predict")
+        return out

@@ -32,33 +32,46 @@ class RewardSpec(ctypes.Structure):
     ]
 
     @classmethod
+    def make(cls, w_vel=0.0, dt=1.0, alive=0.0, ctrl_coef=0.0, dist_coef=0.0, vel_index=0, dist_index=0):
+        """Build a spec; the float64 coefficients are kept beside the fp32 C fields so that the
+        host-side ``evaluate`` reproduces the reference's float64 arithmetic exactly."""
+        spec = cls(w_vel, (1.0 / dt) if w_vel != 0.0 else 0.0, alive, ctrl_coef, dist_coef,
+                   int(vel_index), int(dist_index), 0)
+        spec.exact = dict(w_vel=float(w_vel), dt=float(dt), alive=float(alive), ctrl_coef=float(ctrl_coef),
+                          dist_coef=float(dist_coef))
+        return spec
+
+    @classmethod
     def half_cheetah(cls, obs_dim, dt):
-        return cls(1.0, 1.0 / dt, 0.0, 1e-1 * 0.5, 0.0, obs_dim - 3, 0, 0)
+        return cls.make(w_vel=1.0, dt=dt, ctrl_coef=1e-1 * 0.5, vel_index=obs_dim - 3)
 
     @classmethod
     def ant(cls, obs_dim, dt):
-        return cls(1.0, 1.0 / dt, 0.05, 0.0, 0.0, obs_dim - 3, 0, 0)
+        return cls.make(w_vel=1.0, dt=dt, alive=0.05, vel_index=obs_dim - 3)
 
     @classmethod
     def arm_7dof(cls, obs_dim):
-        return cls(0.0, 0.0, 0.0, 0.01 * 0.5, 1.0, 0, obs_dim - 3, 0)
+        return cls.make(ctrl_coef=0.01 * 0.5, dist_coef=1.0, dist_index=obs_dim - 3)
 
     @classmethod
     def none(cls):
         """All-zero reward (used by ``predict``-only launches)."""
-        return cls(0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0)
+        return cls.make()
 
     def evaluate(self, obs, act, next_obs):
         """Host NumPy evaluation of the same closed form (float64)."""
-        r = np.full((obs.shape[0],), float(self.alive))
-        if self.w_vel != 0.0:
-            r = r + self.w_vel * (next_obs[:, self.vel_index] - obs[:, self.vel_index]) * float(self.inv_dt)
-        if self.ctrl_coef != 0.0:
-            r = r - float(self.ctrl_coef) * np.sum(np.square(act), axis=1)
-        if self.dist_coef != 0.0:
+        ex = getattr(self, "exact", None) or dict(
+            w_vel=float(self.w_vel), dt=(1.0 / float(self.inv_dt)) if self.inv_dt else 1.0,
+            alive=float(self.alive), ctrl_coef=float(self.ctrl_coef), dist_coef=float(self.dist_coef))
+        r = np.zeros((obs.shape[0],))
+        if ex["w_vel"] != 0.0:
+            r = r + ex["w_vel"] * (next_obs[:, self.vel_index] - obs[:, self.vel_index]) / ex["dt"]
+        if ex["dist_coef"] != 0.0:
             d = self.dist_index
-            r = r - float(self.dist_coef) * np.linalg.norm(next_obs[:, d:d + 3], axis=1)
-        return r
+            r = r - ex["dist_coef"] * np.linalg.norm(next_obs[:, d:d + 3], axis=1)
+        if ex["ctrl_coef"] != 0.0:
+            r = r - ex["ctrl_coef"] * np.sum(np.square(act), axis=1)
+        return r + ex["alive"]
 
 
 _BY_CLASS_NAME = {

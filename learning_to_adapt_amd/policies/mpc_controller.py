@@ -1,0 +1,299 @@
+"""``MPCController`` - drop-in for ``learning_to_adapt/policies/mpc_controller.py:6-135``.
+
+Same constructor, ``get_action`` / ``get_actions`` / ``reset`` / ``vectorized`` surface and the
+same consumption of NumPy's legacy global RNG (``np.random.uniform`` for random shooting,
+``:67-69``; ``np.random.normal`` for CEM, ``:85``) as the reference, so that with a fixed seed
+the chosen action matches the reference's bit for bit (modulo declared near-ties).
+
+What changed underneath: the horizon loop (``:116-127`` / ``:92-99``) - ``dynamics_model.predict``
++ ``env.reward`` + return accumulation, h sequential host<->device round trips in the
+reference - is ONE launch of the fused HIP rollout kernel (``l2a_plan_rs``), and the arg-max
+(``:128-129``) comes back as 8 bytes per env.  With ``torch.distributed`` initialised the
+candidates are sharded over the ranks (one process per GPU) and the per-rank best keys are
+combined by a single max all-reduce (RCCL over xGMI); CEM all-gathers the returns instead,
+because its elite rule (``:101``) needs every candidate's rank.
+
+Extra keyword arguments (all optional, defaults reproduce the reference):
+``rng`` (``'numpy'`` = parity mode, host MT19937 as in the reference; ``'device'`` = candidates
+drawn on the GPU with torch's Philox generator - statistically equivalent, not bit-identical),
+``cem_mode`` (``'reference'`` keeps the reference's three CEM quirks, SURVEY.md section 3.3;
+``'fixed'`` = clipped rollouts, true top-k elites, env-consistent row order),
+``shard_candidates`` (use torch.distributed when initialised).
+"""
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..envs.reward_spec import reward_spec_for_env
+from ..utils.serializable import Serializable
+from .base import Policy
+
+
+class MPCController(Policy, Serializable):
+    def __init__(
+            self,
+            name,
+            env,
+            dynamics_model,
+            reward_model=None,
+            discount=1,
+            use_cem=False,
+            n_candidates=1024,
+            horizon=10,
+            num_cem_iters=8,
+            percent_elites=0.1,
+            use_reward_model=False,
+            alpha=0.1,
+            rng="numpy",
+            cem_mode="reference",
+            shard_candidates=True,
+    ):
+        self.dynamics_model = dynamics_model
+        self.reward_model = reward_model
+        self.discount = discount
+        self.n_candidates = n_candidates
+        self.horizon = horizon
+        self.use_cem = use_cem
+        self.num_cem_iters = num_cem_iters
+        self.percent_elites = percent_elites
+        self.env = env
+        self.use_reward_model = use_reward_model
+        self.alpha = alpha
+        assert rng in ("numpy", "device")
+        assert cem_mode in ("reference", "fixed")
+        self.rng = rng
+        self.cem_mode = cem_mode
+        self.shard_candidates = shard_candidates
+
+        self.unwrapped_env = env
+        while hasattr(self.unwrapped_env, 'wrapped_env'):
+            self.unwrapped_env = self.unwrapped_env.wrapped_env
+
+        # make sure that env has reward function (reference :39)
+        assert hasattr(self.unwrapped_env, 'reward'), "env must have a reward function"
+
+        Serializable.quick_init(self, locals())
+        super(MPCController, self).__init__(env=env)
+
+        self._reward_spec = None if use_reward_model else reward_spec_for_env(env)
+        self._bufs = {}
+        self.last_plan = None       # diagnostics of the latest fused plan (returns, keys, ...)
+
+    @property
+    def vectorized(self):
+        return True
+
+    # ------------------------------------------------------------------ reference API
+    def get_action(self, observation):
+        if observation.ndim == 1:
+            observation = observation[None]
+        if self.use_cem:
+            action = self.get_cem_action(observation)
+        else:
+            action = self.get_rs_action(observation)
+        return action, dict()
+
+    def get_actions(self, observations):
+        if self.use_cem:
+            actions = self.get_cem_action(observations)
+        else:
+            actions = self.get_rs_action(observations)
+        return actions, dict()
+
+    def get_random_action(self, n):
+        return np.random.uniform(low=self.action_space.low,
+                                 high=self.action_space.high, size=(n,) + self.action_space.low.shape)
+
+    def get_params_internal(self, **tags):
+        return []
+
+    def reset(self, dones=None):
+        pass
+
+    # ------------------------------------------------------------------ sharding helpers
+    def _dist(self):
+        """(rank, world) when candidates are sharded over torch.distributed ranks."""
+        if self.shard_candidates and torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_rank(), torch.distributed.get_world_size()
+        return 0, 1
+
+    @staticmethod
+    def _shard_range(n, rank, world):
+        return (rank * n) // world, ((rank + 1) * n) // world
+
+    def _fusable(self):
+        return (self._reward_spec is not None) and hasattr(self.dynamics_model, "planner_model")
+
+    def _buf(self, key, shape, dtype, device):
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[key] = t
+        return t
+
+    # ------------------------------------------------------------------ fused rollout of a candidate batch
+    def _device(self):
+        return self.dynamics_model.planner_model().device
+
+    def _upload(self, actions_local):
+        """Host fp32 ``[h, m * n_local, act_dim]`` -> device tensor (one H2D copy per plan step)."""
+        return torch.from_numpy(np.ascontiguousarray(actions_local, dtype=np.float32)).to(self._device())
+
+    def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns):
+        """Launch the fused kernel on this rank's shard.
+
+        ``actions_local``: fp32 CUDA tensor ``[h, m * n_local, act_dim]`` (row = env * n_local + j).
+        Returns ``(best_key int64 CUDA [m], returns fp32 CUDA [m, n_local] or None)``.
+        """
+        native = self.dynamics_model.planner_model()
+        m = len(observations)
+        blocks = self.dynamics_model.planner_blocks(m)
+        if blocks != 1 and blocks != m:
+            raise _lib.L2AError("the dynamics model holds %d adapted weight sets but %d observations "
+                                "were passed" % (blocks, m))
+        dev = native.device
+        obs0 = self._buf("obs0", (m, native.obs_dim), torch.float32, dev)
+        obs0.copy_(torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32)), non_blocking=False)
+        best = self._buf("best", (m,), torch.int64, dev)
+        rets = self._buf("rets", (m, n_local), torch.float32, dev) if want_returns else None
+        native.plan_rs(obs0, actions_local, m, n_local, self.horizon, self.discount, self._reward_spec,
+                       cand_offset=cand_offset, returns_out=rets, best_key=best)
+        return best, rets
+
+    # ------------------------------------------------------------------ random shooting (reference :108-129)
+    def get_rs_action(self, observations):
+        n = self.n_candidates
+        m = len(observations)
+        h = self.horizon
+
+        if not self._fusable():
+            return self._get_rs_action_unfused(observations)
+
+        rank, world = self._dist()
+        lo, hi = self._shard_range(n, rank, world)
+        n_local = hi - lo
+        act_dim = self.action_space.shape[0]
+
+        if self.rng == "numpy":
+            # identical draw and layout to the reference (:114): [h, n*m, act_dim], row = i*n + j
+            a = self.get_random_action(h * n * m).reshape((h, n * m, -1))
+            cand_a = a[0].reshape((m, n, -1))
+            a_loc = a.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32).reshape(h, m * n_local, act_dim)
+            a_dev = self._upload(a_loc)
+        else:
+            dev = self._device()
+            low = torch.as_tensor(self.action_space.low, dtype=torch.float32, device=dev)
+            high = torch.as_tensor(self.action_space.high, dtype=torch.float32, device=dev)
+            a_dev = self._buf("a_dev", (h, m * n_local, act_dim), torch.float32, dev)
+            a_dev.uniform_(0.0, 1.0)
+            a_dev.mul_(high - low).add_(low)
+            cand_a = None
+
+        if n_local > 0:
+            best, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=False)
+        else:   # more ranks than candidates: this rank contributes the neutral key
+            best = torch.zeros((m,), dtype=torch.int64, device=a_dev.device)
+        if world > 1:
+            torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MAX)
+        keys = best.cpu().numpy()
+        idx = np.empty(m, dtype=np.int64)
+        best_ret = np.empty(m, dtype=np.float32)
+        for i in range(m):
+            best_ret[i], idx[i] = _lib.key_decode(keys[i])
+        self.last_plan = dict(best_index=idx, best_return=best_ret, n_local=n_local, shard=(lo, hi))
+
+        if cand_a is not None:
+            return cand_a[range(m), idx]
+        # device RNG: the winning first action lives on the rank that owns the candidate
+        out = torch.zeros((m, act_dim), dtype=torch.float32, device=a_dev.device)
+        first = a_dev[0].reshape(m, n_local, act_dim)
+        for i in range(m):
+            if lo <= idx[i] < hi:
+                out[i] = first[i, idx[i] - lo]
+        if world > 1:
+            torch.distributed.all_reduce(out, op=torch.distributed.ReduceOp.SUM)
+        return out.cpu().numpy().astype(np.float64)
+
+    def _get_rs_action_unfused(self, observations):
+        """No closed-form reward available (custom env reward or ``use_reward_model``): keep the
+        reference's loop shape; the MLP still runs on the GPU through ``dynamics_model.predict``."""
+        n = self.n_candidates
+        m = len(observations)
+        h = self.horizon
+        returns = np.zeros((n * m,))
+        a = self.get_random_action(h * n * m).reshape((h, n * m, -1))
+        cand_a = a[0].reshape((m, n, -1))
+        observation = np.repeat(observations, n, axis=0)
+        for t in range(h):
+            next_observation = self.dynamics_model.predict(observation, a[t])
+            if self.use_reward_model:
+                assert self.reward_model is not None
+                rewards = self.reward_model.predict(observation, a[t], next_observation)
+            else:
+                rewards = self.unwrapped_env.reward(observation, a[t], next_observation)
+            returns += self.discount ** t * rewards
+            observation = next_observation
+        returns = returns.reshape(m, n)
+        return cand_a[range(m), np.argmax(returns, axis=1)]
+
+    # ------------------------------------------------------------------ CEM (reference :71-106)
+    def get_cem_action(self, observations):
+        if not self._fusable():
+            raise _lib.L2AError("CEM planning needs a fusable closed-form reward (env.reward_spec)")
+        n = self.n_candidates
+        m = len(observations)
+        h = self.horizon
+        act_dim = self.action_space.shape[0]
+        reference = (self.cem_mode == "reference")
+
+        num_elites = max(int(self.n_candidates * self.percent_elites), 1)
+        mean = np.zeros((m, h * act_dim))
+        std = np.ones((m, h * act_dim))
+        clip_low = np.concatenate([self.action_space.low] * h)
+        clip_high = np.concatenate([self.action_space.high] * h)
+
+        rank, world = self._dist()
+        lo, hi = self._shard_range(n, rank, world)
+        n_local = hi - lo
+        trace = []
+        cand_a = None
+        returns = None
+
+        for it in range(self.num_cem_iters):
+            z = np.random.normal(size=(n, m, h * act_dim))
+            a = mean + z * std
+            a_stacked = np.clip(a, clip_low, clip_high)
+            if reference:
+                # reference quirks: rollouts use the UNCLIPPED samples, and the flat row order is
+                # candidate-major (row = j*m + i) while observations are env-major (row // n).
+                seq = np.transpose(a.reshape((n * m, h, act_dim)), (1, 0, 2))      # [h, n*m, act]
+            else:
+                seq = np.transpose(a_stacked.transpose(1, 0, 2).reshape((m * n, h, act_dim)), (1, 0, 2))
+            cand_a = seq[0].reshape((m, n, -1))
+            seq_loc = seq.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32)
+            a_dev = self._upload(seq_loc.reshape(h, m * n_local, act_dim))
+            _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+            if world > 1:
+                parts = [torch.empty_like(rets) for _ in range(world)]
+                if any(self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] != n_local
+                       for r in range(world)):
+                    raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
+                torch.distributed.all_gather(parts, rets)
+                rets = torch.cat(parts, dim=1)
+            returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
+            if reference:
+                elites_idx = ((-returns).argsort(axis=-1) < num_elites).T            # :101
+                elites = a_stacked[elites_idx]
+                mean = mean * self.alpha + (1 - self.alpha) * np.mean(elites, axis=0)
+                std = np.std(elites, axis=0)
+            else:
+                order = np.argsort(-returns, axis=1)[:, :num_elites]                  # [m, k]
+                elites = np.stack([a_stacked[order[i], i] for i in range(m)], axis=0)  # [m, k, h*act]
+                mean = mean * self.alpha + (1 - self.alpha) * np.mean(elites, axis=1)
+                std = np.std(elites, axis=1)
+            trace.append(dict(mean=np.array(mean), std=np.array(std), returns=returns))
+
+        idx = np.argmax(returns, axis=1)
+        self.last_plan = dict(best_index=idx, best_return=returns[range(m), idx], cem_trace=trace)
+        return cand_a[range(m), idx]

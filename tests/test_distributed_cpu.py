@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: two `gloo` ranks shard the candidates, combine their best keys with one
+MAX all-reduce (RS) / all-gather their returns (CEM) and must pick exactly the action the
+single-process plan (= the reference planner's golden vector) picks."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, cid, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        import oracle_backend
+        case, seed = cases.split_id(cid)
+        gold = cases.load_golden(cid)
+        ctrl = oracle_backend.install(cases.product_controller(case), case)
+        np.random.seed(seed)                      # every rank draws the same candidate tensor
+        actions, _ = ctrl.get_actions(gold["obs0"])
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), actions=actions,
+                 best=np.asarray(ctrl.last_plan["best_index"]),
+                 shard=np.asarray(ctrl.last_plan.get("shard", (-1, -1))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cid", ["hc_rs_m3_n64_h5_s0", "hc_rs_ragged_n37_h3_s0", "hc_rs_n1_h1_s0",
+                                 "hc_cem_m2_n100_h4_s0"])
+def test_two_rank_plan_equals_single_process_plan(cid, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), cid, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import cases
+    gold = cases.load_golden(cid)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for o in outs:
+        assert np.array_equal(o["best"], gold["best"])
+        np.testing.assert_array_equal(o["actions"], gold["chosen"])
+    if outs[0]["shard"][0] >= 0:
+        assert outs[0]["shard"][1] == outs[1]["shard"][0]          # contiguous, disjoint shards
