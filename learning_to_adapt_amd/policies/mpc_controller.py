@@ -237,6 +237,48 @@ class MPCController(Policy, Serializable):
         returns = returns.reshape(m, n)
         return cand_a[range(m), np.argmax(returns, axis=1)]
 
+    def _cem_iteration(self, observations, mean, std, num_elites, clip_low, clip_high, lo, hi, world):
+        """One CEM iteration (reference ``:85-104``): sample, roll out on the GPU, refit mean/std.
+        Consumes ``n * m * h * act_dim`` normals of the global NumPy stream."""
+        n = self.n_candidates
+        m = len(observations)
+        h = self.horizon
+        act_dim = self.action_space.shape[0]
+        n_local = hi - lo
+        reference = (self.cem_mode == "reference")
+        z = np.random.normal(size=(n, m, h * act_dim))
+        a = mean + z * std
+        a_stacked = np.clip(a, clip_low, clip_high)
+        if reference:
+            # reference quirks: rollouts use the UNCLIPPED samples, and the flat row order is
+            # candidate-major (row = j*m + i) while observations are env-major (row // n).
+            seq = np.transpose(a.reshape((n * m, h, act_dim)), (1, 0, 2))          # [h, n*m, act]
+        else:
+            seq = np.transpose(a_stacked.transpose(1, 0, 2).reshape((m * n, h, act_dim)), (1, 0, 2))
+        cand_a = seq[0].reshape((m, n, -1))
+        seq_loc = seq.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32)
+        a_dev = self._upload(seq_loc.reshape(h, m * n_local, act_dim))
+        _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+        if world > 1:
+            if any(self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] != n_local
+                   for r in range(world)):
+                raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
+            parts = [torch.empty_like(rets) for _ in range(world)]
+            torch.distributed.all_gather(parts, rets)
+            rets = torch.cat(parts, dim=1)
+        returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
+        if reference:
+            elites_idx = ((-returns).argsort(axis=-1) < num_elites).T                # :101
+            elites = a_stacked[elites_idx]
+            mean = mean * self.alpha + (1 - self.alpha) * np.mean(elites, axis=0)
+            std = np.std(elites, axis=0)
+        else:
+            order = np.argsort(-returns, axis=1)[:, :num_elites]                      # [m, k]
+            elites = np.stack([a_stacked[order[i], i] for i in range(m)], axis=0)     # [m, k, h*act]
+            mean = mean * self.alpha + (1 - self.alpha) * np.mean(elites, axis=1)
+            std = np.std(elites, axis=1)
+        return mean, std, returns, cand_a
+
     # ------------------------------------------------------------------ CEM (reference :71-106)
     def get_cem_action(self, observations):
         if not self._fusable():
@@ -245,8 +287,6 @@ class MPCController(Policy, Serializable):
         m = len(observations)
         h = self.horizon
         act_dim = self.action_space.shape[0]
-        reference = (self.cem_mode == "reference")
-
         num_elites = max(int(self.n_candidates * self.percent_elites), 1)
         mean = np.zeros((m, h * act_dim))
         std = np.ones((m, h * act_dim))
@@ -255,43 +295,13 @@ class MPCController(Policy, Serializable):
 
         rank, world = self._dist()
         lo, hi = self._shard_range(n, rank, world)
-        n_local = hi - lo
         trace = []
         cand_a = None
         returns = None
 
         for it in range(self.num_cem_iters):
-            z = np.random.normal(size=(n, m, h * act_dim))
-            a = mean + z * std
-            a_stacked = np.clip(a, clip_low, clip_high)
-            if reference:
-                # reference quirks: rollouts use the UNCLIPPED samples, and the flat row order is
-                # candidate-major (row = j*m + i) while observations are env-major (row // n).
-                seq = np.transpose(a.reshape((n * m, h, act_dim)), (1, 0, 2))      # [h, n*m, act]
-            else:
-                seq = np.transpose(a_stacked.transpose(1, 0, 2).reshape((m * n, h, act_dim)), (1, 0, 2))
-            cand_a = seq[0].reshape((m, n, -1))
-            seq_loc = seq.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32)
-            a_dev = self._upload(seq_loc.reshape(h, m * n_local, act_dim))
-            _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
-            if world > 1:
-                parts = [torch.empty_like(rets) for _ in range(world)]
-                if any(self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] != n_local
-                       for r in range(world)):
-                    raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
-                torch.distributed.all_gather(parts, rets)
-                rets = torch.cat(parts, dim=1)
-            returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
-            if reference:
-                elites_idx = ((-returns).argsort(axis=-1) < num_elites).T            # :101
-                elites = a_stacked[elites_idx]
-                mean = mean * self.alpha + (1 - self.alpha) * np.mean(elites, axis=0)
-                std = np.std(elites, axis=0)
-            else:
-                order = np.argsort(-returns, axis=1)[:, :num_elites]                  # [m, k]
-                elites = np.stack([a_stacked[order[i], i] for i in range(m)], axis=0)  # [m, k, h*act]
-                mean = mean * self.alpha + (1 - self.alpha) * np.mean(elites, axis=1)
-                std = np.std(elites, axis=1)
+            mean, std, returns, cand_a = self._cem_iteration(observations, mean, std, num_elites,
+                                                             clip_low, clip_high, lo, hi, world)
             trace.append(dict(mean=np.array(mean), std=np.array(std), returns=returns))
 
         idx = np.argmax(returns, axis=1)
