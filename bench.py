@@ -125,6 +125,7 @@ def main():
         step(i)
     sync()
     elapsed = time.perf_counter() - t0
+    native.ctx.launch_status()          # raises if any launch flagged a problem
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

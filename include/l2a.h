@@ -83,6 +83,15 @@ const char* l2a_last_error(const l2a_ctx* ctx);
 int l2a_device_info(const l2a_ctx* ctx, char* buf, int cap);
 /* Select the kernel (L2A_KERNEL_*) used by subsequent launches on this context.             */
 int l2a_set_kernel(l2a_ctx* ctx, int kind);
+/* Member-split policy of the MFMA kernel in L2A_MODE_MEAN: 1 (default) = when a plan has at most
+ * (CUs / 2) candidate tiles, two workgroups share each tile - one per half of the ensemble - and
+ * exchange their partial delta sums once per horizon step through global memory; 0 = never.
+ * Results are bit-identical either way (the members are always summed group A + group B).     */
+int l2a_set_split(l2a_ctx* ctx, int policy);
+/* Status word of the launches issued since the last call (caller must have synchronised the
+ * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch
+ * with l2a_set_split(ctx, 0)).  Reading clears it.                                            */
+int l2a_launch_status(l2a_ctx* ctx, int* status_out);
 
 /* ---- model ----------------------------------------------------------------------------- */
 /* Describe the MLP dynamics model: replaces the graph construction of

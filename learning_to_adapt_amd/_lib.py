@@ -21,7 +21,8 @@ MODE_CODES = {"single": 0, "per_block": 1, "mean": 2}
 KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
 
 EXPORTED_SYMBOLS = (
-    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel",
+    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split",
+    "l2a_launch_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_norm",
     "l2a_plan_rs", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
     "l2a_packed_layer_floats", "l2a_pack_layer_host",
@@ -57,6 +58,10 @@ def load():
     lib.l2a_device_info.restype = i32
     lib.l2a_set_kernel.argtypes = [vp, i32]
     lib.l2a_set_kernel.restype = i32
+    lib.l2a_set_split.argtypes = [vp, i32]
+    lib.l2a_set_split.restype = i32
+    lib.l2a_launch_status.argtypes = [vp, c.POINTER(i32)]
+    lib.l2a_launch_status.restype = i32
     lib.l2a_model_create.argtypes = [vp, i32, i32, i32, c.POINTER(i32), i32, i32, i32, i32, c.POINTER(vp)]
     lib.l2a_model_create.restype = i32
     lib.l2a_model_destroy.argtypes = [vp]
@@ -132,3 +137,16 @@ class Context(object):
 
     def set_kernel(self, kind):
         self.check(self.lib.l2a_set_kernel(self.handle, KERNEL_CODES[kind]), "l2a_set_kernel")
+
+    def set_split(self, policy):
+        self.check(self.lib.l2a_set_split(self.handle, int(bool(policy))), "l2a_set_split")
+
+    def launch_status(self):
+        """Status of the launches since the last call (stream must be synchronised).  Raises when a
+        member-split exchange timed out - results of those launches are invalid."""
+        st = ctypes.c_int()
+        self.check(self.lib.l2a_launch_status(self.handle, ctypes.byref(st)), "l2a_launch_status")
+        if st.value != 0:
+            raise L2AError("rollout launch reported status 0x%x (member-split exchange timed out; "
+                           "set L2A_SPLIT=0 to disable the split)" % st.value)
+        return st.value

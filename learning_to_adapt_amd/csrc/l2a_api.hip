@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +28,9 @@ struct HipFail {
 struct l2a_ctx {
     int device = 0;
     int kernel_kind = L2A_KERNEL_AUTO;
+    int split_policy = 1;                 // 1 = split members over two workgroups when it fills the chip
+    unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
+    unsigned int* status_dev = nullptr;
     int num_cu = 0;
     int lds_per_block = 0;
     int clock_khz = 0;
@@ -51,6 +55,9 @@ struct l2a_model {
     long long pk_w0 = 0, pk_wmid = 0, pk_wmid_stride = 0, pk_wout = 0, pk_bout = 0, nm_off = 0;
     std::vector<char> weights_set, norm_set;
     std::vector<std::vector<float>> norm_stage;   // host staging, kept alive for async H2D
+    unsigned long long* xbuf = nullptr;           // member-split exchange granules
+    long long xbuf_granules = 0;
+    unsigned int launch_nonce = 0;
 };
 
 namespace {
@@ -158,10 +165,34 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         p.sa_elems = sa_elems_for(md, nt);
         p.tiles_per_env = ceil_div(p.n, 16 * nt);
         const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
-        const int smem = 2 * p.sa_elems * 16 + e_loop * (32 * md->KG0 + 32 * md->OT) * 4;
+        const int smem = 2 * p.sa_elems * 16 + e_loop * (32 * md->KG0 + 32 * md->OT) * 4 + nt * md->OT * 64 * 16;
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
-        const dim3 grid((unsigned)(p.m * p.tiles_per_env)), block(512);
+        // Member split: two workgroups per candidate tile (group A | group B of the ensemble) when
+        // that still fits one workgroup per CU - e.g. config 2: 125 tiles -> 250 workgroups.
+        const long long pairs = (long long)p.m * p.tiles_per_env;
+        const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+        p.split = (ctx->split_policy != 0 && p.mode == L2A_MODE_MEAN && md->n_sets >= 2 && nt == 1 &&
+                   2 * pairs <= cus && p.h < 4096) ? 1 : 0;
+        if (p.split) {
+            const long long need = pairs * 2 * 2 * (long long)(nt * md->OT * 4 * 64);
+            if (need > md->xbuf_granules) {
+                if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
+                L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));
+                L2A_HIP(ctx, hipMemset(md->xbuf, 0, (size_t)need * 8));
+                md->xbuf_granules = need;
+                md->launch_nonce = 0;
+            }
+            md->launch_nonce += 1;
+            if (md->launch_nonce >= (1u << 20)) {     // tag space exhausted: wipe stale tags, restart
+                L2A_HIP(ctx, hipMemsetAsync(md->xbuf, 0, (size_t)md->xbuf_granules * 8, stream));
+                md->launch_nonce = 1;
+            }
+            p.xtag = md->launch_nonce << 12;
+            p.xbuf = md->xbuf;
+            p.status = ctx->status_dev;
+        }
+        const dim3 grid((unsigned)(pairs * (p.split ? 2 : 1))), block(512);
         int rc = L2A_EINVAL;
         if (nt == 1) {
             if (md->TPW == 4) rc = launch_mfma_shape<1, 4>(md, p, grid, block, smem, stream);
@@ -236,11 +267,40 @@ int l2a_init(int device, l2a_ctx** out) {
     ctx->clock_khz = prop.clockRate;
     ctx->arch = arch;
     ctx->name = prop.name;
+    e = hipHostMalloc(reinterpret_cast<void**>(&ctx->status_host), sizeof(unsigned int), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *ctx->status_host = 0;
+        e = hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->status_dev), ctx->status_host, 0);
+    }
+    if (e != hipSuccess) {
+        std::string msg = std::string("allocating the launch status word: ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, L2A_EHIP, msg);
+    }
+    const char* sp = std::getenv("L2A_SPLIT");
+    if (sp && sp[0] == '0') ctx->split_policy = 0;
     *out = ctx;
     return L2A_OK;
 }
 
-void l2a_destroy(l2a_ctx* ctx) { delete ctx; }
+void l2a_destroy(l2a_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    delete ctx;
+}
+
+int l2a_set_split(l2a_ctx* ctx, int policy) {
+    if (!ctx) return L2A_EINVAL;
+    ctx->split_policy = policy ? 1 : 0;
+    return L2A_OK;
+}
+
+int l2a_launch_status(l2a_ctx* ctx, int* status_out) {
+    if (!ctx || !status_out) return L2A_EINVAL;
+    *status_out = (int)(*ctx->status_host);
+    *ctx->status_host = 0;
+    return L2A_OK;
+}
 
 const char* l2a_last_error(const l2a_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
 
@@ -367,6 +427,7 @@ void l2a_model_destroy(l2a_model* md) {
         (void)hipDeviceSynchronize();
         (void)hipFree(md->wblk);
     }
+    if (md->xbuf) (void)hipFree(md->xbuf);
     delete md;
 }
 

@@ -57,6 +57,11 @@ struct L2AKParams {
     int cand_offset;
     float discount;
     l2a_reward rw;
+    // ---- member split (MFMA kernel, mean mode): two workgroups share one candidate tile ----
+    int split;                  // 0: one workgroup runs all members; 1: group A | group B
+    unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1
+    unsigned long long* xbuf;   // exchange granules [pair][group][slot][NT*OT*4][64]
+    unsigned int* status;       // host-visible word; bit 0 set = exchange timed out
 };
 
 // ------------------------------------------------------------------------------------------

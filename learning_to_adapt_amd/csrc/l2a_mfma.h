@@ -20,7 +20,15 @@
 //   output layer : K split over the 8 waves (TPW k-groups each), partial sums exchanged
 //                  through the idle LDS region, every wave reduces them in the same order,
 //                  so all 8 waves hold bit-identical copies of state / return
-// LDS: two activation regions of sa_elems f32x4 each + the normalisation vectors.
+// LDS: two activation regions of sa_elems f32x4 each + the normalisation vectors (+ 1 KiB per
+// candidate tile and obs tile for the member-split exchange).
+//
+// Ensemble association: the members are always summed as (sum over group A) + (sum over group
+// B), A = first ceil(E/2) members, B = the rest.  With `split` two workgroups own one candidate
+// tile - one per group - and swap their group sums once per horizon step through 8-byte
+// {tag, value} granules in global memory (write-through stores, relaxed agent-scope polling,
+// the data is its own flag: cdna_hip_programming.md G16 recipe R2).  Split and unsplit launches
+// are therefore bit-identical; the split one uses twice the CUs when few tiles exist.
 //
 // Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave
 // (hidden width = 128 * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16).
@@ -114,8 +122,11 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
     const int qq = lane >> 4;
 
     const int bid = l2a_logical_wg(blockIdx.x, gridDim.x);
-    const int env = bid / p.tiles_per_env;
-    const int tb = bid - env * p.tiles_per_env;
+    const int n_pairs = p.m * p.tiles_per_env;
+    const int grp = p.split ? (bid / n_pairs) : 0;          // member group owned by this workgroup
+    const int pairid = bid - grp * n_pairs;
+    const int env = pairid / p.tiles_per_env;
+    const int tb = pairid - env * p.tiles_per_env;
     const int R = p.m * p.n;
     const int obs_dim = p.obs_dim, act_dim = p.act_dim;
 
@@ -131,6 +142,8 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
     // ---- normalisation vectors of every set this workgroup uses -> LDS --------------------
     const bool per_block = (p.mode == L2A_MODE_PER_BLOCK);
     const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
+    const int e_half = (e_loop + 1) >> 1;                   // group A = [0, e_half), B = [e_half, e_loop)
+    f32x4* xlds = reinterpret_cast<f32x4*>(nrm + e_loop * NRM_SET);   // [NT * OT][64], split only
     for (int i = tid; i < e_loop * NRM_SET; i += 512) {
         const int s = i / NRM_SET;
         const int o = i - s * NRM_SET;
@@ -200,13 +213,27 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
         }
         load_actions((t + 1 < p.h) ? t + 1 : t, av_next);   // prefetch the next step's actions
 
-        f32x4 dsum[NT][OT];
+        f32x4 dsum[NT][OT], dgrp[NT][OT];      // dsum: finished group(s); dgrp: group being summed
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int c = 0; c < OT; ++c) dsum[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < OT; ++c) {
+                dsum[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 
-        for (int e = 0; e < e_loop; ++e) {
+        const int e_first = (p.split && grp == 1) ? e_half : 0;
+        const int e_last = (p.split && grp == 0) ? e_half : e_loop;
+        for (int e = e_first; e < e_last; ++e) {
+            if (e == e_half && !p.split) {      // group A complete: park it, start group B
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) {
+                        dsum[nt][c] = dgrp[nt][c];
+                        dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+            }
             const int ws = per_block ? env : e;
             const float* wb = p.wblk + (long long)ws * p.set_stride;
             const float* nr = nrm + e * NRM_SET;    // per_block / single: e == 0
@@ -321,7 +348,7 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
 #pragma unroll
                         for (int w = 1; w < 8; ++w) s += hoth[((w * NT + nt) * OT + c) * 64 + lane];
                         s = l2a_act4(s + bias, p.output_act);
-                        dsum[nt][c] += s * osd + omu;
+                        dgrp[nt][c] += s * osd + omu;
                     }
                 }
             }
@@ -330,6 +357,63 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
             // after finishing these reads; the next layer 0 writes `hcur`, which nobody reads
             // any more (its last readers were the output-layer MFMAs before the barrier above).
         }
+
+        // ---- combine the two member groups ------------------------------------------------
+        if (p.split) {
+            // publish this workgroup's group sum, fetch the partner's (same lane layout)
+            const unsigned int tag = p.xtag + (unsigned int)(t + 1);
+            constexpr int XG = NT * OT * 4 * 64;    // granules per (pair, group, slot)
+            unsigned long long* xown = p.xbuf + ((long long)(pairid * 2 + grp) * 2 + (t & 1)) * XG + lane;
+            unsigned long long* xoth = p.xbuf + ((long long)(pairid * 2 + (grp ^ 1)) * 2 + (t & 1)) * XG + lane;
+            if (wave == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c)
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const unsigned long long g = ((unsigned long long)tag << 32) |
+                                                         (unsigned long long)__float_as_uint(dgrp[nt][c][ii]);
+                            __hip_atomic_store(xown + ((nt * OT + c) * 4 + ii) * 64, g, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                f32x4 oth[NT][OT];
+                unsigned int spins = 0;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c)
+#pragma unroll
+                            for (int ii = 0; ii < 4; ++ii) {
+                                const unsigned long long g = __hip_atomic_load(
+                                    xoth + ((nt * OT + c) * 4 + ii) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                oth[nt][c][ii] = __uint_as_float((unsigned int)g);
+                                ok = ok && ((unsigned int)(g >> 32) == tag);
+                            }
+                    if (__all(ok)) break;
+                    if (++spins > (1u << 22)) {     // partner never arrived: flag it, do not hang
+                        if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) xlds[(nt * OT + c) * 64 + lane] = oth[nt][c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < OT; ++c) dsum[nt][c] = xlds[(nt * OT + c) * 64 + lane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < OT; ++c) dsum[nt][c] += dgrp[nt][c];     // A + B (commutative)
 
         // ---- ensemble mean, reward, state update -------------------------------------------
         const float disc_t = (float)disc_pow;
@@ -364,7 +448,7 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
     }
 
     // ---- results: wave 0 writes returns, arg-max key and (for predict) the final state -----
-    if (wave == 0) {
+    if (wave == 0 && grp == 0) {
         unsigned long long key = 0ull;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

@@ -140,6 +140,10 @@ class MPCController(Policy, Serializable):
         """Host fp32 ``[h, m * n_local, act_dim]`` -> device tensor (one H2D copy per plan step)."""
         return torch.from_numpy(np.ascontiguousarray(actions_local, dtype=np.float32)).to(self._device())
 
+    def _check_status(self):
+        """After a device->host read-back (= stream sync): raise if a launch flagged a problem."""
+        self.dynamics_model.planner_model().ctx.launch_status()
+
     def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns):
         """Launch the fused kernel on this rank's shard.
 
@@ -197,6 +201,7 @@ class MPCController(Policy, Serializable):
         if world > 1:
             torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MAX)
         keys = best.cpu().numpy()
+        self._check_status()
         idx = np.empty(m, dtype=np.int64)
         best_ret = np.empty(m, dtype=np.float32)
         for i in range(m):
@@ -267,6 +272,7 @@ class MPCController(Policy, Serializable):
             torch.distributed.all_gather(parts, rets)
             rets = torch.cat(parts, dim=1)
         returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
+        self._check_status()
         if reference:
             elites_idx = ((-returns).argsort(axis=-1) < num_elites).T                # :101
             elites = a_stacked[elites_idx]

@@ -150,9 +150,13 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                 s = (av[nt, 0, :, ii] * av[nt, 0, :, ii] + s).astype(F32)
                 s = (av[nt, 1, :, ii] * av[nt, 1, :, ii] + s).astype(F32)
             asq[nt] = s
-        dsum = np.zeros((8, NT, OT, 64, 4), dtype=F32)
+        dsum = np.zeros((8, NT, OT, 64, 4), dtype=F32)      # finished group
+        dgrp = np.zeros((8, NT, OT, 64, 4), dtype=F32)      # group being summed (A then B)
+        e_half = (e_loop + 1) >> 1
 
         for e in range(e_loop):
+            if e == e_half:
+                dsum, dgrp = dgrp, np.zeros_like(dgrp)
             ps = sets[env] if mode == "per_block" else sets[e]
             hcur, hoth = lds[cur], lds[cur ^ 1]
             # ---- layer 0 ----
@@ -227,9 +231,10 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                         for w in range(1, 8):
                             s = (s + hoth[(w * NT + nt) * OT + c]).astype(F32)
                         s = act4((s + bias).astype(F32), output_act)
-                        dsum[wave, nt, c] = (dsum[wave, nt, c] + (s * osd + omu).astype(F32)).astype(F32)
+                        dgrp[wave, nt, c] = (dgrp[wave, nt, c] + (s * osd + omu).astype(F32)).astype(F32)
             # (no barrier; `cur` is NOT flipped: the next layer 0 writes the region it just read)
 
+        dsum = (dsum + dgrp).astype(F32)                     # group A + group B
         disc_t = F32(disc_pow)
         disc_pow *= float(F32(discount))
         for wave in range(8):

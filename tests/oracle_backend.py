@@ -39,6 +39,7 @@ def install(controller, case):
             keys[i] = best
         return torch.from_numpy(keys), (torch.from_numpy(rets) if want_returns else None)
 
+    controller._check_status = lambda: None
     controller._device = _device
     controller._upload = _upload
     controller._rollout = _rollout

@@ -164,6 +164,36 @@ def test_mfma_and_valu_kernels_agree():
     assert np.array_equal(k1 & 0x7FFFFFFF, k2 & 0x7FFFFFFF)          # same winner
 
 
+def test_member_split_is_bit_identical_to_single_workgroup():
+    """Config 2 has 125 candidate tiles: by default two workgroups share each tile (ensemble
+    members 0-2 | 3-4) and swap partial delta sums every horizon step.  Disabling the split must
+    not change a single bit, and repeated split launches must be deterministic."""
+    case = cases.CASES["c2_hc_rs_n2000_h30_e5"]
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    a = _rs_actions(case, 1, env)
+    obs0 = cases.load_golden("c2_hc_rs_n2000_h30_e5_s1")["obs0"]
+    ctx = _lib.Context.get(0)
+    try:
+        ctx.set_split(1)
+        r_split, k_split = _plan_returns(native, case, env, obs0, a)
+        r_again, k_again = _plan_returns(native, case, env, obs0, a)
+        ctx.launch_status()
+        ctx.set_split(0)
+        r_one, k_one = _plan_returns(native, case, env, obs0, a)
+    finally:
+        ctx.set_split(1)
+    assert np.array_equal(r_split, r_again) and np.array_equal(k_split, k_again)
+    assert np.array_equal(r_split, r_one) and np.array_equal(k_split, k_one)
+    # h = 1 and h = 2 launches leave low tags behind; a following launch must not be fooled
+    for hh in (1, 2, 3):
+        c = dict(case, h=hh)
+        r1, _ = _plan_returns(native, c, env, obs0, a[:hh])
+        r2, _ = _plan_returns(native, c, env, obs0, a[:hh])
+        assert np.array_equal(r1, r2)
+    ctx.launch_status()
+
+
 def test_mfma_kernel_refuses_ineligible_shape():
     case = cases.CASES["hc_rs_odd_hidden"]
     env, model = cases.product_model(case)
