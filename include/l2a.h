@@ -92,6 +92,10 @@ int l2a_set_split(l2a_ctx* ctx, int policy);
  * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch
  * with l2a_set_split(ctx, 0)).  Reading clears it.                                            */
 int l2a_launch_status(l2a_ctx* ctx, int* status_out);
+/* Developer aid (tools/timeline.py): when `device_ptr` is non-NULL the MFMA kernel's first
+ * candidate tile stamps the shader clock at its phase boundaries into it as u64
+ * [group 2][step h][set 8][slot 8].  NULL (default) disables it.                               */
+int l2a_set_debug_buffer(l2a_ctx* ctx, void* device_ptr);
 
 /* ---- model ----------------------------------------------------------------------------- */
 /* Describe the MLP dynamics model: replaces the graph construction of

@@ -31,6 +31,7 @@ struct l2a_ctx {
     int split_policy = 1;                 // 1 = split members over two workgroups when it fills the chip
     unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
     unsigned int* status_dev = nullptr;
+    unsigned long long* dbg = nullptr;    // optional timeline buffer (l2a_set_debug_buffer)
     int num_cu = 0;
     int lds_per_block = 0;
     int clock_khz = 0;
@@ -113,7 +114,7 @@ int choose_nt(const l2a_model* md, int m, int n, int sa_bytes_nt2) {
 int sa_elems_for(const l2a_model* md, int nt) {
     const int ht = md->H / 16;
     const int a = nt * ht;
-    const int b = 8 * nt * md->OT;
+    const int b = L2A_NW * nt * md->OT;
     return (a > b ? a : b) * 64;
 }
 
@@ -192,16 +193,18 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             p.xbuf = md->xbuf;
             p.status = ctx->status_dev;
         }
-        const dim3 grid((unsigned)(pairs * (p.split ? 2 : 1))), block(512);
+        p.dbg = ctx->dbg;
+        const dim3 grid((unsigned)(pairs * (p.split ? 2 : 1))), block(64 * L2A_NW);
         int rc = L2A_EINVAL;
+        constexpr int T0 = 128 / (16 * L2A_NW), T1 = 256 / (16 * L2A_NW), T2 = 512 / (16 * L2A_NW);
         if (nt == 1) {
-            if (md->TPW == 4) rc = launch_mfma_shape<1, 4>(md, p, grid, block, smem, stream);
-            else if (md->TPW == 2) rc = launch_mfma_shape<1, 2>(md, p, grid, block, smem, stream);
-            else rc = launch_mfma_shape<1, 1>(md, p, grid, block, smem, stream);
+            if (md->TPW == T2) rc = launch_mfma_shape<1, T2>(md, p, grid, block, smem, stream);
+            else if (md->TPW == T1) rc = launch_mfma_shape<1, T1>(md, p, grid, block, smem, stream);
+            else rc = launch_mfma_shape<1, T0>(md, p, grid, block, smem, stream);
         } else {
-            if (md->TPW == 4) rc = launch_mfma_shape<2, 4>(md, p, grid, block, smem, stream);
-            else if (md->TPW == 2) rc = launch_mfma_shape<2, 2>(md, p, grid, block, smem, stream);
-            else rc = launch_mfma_shape<2, 1>(md, p, grid, block, smem, stream);
+            if (md->TPW == T2) rc = launch_mfma_shape<2, T2>(md, p, grid, block, smem, stream);
+            else if (md->TPW == T1) rc = launch_mfma_shape<2, T1>(md, p, grid, block, smem, stream);
+            else rc = launch_mfma_shape<2, T0>(md, p, grid, block, smem, stream);
         }
         if (rc != L2A_OK) return rc;
     } else {
@@ -295,6 +298,12 @@ int l2a_set_split(l2a_ctx* ctx, int policy) {
     return L2A_OK;
 }
 
+int l2a_set_debug_buffer(l2a_ctx* ctx, void* device_ptr) {
+    if (!ctx) return L2A_EINVAL;
+    ctx->dbg = static_cast<unsigned long long*>(device_ptr);
+    return L2A_OK;
+}
+
 int l2a_launch_status(l2a_ctx* ctx, int* status_out) {
     if (!ctx || !status_out) return L2A_EINVAL;
     *status_out = (int)(*ctx->status_host);
@@ -384,7 +393,7 @@ int l2a_model_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_hidden, const
     md->OT = ceil_div(obs_dim, 16);
     md->mfma_ok = mfma_eligible(obs_dim, act_dim, n_hidden, hidden);
     md->H = md->mfma_ok ? hidden[0] : 0;
-    md->TPW = md->mfma_ok ? hidden[0] / 128 : 0;
+    md->TPW = md->mfma_ok ? hidden[0] / (16 * L2A_NW) : 0;
 
     // ---- lay out one weight-set block (offsets in floats, every region 64-B aligned) ------
     long long off = 0;

@@ -62,6 +62,7 @@ struct L2AKParams {
     unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1
     unsigned long long* xbuf;   // exchange granules [pair][group][slot][NT*OT*4][64]
     unsigned int* status;       // host-visible word; bit 0 set = exchange timed out
+    unsigned long long* dbg;    // optional phase timeline (tools/timeline.py); null in production
 };
 
 // ------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 // l2a_mfma.h - the fp32 MFMA rollout kernel (gfx950 / CDNA4 only).  Included by l2a_api.hip.
 //
-// Workgroup = 8 waves (512 threads) owning NT tiles of 16 candidates of one env for the whole
+// Workgroup = L2A_NW waves (4 = one per SIMD) owning NT tiles of 16 candidates of one env for the whole
 // horizon and all weight sets; workgroups never talk to each other (one atomicMax at the end).
 //
 // Data distribution: lane (j = l & 15, qq = l >> 4) holds, for candidate j of a tile,
@@ -17,9 +17,9 @@
 //   hidden layers: same tile ownership; B fragments (activations) come from LDS; A fragments
 //                  (weights, 1 KiB per wave-level load) stream from L2 straight into VGPRs
 //                  with two k-groups in flight ahead of the MFMAs
-//   output layer : K split over the 8 waves (TPW k-groups each), partial sums exchanged
+//   output layer : K split over the waves (TPW k-groups each), partial sums exchanged
 //                  through the idle LDS region, every wave reduces them in the same order,
-//                  so all 8 waves hold bit-identical copies of state / return
+//                  so all waves hold bit-identical copies of state / return
 // LDS: two activation regions of sa_elems f32x4 each + the normalisation vectors (+ 1 KiB per
 // candidate tile and obs tile for the member-split exchange).
 //
@@ -31,60 +31,80 @@
 // are therefore bit-identical; the split one uses twice the CUs when few tiles exist.
 //
 // Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave
-// (hidden width = 128 * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16).
+// (hidden width = 16 * L2A_NW * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16).
 #pragma once
 
 #include "l2a_kernels.h"
+
+// Waves per workgroup.  4 = one wave per SIMD: a lone wave issues its MFMAs back to back (32
+// cycles each) with loads / LDS reads / address math slotted in between, whereas two waves on
+// one SIMD were measured (tools/timeline.py) to leave the matrix pipe ~25 % idle - the older
+// wave is paced to every other slot and the younger one catches only a third of the rest.
+#ifndef L2A_NW
+#define L2A_NW 4
+#endif
 
 // Make `v` opaque to the optimiser at this point (no instructions emitted).  Used on the
 // pre-loop fills of the software-pipeline registers: without it InstCombine folds the
 // loop-carried phi(load, load) into load(phi(addr)) and the prefetch distance collapses to 0.
 #define L2A_OPAQUE(v) asm volatile("" : "+v"(v))
 
-// One hidden->hidden layer for this wave's TPW output tiles.
+// Phase timeline for tools/timeline.py: every wave of candidate tile 0 stamps the shader clock at
+// phase boundaries, dbg[(((grp * h + t) * 8 + e) * 8 + wave) * 8 + slot].  One uniform branch per stamp.
+#define L2A_TS(slot)                                                                        \
+    if (p.dbg && pairid == 0 && e < 8) {                                                    \
+        const unsigned long long ts_ = __builtin_amdgcn_s_memtime();                        \
+        if (lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + e) * 8 + wave) * 8 + (slot)] = ts_; \
+    }
+
+// ------------------------------------------------------------------------------------------
+// Hidden->hidden layer GEMM for this wave's TPW output tiles (accumulators only; the caller
+// owns the epilogue).
 //
 // Software pipeline over the HT k-groups, prefetch distance 2 groups, 4 register buffers in
-// rotation (A, B, C, D <-> group index mod 4) so that a buffer is refilled only after its
-// last use: no loop-carried register copies.  `sched_barrier(0)` pins each refill at the
-// start of its stage (hipcc otherwise sinks the loads next to their consumers), and the
-// pre-loop fills are made opaque so InstCombine cannot fold phi(load, load) into
-// load(phi(addr)) and collapse the prefetch distance.
+// rotation (A, B, C, D <-> group index mod 4) so that a buffer is refilled only after its last
+// use: no loop-carried register copies.  `sched_barrier(0)` pins each refill inside its stage
+// (hipcc otherwise sinks the loads next to their consumers) and the incoming buffers are made
+// opaque so InstCombine cannot fold phi(load, load) into load(phi(addr)) and collapse the
+// prefetch distance.  aA / aB arrive PRELOADED with k-groups 0 and 1 (issued by the previous
+// phase, before its barrier).  The last two refill slots of the loop - which would otherwise
+// reload the final k-group - fetch the NEXT phase's first operands instead:
+//   LAST == false : k-groups 0 / 1 of the next hidden layer (wnext) back into aA / aB
+//   LAST == true  : the output layer's A fragments for this wave's k-groups into pfO
+// ------------------------------------------------------------------------------------------
+#define L2A_STAGE_MFMA(CA, CB)                                                             \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                       \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
+            _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                             \
+                acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);
+
 #define L2A_STAGE(CA, CB, FA, FB, GF)                                                      \
     {                                                                                      \
-        const int gf_ = ((GF) < HT) ? (GF) : HT - 1;                                       \
         _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                                 \
-            FA[tt] = wl[((c0 + tt) * HT + gf_) * 64];                                      \
+            FA[tt] = wl[((c0 + tt) * HT + (GF)) * 64];                                     \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
-            FB[nt] = hin[(nt * HT + gf_) * 64 + lane];                                     \
-        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                   \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                              \
-                _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                         \
-                    acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);           \
+            FB[nt] = hin[(nt * HT + (GF)) * 64 + lane];                                    \
+        L2A_STAGE_MFMA(CA, CB)                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }
 
-template <int NT, int TPW>
-__device__ __forceinline__ void l2a_hidden_layer(const f32x4* __restrict__ wl,   // lane applied
-                                                 const float* __restrict__ bl,
-                                                 const f32x4* hin, f32x4* hout,
-                                                 int wave, int lane, int qq, int act) {
-    constexpr int HT = 8 * TPW;
+template <int NT, int TPW, int OT, bool LAST>
+__device__ __forceinline__ void l2a_hidden_gemm(const f32x4* __restrict__ wl,      // lane applied
+                                                const f32x4* __restrict__ wnext,   // lane applied
+                                                const float* __restrict__ bl,
+                                                const f32x4* hin, f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
+                                                f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW],
+                                                f32x4 (&bias)[TPW], int wave, int lane, int qq) {
+    constexpr int HT = L2A_NW * TPW;
     static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
     const int c0 = wave * TPW;
-    f32x4 acc[NT][TPW];
-    f32x4 aA[TPW], aB[TPW], aC[TPW], aD[TPW], bA[NT], bB[NT], bC[NT], bD[NT], bias[TPW];
-#pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
-        aA[tt] = wl[((c0 + tt) * HT + 0) * 64];
-        aB[tt] = wl[((c0 + tt) * HT + 1) * 64];
-        bias[tt] = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    f32x4 aC[TPW], aD[TPW], bA[NT], bB[NT], bC[NT], bD[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         bA[nt] = hin[(nt * HT + 0) * 64 + lane];
         bB[nt] = hin[(nt * HT + 1) * 64 + lane];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) { L2A_OPAQUE(aA[tt]); L2A_OPAQUE(aB[tt]); }
@@ -93,22 +113,51 @@ __device__ __forceinline__ void l2a_hidden_layer(const f32x4* __restrict__ wl,  
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll 1
-    for (int g = 0; g < HT; g += 4) {
+    for (int g = 0; g < HT - 4; g += 4) {
         L2A_STAGE(aA, bA, aC, bC, g + 2)
         L2A_STAGE(aB, bB, aD, bD, g + 3)
         L2A_STAGE(aC, bC, aA, bA, g + 4)
         L2A_STAGE(aD, bD, aB, bB, g + 5)
     }
+    // ---- peeled last iteration (k-groups HT-4 .. HT-1) ------------------------------------
+    L2A_STAGE(aA, bA, aC, bC, HT - 2)
+    L2A_STAGE(aB, bB, aD, bD, HT - 1)
 #pragma unroll
-    for (int tt = 0; tt < TPW; ++tt)
+    for (int tt = 0; tt < TPW; ++tt)    // epilogue bias, in flight under the last 2 stages
+        bias[tt] = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
+    {   // stage 2: consume C; aA is free -> next phase's first operands
+        if (LAST) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            hout[(nt * HT + c0 + tt) * 64 + lane] = l2a_act4(acc[nt][tt] + bias[tt], act);
+            for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+                    if (((tt * OT + c) & 1) == 0) pfO[tt][c] = wnext[(c * HT + c0 + tt) * 64];
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) aA[tt] = wnext[((c0 + tt) * HT + 0) * 64];
+        }
+        L2A_STAGE_MFMA(aC, bC)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // stage 3: consume D; aB is free
+        if (LAST) {
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+                    if (((tt * OT + c) & 1) == 1) pfO[tt][c] = wnext[(c * HT + c0 + tt) * 64];
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) aB[tt] = wnext[((c0 + tt) * HT + 1) * 64];
+        }
+        L2A_STAGE_MFMA(aD, bD)
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int NT, int TPW, int OT, int KG0>
-__global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
-    constexpr int HT = 8 * TPW;
+__global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
+    constexpr int HT = L2A_NW * TPW;
     constexpr int NRM_SET = 32 * KG0 + 32 * OT;
     extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
     f32x4* buf0 = reinterpret_cast<f32x4*>(l2a_smem);
@@ -120,6 +169,7 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jc = lane & 15;
     const int qq = lane >> 4;
+    const int c0 = wave * TPW;
 
     const int bid = l2a_logical_wg(blockIdx.x, gridDim.x);
     const int n_pairs = p.m * p.tiles_per_env;
@@ -129,6 +179,7 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
     const int tb = pairid - env * p.tiles_per_env;
     const int R = p.m * p.n;
     const int obs_dim = p.obs_dim, act_dim = p.act_dim;
+    const int n_hidden = p.n_hidden;
 
     int cand[NT], row[NT];
     bool valid[NT];
@@ -144,7 +195,7 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
     const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
     const int e_half = (e_loop + 1) >> 1;                   // group A = [0, e_half), B = [e_half, e_loop)
     f32x4* xlds = reinterpret_cast<f32x4*>(nrm + e_loop * NRM_SET);   // [NT * OT][64], split only
-    for (int i = tid; i < e_loop * NRM_SET; i += 512) {
+    for (int i = tid; i < e_loop * NRM_SET; i += 64 * L2A_NW) {
         const int s = i / NRM_SET;
         const int o = i - s * NRM_SET;
         const int ws = per_block ? env : s;
@@ -196,6 +247,23 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
     const float e_count = (float)e_loop;
     double disc_pow = 1.0;      // discount ** t, carried in float64 like the reference (:126)
 
+    const int e_first = (p.split && grp == 1) ? e_half : 0;
+    const int e_last = (p.split && grp == 0) ? e_half : e_loop;
+    auto set_base = [&](int e) { return p.wblk + (long long)(per_block ? env : e) * p.set_stride; };
+
+    // Operands every phase receives preloaded from the phase before it (issued ahead of the
+    // barrier that separates them, so a phase never starts with an exposed L2 round trip).
+    f32x4 pfL0[KG0][TPW];       // layer-0 A fragments of the upcoming (step, set)
+    f32x4 pfA[TPW], pfB[TPW];   // k-groups 0 / 1 of the upcoming hidden->hidden layer
+    f32x4 pfO[TPW][OT];         // output-layer A fragments of this wave's k-groups
+    {
+        const f32x4* w0 = reinterpret_cast<const f32x4*>(set_base(e_first) + p.pk_w0) + lane;
+#pragma unroll
+        for (int g = 0; g < KG0; ++g)
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = w0[((c0 + tt) * KG0 + g) * 64];
+    }
+
     for (int t = 0; t < p.h; ++t) {
         f32x4 av[NT][2];
         float asq[NT];
@@ -222,8 +290,6 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
                 dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 
-        const int e_first = (p.split && grp == 1) ? e_half : 0;
-        const int e_last = (p.split && grp == 0) ? e_half : e_loop;
         for (int e = e_first; e < e_last; ++e) {
             if (e == e_half && !p.split) {      // group A complete: park it, start group B
 #pragma unroll
@@ -234,21 +300,38 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
                         dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
             }
-            const int ws = per_block ? env : e;
-            const float* wb = p.wblk + (long long)ws * p.set_stride;
+            const float* wb = set_base(e);
+            const float* wb_next = set_base((e + 1 < e_last) ? e + 1 : e_first);   // next (step, set)
             const float* nr = nrm + e * NRM_SET;    // per_block / single: e == 0
+            const f32x4* wo = reinterpret_cast<const f32x4*>(wb + p.pk_wout) + lane;
+            const f32x4* wmid = reinterpret_cast<const f32x4*>(wb + p.pk_wmid) + lane;
+            const long long mid_stride = p.pk_wmid_stride >> 2;     // in f32x4
 
-            // ---- layer 0 -------------------------------------------------------------------
+            f32x4 hreg[NT][TPW];    // activations of the LAST hidden layer (stay in registers)
+            L2A_TS(0)
+
+            // ---- layer 0: B = normalised [obs | act] built from the state fragment ---------
             {
-                const f32x4* w0 = reinterpret_cast<const f32x4*>(wb + p.pk_w0) + lane;
-                const float* b0p = wb + p.raw_b[0];
-                const int c0 = wave * TPW;
                 f32x4 a[KG0][TPW];
 #pragma unroll
                 for (int g = 0; g < KG0; ++g)
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) a[g][tt] = w0[((c0 + tt) * KG0 + g) * 64];
+                    for (int tt = 0; tt < TPW; ++tt) { a[g][tt] = pfL0[g][tt]; L2A_OPAQUE(a[g][tt]); }
+                // operands of the phase after this one
+                if (n_hidden == 1) {
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c) pfO[tt][c] = wo[(c * HT + c0 + tt) * 64];
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt) {
+                        pfA[tt] = wmid[((c0 + tt) * HT + 0) * 64];
+                        pfB[tt] = wmid[((c0 + tt) * HT + 1) * 64];
+                    }
+                }
                 f32x4 bias[TPW];
+                const float* b0p = wb + p.raw_b[0];
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt)
                     bias[tt] = *reinterpret_cast<const f32x4*>(b0p + 16 * (c0 + tt) + 4 * qq);
@@ -288,30 +371,59 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
                 for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        hcur[(nt * HT + c0 + tt) * 64 + lane] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
+                        hreg[nt][tt] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
+                if (n_hidden > 1) {
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) hcur[(nt * HT + c0 + tt) * 64 + lane] = hreg[nt][tt];
+                }
             }
-            __syncthreads();
 
-            // ---- hidden -> hidden layers ---------------------------------------------------
-            for (int l = 1; l < p.n_hidden; ++l) {
-                const f32x4* wl = reinterpret_cast<const f32x4*>(
-                                      wb + p.pk_wmid + (long long)(l - 1) * p.pk_wmid_stride) + lane;
-                l2a_hidden_layer<NT, TPW>(wl, wb + p.raw_b[l], hcur, hoth, wave, lane, qq, p.hidden_act);
+            // ---- hidden -> hidden layers; the last one keeps its output in registers -------
+            L2A_TS(1)
+            if (n_hidden > 1) {
                 __syncthreads();
-                f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
+                L2A_TS(2)
+                f32x4 acc[NT][TPW], bias[TPW];
+                for (int l = 1; l < n_hidden - 1; ++l) {
+                    const f32x4* wl = wmid + (long long)(l - 1) * mid_stride;
+                    l2a_hidden_gemm<NT, TPW, OT, false>(wl, wl + mid_stride, wb + p.raw_b[l], hcur, pfA, pfB, pfO,
+                                                        acc, bias, wave, lane, qq);
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            hoth[(nt * HT + c0 + tt) * 64 + lane] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
+                    __syncthreads();
+                    f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
+                }
+                l2a_hidden_gemm<NT, TPW, OT, true>(wmid + (long long)(n_hidden - 2) * mid_stride, wo,
+                                                   wb + p.raw_b[n_hidden - 1], hcur, pfA, pfB, pfO, acc, bias,
+                                                   wave, lane, qq);
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        hreg[nt][tt] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
             }
 
-            // ---- output layer: K split over the 8 waves, partials through LDS --------------
+            L2A_TS(3)
+            // ---- output layer, fused: this wave's hidden tiles ARE its share of K -----------
+            // (hidden tile c0 + tt of the last hidden layer == k-group c0 + tt of the output layer,
+            // and its D fragment is the B fragment: no LDS round trip, no barrier in between)
             {
-                const f32x4* wo = reinterpret_cast<const f32x4*>(wb + p.pk_wout) + lane;
-                f32x4 a[TPW][OT], b[TPW][NT];
+                f32x4 a[TPW][OT];
 #pragma unroll
-                for (int gi = 0; gi < TPW; ++gi) {
-                    const int g = wave * TPW + gi;
+                for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-                    for (int c = 0; c < OT; ++c) a[gi][c] = wo[(c * HT + g) * 64];
+                    for (int c = 0; c < OT; ++c) { a[tt][c] = pfO[tt][c]; L2A_OPAQUE(a[tt][c]); }
+                {   // layer-0 operands of the next (step, set): in flight across the barrier below
+                    const f32x4* w0n = reinterpret_cast<const f32x4*>(wb_next + p.pk_w0) + lane;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) b[gi][nt] = hcur[(nt * HT + g) * 64 + lane];
+                    for (int g = 0; g < KG0; ++g)
+#pragma unroll
+                        for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = w0n[((c0 + tt) * KG0 + g) * 64];
                 }
                 f32x4 acc[NT][OT];
 #pragma unroll
@@ -319,14 +431,14 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
 #pragma unroll
                     for (int c = 0; c < OT; ++c) acc[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int gi = 0; gi < TPW; ++gi)
+                for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                             for (int c = 0; c < OT; ++c)
-                                acc[nt][c] = L2A_MFMA(a[gi][c][ii], b[gi][nt][ii], acc[nt][c]);
+                                acc[nt][c] = L2A_MFMA(a[tt][c][ii], hreg[nt][tt][ii], acc[nt][c]);
                 // partial of wave w, tile (nt, c) -> hoth[((w * NT + nt) * OT + c) * 64 + lane]
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -334,7 +446,9 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
                     for (int c = 0; c < OT; ++c)
                         hoth[((wave * NT + nt) * OT + c) * 64 + lane] = acc[nt][c];
             }
+            L2A_TS(4)
             __syncthreads();
+            L2A_TS(5)
             {
                 const float* bo = wb + p.pk_bout;
 #pragma unroll
@@ -346,19 +460,22 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
                     for (int nt = 0; nt < NT; ++nt) {
                         f32x4 s = hoth[((0 * NT + nt) * OT + c) * 64 + lane];
 #pragma unroll
-                        for (int w = 1; w < 8; ++w) s += hoth[((w * NT + nt) * OT + c) * 64 + lane];
+                        for (int w = 1; w < L2A_NW; ++w) s += hoth[((w * NT + nt) * OT + c) * 64 + lane];
                         s = l2a_act4(s + bias, p.output_act);
                         dgrp[nt][c] += s * osd + omu;
                     }
                 }
             }
-            // No barrier here: the next writes to `hoth` (a hidden layer, or the next output
-            // partials) come after the layer-0 barrier below, which every wave reaches only
-            // after finishing these reads; the next layer 0 writes `hcur`, which nobody reads
-            // any more (its last readers were the output-layer MFMAs before the barrier above).
+            // LDS hazards.  The partial sums live in `hoth`; `hcur` was last read by the final
+            // hidden layer, before the barrier above.  n_hidden >= 2: the next writes are layer 0
+            // -> `hcur` (free) and, only after the layer-0 barrier, `hoth` again (every wave has
+            // finished these reads by then).  n_hidden == 1: there is no layer-0 barrier, the next
+            // partial sums would land in `hoth` while slow waves still read it -> alternate regions.
+            if (n_hidden == 1) { f32x4* tmp = hcur; hcur = hoth; hoth = tmp; }
+            L2A_TS(6)
         }
 
-        // ---- combine the two member groups ------------------------------------------------
+    // ---- combine the two member groups ------------------------------------------------
         if (p.split) {
             // publish this workgroup's group sum, fetch the partner's (same lane layout)
             const unsigned int tag = p.xtag + (unsigned int)(t + 1);
@@ -445,6 +562,7 @@ __global__ void __launch_bounds__(512) l2a_rollout_mfma_k(const L2AKParams p) {
             if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
             ret[nt] = fmaf(disc_t, r, ret[nt]);
         }
+        { const int e = 7; L2A_TS(7) }     // end of the step (after exchange, reward, state update)
     }
 
     // ---- results: wave 0 writes returns, arg-max key and (for predict) the final state -----

@@ -15,6 +15,7 @@ supplies ``A[i = l & 15][k = l >> 4]`` and ``B[k = l >> 4][j = l & 15]`` and hol
 
 import numpy as np
 
+NW = 4          # waves per workgroup (L2A_NW in csrc/l2a_mfma.h)
 LANE = np.arange(64)
 JC = LANE & 15
 QQ = LANE >> 4
@@ -100,7 +101,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
     l2a_reward fields.  Returns (ret[NT, 16], valid[NT, 16], final_state[NT, 16, obs_dim])."""
     ps0 = sets[0]
     HT, KG0, OT = ps0.HT, ps0.KG0, ps0.OT
-    TPW = HT // 8
+    TPW = HT // NW
     h = actions.shape[0]
     R = m * n
     e_loop = len(sets) if mode == "mean" else 1
@@ -114,7 +115,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
         row[nt] = env * n + np.where(valid[nt], cand[nt], n - 1)
 
     # every wave keeps its own copy of the state; emulate all 8 and assert they stay identical
-    st = np.zeros((8, NT, OT, 64, 4), dtype=F32)
+    st = np.zeros((NW, NT, OT, 64, 4), dtype=F32)
     for nt in range(NT):
         for c in range(OT):
             for ii in range(4):
@@ -135,8 +136,8 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                     dst[nt, s, :, ii] = np.where(ok, v, F32(0))
         return dst
 
-    ret = np.zeros((8, NT, 64), dtype=F32)
-    sa = max(NT * HT, 8 * NT * OT)
+    ret = np.zeros((NW, NT, 64), dtype=F32)
+    sa = max(NT * HT, NW * NT * OT)
     lds = [np.zeros((sa, 64, 4), dtype=F32), np.zeros((sa, 64, 4), dtype=F32)]
     cur = 0
     disc_pow = 1.0
@@ -150,8 +151,8 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                 s = (av[nt, 0, :, ii] * av[nt, 0, :, ii] + s).astype(F32)
                 s = (av[nt, 1, :, ii] * av[nt, 1, :, ii] + s).astype(F32)
             asq[nt] = s
-        dsum = np.zeros((8, NT, OT, 64, 4), dtype=F32)      # finished group
-        dgrp = np.zeros((8, NT, OT, 64, 4), dtype=F32)      # group being summed (A then B)
+        dsum = np.zeros((NW, NT, OT, 64, 4), dtype=F32)      # finished group
+        dgrp = np.zeros((NW, NT, OT, 64, 4), dtype=F32)      # group being summed (A then B)
         e_half = (e_loop + 1) >> 1
 
         for e in range(e_loop):
@@ -160,7 +161,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
             ps = sets[env] if mode == "per_block" else sets[e]
             hcur, hoth = lds[cur], lds[cur ^ 1]
             # ---- layer 0 ----
-            for wave in range(8):
+            for wave in range(NW):
                 c0 = wave * TPW
                 acc = np.zeros((NT, TPW, 64, 4), dtype=F32)
                 for g in range(KG0):
@@ -189,7 +190,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
             for l in range(1, ps.n_hidden):
                 wl = ps.wmid[l - 1]
                 bl = ps.bmid[l - 1]
-                for wave in range(8):
+                for wave in range(NW):
                     c0 = wave * TPW
                     acc = np.zeros((NT, TPW, 64, 4), dtype=F32)
                     for g in range(HT):
@@ -207,7 +208,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                 cur ^= 1
                 hcur, hoth = lds[cur], lds[cur ^ 1]
             # ---- output layer: K split over waves ----
-            for wave in range(8):
+            for wave in range(NW):
                 acc = np.zeros((NT, OT, 64, 4), dtype=F32)
                 for gi in range(TPW):
                     g = wave * TPW + gi
@@ -221,14 +222,14 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                     for c in range(OT):
                         hoth[(wave * NT + nt) * OT + c] = acc[nt, c]
             # barrier
-            for wave in range(8):
+            for wave in range(NW):
                 for c in range(OT):
                     bias = ps.bout[16 * c + 4 * QQ[:, None] + np.arange(4)[None, :]]
                     omu = ps.out_mu[16 * c + 4 * QQ[:, None] + np.arange(4)[None, :]]
                     osd = ps.out_sd[16 * c + 4 * QQ[:, None] + np.arange(4)[None, :]]
                     for nt in range(NT):
                         s = np.array(hoth[(0 * NT + nt) * OT + c])
-                        for w in range(1, 8):
+                        for w in range(1, NW):
                             s = (s + hoth[(w * NT + nt) * OT + c]).astype(F32)
                         s = act4((s + bias).astype(F32), output_act)
                         dgrp[wave, nt, c] = (dgrp[wave, nt, c] + (s * osd + omu).astype(F32)).astype(F32)
@@ -237,7 +238,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
         dsum = (dsum + dgrp).astype(F32)                     # group A + group B
         disc_t = F32(disc_pow)
         disc_pow *= float(F32(discount))
-        for wave in range(8):
+        for wave in range(NW):
             for nt in range(NT):
                 plin = np.where(QQ == 0, F32(reward["alive"]), F32(0)) - F32(reward["ctrl_coef"]) * asq[nt]
                 plin = plin.astype(F32)
@@ -264,7 +265,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                     r = (r - F32(reward["dist_coef"]) * np.sqrt(psq)).astype(F32)
                 ret[wave, nt] = (disc_t * r + ret[wave, nt]).astype(F32)
 
-    for wave in range(1, 8):
+    for wave in range(1, NW):
         assert np.array_equal(st[wave], st[0]), "waves diverged"
         assert np.array_equal(ret[wave], ret[0])
 

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Phase timeline of the MFMA rollout kernel on config 2 (developer aid, needs a GPU).
+
+Stamps (shader clock, wave 0 of candidate tile 0, both member groups): per (step, set)
+0 start | 1 layer 0 done | 2 past barrier | 3 last hidden GEMM + epilogue done |
+4 output partials written | 5 past barrier | 6 partials reduced ; slot 7 of set 7 = end of step.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+from learning_to_adapt_amd import _lib  # noqa: E402
+
+case = cases.CASES["c2_hc_rs_n2000_h30_e5"]
+env, model = cases.product_model(case)
+native = model.planner_model()
+dev = native.device
+gold = cases.load_golden("c2_hc_rs_n2000_h30_e5_s0")
+obs0 = torch.from_numpy(gold["obs0"].astype(np.float32)).to(dev)
+a = (torch.rand((30, 2000, 6), device=dev) * 2 - 1)
+best = torch.zeros(1, dtype=torch.int64, device=dev)
+h = 30
+for _ in range(3):
+    native.plan_rs(obs0, a, 1, 2000, h, 1.0, env.reward_spec, best_key=best)
+torch.cuda.synchronize()
+dbg = torch.zeros((2, h, 8, 8, 8), dtype=torch.int64, device=dev)
+native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(dbg.data_ptr())), "dbg")
+native.plan_rs(obs0, a, 1, 2000, h, 1.0, env.reward_spec, best_key=best)
+torch.cuda.synchronize()
+native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(0)), "dbg")
+d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
+names = ["L0", "bar0", "hidden", "out", "bar1", "reduce"]
+for grp, members in ((0, (0, 1, 2)), (1, (3, 4))):
+    print("group %d members %s" % (grp, members))
+    for e in members:
+        print("  set %d (median over steps 2.., clocks):" % e)
+        for w in range(8):
+            seg = np.diff(d[grp, 2:, e, w, :7], axis=1)
+            med = np.median(seg, axis=0)
+            # arrival offsets relative to wave 0 at the start of the set and at the two barriers
+            off0 = np.median(d[grp, 2:, e, w, 0] - d[grp, 2:, e, 0, 0])
+            off4 = np.median(d[grp, 2:, e, w, 4] - d[grp, 2:, e, 0, 4])
+            print("    wave %d: " % w + "  ".join("%s %6.0f" % (n, v) for n, v in zip(names, med)) +
+                  "  | start vs w0 %+6.0f  reach bar1 vs w0 %+6.0f" % (off0, off4))
+    step = np.diff(d[grp, :, 7, 0, 7])
+    last_end = d[grp, :, 7, 0, 7] - d[grp, :, members[-1], 0, 6]
+    print("  step period: median %d clk (min %d max %d); set-loop-end -> step end (exchange+reward) %d clk"
+          % (np.median(step), step.min(), step.max(), np.median(last_end)))
