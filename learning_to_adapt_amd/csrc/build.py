@@ -1,18 +1,25 @@
 """Build libl2a_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
     python learning_to_adapt_amd/csrc/build.py [--force]
+
+The MFMA kernel template is instantiated in six translation units (one per (NT, TPW) pair), which
+are compiled in parallel and linked with the API unit.
 """
 
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libl2a_hip.so")
-SOURCES = ["l2a_api.hip"]
-HEADERS = ["l2a_kernels.h", "l2a_mfma.h", os.path.join("..", "..", "include", "l2a.h")]
+OBJ_DIR = os.path.join(HERE, "_obj")
+HEADERS = ["l2a_kernels.h", "l2a_valu.h", "l2a_mfma.h", "l2a_mfma_launch.h", os.path.join("..", "..", "include", "l2a.h")]
+SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip"]
+INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8)]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _hipcc():
@@ -30,18 +37,40 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and up_to_date():
+def _compile(job):
+    src, obj, defs = job
+    cmd = [_hipcc()] + FLAGS + defs + ["-c", os.path.join(HERE, src), "-o", obj]
+    subprocess.check_call(cmd, cwd=HERE)
+    return obj
+
+
+def build(force=False, verbose=True, only=None):
+    """``only``: optional list of (NT, TPW) pairs to (re)compile - the others reuse their cached
+    objects (developer shortcut; a clean build compiles all six)."""
+    if not force and only is None and up_to_date():
         if verbose:
             print("[l2a] %s is up to date" % OUT)
         return OUT
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    jobs = [("l2a_api.hip", os.path.join(OBJ_DIR, "l2a_api.o"), [])]
+    for nt, tpw in INSTANCES:
+        obj = os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % (nt, tpw))
+        if only is not None and (nt, tpw) not in only and os.path.exists(obj):
+            continue
+        jobs.append(("l2a_mfma_inst.hip", obj, ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw]))
     if verbose:
-        print("[l2a] " + " ".join(cmd))
-    subprocess.check_call(cmd, cwd=HERE)
+        print("[l2a] hipcc %s : %d translation units, %d parallel jobs"
+              % (" ".join(FLAGS), len(jobs), min(len(jobs), os.cpu_count() or 1)))
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+        list(pool.map(_compile, jobs))
+    objs = [os.path.join(OBJ_DIR, "l2a_api.o")] + [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
     return OUT
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    only = None
+    for a in sys.argv[1:]:
+        if a.startswith("--only="):
+            only = [tuple(int(x) for x in part.split("x")) for part in a[len("--only="):].split(",")]
+    build(force="--force" in sys.argv, only=only)

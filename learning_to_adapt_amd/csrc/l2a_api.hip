@@ -5,7 +5,8 @@
 // of the fused rollout kernels in l2a_kernels.h.  Everything is enqueued on the caller's stream.
 
 #include "l2a_kernels.h"
-#include "l2a_mfma.h"
+#include "l2a_valu.h"
+#include "l2a_mfma_launch.h"
 
 #include <cmath>
 #include <cstdio>
@@ -63,6 +64,8 @@ struct l2a_model {
 
 namespace {
 
+inline bool fast_act(int a) { return a == L2A_ACT_RELU || a == L2A_ACT_IDENTITY; }
+
 int fail(const l2a_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_init_error = msg;
     return code;
@@ -101,9 +104,9 @@ int allow_big_lds(const l2a_ctx* ctx, K kernel, int bytes) {
 }
 
 // Launch geometry of the MFMA kernel for (m, n): NT candidate tiles per workgroup.
-int choose_nt(const l2a_model* md, int m, int n, int sa_bytes_nt2) {
+int choose_nt(const l2a_model* md, int m, int n, int sa_bytes_nt2, int other_bytes_nt2) {
     const int cus = md->ctx->num_cu > 0 ? md->ctx->num_cu : 256;
-    if (2 * sa_bytes_nt2 + 8192 > md->ctx->lds_per_block) return 1;
+    if (2 * sa_bytes_nt2 + other_bytes_nt2 > md->ctx->lds_per_block) return 1;
     const long long wg1 = (long long)m * ceil_div(n, 16);
     const long long wg2 = (long long)m * ceil_div(n, 32);
     const double cost1 = (double)((wg1 + cus - 1) / cus) * 1.0;
@@ -116,32 +119,6 @@ int sa_elems_for(const l2a_model* md, int nt) {
     const int a = nt * ht;
     const int b = L2A_NW * nt * md->OT;
     return (a > b ? a : b) * 64;
-}
-
-template <int NT, int TPW, int OT, int KG0>
-int launch_mfma_inst(const l2a_model* md, const L2AKParams& p, dim3 grid, dim3 block, int smem,
-                     hipStream_t stream) {
-    int rc = allow_big_lds(md->ctx, l2a_rollout_mfma_k<NT, TPW, OT, KG0>, smem);
-    if (rc != L2A_OK) return rc;
-    hipLaunchKernelGGL((l2a_rollout_mfma_k<NT, TPW, OT, KG0>), grid, block, smem, stream, p);
-    return L2A_OK;
-}
-
-// (OT, KG0) = (ceil(obs/16), ceil((obs+act)/16)); act_dim <= 16 makes KG0 either OT or OT + 1.
-template <int NT, int TPW>
-int launch_mfma_shape(const l2a_model* md, const L2AKParams& p, dim3 grid, dim3 block, int smem,
-                      hipStream_t stream) {
-    switch (md->OT * 8 + md->KG0) {
-        case 1 * 8 + 1: return launch_mfma_inst<NT, TPW, 1, 1>(md, p, grid, block, smem, stream);
-        case 1 * 8 + 2: return launch_mfma_inst<NT, TPW, 1, 2>(md, p, grid, block, smem, stream);
-        case 2 * 8 + 2: return launch_mfma_inst<NT, TPW, 2, 2>(md, p, grid, block, smem, stream);
-        case 2 * 8 + 3: return launch_mfma_inst<NT, TPW, 2, 3>(md, p, grid, block, smem, stream);
-        case 3 * 8 + 3: return launch_mfma_inst<NT, TPW, 3, 3>(md, p, grid, block, smem, stream);
-        case 3 * 8 + 4: return launch_mfma_inst<NT, TPW, 3, 4>(md, p, grid, block, smem, stream);
-        case 4 * 8 + 4: return launch_mfma_inst<NT, TPW, 4, 4>(md, p, grid, block, smem, stream);
-        case 4 * 8 + 5: return launch_mfma_inst<NT, TPW, 4, 5>(md, p, grid, block, smem, stream);
-        default: return fail(md->ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim)");
-    }
 }
 
 int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
@@ -162,11 +139,14 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
                                      "(needs equal hidden widths of 128/256/512, obs_dim<=64, act_dim<=16)");
 
     if (kind == L2A_KERNEL_MFMA) {
-        const int nt = choose_nt(md, p.m, p.n, sa_elems_for(md, 2) * 16);
+        const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
+        const int cst_bytes = e_loop0 * (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4;
+        const int nt = choose_nt(md, p.m, p.n, sa_elems_for(md, 2) * 16, cst_bytes + 2 * md->OT * 64 * 16);
         p.sa_elems = sa_elems_for(md, nt);
         p.tiles_per_env = ceil_div(p.n, 16 * nt);
         const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
-        const int smem = 2 * p.sa_elems * 16 + e_loop * (32 * md->KG0 + 32 * md->OT) * 4 + nt * md->OT * 64 * 16;
+        p.cst_set = 32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H;
+        const int smem = 2 * p.sa_elems * 16 + e_loop * p.cst_set * 4 + nt * md->OT * 64 * 16;
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
         // Member split: two workgroups per candidate tile (group A | group B of the ensemble) when
@@ -195,17 +175,11 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         }
         p.dbg = ctx->dbg;
         const dim3 grid((unsigned)(pairs * (p.split ? 2 : 1))), block(64 * L2A_NW);
-        int rc = L2A_EINVAL;
-        constexpr int T0 = 128 / (16 * L2A_NW), T1 = 256 / (16 * L2A_NW), T2 = 512 / (16 * L2A_NW);
-        if (nt == 1) {
-            if (md->TPW == T2) rc = launch_mfma_shape<1, T2>(md, p, grid, block, smem, stream);
-            else if (md->TPW == T1) rc = launch_mfma_shape<1, T1>(md, p, grid, block, smem, stream);
-            else rc = launch_mfma_shape<1, T0>(md, p, grid, block, smem, stream);
-        } else {
-            if (md->TPW == T2) rc = launch_mfma_shape<2, T2>(md, p, grid, block, smem, stream);
-            else if (md->TPW == T1) rc = launch_mfma_shape<2, T1>(md, p, grid, block, smem, stream);
-            else rc = launch_mfma_shape<2, T0>(md, p, grid, block, smem, stream);
-        }
+        const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
+        int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, &p, grid.x, smem, stream);
+        if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");
+        if (rc != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch: ") + hipGetErrorString((hipError_t)rc));
+        rc = L2A_OK;
         if (rc != L2A_OK) return rc;
     } else {
         p.tiles_per_env = ceil_div(p.n, L2A_VT);
@@ -237,6 +211,8 @@ void fill_model_params(const l2a_model* md, L2AKParams& p) {
     p.hidden_act = md->hidden_act; p.output_act = md->output_act;
     p.mode = md->mode; p.n_sets = md->n_sets;
     p.KG0 = md->KG0; p.OT = md->OT; p.hmax = md->hmax;
+    p.hid_floor = (md->hidden_act == L2A_ACT_RELU) ? 0.0f : -INFINITY;
+    p.out_floor = (md->output_act == L2A_ACT_RELU) ? 0.0f : -INFINITY;
 }
 
 }  // namespace

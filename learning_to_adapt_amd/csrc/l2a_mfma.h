@@ -20,7 +20,8 @@
 //   output layer : K split over the waves (TPW k-groups each), partial sums exchanged
 //                  through the idle LDS region, every wave reduces them in the same order,
 //                  so all waves hold bit-identical copies of state / return
-// LDS: two activation regions of sa_elems f32x4 each + the normalisation vectors (+ 1 KiB per
+// LDS: two activation regions of sa_elems f32x4 each + per-set constants (normalisation vectors
+// and all biases, so no phase waits on a global load behind the weight prefetch) (+ 1 KiB per
 // candidate tile and obs tile for the member-split exchange).
 //
 // Ensemble association: the members are always summed as (sum over group A) + (sum over group
@@ -44,17 +45,41 @@
 #define L2A_NW 4
 #endif
 
+// Weight fragments are fetched with raw buffer loads: address = descriptor base (SGPRs, wave
+// uniform) + per-lane VGPR offset + SGPR offset + 12-bit immediate.  All address arithmetic of the
+// hot loop then lives in one SALU add per iteration instead of two VALU adds per load (the VALU
+// slots between MFMAs are not free: tools/timeline.py measured ~39 instead of 32 cycles per MFMA
+// with flat 64-bit addressing).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t l2a_rsrc(const void* base, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 l2a_ldw(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+// Activation.  GACT == false covers relu and identity branch-free as max(x, floor) with floor = 0
+// or -inf: the generic path (tanh / sigmoid / swish) inlines ~10 KiB of code per call site, and
+// jumping around it in every epilogue cost ~2k cycles per layer in instruction fetch.
+template <bool GACT>
+__device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
+    if (GACT) return l2a_act4(v, kind);
+    v.x = fmaxf(v.x, floor); v.y = fmaxf(v.y, floor);
+    v.z = fmaxf(v.z, floor); v.w = fmaxf(v.w, floor);
+    return v;
+}
+
 // Make `v` opaque to the optimiser at this point (no instructions emitted).  Used on the
 // pre-loop fills of the software-pipeline registers: without it InstCombine folds the
 // loop-carried phi(load, load) into load(phi(addr)) and the prefetch distance collapses to 0.
 #define L2A_OPAQUE(v) asm volatile("" : "+v"(v))
 
 // Phase timeline for tools/timeline.py: every wave of candidate tile 0 stamps the shader clock at
-// phase boundaries, dbg[(((grp * h + t) * 8 + e) * 8 + wave) * 8 + slot].  One uniform branch per stamp.
+// phase boundaries, dbg[(((grp * h + t) * 8 + e) * 8 + wave) * 16 + slot].  One uniform branch per stamp.
 #define L2A_TS(slot)                                                                        \
     if (p.dbg && pairid == 0 && e < 8) {                                                    \
         const unsigned long long ts_ = __builtin_amdgcn_s_memtime();                        \
-        if (lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + e) * 8 + wave) * 8 + (slot)] = ts_; \
+        if (lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + e) * 8 + wave) * 16 + (slot)] = ts_; \
     }
 
 // ------------------------------------------------------------------------------------------
@@ -78,23 +103,26 @@
             _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                             \
                 acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);
 
-#define L2A_STAGE(CA, CB, FA, FB, GF)                                                      \
+#define L2A_STAGE(CA, CB, FA, FB, SOFF, IMM, GF)                                           \
     {                                                                                      \
         _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                                 \
-            FA[tt] = wl[((c0 + tt) * HT + (GF)) * 64];                                     \
+            FA[tt] = l2a_ldw(rs, voff[tt] + (IMM), (SOFF));                                \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
             FB[nt] = hin[(nt * HT + (GF)) * 64 + lane];                                    \
+        _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt) L2A_OPAQUE(CA[tt]);             \
         L2A_STAGE_MFMA(CA, CB)                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }
 
+// rs   : descriptor of this layer's packed weights [tile][k-group][64 lanes][4]
+// rsn  : descriptor of the next phase's packed weights (next hidden layer, or the output layer)
+// voff : per-tile byte offset of this lane inside a layer, 16 * lane + (c0 + tt) * HT * 1024
 template <int NT, int TPW, int OT, bool LAST>
-__device__ __forceinline__ void l2a_hidden_gemm(const f32x4* __restrict__ wl,      // lane applied
-                                                const f32x4* __restrict__ wnext,   // lane applied
-                                                const float* __restrict__ bl,
-                                                const f32x4* hin, f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
+__device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
+                                                const int (&voff)[TPW], const f32x4* hin,
+                                                f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
                                                 f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW],
-                                                f32x4 (&bias)[TPW], int wave, int lane, int qq) {
+                                                int wave, int lane) {
     constexpr int HT = L2A_NW * TPW;
     static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
     const int c0 = wave * TPW;
@@ -114,27 +142,26 @@ __device__ __forceinline__ void l2a_hidden_gemm(const f32x4* __restrict__ wl,   
 
 #pragma unroll 1
     for (int g = 0; g < HT - 4; g += 4) {
-        L2A_STAGE(aA, bA, aC, bC, g + 2)
-        L2A_STAGE(aB, bB, aD, bD, g + 3)
-        L2A_STAGE(aC, bC, aA, bA, g + 4)
-        L2A_STAGE(aD, bD, aB, bB, g + 5)
+        const int soff = (g + 2) * 1024;      // byte offset of k-group g + 2 inside a tile
+        L2A_STAGE(aA, bA, aC, bC, soff, 0, g + 2)
+        L2A_STAGE(aB, bB, aD, bD, soff, 1024, g + 3)
+        L2A_STAGE(aC, bC, aA, bA, soff, 2048, g + 4)
+        L2A_STAGE(aD, bD, aB, bB, soff, 3072, g + 5)
     }
     // ---- peeled last iteration (k-groups HT-4 .. HT-1) ------------------------------------
-    L2A_STAGE(aA, bA, aC, bC, HT - 2)
-    L2A_STAGE(aB, bB, aD, bD, HT - 1)
-#pragma unroll
-    for (int tt = 0; tt < TPW; ++tt)    // epilogue bias, in flight under the last 2 stages
-        bias[tt] = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
+    L2A_STAGE(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2)
+    L2A_STAGE(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1)
     {   // stage 2: consume C; aA is free -> next phase's first operands
-        if (LAST) {
+        if (LAST) {     // output layer: fragment (tile c, k-group c0 + tt) -> voff[tt] / HT + c * HT * 1024
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
                 for (int c = 0; c < OT; ++c)
-                    if (((tt * OT + c) & 1) == 0) pfO[tt][c] = wnext[(c * HT + c0 + tt) * 64];
+                    if (((tt * OT + c) & 1) == 0)
+                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
         } else {
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) aA[tt] = wnext[((c0 + tt) * HT + 0) * 64];
+            for (int tt = 0; tt < TPW; ++tt) aA[tt] = l2a_ldw(rsn, voff[tt], 0);
         }
         L2A_STAGE_MFMA(aC, bC)
         __builtin_amdgcn_sched_barrier(0);
@@ -145,20 +172,25 @@ __device__ __forceinline__ void l2a_hidden_gemm(const f32x4* __restrict__ wl,   
             for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
                 for (int c = 0; c < OT; ++c)
-                    if (((tt * OT + c) & 1) == 1) pfO[tt][c] = wnext[(c * HT + c0 + tt) * 64];
+                    if (((tt * OT + c) & 1) == 1)
+                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
         } else {
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) aB[tt] = wnext[((c0 + tt) * HT + 1) * 64];
+            for (int tt = 0; tt < TPW; ++tt) aB[tt] = l2a_ldw(rsn, voff[tt] + 1024, 0);
         }
         L2A_STAGE_MFMA(aD, bD)
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int NT, int TPW, int OT, int KG0>
+template <int NT, int TPW, int OT, int KG0, bool GACT>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
     constexpr int HT = L2A_NW * TPW;
-    constexpr int NRM_SET = 32 * KG0 + 32 * OT;
+    // Per-set constants cached in LDS: [in_mu 16 KG0][in_inv 16 KG0][out_mu 16 OT][out_sd 16 OT]
+    // [out_bias 16 OT][hidden biases n_hidden x H] - p.cst_set floats per weight set.
+    constexpr int CST_BOUT = 32 * KG0 + 32 * OT;
+    constexpr int CST_BHID = CST_BOUT + 16 * OT;
+    const int NRM_SET = p.cst_set;
     extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
     f32x4* buf0 = reinterpret_cast<f32x4*>(l2a_smem);
     f32x4* buf1 = buf0 + p.sa_elems;
@@ -198,8 +230,15 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     for (int i = tid; i < e_loop * NRM_SET; i += 64 * L2A_NW) {
         const int s = i / NRM_SET;
         const int o = i - s * NRM_SET;
-        const int ws = per_block ? env : s;
-        nrm[i] = p.wblk[(long long)ws * p.set_stride + p.nm_off + o];
+        const float* src = p.wblk + (long long)(per_block ? env : s) * p.set_stride;
+        float v;
+        if (o < CST_BOUT) v = src[p.nm_off + o];
+        else if (o < CST_BHID) v = src[p.pk_bout + (o - CST_BOUT)];
+        else {
+            const int l = (o - CST_BHID) / (16 * HT);
+            v = src[p.raw_b[l] + (o - CST_BHID - l * 16 * HT)];
+        }
+        nrm[i] = v;
     }
 
     // ---- state fragment -------------------------------------------------------------------
@@ -256,12 +295,20 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     f32x4 pfL0[KG0][TPW];       // layer-0 A fragments of the upcoming (step, set)
     f32x4 pfA[TPW], pfB[TPW];   // k-groups 0 / 1 of the upcoming hidden->hidden layer
     f32x4 pfO[TPW][OT];         // output-layer A fragments of this wave's k-groups
+    int voff[TPW], voff0[TPW];      // this lane's byte offset of tile c0 + tt in a hidden / layer-0 matrix
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        voff[tt] = lane * 16 + (c0 + tt) * HT * 1024;
+        voff0[tt] = lane * 16 + (c0 + tt) * KG0 * 1024;
+    }
+    const long long w0_bytes = (long long)HT * KG0 * 1024, wm_bytes = (long long)HT * HT * 1024,
+                    wo_bytes = (long long)OT * HT * 1024;
     {
-        const f32x4* w0 = reinterpret_cast<const f32x4*>(set_base(e_first) + p.pk_w0) + lane;
+        const __amdgpu_buffer_rsrc_t r0 = l2a_rsrc(set_base(e_first) + p.pk_w0, w0_bytes);
 #pragma unroll
         for (int g = 0; g < KG0; ++g)
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = w0[((c0 + tt) * KG0 + g) * 64];
+            for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0, voff0[tt] + g * 1024, 0);
     }
 
     for (int t = 0; t < p.h; ++t) {
@@ -303,9 +350,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             const float* wb = set_base(e);
             const float* wb_next = set_base((e + 1 < e_last) ? e + 1 : e_first);   // next (step, set)
             const float* nr = nrm + e * NRM_SET;    // per_block / single: e == 0
-            const f32x4* wo = reinterpret_cast<const f32x4*>(wb + p.pk_wout) + lane;
-            const f32x4* wmid = reinterpret_cast<const f32x4*>(wb + p.pk_wmid) + lane;
-            const long long mid_stride = p.pk_wmid_stride >> 2;     // in f32x4
+            const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
 
             f32x4 hreg[NT][TPW];    // activations of the LAST hidden layer (stay in registers)
             L2A_TS(0)
@@ -317,24 +362,22 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 for (int g = 0; g < KG0; ++g)
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt) { a[g][tt] = pfL0[g][tt]; L2A_OPAQUE(a[g][tt]); }
+                L2A_TS(8)
                 // operands of the phase after this one
                 if (n_hidden == 1) {
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-                        for (int c = 0; c < OT; ++c) pfO[tt][c] = wo[(c * HT + c0 + tt) * 64];
+                        for (int c = 0; c < OT; ++c)
+                            pfO[tt][c] = l2a_ldw(rs_out, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
                 } else {
+                    const __amdgpu_buffer_rsrc_t rs1 = l2a_rsrc(wb + p.pk_wmid, wm_bytes);
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt) {
-                        pfA[tt] = wmid[((c0 + tt) * HT + 0) * 64];
-                        pfB[tt] = wmid[((c0 + tt) * HT + 1) * 64];
+                        pfA[tt] = l2a_ldw(rs1, voff[tt], 0);
+                        pfB[tt] = l2a_ldw(rs1, voff[tt] + 1024, 0);
                     }
                 }
-                f32x4 bias[TPW];
-                const float* b0p = wb + p.raw_b[0];
-#pragma unroll
-                for (int tt = 0; tt < TPW; ++tt)
-                    bias[tt] = *reinterpret_cast<const f32x4*>(b0p + 16 * (c0 + tt) + 4 * qq);
                 f32x4 acc[NT][TPW];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -367,11 +410,15 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                             for (int tt = 0; tt < TPW; ++tt)
                                 acc[nt][tt] = L2A_MFMA(a[g][tt][ii], x[nt][ii], acc[nt][tt]);
                 }
+                L2A_TS(9)
 #pragma unroll
-                for (int tt = 0; tt < TPW; ++tt)
+                for (int tt = 0; tt < TPW; ++tt) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BHID + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        hreg[nt][tt] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
+                        hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                }
+                L2A_TS(10)
                 if (n_hidden > 1) {
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt)
@@ -385,27 +432,33 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             if (n_hidden > 1) {
                 __syncthreads();
                 L2A_TS(2)
-                f32x4 acc[NT][TPW], bias[TPW];
+                f32x4 acc[NT][TPW];
                 for (int l = 1; l < n_hidden - 1; ++l) {
-                    const f32x4* wl = wmid + (long long)(l - 1) * mid_stride;
-                    l2a_hidden_gemm<NT, TPW, OT, false>(wl, wl + mid_stride, wb + p.raw_b[l], hcur, pfA, pfB, pfO,
-                                                        acc, bias, wave, lane, qq);
+                    const float* wl = wb + p.pk_wmid + (long long)(l - 1) * p.pk_wmid_stride;
+                    l2a_hidden_gemm<NT, TPW, OT, false>(l2a_rsrc(wl, wm_bytes), l2a_rsrc(wl + p.pk_wmid_stride, wm_bytes),
+                                                        voff, hcur, pfA, pfB, pfO, acc, wave, lane);
+                    const float* bl = nr + CST_BHID + l * (16 * HT);
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt)
+                    for (int tt = 0; tt < TPW; ++tt) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            hoth[(nt * HT + c0 + tt) * 64 + lane] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
+                            hoth[(nt * HT + c0 + tt) * 64 + lane] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                    }
                     __syncthreads();
                     f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
                 }
-                l2a_hidden_gemm<NT, TPW, OT, true>(wmid + (long long)(n_hidden - 2) * mid_stride, wo,
-                                                   wb + p.raw_b[n_hidden - 1], hcur, pfA, pfB, pfO, acc, bias,
-                                                   wave, lane, qq);
+                l2a_hidden_gemm<NT, TPW, OT, true>(
+                    l2a_rsrc(wb + p.pk_wmid + (long long)(n_hidden - 2) * p.pk_wmid_stride, wm_bytes), rs_out, voff,
+                    hcur, pfA, pfB, pfO, acc, wave, lane);
+                const float* bl = nr + CST_BHID + (n_hidden - 1) * (16 * HT);
 #pragma unroll
-                for (int tt = 0; tt < TPW; ++tt)
+                for (int tt = 0; tt < TPW; ++tt) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        hreg[nt][tt] = l2a_act4(acc[nt][tt] + bias[tt], p.hidden_act);
+                        hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                }
             }
 
             L2A_TS(3)
@@ -419,11 +472,11 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                     for (int c = 0; c < OT; ++c) { a[tt][c] = pfO[tt][c]; L2A_OPAQUE(a[tt][c]); }
                 {   // layer-0 operands of the next (step, set): in flight across the barrier below
-                    const f32x4* w0n = reinterpret_cast<const f32x4*>(wb_next + p.pk_w0) + lane;
+                    const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(wb_next + p.pk_w0, w0_bytes);
 #pragma unroll
                     for (int g = 0; g < KG0; ++g)
 #pragma unroll
-                        for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = w0n[((c0 + tt) * KG0 + g) * 64];
+                        for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0n, voff0[tt] + g * 1024, 0);
                 }
                 f32x4 acc[NT][OT];
 #pragma unroll
@@ -450,10 +503,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             __syncthreads();
             L2A_TS(5)
             {
-                const float* bo = wb + p.pk_bout;
 #pragma unroll
                 for (int c = 0; c < OT; ++c) {
-                    const f32x4 bias = *reinterpret_cast<const f32x4*>(bo + 16 * c + 4 * qq);
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BOUT + 16 * c + 4 * qq);
                     const f32x4 omu = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * c + 4 * qq);
                     const f32x4 osd = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
 #pragma unroll
@@ -461,7 +513,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         f32x4 s = hoth[((0 * NT + nt) * OT + c) * 64 + lane];
 #pragma unroll
                         for (int w = 1; w < L2A_NW; ++w) s += hoth[((w * NT + nt) * OT + c) * 64 + lane];
-                        s = l2a_act4(s + bias, p.output_act);
+                        s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
                         dgrp[nt][c] += s * osd + omu;
                     }
                 }

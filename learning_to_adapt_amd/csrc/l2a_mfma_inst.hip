@@ -1,0 +1,46 @@
+// l2a_mfma_inst.hip - one translation unit per (L2A_INST_NT, L2A_INST_TPW): instantiates the MFMA
+// rollout kernel for every (OT, KG0, GACT) and exports its launcher (see l2a_mfma_launch.h).
+#include "l2a_mfma.h"
+
+#if !defined(L2A_INST_NT) || !defined(L2A_INST_TPW)
+#error "compile with -DL2A_INST_NT=<1|2> -DL2A_INST_TPW=<2|4|8>"
+#endif
+
+namespace {
+
+template <int OT, int KG0, bool GACT>
+int launch_one(const L2AKParams* p, unsigned grid, int smem, hipStream_t stream) {
+    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * L2A_NW), smem, stream, *p);
+    return 0;
+}
+
+template <bool GACT>
+int launch_shape(int ot, int kg0, const L2AKParams* p, unsigned grid, int smem, hipStream_t stream) {
+    // (OT, KG0) = (ceil(obs/16), ceil((obs+act)/16)); act_dim <= 16 makes KG0 either OT or OT + 1.
+    switch (ot * 8 + kg0) {
+        case 1 * 8 + 1: return launch_one<1, 1, GACT>(p, grid, smem, stream);
+        case 1 * 8 + 2: return launch_one<1, 2, GACT>(p, grid, smem, stream);
+        case 2 * 8 + 2: return launch_one<2, 2, GACT>(p, grid, smem, stream);
+        case 2 * 8 + 3: return launch_one<2, 3, GACT>(p, grid, smem, stream);
+        case 3 * 8 + 3: return launch_one<3, 3, GACT>(p, grid, smem, stream);
+        case 3 * 8 + 4: return launch_one<3, 4, GACT>(p, grid, smem, stream);
+        case 4 * 8 + 4: return launch_one<4, 4, GACT>(p, grid, smem, stream);
+        case 4 * 8 + 5: return launch_one<4, 5, GACT>(p, grid, smem, stream);
+        default: return -100;
+    }
+}
+
+}  // namespace
+
+#define L2A_CAT3(a, b, c) a##b##_##c
+#define L2A_NAME(nt, tpw) L2A_CAT3(l2a_launch_mfma_, nt, tpw)
+
+int L2A_NAME(L2A_INST_NT, L2A_INST_TPW)(int ot, int kg0, int gact, const L2AKParams* p, unsigned grid, int smem,
+                                         hipStream_t stream) {
+    return gact ? launch_shape<true>(ot, kg0, p, grid, smem, stream)
+                : launch_shape<false>(ot, kg0, p, grid, smem, stream);
+}

@@ -1,0 +1,34 @@
+// l2a_mfma_launch.h - host-side entry points of the MFMA kernel instances.
+//
+// The kernel template (l2a_mfma.h) is instantiated for 2 x 3 x 8 x 2 parameter combinations;
+// they are spread over one translation unit per (NT, TPW) pair (l2a_mfma_inst.hip compiled six
+// times with different -D flags) so that the library builds in parallel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+struct L2AKParams;
+
+#ifndef L2A_NW
+#define L2A_NW 4
+#endif
+
+// Returns 0, a hipError_t (> 0) or -100 when no instance exists for the shape.
+#define L2A_DECL_LAUNCH(NT_, TPW_)                                                               \
+    int l2a_launch_mfma_##NT_##_##TPW_(int ot, int kg0, int gact, const L2AKParams* p, unsigned grid, \
+                                       int smem, hipStream_t stream);
+L2A_DECL_LAUNCH(1, 2) L2A_DECL_LAUNCH(1, 4) L2A_DECL_LAUNCH(1, 8)
+L2A_DECL_LAUNCH(2, 2) L2A_DECL_LAUNCH(2, 4) L2A_DECL_LAUNCH(2, 8)
+#undef L2A_DECL_LAUNCH
+
+inline int l2a_launch_mfma(int nt, int tpw, int ot, int kg0, int gact, const L2AKParams* p, unsigned grid,
+                           int smem, hipStream_t stream) {
+    static_assert(L2A_NW == 4, "instances are generated for 4-wave workgroups (TPW = H / 64)");
+    if (nt == 1 && tpw == 2) return l2a_launch_mfma_1_2(ot, kg0, gact, p, grid, smem, stream);
+    if (nt == 1 && tpw == 4) return l2a_launch_mfma_1_4(ot, kg0, gact, p, grid, smem, stream);
+    if (nt == 1 && tpw == 8) return l2a_launch_mfma_1_8(ot, kg0, gact, p, grid, smem, stream);
+    if (nt == 2 && tpw == 2) return l2a_launch_mfma_2_2(ot, kg0, gact, p, grid, smem, stream);
+    if (nt == 2 && tpw == 4) return l2a_launch_mfma_2_4(ot, kg0, gact, p, grid, smem, stream);
+    if (nt == 2 && tpw == 8) return l2a_launch_mfma_2_8(ot, kg0, gact, p, grid, smem, stream);
+    return -100;
+}

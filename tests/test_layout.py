@@ -26,5 +26,6 @@ def test_gpu_side_files_do_not_read_the_reference():
 def test_required_files_exist():
     for rel in ("include/l2a.h", "oracle/__init__.py", "tests/golden/cases.json", "tools/gen_golden.py",
                 "learning_to_adapt_amd/csrc/l2a_api.hip", "learning_to_adapt_amd/csrc/l2a_mfma.h",
-                "learning_to_adapt_amd/csrc/l2a_kernels.h"):
+                "learning_to_adapt_amd/csrc/l2a_kernels.h", "learning_to_adapt_amd/csrc/l2a_valu.h",
+                "learning_to_adapt_amd/csrc/l2a_mfma_inst.hip"):
         assert os.path.exists(os.path.join(ROOT, rel)), rel

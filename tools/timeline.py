@@ -30,7 +30,7 @@ h = 30
 for _ in range(3):
     native.plan_rs(obs0, a, 1, 2000, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
-dbg = torch.zeros((2, h, 8, 8, 8), dtype=torch.int64, device=dev)
+dbg = torch.zeros((2, h, 8, 8, 16), dtype=torch.int64, device=dev)
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(dbg.data_ptr())), "dbg")
 native.plan_rs(obs0, a, 1, 2000, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
@@ -47,8 +47,13 @@ for grp, members in ((0, (0, 1, 2)), (1, (3, 4))):
             # arrival offsets relative to wave 0 at the start of the set and at the two barriers
             off0 = np.median(d[grp, 2:, e, w, 0] - d[grp, 2:, e, 0, 0])
             off4 = np.median(d[grp, 2:, e, w, 4] - d[grp, 2:, e, 0, 4])
+            sub = [np.median(d[grp, 2:, e, w, 8] - d[grp, 2:, e, w, 0]), np.median(d[grp, 2:, e, w, 9] - d[grp, 2:, e, w, 8]),
+                   np.median(d[grp, 2:, e, w, 10] - d[grp, 2:, e, w, 9]), np.median(d[grp, 2:, e, w, 1] - d[grp, 2:, e, w, 10])]
+            if w >= 4 and d[grp, 2:, e, w, 0].max() == 0:
+                continue
             print("    wave %d: " % w + "  ".join("%s %6.0f" % (n, v) for n, v in zip(names, med)) +
-                  "  | start vs w0 %+6.0f  reach bar1 vs w0 %+6.0f" % (off0, off4))
+                  "  | start vs w0 %+6.0f  reach bar1 vs w0 %+6.0f | L0: wait-pfL0 %5.0f  mfma %5.0f  epilogue %5.0f  lds-write %5.0f"
+                  % (off0, off4, sub[0], sub[1], sub[2], sub[3]))
     step = np.diff(d[grp, :, 7, 0, 7])
     last_end = d[grp, :, 7, 0, 7] - d[grp, :, members[-1], 0, 6]
     print("  step period: median %d clk (min %d max %d); set-loop-end -> step end (exchange+reward) %d clk"
