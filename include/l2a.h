@@ -83,10 +83,14 @@ const char* l2a_last_error(const l2a_ctx* ctx);
 int l2a_device_info(const l2a_ctx* ctx, char* buf, int cap);
 /* Select the kernel (L2A_KERNEL_*) used by subsequent launches on this context.             */
 int l2a_set_kernel(l2a_ctx* ctx, int kind);
-/* Member-split policy of the MFMA kernel in L2A_MODE_MEAN: 1 (default) = when a plan has at most
- * (CUs / 2) candidate tiles, two workgroups share each tile - one per half of the ensemble - and
- * exchange their partial delta sums once per horizon step through global memory; 0 = never.
- * Results are bit-identical either way (the members are always summed group A + group B).     */
+/* Tile-split policy of the MFMA kernel.  When a plan has at most (CUs / 2) candidate tiles, two
+ * workgroups can share each tile and exchange partial sums once per horizon step through global
+ * memory: 0 = never; 2 = split the ensemble into two groups of whole sets (needs >= 2 sets);
+ * 1 (default) = as 2, and additionally the middle set of an odd ensemble - or the only set of a
+ * single / per-block model - is shared, each workgroup computing the last hidden layer and the
+ * output layer for one half of the hidden units (needs >= 2 hidden layers).  Results are
+ * bit-identical under all three policies: the summation order is fixed (sets: group A + group B;
+ * output layer: eight chunks of hidden units, ((c0+c1)+c2)+c3 + ((c4+c5)+c6)+c7).            */
 int l2a_set_split(l2a_ctx* ctx, int policy);
 /* Status word of the launches issued since the last call (caller must have synchronised the
  * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch

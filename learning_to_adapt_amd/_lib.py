@@ -141,7 +141,8 @@ class Context(object):
         self.check(self.lib.l2a_set_kernel(self.handle, KERNEL_CODES[kind]), "l2a_set_kernel")
 
     def set_split(self, policy):
-        self.check(self.lib.l2a_set_split(self.handle, int(bool(policy))), "l2a_set_split")
+        """0 = never, 1 = auto (default; shares the middle set of odd ensembles), 2 = whole sets only."""
+        self.check(self.lib.l2a_set_split(self.handle, int(policy)), "l2a_set_split")
 
     def launch_status(self):
         """Status of the launches since the last call (stream must be synchronised).  Raises when a

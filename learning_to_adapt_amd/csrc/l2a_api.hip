@@ -117,7 +117,7 @@ int choose_nt(const l2a_model* md, int m, int n, int sa_bytes_nt2, int other_byt
 int sa_elems_for(const l2a_model* md, int nt) {
     const int ht = md->H / 16;
     const int a = nt * ht;
-    const int b = L2A_NW * nt * md->OT;
+    const int b = 2 * L2A_NW * nt * md->OT;     // output-layer chunk partials
     return (a > b ? a : b) * 64;
 }
 
@@ -141,22 +141,28 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     if (kind == L2A_KERNEL_MFMA) {
         const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
         const int cst_bytes = e_loop0 * (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4;
-        const int nt = choose_nt(md, p.m, p.n, sa_elems_for(md, 2) * 16, cst_bytes + 2 * md->OT * 64 * 16);
+        const int nt = choose_nt(md, p.m, p.n, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16);
         p.sa_elems = sa_elems_for(md, nt);
         p.tiles_per_env = ceil_div(p.n, 16 * nt);
         const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
         p.cst_set = 32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H;
-        const int smem = 2 * p.sa_elems * 16 + e_loop * p.cst_set * 4 + nt * md->OT * 64 * 16;
+        const int smem = 2 * p.sa_elems * 16 + e_loop * p.cst_set * 4 + 2 * nt * md->OT * 64 * 16;
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
         // Member split: two workgroups per candidate tile (group A | group B of the ensemble) when
         // that still fits one workgroup per CU - e.g. config 2: 125 tiles -> 250 workgroups.
         const long long pairs = (long long)p.m * p.tiles_per_env;
         const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-        p.split = (ctx->split_policy != 0 && p.mode == L2A_MODE_MEAN && md->n_sets >= 2 && nt == 1 &&
-                   2 * pairs <= cus && p.h < 4096) ? 1 : 0;
+        // 1 = group A | group B; 2 = additionally the middle set of an odd ensemble (or the single
+        // set of a lone model) is shared: each workgroup runs the last hidden layer and the output
+        // layer for one half of its hidden tiles (needs >= 2 hidden layers).
+        p.split = 0;
+        if (ctx->split_policy != 0 && nt == 1 && 2 * pairs <= cus && p.h < 4096) {
+            if ((e_loop & 1) && md->n_hidden >= 2 && ctx->split_policy == 1) p.split = 2;
+            else if (e_loop >= 2) p.split = 1;
+        }
         if (p.split) {
-            const long long need = pairs * 2 * 2 * (long long)(nt * md->OT * 4 * 64);
+            const long long need = pairs * 2 * 2 * (long long)(2 * nt * md->OT * 4 * 64);
             if (need > md->xbuf_granules) {
                 if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
                 L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));
@@ -257,7 +263,7 @@ int l2a_init(int device, l2a_ctx** out) {
         return fail(nullptr, L2A_EHIP, msg);
     }
     const char* sp = std::getenv("L2A_SPLIT");
-    if (sp && sp[0] == '0') ctx->split_policy = 0;
+    if (sp && sp[0] >= '0' && sp[0] <= '2') ctx->split_policy = sp[0] - '0';
     *out = ctx;
     return L2A_OK;
 }
@@ -270,7 +276,8 @@ void l2a_destroy(l2a_ctx* ctx) {
 
 int l2a_set_split(l2a_ctx* ctx, int policy) {
     if (!ctx) return L2A_EINVAL;
-    ctx->split_policy = policy ? 1 : 0;
+    if (policy < 0 || policy > 2) return fail(ctx, L2A_EINVAL, "split policy must be 0, 1 or 2");
+    ctx->split_policy = policy;
     return L2A_OK;
 }
 

@@ -78,7 +78,8 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
 // phase boundaries, dbg[(((grp * h + t) * 8 + e) * 8 + wave) * 16 + slot].  One uniform branch per stamp.
 #define L2A_TS(slot)                                                                        \
     if (p.dbg && pairid == 0 && e < 8) {                                                    \
-        const unsigned long long ts_ = __builtin_amdgcn_s_memtime();                        \
+        unsigned long long ts_;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");       \
         if (lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + e) * 8 + wave) * 16 + (slot)] = ts_; \
     }
 
@@ -100,42 +101,47 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
 #define L2A_STAGE_MFMA(CA, CB)                                                             \
     _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                       \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
-            _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                             \
+            _Pragma("unroll") for (int tt = 0; tt < TW; ++tt)                              \
                 acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);
 
 #define L2A_STAGE(CA, CB, FA, FB, SOFF, IMM, GF)                                           \
     {                                                                                      \
-        _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt)                                 \
+        _Pragma("unroll") for (int tt = 0; tt < TW; ++tt)                                  \
             FA[tt] = l2a_ldw(rs, voff[tt] + (IMM), (SOFF));                                \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
             FB[nt] = hin[(nt * HT + (GF)) * 64 + lane];                                    \
-        _Pragma("unroll") for (int tt = 0; tt < TPW; ++tt) L2A_OPAQUE(CA[tt]);             \
         L2A_STAGE_MFMA(CA, CB)                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }
 
-// rs   : descriptor of this layer's packed weights [tile][k-group][64 lanes][4]
-// rsn  : descriptor of the next phase's packed weights (next hidden layer, or the output layer)
-// voff : per-tile byte offset of this lane inside a layer, 16 * lane + (c0 + tt) * HT * 1024
-template <int NT, int TPW, int OT, bool LAST>
+// TW    : output tiles this wave computes here (TPW, or TPW / 2 for a half member)
+// rs    : descriptor of this layer's packed weights [tile][k-group][64 lanes][4]
+// rsn   : descriptor of the next phase's packed weights (next hidden layer, or the output layer)
+// voff  : byte offset of this lane in the layer for each of its tiles, 16 lane + tile * HT * 1024
+// LAST == false: voffn / twn = offsets / count of the tiles this wave computes in the NEXT layer
+// LAST == true : tile0 = global index of this wave's first tile (selects the output fragments)
+// Output-layer fragments fetched a phase ahead: the first L2A_PFT tiles only (the rest are loaded
+// when the output phase starts and land under the MFMAs of the first tiles) - register budget.
+#define L2A_PFT(TW_, OT_) ((OT_) <= 2 ? ((TW_) < 4 ? (TW_) : 4) : ((TW_) < 2 ? (TW_) : 2))
+
+template <int NT, int TW, int TPW, int OT, bool LAST>
 __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
-                                                const int (&voff)[TPW], const f32x4* hin,
+                                                const int (&voff)[TPW], const int (&voffn)[TPW], int twn,
+                                                int tile0, const f32x4* hin,
                                                 f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
-                                                f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW],
-                                                int wave, int lane) {
+                                                f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW], int lane) {
     constexpr int HT = L2A_NW * TPW;
     static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
-    const int c0 = wave * TPW;
-    f32x4 aC[TPW], aD[TPW], bA[NT], bB[NT], bC[NT], bD[NT];
+    f32x4 aC[TW], aD[TW], bA[NT], bB[NT], bC[NT], bD[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         bA[nt] = hin[(nt * HT + 0) * 64 + lane];
         bB[nt] = hin[(nt * HT + 1) * 64 + lane];
 #pragma unroll
-        for (int tt = 0; tt < TPW; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < TW; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) { L2A_OPAQUE(aA[tt]); L2A_OPAQUE(aB[tt]); }
+    // (the weight buffers come from buffer-load intrinsics, which InstCombine leaves alone; only the
+    // LDS reads are plain loads that it would sink into the loop)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { L2A_OPAQUE(bA[nt]); L2A_OPAQUE(bB[nt]); }
     __builtin_amdgcn_sched_barrier(0);
@@ -152,16 +158,17 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
     L2A_STAGE(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2)
     L2A_STAGE(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1)
     {   // stage 2: consume C; aA is free -> next phase's first operands
-        if (LAST) {     // output layer: fragment (tile c, k-group c0 + tt) -> voff[tt] / HT + c * HT * 1024
+        if (LAST) {     // output layer: A fragment (obs tile c, k-group = hidden tile tile0 + tt)
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt)
+            for (int tt = 0; tt < L2A_PFT(TW, OT); ++tt)
 #pragma unroll
                 for (int c = 0; c < OT; ++c)
                     if (((tt * OT + c) & 1) == 0)
-                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
+                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (tile0 + tt) * 1024, c * HT * 1024);
         } else {
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) aA[tt] = l2a_ldw(rsn, voff[tt], 0);
+            for (int tt = 0; tt < TPW; ++tt)
+                if (tt < twn) aA[tt] = l2a_ldw(rsn, voffn[tt], 0);
         }
         L2A_STAGE_MFMA(aC, bC)
         __builtin_amdgcn_sched_barrier(0);
@@ -169,23 +176,75 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
     {   // stage 3: consume D; aB is free
         if (LAST) {
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt)
+            for (int tt = 0; tt < L2A_PFT(TW, OT); ++tt)
 #pragma unroll
                 for (int c = 0; c < OT; ++c)
                     if (((tt * OT + c) & 1) == 1)
-                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
+                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (tile0 + tt) * 1024, c * HT * 1024);
         } else {
 #pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) aB[tt] = l2a_ldw(rsn, voff[tt] + 1024, 0);
+            for (int tt = 0; tt < TPW; ++tt)
+                if (tt < twn) aB[tt] = l2a_ldw(rsn, voffn[tt] + 1024, 0);
         }
         L2A_STAGE_MFMA(aD, bD)
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
+// Output layer for the TW hidden tiles whose activations `hreg` this wave holds in registers
+// (hidden tile == k-group of the output layer, D fragment == B fragment: no LDS round trip).
+// The K reduction is cut into chunks of TPW / 2 k-groups, each its own MFMA chain, written to
+// pbuf[(chunk * NT + nt) * OT + c]; a full member's wave owns chunks 2w and 2w + 1, a half
+// member's wave owns chunk w of its workgroup's half.  Also launches the next (step, set)'s
+// layer-0 operand loads so that they are in flight across the barrier that follows.
+template <int NT, int TW, int TPW, int OT>
+__device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x4 (&pfO)[TPW][OT],
+                                              __amdgpu_buffer_rsrc_t rs_out, int tile0,
+                                              __amdgpu_buffer_rsrc_t r0n, const int (&voff0)[TPW],
+                                              f32x4 (&pfL0)[TPW], f32x4* pbuf, int chunk0, int lane) {
+    constexpr int HT = L2A_NW * TPW;
+    constexpr int CS = TPW / 2;         // tiles per chunk
+    constexpr int NCH = TW / CS;        // chunks this wave owns (2 = full member, 1 = half member)
+    f32x4 a[TW][OT];
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt)
+#pragma unroll
+        for (int c = 0; c < OT; ++c)
+            a[tt][c] = (tt < L2A_PFT(TW, OT)) ? pfO[tt][c]
+                                              : l2a_ldw(rs_out, lane * 16 + (tile0 + tt) * 1024, c * HT * 1024);
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0n, voff0[tt], 0);     // k-group 0 only
+    f32x4 acc[NCH][NT][OT];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < OT; ++c) acc[ch][nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t2 = 0; t2 < CS; ++t2)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c)
+                        acc[ch][nt][c] = L2A_MFMA(a[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], acc[ch][nt][c]);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < OT; ++c) pbuf[(((chunk0 + ch) * NT + nt) * OT + c) * 64 + lane] = acc[ch][nt][c];
+}
+
 template <int NT, int TPW, int OT, int KG0, bool GACT>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
     constexpr int HT = L2A_NW * TPW;
+    constexpr int TH = TPW / 2;         // tiles per wave of a half member
+    static_assert(TPW % 2 == 0, "half members split a wave's tiles in two");
     // Per-set constants cached in LDS: [in_mu 16 KG0][in_inv 16 KG0][out_mu 16 OT][out_sd 16 OT]
     // [out_bias 16 OT][hidden biases n_hidden x H] - p.cst_set floats per weight set.
     constexpr int CST_BOUT = 32 * KG0 + 32 * OT;
@@ -205,7 +264,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
     const int bid = l2a_logical_wg(blockIdx.x, gridDim.x);
     const int n_pairs = p.m * p.tiles_per_env;
-    const int grp = p.split ? (bid / n_pairs) : 0;          // member group owned by this workgroup
+    const int grp = p.split ? (bid / n_pairs) : 0;          // which of the two workgroups of a tile
     const int pairid = bid - grp * n_pairs;
     const int env = pairid / p.tiles_per_env;
     const int tb = pairid - env * p.tiles_per_env;
@@ -222,11 +281,11 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         row[nt] = env * p.n + (valid[nt] ? cand[nt] : p.n - 1);
     }
 
-    // ---- normalisation vectors of every set this workgroup uses -> LDS --------------------
+    // ---- constants of every set this workgroup uses -> LDS ---------------------------------
     const bool per_block = (p.mode == L2A_MODE_PER_BLOCK);
     const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
     const int e_half = (e_loop + 1) >> 1;                   // group A = [0, e_half), B = [e_half, e_loop)
-    f32x4* xlds = reinterpret_cast<f32x4*>(nrm + e_loop * NRM_SET);   // [NT * OT][64], split only
+    f32x4* xlds = reinterpret_cast<f32x4*>(nrm + e_loop * NRM_SET);   // [2][NT * OT][64], split only
     for (int i = tid; i < e_loop * NRM_SET; i += 64 * L2A_NW) {
         const int s = i / NRM_SET;
         const int o = i - s * NRM_SET;
@@ -286,19 +345,27 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const float e_count = (float)e_loop;
     double disc_pow = 1.0;      // discount ** t, carried in float64 like the reference (:126)
 
-    const int e_first = (p.split && grp == 1) ? e_half : 0;
+    // Which sets this workgroup runs (p.split: 0 = all; 1 = group A | group B; 2 = as 1, but the
+    // last set of group A is SHARED: both workgroups run it as a "half member" - layer 0 and the
+    // inner hidden layers in full, the last hidden layer and the output layer for one half of the
+    // hidden tiles each - which balances odd ensembles and lets a single model use two CUs).
+    const int e_shared = (p.split == 2) ? e_half - 1 : -1;
+    const int e_first = (p.split && grp == 1) ? (p.split == 2 ? e_shared : e_half) : 0;
     const int e_last = (p.split && grp == 0) ? e_half : e_loop;
     auto set_base = [&](int e) { return p.wblk + (long long)(per_block ? env : e) * p.set_stride; };
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
     // barrier that separates them, so a phase never starts with an exposed L2 round trip).
-    f32x4 pfL0[KG0][TPW];       // layer-0 A fragments of the upcoming (step, set)
+    f32x4 pfL0[TPW];            // layer-0 A fragments (k-group 0) of the upcoming (step, set)
     f32x4 pfA[TPW], pfB[TPW];   // k-groups 0 / 1 of the upcoming hidden->hidden layer
     f32x4 pfO[TPW][OT];         // output-layer A fragments of this wave's k-groups
-    int voff[TPW], voff0[TPW];      // this lane's byte offset of tile c0 + tt in a hidden / layer-0 matrix
+    // this lane's byte offset of its tiles in a hidden matrix (full member / half member) and in layer 0
+    int voff[TPW], voffh[TPW], voff0[TPW];
+    const int tile0h = grp * (HT / 2) + wave * TH;          // first tile of this wave in a half member
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         voff[tt] = lane * 16 + (c0 + tt) * HT * 1024;
+        voffh[tt] = lane * 16 + (tile0h + (tt < TH ? tt : 0)) * HT * 1024;
         voff0[tt] = lane * 16 + (c0 + tt) * KG0 * 1024;
     }
     const long long w0_bytes = (long long)HT * KG0 * 1024, wm_bytes = (long long)HT * HT * 1024,
@@ -306,9 +373,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     {
         const __amdgpu_buffer_rsrc_t r0 = l2a_rsrc(set_base(e_first) + p.pk_w0, w0_bytes);
 #pragma unroll
-        for (int g = 0; g < KG0; ++g)
-#pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0, voff0[tt] + g * 1024, 0);
+        for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0, voff0[tt], 0);
     }
 
     for (int t = 0; t < p.h; ++t) {
@@ -328,13 +393,16 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         }
         load_actions((t + 1 < p.h) ? t + 1 : t, av_next);   // prefetch the next step's actions
 
-        f32x4 dsum[NT][OT], dgrp[NT][OT];      // dsum: finished group(s); dgrp: group being summed
+        // dsum: finished group; dgrp: group being summed; qsh: this workgroup's half of the shared
+        // set's raw output sum (split == 2)
+        f32x4 dsum[NT][OT], dgrp[NT][OT], qsh[NT][OT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int c = 0; c < OT; ++c) {
                 dsum[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                qsh[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 
         for (int e = e_first; e < e_last; ++e) {
@@ -347,35 +415,44 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
             }
+            const bool is_half = (e == e_shared);
             const float* wb = set_base(e);
             const float* wb_next = set_base((e + 1 < e_last) ? e + 1 : e_first);   // next (step, set)
             const float* nr = nrm + e * NRM_SET;    // per_block / single: e == 0
             const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
+            const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(wb_next + p.pk_w0, w0_bytes);
 
             f32x4 hreg[NT][TPW];    // activations of the LAST hidden layer (stay in registers)
             L2A_TS(0)
 
             // ---- layer 0: B = normalised [obs | act] built from the state fragment ---------
             {
+                // k-group 0 arrived with the previous phase; the others land under its MFMAs
+                const __amdgpu_buffer_rsrc_t r0 = l2a_rsrc(wb + p.pk_w0, w0_bytes);
                 f32x4 a[KG0][TPW];
 #pragma unroll
                 for (int g = 0; g < KG0; ++g)
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) { a[g][tt] = pfL0[g][tt]; L2A_OPAQUE(a[g][tt]); }
+                    for (int tt = 0; tt < TPW; ++tt)
+                        a[g][tt] = (g == 0) ? pfL0[tt] : l2a_ldw(r0, voff0[tt] + g * 1024, 0);
                 L2A_TS(8)
                 // operands of the phase after this one
                 if (n_hidden == 1) {
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt)
+                    for (int tt = 0; tt < L2A_PFT(TPW, OT); ++tt)
 #pragma unroll
                         for (int c = 0; c < OT; ++c)
                             pfO[tt][c] = l2a_ldw(rs_out, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
                 } else {
                     const __amdgpu_buffer_rsrc_t rs1 = l2a_rsrc(wb + p.pk_wmid, wm_bytes);
+                    const bool next_half = is_half && n_hidden == 2;
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt) {
-                        pfA[tt] = l2a_ldw(rs1, voff[tt], 0);
-                        pfB[tt] = l2a_ldw(rs1, voff[tt] + 1024, 0);
+                        if (tt < TH || !next_half) {
+                            const int vo = next_half ? voffh[tt] : voff[tt];
+                            pfA[tt] = l2a_ldw(rs1, vo, 0);
+                            pfB[tt] = l2a_ldw(rs1, vo + 1024, 0);
+                        }
                     }
                 }
                 f32x4 acc[NT][TPW];
@@ -427,7 +504,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 }
             }
 
-            // ---- hidden -> hidden layers; the last one keeps its output in registers -------
+            // ---- hidden -> hidden layers; the last one keeps its output in registers and feeds
+            //      the output layer directly --------------------------------------------------
             L2A_TS(1)
             if (n_hidden > 1) {
                 __syncthreads();
@@ -435,8 +513,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 f32x4 acc[NT][TPW];
                 for (int l = 1; l < n_hidden - 1; ++l) {
                     const float* wl = wb + p.pk_wmid + (long long)(l - 1) * p.pk_wmid_stride;
-                    l2a_hidden_gemm<NT, TPW, OT, false>(l2a_rsrc(wl, wm_bytes), l2a_rsrc(wl + p.pk_wmid_stride, wm_bytes),
-                                                        voff, hcur, pfA, pfB, pfO, acc, wave, lane);
+                    const bool next_half = is_half && (l == n_hidden - 2);
+                    l2a_hidden_gemm<NT, TPW, TPW, OT, false>(l2a_rsrc(wl, wm_bytes), l2a_rsrc(wl + p.pk_wmid_stride, wm_bytes),
+                                                             voff, next_half ? voffh : voff, next_half ? TH : TPW, 0,
+                                                             hcur, pfA, pfB, pfO, acc, lane);
                     const float* bl = nr + CST_BHID + l * (16 * HT);
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt) {
@@ -448,73 +528,65 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     __syncthreads();
                     f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
                 }
-                l2a_hidden_gemm<NT, TPW, OT, true>(
-                    l2a_rsrc(wb + p.pk_wmid + (long long)(n_hidden - 2) * p.pk_wmid_stride, wm_bytes), rs_out, voff,
-                    hcur, pfA, pfB, pfO, acc, wave, lane);
+                const __amdgpu_buffer_rsrc_t rs_last =
+                    l2a_rsrc(wb + p.pk_wmid + (long long)(n_hidden - 2) * p.pk_wmid_stride, wm_bytes);
                 const float* bl = nr + CST_BHID + (n_hidden - 1) * (16 * HT);
+                if (!is_half) {
+                    l2a_hidden_gemm<NT, TPW, TPW, OT, true>(rs_last, rs_out, voff, voff, TPW, c0, hcur, pfA, pfB, pfO,
+                                                            acc, lane);
 #pragma unroll
-                for (int tt = 0; tt < TPW; ++tt) {
-                    const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
-                }
-            }
-
-            L2A_TS(3)
-            // ---- output layer, fused: this wave's hidden tiles ARE its share of K -----------
-            // (hidden tile c0 + tt of the last hidden layer == k-group c0 + tt of the output layer,
-            // and its D fragment is the B fragment: no LDS round trip, no barrier in between)
-            {
-                f32x4 a[TPW][OT];
-#pragma unroll
-                for (int tt = 0; tt < TPW; ++tt)
-#pragma unroll
-                    for (int c = 0; c < OT; ++c) { a[tt][c] = pfO[tt][c]; L2A_OPAQUE(a[tt][c]); }
-                {   // layer-0 operands of the next (step, set): in flight across the barrier below
-                    const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(wb_next + p.pk_w0, w0_bytes);
-#pragma unroll
-                    for (int g = 0; g < KG0; ++g)
-#pragma unroll
-                        for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0n, voff0[tt] + g * 1024, 0);
-                }
-                f32x4 acc[NT][OT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int c = 0; c < OT; ++c) acc[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int tt = 0; tt < TPW; ++tt)
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
+                    for (int tt = 0; tt < TPW; ++tt) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
+                            hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                    }
+                    L2A_TS(3)
+                    l2a_out_phase<NT, TPW, TPW, OT>(hreg, pfO, rs_out, c0, r0n, voff0, pfL0, hoth, 2 * wave, lane);
+                } else {
+                    l2a_hidden_gemm<NT, TH, TPW, OT, true>(rs_last, rs_out, voffh, voffh, TH, tile0h, hcur, pfA, pfB,
+                                                           pfO, acc, lane);
 #pragma unroll
-                            for (int c = 0; c < OT; ++c)
-                                acc[nt][c] = L2A_MFMA(a[tt][c][ii], hreg[nt][tt][ii], acc[nt][c]);
-                // partial of wave w, tile (nt, c) -> hoth[((w * NT + nt) * OT + c) * 64 + lane]
+                    for (int tt = 0; tt < TH; ++tt) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (tile0h + tt) + 4 * qq);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int c = 0; c < OT; ++c)
-                        hoth[((wave * NT + nt) * OT + c) * 64 + lane] = acc[nt][c];
+                        for (int nt = 0; nt < NT; ++nt)
+                            hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                    }
+                    L2A_TS(3)
+                    l2a_out_phase<NT, TH, TPW, OT>(hreg, pfO, rs_out, tile0h, r0n, voff0, pfL0, hoth, wave, lane);
+                }
+            } else {
+                L2A_TS(3)
+                l2a_out_phase<NT, TPW, TPW, OT>(hreg, pfO, rs_out, c0, r0n, voff0, pfL0, hoth, 2 * wave, lane);
             }
             L2A_TS(4)
             __syncthreads();
             L2A_TS(5)
             {
+                // Sum the chunk partials in the canonical order ((c0+c1)+c2)+c3 [+ ((c4+c5)+c6)+c7].
+                // A half member holds only its own four chunks; the other four arrive at the end of
+                // the step from the partner workgroup.
 #pragma unroll
                 for (int c = 0; c < OT; ++c) {
-                    const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BOUT + 16 * c + 4 * qq);
-                    const f32x4 omu = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * c + 4 * qq);
-                    const f32x4 osd = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         f32x4 s = hoth[((0 * NT + nt) * OT + c) * 64 + lane];
 #pragma unroll
                         for (int w = 1; w < L2A_NW; ++w) s += hoth[((w * NT + nt) * OT + c) * 64 + lane];
-                        s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
-                        dgrp[nt][c] += s * osd + omu;
+                        if (is_half) {
+                            qsh[nt][c] = s;
+                        } else {
+                            f32x4 s2 = hoth[((L2A_NW * NT + nt) * OT + c) * 64 + lane];
+#pragma unroll
+                            for (int w = 1; w < L2A_NW; ++w) s2 += hoth[(((L2A_NW + w) * NT + nt) * OT + c) * 64 + lane];
+                            s += s2;
+                            const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BOUT + 16 * c + 4 * qq);
+                            const f32x4 omu = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * c + 4 * qq);
+                            const f32x4 osd = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
+                            s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
+                            dgrp[nt][c] += s * osd + omu;
+                        }
                     }
                 }
             }
@@ -527,40 +599,55 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             L2A_TS(6)
         }
 
-    // ---- combine the two member groups ------------------------------------------------
+        // ---- combine the two workgroups of a tile ---------------------------------------------
+        { const int e = 7; L2A_TS(9) }
         if (p.split) {
-            // publish this workgroup's group sum, fetch the partner's (same lane layout)
+            // publish this workgroup's group sum (+ its half of the shared set), fetch the partner's
             const unsigned int tag = p.xtag + (unsigned int)(t + 1);
-            constexpr int XG = NT * OT * 4 * 64;    // granules per (pair, group, slot)
+            constexpr int XG = 2 * NT * OT * 4 * 64;    // granules per (pair, group, slot)
+            const int nx = (p.split == 2) ? 2 : 1;
             unsigned long long* xown = p.xbuf + ((long long)(pairid * 2 + grp) * 2 + (t & 1)) * XG + lane;
             unsigned long long* xoth = p.xbuf + ((long long)(pairid * 2 + (grp ^ 1)) * 2 + (t & 1)) * XG + lane;
             if (wave == 0) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int c = 0; c < OT; ++c)
-#pragma unroll
-                        for (int ii = 0; ii < 4; ++ii) {
-                            const unsigned long long g = ((unsigned long long)tag << 32) |
-                                                         (unsigned long long)__float_as_uint(dgrp[nt][c][ii]);
-                            __hip_atomic_store(xown + ((nt * OT + c) * 4 + ii) * 64, g, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                f32x4 oth[NT][OT];
-                unsigned int spins = 0;
-                while (true) {
-                    bool ok = true;
+                for (int k = 0; k < 2; ++k)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int c = 0; c < OT; ++c)
 #pragma unroll
                             for (int ii = 0; ii < 4; ++ii) {
-                                const unsigned long long g = __hip_atomic_load(
-                                    xoth + ((nt * OT + c) * 4 + ii) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                oth[nt][c][ii] = __uint_as_float((unsigned int)g);
-                                ok = ok && ((unsigned int)(g >> 32) == tag);
+                                if (k < nx) {
+                                    const float v = k ? qsh[nt][c][ii] : dgrp[nt][c][ii];
+                                    const unsigned long long g = ((unsigned long long)tag << 32) |
+                                                                 (unsigned long long)__float_as_uint(v);
+                                    __hip_atomic_store(xown + (((k * NT + nt) * OT + c) * 4 + ii) * 64, g,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
                             }
+                { const int e = 7; L2A_TS(11) }
+                f32x4 oth[2][NT][OT];
+                unsigned int spins = 0;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+#pragma unroll
+                                for (int ii = 0; ii < 4; ++ii) {
+                                    if (k < nx) {
+                                        const unsigned long long g = __hip_atomic_load(
+                                            xoth + (((k * NT + nt) * OT + c) * 4 + ii) * 64, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+                                        oth[k][nt][c][ii] = __uint_as_float((unsigned int)g);
+                                        ok = ok && ((unsigned int)(g >> 32) == tag);
+                                    } else {
+                                        oth[k][nt][c][ii] = 0.0f;
+                                    }
+                                }
                     if (__all(ok)) break;
                     if (++spins > (1u << 22)) {     // partner never arrived: flag it, do not hang
                         if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -569,20 +656,42 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     __builtin_amdgcn_s_sleep(8);
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int c = 0; c < OT; ++c) xlds[(nt * OT + c) * 64 + lane] = oth[nt][c];
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c) xlds[((k * NT + nt) * OT + c) * 64 + lane] = oth[k][nt][c];
+                { const int e = 7; L2A_TS(12) }
+                if (p.dbg && pairid == 0 && lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + 7) * 8 + wave) * 16 + 14] = spins;
             }
+            { const int e = 7; L2A_TS(10) }
             __syncthreads();
+            { const int e = 7; L2A_TS(13) }
+            const float* nrs = nrm + (e_shared < 0 ? 0 : e_shared) * NRM_SET;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int c = 0; c < OT; ++c) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(nrs + CST_BOUT + 16 * c + 4 * qq);
+                const f32x4 omu = *reinterpret_cast<const f32x4*>(nrs + 32 * KG0 + 16 * c + 4 * qq);
+                const f32x4 osd = *reinterpret_cast<const f32x4*>(nrs + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
 #pragma unroll
-                for (int c = 0; c < OT; ++c) dsum[nt][c] = xlds[(nt * OT + c) * 64 + lane];
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 og = xlds[((0 * NT + nt) * OT + c) * 64 + lane];      // partner's group sum
+                    f32x4 ga = (grp == 0) ? dgrp[nt][c] : og;                          // group A (without the shared set)
+                    const f32x4 gb = (grp == 0) ? og : dgrp[nt][c];                    // group B
+                    if (p.split == 2) {
+                        f32x4 s = qsh[nt][c] + xlds[((1 * NT + nt) * OT + c) * 64 + lane];   // S1 + S2
+                        s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
+                        ga += s * osd + omu;        // the shared set is the last member of group A
+                    }
+                    dsum[nt][c] = ga;
+                    dgrp[nt][c] = gb;
+                }
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int c = 0; c < OT; ++c) dsum[nt][c] += dgrp[nt][c];     // A + B (commutative)
+            for (int c = 0; c < OT; ++c) dsum[nt][c] += dgrp[nt][c];     // group A + group B
 
         // ---- ensemble mean, reward, state update -------------------------------------------
         const float disc_t = (float)disc_pow;

@@ -137,7 +137,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
         return dst
 
     ret = np.zeros((NW, NT, 64), dtype=F32)
-    sa = max(NT * HT, NW * NT * OT)
+    sa = max(NT * HT, 2 * NW * NT * OT)
     lds = [np.zeros((sa, 64, 4), dtype=F32), np.zeros((sa, 64, 4), dtype=F32)]
     cur = 0
     disc_pow = 1.0
@@ -207,20 +207,22 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                 # barrier + swap
                 cur ^= 1
                 hcur, hoth = lds[cur], lds[cur ^ 1]
-            # ---- output layer: K split over waves ----
+            # ---- output layer: K cut into 2 * NW chunks of TPW / 2 k-groups (canonical order) ----
+            CS = TPW // 2
             for wave in range(NW):
-                acc = np.zeros((NT, OT, 64, 4), dtype=F32)
-                for gi in range(TPW):
-                    g = wave * TPW + gi
-                    for ii in range(4):
-                        for nt in range(NT):
-                            b = hcur[nt * HT + g][:, ii]
-                            for c in range(OT):
-                                a = ps.wout[c * HT + g, :, ii]
-                                acc[nt, c] = mfma_16x16x4(a, b, acc[nt, c])
-                for nt in range(NT):
-                    for c in range(OT):
-                        hoth[(wave * NT + nt) * OT + c] = acc[nt, c]
+                for ch in range(2):
+                    acc = np.zeros((NT, OT, 64, 4), dtype=F32)
+                    for t2 in range(CS):
+                        g = wave * TPW + ch * CS + t2
+                        for ii in range(4):
+                            for nt in range(NT):
+                                b = hcur[nt * HT + g][:, ii]
+                                for c in range(OT):
+                                    a = ps.wout[c * HT + g, :, ii]
+                                    acc[nt, c] = mfma_16x16x4(a, b, acc[nt, c])
+                    for nt in range(NT):
+                        for c in range(OT):
+                            hoth[((2 * wave + ch) * NT + nt) * OT + c] = acc[nt, c]
             # barrier
             for wave in range(NW):
                 for c in range(OT):
@@ -228,9 +230,13 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                     omu = ps.out_mu[16 * c + 4 * QQ[:, None] + np.arange(4)[None, :]]
                     osd = ps.out_sd[16 * c + 4 * QQ[:, None] + np.arange(4)[None, :]]
                     for nt in range(NT):
-                        s = np.array(hoth[(0 * NT + nt) * OT + c])
+                        s1 = np.array(hoth[(0 * NT + nt) * OT + c])
                         for w in range(1, NW):
-                            s = (s + hoth[(w * NT + nt) * OT + c]).astype(F32)
+                            s1 = (s1 + hoth[(w * NT + nt) * OT + c]).astype(F32)
+                        s2 = np.array(hoth[(NW * NT + nt) * OT + c])
+                        for w in range(1, NW):
+                            s2 = (s2 + hoth[((NW + w) * NT + nt) * OT + c]).astype(F32)
+                        s = (s1 + s2).astype(F32)
                         s = act4((s + bias).astype(F32), output_act)
                         dgrp[wave, nt, c] = (dgrp[wave, nt, c] + (s * osd + omu).astype(F32)).astype(F32)
             # (no barrier; `cur` is NOT flipped: the next layer 0 writes the region it just read)

@@ -164,29 +164,63 @@ def test_mfma_and_valu_kernels_agree():
     assert np.array_equal(k1 & 0x7FFFFFFF, k2 & 0x7FFFFFFF)          # same winner
 
 
-def test_member_split_is_bit_identical_to_single_workgroup():
-    """Config 2 has 125 candidate tiles: by default two workgroups share each tile (ensemble
-    members 0-2 | 3-4) and swap partial delta sums every horizon step.  Disabling the split must
-    not change a single bit, and repeated split launches must be deterministic."""
+SPLIT_CASES = [
+    # name, overrides - every flavour of the tile split: odd ensemble (shared middle set), even
+    # ensemble (whole sets), single model (the only set is shared), 3 hidden layers (inner layers
+    # run in full on both workgroups), 1 hidden layer (whole sets only), two envs.
+    ("c2_hc_rs_n2000_h30_e5", {}),
+    ("c1_hc_rs_n500_h10_e1", {}),
+    ("hc_rs_m2_n100_h7_e2", {}),
+    ("hc_rs_m3_n64_h5", {}),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[256, 256, 256], E=3, n=300, h=6)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128], E=3, n=200, h=5)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128], E=1, n=200, h=5)),
+    ("ant_rs_n300_h6_e3", {}),
+]
+
+
+@pytest.mark.parametrize("name,over", SPLIT_CASES)
+def test_tile_split_is_bit_identical_to_single_workgroup(name, over):
+    """Two workgroups per candidate tile (policy 1: shared middle set; policy 2: whole sets) must
+    reproduce the one-workgroup launch (policy 0) bit for bit, deterministically, and agree with
+    the oracle."""
+    case = dict(cases.CASES[name], **over)
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    a = _rs_actions(case, 1, env)
+    obs0 = np.random.RandomState(11).randn(case["m"], env.observation_space.shape[0])
+    ctx = _lib.Context.get(0)
+    out = {}
+    try:
+        for policy in (1, 2, 0):
+            ctx.set_split(policy)
+            r1, k1 = _plan_returns(native, case, env, obs0, a)
+            r2, k2 = _plan_returns(native, case, env, obs0, a)
+            ctx.launch_status()
+            assert np.array_equal(r1, r2) and np.array_equal(k1, k2)
+            out[policy] = (r1, k1)
+    finally:
+        ctx.set_split(1)
+    for policy in (1, 2):
+        assert np.array_equal(out[policy][0], out[0][0]), "policy %d differs from the unsplit launch" % policy
+        assert np.array_equal(out[policy][1], out[0][1])
+    from oracle import make_reward
+    from oracle.planner import rollout_returns
+    want = rollout_returns(cases.oracle_dynamics(case), make_reward(case["env"], env.dt), obs0, a, case["n"],
+                           case.get("discount", 1.0)).reshape(case["m"], case["n"])
+    assert rel_err(out[1][0], want) < RTOL
+
+
+def test_split_survives_stale_tags_of_short_launches():
+    """h = 1 and h = 2 launches leave low tags in the exchange buffer; later launches must not
+    mistake them for fresh data."""
     case = cases.CASES["c2_hc_rs_n2000_h30_e5"]
     env, model = cases.product_model(case)
     native = model.planner_model()
     a = _rs_actions(case, 1, env)
     obs0 = cases.load_golden("c2_hc_rs_n2000_h30_e5_s1")["obs0"]
     ctx = _lib.Context.get(0)
-    try:
-        ctx.set_split(1)
-        r_split, k_split = _plan_returns(native, case, env, obs0, a)
-        r_again, k_again = _plan_returns(native, case, env, obs0, a)
-        ctx.launch_status()
-        ctx.set_split(0)
-        r_one, k_one = _plan_returns(native, case, env, obs0, a)
-    finally:
-        ctx.set_split(1)
-    assert np.array_equal(r_split, r_again) and np.array_equal(k_split, k_again)
-    assert np.array_equal(r_split, r_one) and np.array_equal(k_split, k_one)
-    # h = 1 and h = 2 launches leave low tags behind; a following launch must not be fooled
-    for hh in (1, 2, 3):
+    for hh in (1, 2, 3, 1, 30, 2):
         c = dict(case, h=hh)
         r1, _ = _plan_returns(native, c, env, obs0, a[:hh])
         r2, _ = _plan_returns(native, c, env, obs0, a[:hh])

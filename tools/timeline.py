@@ -58,3 +58,26 @@ for grp, members in ((0, (0, 1, 2)), (1, (3, 4))):
     last_end = d[grp, :, 7, 0, 7] - d[grp, :, members[-1], 0, 6]
     print("  step period: median %d clk (min %d max %d); set-loop-end -> step end (exchange+reward) %d clk"
           % (np.median(step), step.min(), step.max(), np.median(last_end)))
+
+print("\nper-step schedule, wave 0 (clocks since the step began; median over steps 2..):")
+for grp in (0, 1):
+    sets = [e for e in range(8) if d[grp, 5, e, 0, 0] != 0 and e != 7]
+    t_end_prev = d[grp, 1:-1, 7, 0, 7]                      # end of the previous step
+    line = []
+    for e in sets:
+        for slot, nm in ((0, "start"), (1, "L0"), (3, "gemm"), (4, "out"), (6, "red")):
+            line.append("s%d.%s %6.0f" % (e, nm, np.median(d[grp, 2:, e, 0, slot] - t_end_prev)))
+    line.append("step.end %6.0f" % np.median(d[grp, 2:, 7, 0, 7] - t_end_prev))
+    print("  group %d: " % grp + "  ".join(line))
+
+print("\nexchange (wave 0, clocks since the last set's reduce ended; median over steps 2..):")
+for grp in (0, 1):
+    sets = [e for e in range(8) if d[grp, 5, e, 0, 0] != 0 and e != 7]
+    base = d[grp, 2:, sets[-1], 0, 6]
+    x = d[grp, 2:, 7, 0, :]
+    print("  group %d: enter %5.0f  published %5.0f  swept %5.0f (sweeps: median %d max %d)  wave0@barrier %5.0f  past barrier %5.0f  step end %5.0f"
+          % (grp, np.median(x[:, 9] - base), np.median(x[:, 11] - base), np.median(x[:, 12] - base),
+             np.median(x[:, 14]) + 1, x[:, 14].max() + 1, np.median(x[:, 10] - base), np.median(x[:, 13] - base),
+             np.median(x[:, 7] - base)))
+    w = d[grp, 2:, 7, :4, 10] - base[:, None]
+    print("           waves reach the post-exchange barrier at", np.median(w, axis=0).astype(int).tolist())
