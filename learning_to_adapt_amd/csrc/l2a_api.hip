@@ -162,7 +162,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             else if (e_loop >= 2) p.split = 1;
         }
         if (p.split) {
-            const long long need = pairs * 2 * 2 * (long long)(2 * nt * md->OT * 4 * 64);
+            const long long need = pairs * 2 * 2 * 2 * (long long)(nt * md->OT * 2 * 64 * 16) / 8;   // in 8-byte units
             if (need > md->xbuf_granules) {
                 if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
                 L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));

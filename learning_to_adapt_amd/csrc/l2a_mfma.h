@@ -122,7 +122,7 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
 // LAST == true : tile0 = global index of this wave's first tile (selects the output fragments)
 // Output-layer fragments fetched a phase ahead: the first L2A_PFT tiles only (the rest are loaded
 // when the output phase starts and land under the MFMAs of the first tiles) - register budget.
-#define L2A_PFT(TW_, OT_) ((OT_) <= 2 ? ((TW_) < 4 ? (TW_) : 4) : ((TW_) < 2 ? (TW_) : 2))
+#define L2A_PFT(TW_, OT_) ((OT_) <= 2 ? ((TW_) < 6 ? (TW_) : 6) : ((TW_) < 2 ? (TW_) : 2))
 
 template <int NT, int TW, int TPW, int OT, bool LAST>
 __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
@@ -349,10 +349,15 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     // last set of group A is SHARED: both workgroups run it as a "half member" - layer 0 and the
     // inner hidden layers in full, the last hidden layer and the output layer for one half of the
     // hidden tiles each - which balances odd ensembles and lets a single model use two CUs).
+    // Both workgroups run their full sets first and the shared one last, so the group sums of
+    // the full sets can be published (and travel) while the half set is still being computed.
     const int e_shared = (p.split == 2) ? e_half - 1 : -1;
-    const int e_first = (p.split && grp == 1) ? (p.split == 2 ? e_shared : e_half) : 0;
-    const int e_last = (p.split && grp == 0) ? e_half : e_loop;
+    const int n_full = !p.split ? e_loop : (grp == 0 ? e_half - (p.split == 2 ? 1 : 0) : e_loop - e_half);
+    const int n_seq = n_full + (p.split == 2 ? 1 : 0);
+    const int full0 = (p.split && grp == 1) ? e_half : 0;       // first full set of this workgroup
+    auto seq = [&](int i) { return (i < n_full) ? full0 + i : e_shared; };
     auto set_base = [&](int e) { return p.wblk + (long long)(per_block ? env : e) * p.set_stride; };
+    const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, p.split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
     // barrier that separates them, so a phase never starts with an exposed L2 round trip).
@@ -371,7 +376,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const long long w0_bytes = (long long)HT * KG0 * 1024, wm_bytes = (long long)HT * HT * 1024,
                     wo_bytes = (long long)OT * HT * 1024;
     {
-        const __amdgpu_buffer_rsrc_t r0 = l2a_rsrc(set_base(e_first) + p.pk_w0, w0_bytes);
+        const __amdgpu_buffer_rsrc_t r0 = l2a_rsrc(set_base(seq(0)) + p.pk_w0, w0_bytes);
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0, voff0[tt], 0);
     }
@@ -405,7 +410,45 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 qsh[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 
-        for (int e = e_first; e < e_last; ++e) {
+        // Exchange records (split): region 0 = group sum of the full sets, region 1 = this half of
+        // the shared set's raw output sum.  A value v of lane l travels as 16-byte self-validating
+        // granules {tag, v.x, tag, v.y} {tag, v.z, tag, v.w}: write-through (sc1) stores, sc1 loads,
+        // no flag and no fence - a granule is accepted when its tags match (G16 recipe R2).
+        const unsigned int xtag = p.xtag + (unsigned int)(t + 1);
+        constexpr int XREG = NT * OT * 2 * 64 * 16;             // bytes per region
+        auto xbase = [&](int g, int region) { return (((pairid * 2 + g) * 2 + (t & 1)) * 2 + region) * XREG + lane * 16; };
+        auto xput = [&](int region, const f32x4 (&v)[NT][OT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        u32x4 g;
+                        g.x = xtag; g.y = __float_as_uint(v[nt][c][2 * hh]);
+                        g.z = xtag; g.w = __float_as_uint(v[nt][c][2 * hh + 1]);
+                        __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, 16);
+                    }
+        };
+        auto xget = [&](int region, f32x4 (&v)[NT][OT]) {
+            bool ok = true;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(
+                            xrs, xbase(grp ^ 1, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, 16);
+                        v[nt][c][2 * hh] = __uint_as_float(g.y);
+                        v[nt][c][2 * hh + 1] = __uint_as_float(g.w);
+                        ok = ok && (g.x == xtag) && (g.z == xtag);
+                    }
+            return ok;
+        };
+
+        for (int i = 0; i < n_seq; ++i) {
+            const int e = seq(i);
             if (e == e_half && !p.split) {      // group A complete: park it, start group B
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -417,7 +460,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             }
             const bool is_half = (e == e_shared);
             const float* wb = set_base(e);
-            const float* wb_next = set_base((e + 1 < e_last) ? e + 1 : e_first);   // next (step, set)
+            const float* wb_next = set_base(seq((i + 1 < n_seq) ? i + 1 : 0));      // next (step, set)
             const float* nr = nrm + e * NRM_SET;    // per_block / single: e == 0
             const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
             const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(wb_next + p.pk_w0, w0_bytes);
@@ -596,64 +639,38 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             // finished these reads by then).  n_hidden == 1: there is no layer-0 barrier, the next
             // partial sums would land in `hoth` while slow waves still read it -> alternate regions.
             if (n_hidden == 1) { f32x4* tmp = hcur; hcur = hoth; hoth = tmp; }
+            if (p.split == 2 && i == n_full - 1 && wave == 0) xput(0, dgrp);   // travels under the half set
             L2A_TS(6)
         }
 
         // ---- combine the two workgroups of a tile ---------------------------------------------
         { const int e = 7; L2A_TS(9) }
         if (p.split) {
-            // publish this workgroup's group sum (+ its half of the shared set), fetch the partner's
-            const unsigned int tag = p.xtag + (unsigned int)(t + 1);
-            constexpr int XG = 2 * NT * OT * 4 * 64;    // granules per (pair, group, slot)
-            const int nx = (p.split == 2) ? 2 : 1;
-            unsigned long long* xown = p.xbuf + ((long long)(pairid * 2 + grp) * 2 + (t & 1)) * XG + lane;
-            unsigned long long* xoth = p.xbuf + ((long long)(pairid * 2 + (grp ^ 1)) * 2 + (t & 1)) * XG + lane;
             if (wave == 0) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int c = 0; c < OT; ++c)
-#pragma unroll
-                            for (int ii = 0; ii < 4; ++ii) {
-                                if (k < nx) {
-                                    const float v = k ? qsh[nt][c][ii] : dgrp[nt][c][ii];
-                                    const unsigned long long g = ((unsigned long long)tag << 32) |
-                                                                 (unsigned long long)__float_as_uint(v);
-                                    __hip_atomic_store(xown + (((k * NT + nt) * OT + c) * 4 + ii) * 64, g,
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                            }
+                if (p.split == 2) xput(1, qsh);
+                else xput(0, dgrp);
                 { const int e = 7; L2A_TS(11) }
                 f32x4 oth[2][NT][OT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) {
+                        oth[0][nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        oth[1][nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                // single model (E == 1): there are no full sets, region 0 is never written - skip it
+                const bool want0 = (p.split == 1) || (e_loop > 1);
                 unsigned int spins = 0;
                 while (true) {
                     bool ok = true;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                            for (int c = 0; c < OT; ++c)
-#pragma unroll
-                                for (int ii = 0; ii < 4; ++ii) {
-                                    if (k < nx) {
-                                        const unsigned long long g = __hip_atomic_load(
-                                            xoth + (((k * NT + nt) * OT + c) * 4 + ii) * 64, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-                                        oth[k][nt][c][ii] = __uint_as_float((unsigned int)g);
-                                        ok = ok && ((unsigned int)(g >> 32) == tag);
-                                    } else {
-                                        oth[k][nt][c][ii] = 0.0f;
-                                    }
-                                }
+                    if (p.split == 2) ok = xget(1, oth[1]);
+                    if (want0 && __all(ok)) ok = xget(0, oth[0]);
                     if (__all(ok)) break;
                     if (++spins > (1u << 22)) {     // partner never arrived: flag it, do not hang
                         if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(4);
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
