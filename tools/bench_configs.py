@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Kernel-only timings of every BASELINE.json config (and kernel / split variants of config 2)
+on ONE MI355X.  Developer report that feeds DESIGN.md; the contract benchmark is bench.py.
+
+    python tools/bench_configs.py > profiles/rNN_configs.jsonl
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+from learning_to_adapt_amd import _lib  # noqa: E402
+
+PEAK = 157.3
+
+
+def flops(case, env):
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    sizes = [od + ad] + list(case["hidden"]) + [od]
+    mac = sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
+    e_eff = case["E"] if case["mode"] == "mean" else 1
+    return 2.0 * mac * e_eff * case["n"] * case["m"] * case["h"]
+
+
+def time_plan(native, case, env, reps=30, split=None, kernel="auto"):
+    ctx = _lib.Context.get(0)
+    ctx.set_kernel(kernel)
+    if split is not None:
+        ctx.set_split(split)
+    dev = native.device
+    m, n, h = case["m"], case["n"], case["h"]
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    obs0 = torch.randn((m, od), device=dev)
+    low = torch.as_tensor(env.action_space.low, dtype=torch.float32, device=dev)
+    high = torch.as_tensor(env.action_space.high, dtype=torch.float32, device=dev)
+    a = torch.rand((h, m * n, ad), device=dev) * (high - low) + low
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    for _ in range(3):
+        native.plan_rs(obs0, a, m, n, h, case.get("discount", 1.0), env.reward_spec, best_key=best)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in evs:
+        s.record()
+        native.plan_rs(obs0, a, m, n, h, case.get("discount", 1.0), env.reward_spec, best_key=best)
+        e.record()
+    torch.cuda.synchronize()
+    ctx.launch_status()
+    ctx.set_kernel("auto")
+    ctx.set_split(1)
+    return float(np.median([s.elapsed_time(e) for s, e in evs]))
+
+
+def report(tag, case, env, ms, **extra):
+    fl = flops(case, env)
+    row = dict(config=tag, n=case["n"], h=case["h"], m=case["m"], E=case["E"], mode=case["mode"],
+               hidden=case["hidden"], kernel_ms=round(ms, 4), plan_steps_per_s=round(1e3 / ms, 2),
+               tflops=round(fl / ms / 1e9, 2), frac_fp32_peak=round(fl / ms / 1e9 / PEAK, 4),
+               mlp_steps_per_ms=round(case["n"] * case["m"] * case["h"] *
+                                      (case["E"] if case["mode"] == "mean" else 1) / ms, 1))
+    row.update(extra)
+    print(json.dumps(row), flush=True)
+
+
+def main():
+    C = cases.CASES
+    # config 2 under every policy / kernel
+    case = C["c2_hc_rs_n2000_h30_e5"]
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    for split, name in ((1, "shared-set split (default)"), (2, "whole-set split"), (0, "one workgroup per tile")):
+        report("config 2, MFMA kernel, " + name, case, env, time_plan(native, case, env, split=split))
+    report("config 2, VALU kernel (fp32 FMA, no matrix cores)", case, env, time_plan(native, case, env, reps=5, kernel="valu"))
+    # config 1 shape on the GPU (the reference's CPU-runnable case)
+    for name in ("c1_hc_rs_n500_h10_e1", "c3_ant_rs_n2000_h20_pb5", "c3b_ant_rs_n500_h10_pb5_3x512",
+                 "c4_hc_rs_n16000_h30_e5"):
+        case = C[name]
+        env, model = cases.product_model(case)
+        report(name + " (single GPU)", case, env, time_plan(model.planner_model(), case, env))
+    # GrBAL default shape: 3 x 512, n = 2000, h = 20, 5 adapted sets
+    case = dict(C["c3_ant_rs_n2000_h20_pb5"], hidden=[512, 512, 512])
+    env, model = cases.product_model(case)
+    report("config 3 with the run_grbal.py default 3x512 network", case, env, time_plan(model.planner_model(), case, env))
+    # config 5: one CEM plan step (5 iterations x 4000 candidates) through the drop-in controller
+    case = C["c5_hc_cem_n4000_h30_e5"]
+    ctrl = cases.product_controller(case)
+    gold = cases.load_golden("c5_hc_cem_n4000_h30_e5_s0")
+    np.random.seed(0)
+    ctrl.get_actions(gold["obs0"])
+    t0 = time.perf_counter()
+    k = 3
+    for _ in range(k):
+        ctrl.get_actions(gold["obs0"])
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / k
+    env, model = cases.product_model(case)
+    one = dict(case, n=4000)
+    k_ms = time_plan(model.planner_model(), one, env)
+    report("config 5: CEM rollout kernel, one iteration (n=4000)", one, env, k_ms,
+           cem_plan_step_ms_end_to_end_host_rng=round(ms, 2), cem_iters=5,
+           note="end-to-end includes 5 x np.random.normal(720k) + clip + elite statistics on the host")
+    # host<->device inclusive: get_actions through the controller (parity mode: host MT19937 + H2D per step)
+    case = C["c2_hc_rs_n2000_h30_e5"]
+    for mode in ("numpy", "device"):
+        ctrl = cases.product_controller(case, rng=mode)
+        gold = cases.load_golden("c2_hc_rs_n2000_h30_e5_s0")
+        ctrl.get_actions(gold["obs0"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            ctrl.get_actions(gold["obs0"])
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 30
+        print(json.dumps(dict(config="config 2 end to end through MPCController.get_actions, rng=" + mode,
+                              ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
