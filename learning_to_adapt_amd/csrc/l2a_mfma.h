@@ -35,6 +35,8 @@
 // (hidden width = 16 * L2A_NW * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16).
 #pragma once
 
+#include <type_traits>
+
 #include "l2a_kernels.h"
 
 // Waves per workgroup.  4 = one wave per SIMD: a lone wave issues its MFMAs back to back (32
@@ -101,7 +103,7 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
 #define L2A_STAGE_MFMA(CA, CB)                                                             \
     _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                       \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
-            _Pragma("unroll") for (int tt = 0; tt < TW; ++tt)                              \
+            _Pragma("unroll") for (int tt = TW - 1; tt >= 0; --tt)   /* last-loaded tile first: one vmcnt wait per stage */ \
                 acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);
 
 #define L2A_STAGE(CA, CB, FA, FB, SOFF, IMM, GF)                                           \
@@ -111,6 +113,12 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
             FB[nt] = hin[(nt * HT + (GF)) * 64 + lane];                                    \
         L2A_STAGE_MFMA(CA, CB)                                                             \
+        /* interleave: one weight load per 4 NT MFMAs (8 back-to-back VMEM issues stall the pipe) */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);                                \
+        _Pragma("unroll") for (int tt = 0; tt < TW; ++tt) {                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                        \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                             \
+        }                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }
 
@@ -232,6 +240,23 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
 #pragma unroll
                     for (int c = 0; c < OT; ++c)
                         acc[ch][nt][c] = L2A_MFMA(a[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], acc[ch][nt][c]);
+    // issue order hint: the late output fragments first (one per 4 MFMAs), then the next layer-0
+    // operands spread over the remaining MFMAs - 8 VMEM issues in a row would idle the matrix pipe
+    {
+        constexpr int NLATE = (TW - L2A_PFT(TW, OT)) * OT;
+        constexpr int NMFMA = TW * 4 * NT * OT;
+#pragma unroll
+        for (int i = 0; i < NLATE; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        constexpr int PER = (NMFMA - 2 * NLATE) / TPW > 0 ? (NMFMA - 2 * NLATE) / TPW : 1;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -479,6 +504,52 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     for (int tt = 0; tt < TPW; ++tt)
                         a[g][tt] = (g == 0) ? pfL0[tt] : l2a_ldw(r0, voff0[tt] + g * 1024, 0);
                 L2A_TS(8)
+                f32x4 acc[NT][TPW];
+                // layer-0 MFMAs; called from both branches below so that each branch's operand
+                // prefetch shares a basic block with them and can be interleaved (NPF loads)
+                auto l0_mfma = [&](auto npf_tag) {
+                    constexpr int NPF = decltype(npf_tag)::value;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int tt = 0; tt < TPW; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int g = 0; g < KG0; ++g) {
+                        const f32x4 mu = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
+                        const f32x4 iv = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
+                        f32x4 x[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (g < OT) sv = st[nt][g < OT ? g : 0];
+                            f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (g == ga0) aa = av[nt][0];
+                            if (g == ga0 + 1) aa = av[nt][1];
+#pragma unroll
+                            for (int ii = 0; ii < 4; ++ii) {
+                                const int k = 16 * g + 4 * qq + ii;
+                                const float v = (k < obs_dim) ? sv[ii] : aa[ii];
+                                x[nt][ii] = (v - mu[ii]) * iv[ii];
+                            }
+                        }
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int tt = 0; tt < TPW; ++tt)
+                                    acc[nt][tt] = L2A_MFMA(a[g][tt][ii], x[nt][ii], acc[nt][tt]);
+                    }
+                    // hint: the a[g >= 1] loads first, then one prefetch load per few MFMAs
+                    constexpr int NM = KG0 * 4 * NT * TPW;
+                    constexpr int PER = NM / (NPF > 0 ? NPF : 1) > 0 ? NM / (NPF > 0 ? NPF : 1) : 1;
+                    __builtin_amdgcn_sched_group_barrier(0x020, (KG0 - 1) * TPW, 0);
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                };
                 // operands of the phase after this one
                 if (n_hidden == 1) {
 #pragma unroll
@@ -486,49 +557,25 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                         for (int c = 0; c < OT; ++c)
                             pfO[tt][c] = l2a_ldw(rs_out, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
+                    l0_mfma(std::integral_constant<int, L2A_PFT(TPW, OT) * OT>{});
                 } else {
                     const __amdgpu_buffer_rsrc_t rs1 = l2a_rsrc(wb + p.pk_wmid, wm_bytes);
                     const bool next_half = is_half && n_hidden == 2;
+                    if (next_half) {
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) {
-                        if (tt < TH || !next_half) {
-                            const int vo = next_half ? voffh[tt] : voff[tt];
-                            pfA[tt] = l2a_ldw(rs1, vo, 0);
-                            pfB[tt] = l2a_ldw(rs1, vo + 1024, 0);
+                        for (int tt = 0; tt < TH; ++tt) {
+                            pfA[tt] = l2a_ldw(rs1, voffh[tt], 0);
+                            pfB[tt] = l2a_ldw(rs1, voffh[tt] + 1024, 0);
                         }
-                    }
-                }
-                f32x4 acc[NT][TPW];
+                        l0_mfma(std::integral_constant<int, 2 * TH>{});
+                    } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int g = 0; g < KG0; ++g) {
-                    const f32x4 mu = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
-                    const f32x4 iv = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
-                    f32x4 x[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (g < OT) sv = st[nt][g < OT ? g : 0];
-                        f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (g == ga0) aa = av[nt][0];
-                        if (g == ga0 + 1) aa = av[nt][1];
-#pragma unroll
-                        for (int ii = 0; ii < 4; ++ii) {
-                            const int k = 16 * g + 4 * qq + ii;
-                            const float v = (k < obs_dim) ? sv[ii] : aa[ii];
-                            x[nt][ii] = (v - mu[ii]) * iv[ii];
+                        for (int tt = 0; tt < TPW; ++tt) {
+                            pfA[tt] = l2a_ldw(rs1, voff[tt], 0);
+                            pfB[tt] = l2a_ldw(rs1, voff[tt] + 1024, 0);
                         }
+                        l0_mfma(std::integral_constant<int, 2 * TPW>{});
                     }
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                            for (int tt = 0; tt < TPW; ++tt)
-                                acc[nt][tt] = L2A_MFMA(a[g][tt][ii], x[nt][ii], acc[nt][tt]);
                 }
                 L2A_TS(9)
 #pragma unroll
