@@ -27,7 +27,7 @@ import torch
 from .. import _lib
 from ..envs.reward_spec import reward_spec_for_env
 from ..utils.serializable import Serializable
-from .base import Policy
+from .policy import Policy, innermost_env
 
 
 class MPCController(Policy, Serializable):
@@ -66,9 +66,7 @@ class MPCController(Policy, Serializable):
         self.cem_mode = cem_mode
         self.shard_candidates = shard_candidates
 
-        self.unwrapped_env = env
-        while hasattr(self.unwrapped_env, 'wrapped_env'):
-            self.unwrapped_env = self.unwrapped_env.wrapped_env
+        self.unwrapped_env = innermost_env(env)
 
         # make sure that env has reward function (reference :39)
         assert hasattr(self.unwrapped_env, 'reward'), "env must have a reward function"

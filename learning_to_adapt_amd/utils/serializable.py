@@ -1,50 +1,58 @@
-"""Constructor-argument pickling, the contract of ``learning_to_adapt/utils/serializable.py``.
+"""Pickling by constructor arguments - the contract of ``learning_to_adapt/utils/serializable.py``.
 
 The reference trainer snapshots ``policy`` / ``dynamics_model`` with ``joblib.dump``
-(``trainers/mb_trainer.py:105-108``); objects are rebuilt by calling their constructor
-again with the recorded arguments.  Subclasses call ``Serializable.quick_init(self,
-locals())`` first thing in ``__init__`` - same call shape as the reference so that
-drop-in subclasses keep working.
+(``trainers/mb_trainer.py:105-108``); such objects are rebuilt by calling their constructor with the
+arguments recorded at construction.  A class opts in by calling ``Serializable.quick_init(self,
+locals())`` as the first statement of ``__init__`` (same call shape as the reference, so classes
+written against it keep working); the pickled state uses the reference's keys ``__args`` /
+``__kwargs``.
 """
 
 import inspect
 
 
 class Serializable(object):
-    def __init__(self, *args, **kwargs):
-        self.__args = args
-        self.__kwargs = kwargs
+    _ctor_record = None
 
-    def quick_init(self, locals_):
-        if getattr(self, "_serializable_initialized", False):
+    def quick_init(self, frame_locals):
+        """Record the arguments of the outermost constructor call (later calls are ignored)."""
+        if self.__dict__.get("_ctor_record") is not None:
             return
-        spec = inspect.getfullargspec(self.__init__)
-        kwargs = locals_[spec.varkw] if spec.varkw else dict()
-        varargs = locals_[spec.varargs] if spec.varargs else tuple()
-        positional = [locals_[name] for name in spec.args][1:]   # drop self
-        self.__args = tuple(positional) + tuple(varargs)
-        self.__kwargs = kwargs
-        self._serializable_initialized = True
+        positional, keyword = [], {}
+        parameters = list(inspect.signature(type(self).__init__).parameters.values())[1:]
+        for par in parameters:
+            if par.kind is inspect.Parameter.VAR_POSITIONAL:
+                positional.extend(frame_locals[par.name])
+            elif par.kind is inspect.Parameter.VAR_KEYWORD:
+                keyword.update(frame_locals[par.name])
+            else:
+                positional.append(frame_locals[par.name])
+        self._ctor_record = (tuple(positional), keyword)
+
+    def _recorded(self):
+        if self._ctor_record is None:
+            raise RuntimeError("%s.__init__ never called Serializable.quick_init" % type(self).__name__)
+        return self._ctor_record
 
     def __getstate__(self):
-        return {"__args": self.__args, "__kwargs": self.__kwargs}
+        args, kwargs = self._recorded()
+        return {"__args": args, "__kwargs": kwargs}
 
-    def __setstate__(self, d):
-        fresh = type(self)(*d["__args"], **d["__kwargs"])
-        self.__dict__.update(fresh.__dict__)
+    def __setstate__(self, state):
+        rebuilt = type(self)(*state["__args"], **state["__kwargs"])
+        self.__dict__.update(rebuilt.__dict__)
 
     @classmethod
     def clone(cls, obj, **overrides):
-        assert isinstance(obj, Serializable)
-        d = obj.__getstate__()
-        names = inspect.getfullargspec(obj.__init__).args[1:]
-        args = list(d["__args"])
-        kwargs = dict(d["__kwargs"])
-        for key, val in overrides.items():
-            if key in names:
-                args[names.index(key)] = val
+        """A copy of ``obj`` built with some constructor arguments replaced."""
+        args, kwargs = obj._recorded()
+        names = [par.name for par in list(inspect.signature(type(obj).__init__).parameters.values())[1:]]
+        args, kwargs = list(args), dict(kwargs)
+        for key, value in overrides.items():
+            if key in names and names.index(key) < len(args):
+                args[names.index(key)] = value
             else:
-                kwargs[key] = val
-        out = type(obj).__new__(type(obj))
-        out.__setstate__({"__args": tuple(args), "__kwargs": kwargs})
-        return out
+                kwargs[key] = value
+        twin = type(obj).__new__(type(obj))
+        twin.__setstate__({"__args": tuple(args), "__kwargs": kwargs})
+        return twin

@@ -176,6 +176,9 @@ SPLIT_CASES = [
     ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128], E=3, n=200, h=5)),
     ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128], E=1, n=200, h=5)),
     ("ant_rs_n300_h6_e3", {}),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128, 128], E=1, n=150, h=4)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128, 128], E=2, n=150, h=4, activation="tanh")),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[256, 256, 256, 256], E=1, n=90, h=3)),
 ]
 
 
@@ -402,6 +405,30 @@ def test_plan_before_weights_is_an_error_not_garbage():
         nm.plan_rs(torch.zeros((1, 20), device=dev), torch.zeros((2, 16, 6), device=dev), 1, 16, 2, 1.0,
                    RewardSpec.half_cheetah(20, 0.01), best_key=torch.zeros(1, dtype=torch.int64, device=dev))
     nm.close()
+
+
+def test_invalid_plans_are_rejected():
+    case = cases.CASES["c1_hc_rs_n500_h10_e1"]
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    obs0 = torch.zeros((1, 20), device=dev)
+    key = torch.zeros(1, dtype=torch.int64, device=dev)
+    acts = torch.zeros((2, 16, 6), device=dev)
+    from learning_to_adapt_amd.envs import RewardSpec
+    ok = RewardSpec.half_cheetah(20, 0.01)
+    for kwargs in (dict(m=1, n=0, h=2), dict(m=0, n=16, h=2), dict(m=1, n=16, h=0)):
+        rc = native.lib.l2a_plan_rs(native.handle, ctypes.c_void_p(obs0.data_ptr()), ctypes.c_void_p(acts.data_ptr()),
+                                    kwargs["m"], kwargs["n"], kwargs["h"], 1.0, ctypes.byref(ok), 0, None,
+                                    ctypes.c_void_p(key.data_ptr()), None)
+        assert rc == -1 and b"must be >= 1" in native.lib.l2a_last_error(native.ctx.handle)
+    bad = RewardSpec.make(w_vel=1.0, dt=0.01, vel_index=25)
+    rc = native.lib.l2a_plan_rs(native.handle, ctypes.c_void_p(obs0.data_ptr()), ctypes.c_void_p(acts.data_ptr()),
+                                1, 16, 2, 1.0, ctypes.byref(bad), 0, None, ctypes.c_void_p(key.data_ptr()), None)
+    assert rc == -1 and b"vel_index" in native.lib.l2a_last_error(native.ctx.handle)
+    rc = native.lib.l2a_plan_rs(native.handle, None, ctypes.c_void_p(acts.data_ptr()), 1, 16, 2, 1.0,
+                                ctypes.byref(ok), 0, None, ctypes.c_void_p(key.data_ptr()), None)
+    assert rc == -1
 
 
 def test_device_info_reports_gfx950():
