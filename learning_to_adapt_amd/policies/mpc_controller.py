@@ -188,7 +188,13 @@ class MPCController(Policy, Serializable):
             low = torch.as_tensor(self.action_space.low, dtype=torch.float32, device=dev)
             high = torch.as_tensor(self.action_space.high, dtype=torch.float32, device=dev)
             a_dev = self._buf("a_dev", (h, m * n_local, act_dim), torch.float32, dev)
-            a_dev.uniform_(0.0, 1.0)
+            gen = self._bufs.get("rs_gen")
+            if gen is None or gen.device != dev:
+                # every rank must draw DIFFERENT candidates for its shard
+                gen = torch.Generator(device=dev)
+                gen.manual_seed((int(torch.initial_seed()) + 7919 * rank) & 0x7FFFFFFF)
+                self._bufs["rs_gen"] = gen
+            a_dev.uniform_(0.0, 1.0, generator=gen)
             a_dev.mul_(high - low).add_(low)
             cand_a = None
 

@@ -58,3 +58,40 @@ def test_two_rank_plan_equals_single_process_plan(cid, tmp_path):
         np.testing.assert_array_equal(o["actions"], gold["chosen"])
     if outs[0]["shard"][0] >= 0:
         assert outs[0]["shard"][1] == outs[1]["shard"][0]          # contiguous, disjoint shards
+
+
+def _worker_device_rng(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        import oracle_backend
+        case = cases.CASES["hc_rs_m3_n64_h5"]
+        gold = cases.load_golden("hc_rs_m3_n64_h5_s0")
+        ctrl = oracle_backend.install(cases.product_controller(case, rng="device"), case)
+        torch.manual_seed(5)                              # same seed on every rank
+        actions, _ = ctrl.get_actions(gold["obs0"])
+        first = ctrl._bufs["a_dev"][0].reshape(3, -1, 6).numpy().copy()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), actions=actions, first=first,
+                 best=np.asarray(ctrl.last_plan["best_index"]), ret=np.asarray(ctrl.last_plan["best_return"]),
+                 shard=np.asarray(ctrl.last_plan["shard"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_rng_ranks_draw_different_candidates_and_agree(tmp_path):
+    world = 2
+    mp.spawn(_worker_device_rng, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert not np.array_equal(outs[0]["first"], outs[1]["first"])          # different shards
+    np.testing.assert_array_equal(outs[0]["actions"], outs[1]["actions"])   # same decision everywhere
+    assert np.array_equal(outs[0]["best"], outs[1]["best"])
+    # the winner's first action is the owner rank's candidate
+    for i in range(3):
+        idx = int(outs[0]["best"][i])
+        owner = 0 if idx < outs[0]["shard"][1] else 1
+        lo = int(outs[owner]["shard"][0])
+        np.testing.assert_allclose(outs[0]["actions"][i], outs[owner]["first"][i, idx - lo], rtol=1e-6)
