@@ -19,11 +19,6 @@ namespace {
 
 std::string g_init_error;
 
-struct HipFail {
-    hipError_t code;
-    const char* what;
-};
-
 }  // namespace
 
 struct l2a_ctx {

@@ -1,38 +1,47 @@
-// l2a_mfma.h - the fp32 MFMA rollout kernel (gfx950 / CDNA4 only).  Included by l2a_api.hip.
+// l2a_mfma.h - the fp32 MFMA rollout kernel (gfx950 / CDNA4 only).  Included by l2a_mfma_inst.hip
+// (one translation unit per (NT, TPW); launchers declared in l2a_mfma_launch.h).
 //
-// Workgroup = L2A_NW waves (4 = one per SIMD) owning NT tiles of 16 candidates of one env for the whole
-// horizon and all weight sets; workgroups never talk to each other (one atomicMax at the end).
+// Workgroup = L2A_NW waves (4 = one per SIMD) owning NT tiles of 16 candidates of one env for the
+// whole horizon.  Tiles never talk to each other; when a plan has few tiles, TWO workgroups share a
+// tile and swap partial sums once per horizon step (see "Tile split").  One atomicMax per tile at
+// the end.
 //
-// Data distribution: lane (j = l & 15, qq = l >> 4) holds, for candidate j of a tile,
-// features 16c + 4qq + 0..3 of every 16-feature tile c - for the state, the deltas and the
-// hidden activations alike.  That is at once the D-fragment layout of
-// v_mfma_f32_16x16x4_f32 (computed as D = W^T-tile x activations) and, thanks to the k
-// permutation baked into the packed weights (l2a_kernels.h), the B-fragment layout of the
-// next layer: layers chain through LDS with one 16-byte write and one 16-byte read per lane
-// and tile, no transposes, no bank conflicts (every access is lane-linear).
+// Data distribution: lane (j = l & 15, qq = l >> 4) holds, for candidate j of a tile, features
+// 16c + 4qq + 0..3 of every 16-feature tile c - for the state, the deltas and the hidden
+// activations alike.  That is at once the D-fragment layout of v_mfma_f32_16x16x4_f32 (computed
+// as D = W^T-tile x activations) and, thanks to the k permutation baked into the packed weights
+// (l2a_kernels.h), the B-fragment layout of the next layer: layers chain through LDS with one
+// 16-byte write and one 16-byte read per lane and tile, no transposes, no bank conflicts.
 //
 // Per (step, weight set):
-//   layer 0      : wave w computes hidden tiles [w*TPW, (w+1)*TPW); B = normalised [obs|act]
-//                  built in registers from the state fragment; K = in_dim (KG0 k-groups)
-//   hidden layers: same tile ownership; B fragments (activations) come from LDS; A fragments
-//                  (weights, 1 KiB per wave-level load) stream from L2 straight into VGPRs
-//                  with two k-groups in flight ahead of the MFMAs
-//   output layer : K split over the waves (TPW k-groups each), partial sums exchanged
-//                  through the idle LDS region, every wave reduces them in the same order,
-//                  so all waves hold bit-identical copies of state / return
-// LDS: two activation regions of sa_elems f32x4 each + per-set constants (normalisation vectors
-// and all biases, so no phase waits on a global load behind the weight prefetch) (+ 1 KiB per
-// candidate tile and obs tile for the member-split exchange).
+//   layer 0      : wave w computes hidden tiles [w*TPW, (w+1)*TPW); B = normalised [obs|act] built
+//                  in registers from the state fragment; K = in_dim (KG0 k-groups); result -> LDS
+//   hidden GEMMs : same tile ownership; B fragments (activations) come from LDS; A fragments
+//                  (weights, 1 KiB per wave-level buffer load) stream from L2 into registers, two
+//                  k-groups ahead of the MFMAs, one load issued per four MFMAs
+//   output layer : fused into the last hidden layer - hidden tile c IS k-group c of the output
+//                  layer and its D fragment IS the B fragment, so every wave multiplies its own
+//                  registers; chunk partials go through LDS, one barrier, every wave sums them in
+//                  the canonical order, so all waves hold bit-identical copies of state / return
+//   every phase issues the FIRST operands of the next phase before the barrier that separates them
+// LDS: two activation regions of sa_elems f32x4 each + per-set constants (normalisation vectors and
+// all biases) + 2 KiB per (candidate tile, obs tile) of exchange staging.
 //
-// Ensemble association: the members are always summed as (sum over group A) + (sum over group
-// B), A = first ceil(E/2) members, B = the rest.  With `split` two workgroups own one candidate
-// tile - one per group - and swap their group sums once per horizon step through 8-byte
-// {tag, value} granules in global memory (write-through stores, relaxed agent-scope polling,
-// the data is its own flag: cdna_hip_programming.md G16 recipe R2).  Split and unsplit launches
-// are therefore bit-identical; the split one uses twice the CUs when few tiles exist.
+// Fixed summation order (every launch geometry gives the same bits): sets are summed as (group A)
+// + (group B), A = first ceil(E/2) sets; the output layer's K reduction is cut into 2 * L2A_NW
+// chunks of TPW / 2 k-groups, ((c0+c1)+c2)+c3 + ((c4+c5)+c6)+c7.
 //
-// Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave
-// (hidden width = 16 * L2A_NW * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16).
+// Tile split (p.split): 1 = workgroup 0 runs group A, workgroup 1 group B; 2 = additionally the
+// last set of group A is SHARED - both workgroups run it as a "half member": layer 0 and the inner
+// hidden layers in full, the last hidden layer and the output layer for one half of the hidden
+// tiles each (this balances odd ensembles and lets a single model use two CUs).  Partial sums
+// travel through 16-byte self-validating {tag, v, tag, v} granules in global memory: write-through
+// (sc1) stores, sc1 loads, no flag and no fence (cdna_hip_programming.md G16 recipe R2); the group
+// sums are published before the half member starts.  Spins are bounded (status word, never a hang).
+//
+// Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave (hidden
+// width = 16 * L2A_NW * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16), GACT =
+// generic activation functions (false: relu / identity only, branch-free).
 #pragma once
 
 #include <type_traits>
@@ -709,9 +718,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 const bool want0 = (p.split == 1) || (e_loop > 1);
                 unsigned int spins = 0;
                 while (true) {
+                    // both regions in ONE round trip (an sc1 load sweep costs ~3k cycles whatever its size)
                     bool ok = true;
                     if (p.split == 2) ok = xget(1, oth[1]);
-                    if (want0 && __all(ok)) ok = xget(0, oth[0]);
+                    if (want0) ok = xget(0, oth[0]) && ok;
                     if (__all(ok)) break;
                     if (++spins > (1u << 22)) {     // partner never arrived: flag it, do not hang
                         if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
