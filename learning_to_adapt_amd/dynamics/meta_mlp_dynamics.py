@@ -56,6 +56,7 @@ class MetaMLPDynamicsModel(Serializable):
         self._dataset_train = None
         self._dataset_test = None
         self._prev_params = None
+        self._params_dev = None          # (list identity, device, device copies) of self._params
         self._adapted_param_values = None
         self._num_adapted_models = 0
 
@@ -104,6 +105,16 @@ class MetaMLPDynamicsModel(Serializable):
     def mode(self):
         return "per_block" if self._adapted_param_values is not None else "single"
 
+    def _device_params(self, dev):
+        """Device-resident copy of the base parameters.  ``self._params`` is only ever replaced as a
+        whole list, so its identity is the cache key; the controller step then runs no CPU tensor op
+        (a CPU ``clone`` wakes torch's whole intra-op thread pool: measured 85 ms stalls on a 128-core host)."""
+        dev = torch.device(dev)
+        c = self._params_dev
+        if c is None or c[0] is not self._params or c[1] != dev:
+            self._params_dev = c = (self._params, dev, [p.to(dev) for p in self._params])
+        return c[2]
+
     def planner_blocks(self, m):
         return self._num_adapted_models if self._adapted_param_values is not None else 1
 
@@ -129,7 +140,7 @@ class MetaMLPDynamicsModel(Serializable):
                                             self.hidden_nonlinearity, self.output_nonlinearity, 1, "single")
             self._base_dirty = True
         if self._base_dirty:
-            self._native_base.set_weights(0, self._params)
+            self._native_base.set_weights(0, self._device_params(self._native_base.device))
             self._native_base.set_norm(0, self._norm())
             self._base_dirty = False
         return self._native_base
@@ -154,8 +165,7 @@ class MetaMLPDynamicsModel(Serializable):
         self._num_adapted_models = len(obs)
         assert len(obs) == len(act) == len(obs_next)
         dev = core.training_device()
-        base = [p.to(dev) for p in self._params]
-        adapted = []
+        xs, ys = [], []
         for ob, ac, ob_next in zip(obs, act, obs_next):
             ob = np.asarray(ob, dtype=np.float64)
             ac = np.asarray(ac, dtype=np.float64)
@@ -170,17 +180,40 @@ class MetaMLPDynamicsModel(Serializable):
                 d_n = core.normalize(ob_next - ob, nm["delta"][0], nm["delta"][1])
             else:
                 o_n, a_n, d_n = ob, ac, ob_next - ob
-            # Only the real rows enter the pre-update loss: the reference pads each task with an
-            # equal number of zero rows and then splits the task batch in two, pre = real half
-            # (:324-326, :99-103).
-            x = torch.as_tensor(np.concatenate([o_n, a_n], axis=1), dtype=torch.float32, device=dev)
-            y = torch.as_tensor(d_n, dtype=torch.float32, device=dev)
-            params = [p.detach().clone().requires_grad_(True) for p in base]
-            pred = core.mlp_forward(x, params, self.hidden_nonlinearity, self.output_nonlinearity)
-            loss = torch.mean((y - pred) ** 2)                                      # :118
+            xs.append(np.concatenate([o_n, a_n], axis=1))
+            ys.append(d_n)
+        # Only the real rows enter the pre-update loss: the reference pads each task with an equal
+        # number of zero rows and then splits the task batch in two, pre = real half (:324-326, :99-103).
+        if len({x.shape[0] for x in xs}) == 1:
+            # all envs in ONE batched forward/backward: every env gets its own copy of theta, so the
+            # gradient of sum_i L_i w.r.t. copy i is exactly grad L_i (:409-421)
+            m = len(xs)
+            x = torch.from_numpy(np.stack(xs).astype(np.float32)).to(dev)              # [m, rows, in]
+            y = torch.from_numpy(np.stack(ys).astype(np.float32)).to(dev)
+            params = [p.unsqueeze(0).expand((m,) + tuple(p.shape)).clone().requires_grad_(True)
+                      for p in self._device_params(dev)]
+            hid, out = core.torch_act(self.hidden_nonlinearity), core.torch_act(self.output_nonlinearity)
+            n_layers = len(params) // 2
+            t = x
+            for li in range(n_layers):
+                t = torch.baddbmm(params[2 * li + 1].unsqueeze(1), t, params[2 * li])
+                t = hid(t) if li < n_layers - 1 else out(t)
+            loss = torch.mean((y - t) ** 2, dim=(1, 2)).sum()                          # sum_i L_i (:118)
             grads = torch.autograd.grad(loss, params)
-            adapted.append([(p - self.inner_learning_rate * g).detach() for p, g in zip(params, grads)])  # :415-417
-        self._prev_params = [p.clone() for p in self._params]
+            stacked = [(p - self.inner_learning_rate * g).detach() for p, g in zip(params, grads)]
+            adapted = [[q[i] for q in stacked] for i in range(m)]
+        else:
+            base = self._device_params(dev)
+            adapted = []
+            for x_np, y_np in zip(xs, ys):
+                x = torch.from_numpy(x_np.astype(np.float32)).to(dev)
+                y = torch.from_numpy(y_np.astype(np.float32)).to(dev)
+                params = [p.detach().clone().requires_grad_(True) for p in base]
+                pred = core.mlp_forward(x, params, self.hidden_nonlinearity, self.output_nonlinearity)
+                loss = torch.mean((y - pred) ** 2)                                      # :118
+                grads = torch.autograd.grad(loss, params)
+                adapted.append([(p - self.inner_learning_rate * g).detach() for p, g in zip(params, grads)])  # :415-417
+        self._prev_params = self._params      # parameter tensors are never modified in place
         self._adapted_param_values = adapted
         self._adapted_dirty = True
 

@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
+from learning_to_adapt_amd.envs import SyntheticEnv  # noqa: E402
+cases.SyntheticEnv = SyntheticEnv
 from learning_to_adapt_amd import _lib  # noqa: E402
 
 PEAK = 157.3
@@ -87,6 +89,39 @@ def main():
     case = dict(C["c3_ant_rs_n2000_h20_pb5"], hidden=[512, 512, 512])
     env, model = cases.product_model(case)
     report("config 3 with the run_grbal.py default 3x512 network", case, env, time_plan(model.planner_model(), case, env))
+    # GrBAL controller step (samplers/sampler.py:81-91): switch_to_pre_adapt + adapt (5 envs x 16
+    # transitions, one SGD step each) + re-upload of the 5 adapted sets + plan (config 3, 3x512)
+    from learning_to_adapt_amd.dynamics import MetaMLPDynamicsModel
+    from learning_to_adapt_amd.policies import MPCController
+    from learning_to_adapt_amd.utils import synthetic
+    env = cases.SyntheticEnv("ant")
+    gm = MetaMLPDynamicsModel(name="dyn", env=env, hidden_sizes=(512, 512, 512), inner_learning_rate=0.01, init_seed=0)
+    gm.set_normalization(synthetic.make_norm(41, 8, env.action_space.low, env.action_space.high, 2000))
+    rs = np.random.RandomState(0)
+    ob = [rs.randn(16, 41) for _ in range(5)]
+    ac = [rs.uniform(-150, 150, (16, 8)) for _ in range(5)]
+    nx = [o + 0.1 * rs.randn(16, 41) for o in ob]
+    for mode in ("numpy", "device"):
+        gc = MPCController(name="p", env=env, dynamics_model=gm, n_candidates=2000, horizon=20, rng=mode)
+        obs0 = rs.randn(5, 41)
+        t_adapt, t_all = [], []
+        for it in range(21):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gm.switch_to_pre_adapt()
+            gm.adapt(ob, ac, nx)
+            gm.planner_model()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            gc.get_actions(obs0)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if it > 0:
+                t_adapt.append(t1 - t0)
+                t_all.append(t2 - t0)
+        print(json.dumps(dict(config="GrBAL controller step (adapt 5 envs + plan config 3 / 3x512), rng=" + mode,
+                              adapt_and_upload_ms=round(1e3 * float(np.median(t_adapt)), 3), step_ms=round(1e3 * float(np.median(t_all)), 3),
+                              step_ms_mean=round(1e3 * float(np.mean(t_all)), 3), step_ms_max=round(1e3 * float(np.max(t_all)), 3))), flush=True)
     # config 5: one CEM plan step (5 iterations x 4000 candidates) through the drop-in controller
     case = C["c5_hc_cem_n4000_h30_e5"]
     ctrl = cases.product_controller(case)
