@@ -42,6 +42,48 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector pea
 PEAK_HBM_GBS = 8000.0
 
 
+def cpu_table():
+    """SURVEY.md 8(d) 'CPU baseline beside it': the oracle on this host, median of 5 runs after one
+    warm-up (3 runs for the config-4 shape), at 1 thread and at the fastest probed thread count."""
+    import cases
+    from oracle import make_reward
+    from oracle.planner import rollout_returns
+    from threadpoolctl import threadpool_limits
+    ncpu = os.cpu_count() or 1
+    rows = [("config 1 (n=500, h=10, E=1)", "c1_hc_rs_n500_h10_e1", {}, 5),
+            ("config 2 shape with E=1", "c2_hc_rs_n2000_h30_e5", {"E": 1}, 5),
+            ("config 2 (n=2000, h=30, E=5)", "c2_hc_rs_n2000_h30_e5", {}, 5),
+            ("config 4 shape (n=16000, h=30, E=5), one host", "c2_hc_rs_n2000_h30_e5", {"n": 16000}, 3)]
+    for label, name, over, reps in rows:
+        case = dict(cases.CASES[name], **over)
+        env = cases.recipe(case)[0]
+        dyn = cases.oracle_dynamics(case)
+        reward = make_reward("half_cheetah", env.dt)
+        n, h, m = case["n"], case["h"], case["m"]
+        np.random.seed(0)
+        a = np.random.uniform(low=env.action_space.low, high=env.action_space.high,
+                              size=(h * n * m, ACT_DIM)).reshape((h, n * m, ACT_DIM))
+        obs0 = np.random.RandomState(1).randn(m, OBS_DIM)
+
+        def once():
+            t = time.perf_counter()
+            rollout_returns(dyn, reward, obs0, a, n, 1.0)
+            return time.perf_counter() - t
+        probe = {}
+        for thr in sorted(set([t for t in (1, 8, 16, 32, 64) if t <= ncpu] + [ncpu])):
+            with threadpool_limits(limits=thr):
+                once()
+                probe[thr] = once()
+        best = min((t for t in probe if t != 1), key=lambda t: probe[t], default=1)
+        out = {"config": label, "host_cpus": ncpu, "probe_s": {str(k): round(v, 4) for k, v in probe.items()}}
+        for tag, thr in (("threads_1", 1), ("threads_best", best)):
+            with threadpool_limits(limits=thr):
+                ts = sorted(once() for _ in range(reps))
+            out[tag] = {"threads": thr, "s_per_step": round(ts[len(ts) // 2], 4),
+                        "steps_per_s": round(1.0 / ts[len(ts) // 2], 4)}
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,7 +91,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps to time (0 = auto, ~10-30 s)")
+    ap.add_argument("--cpu-table", action="store_true",
+                    help="no GPU work: time the oracle (CPU restatement) on configs 1, 2 (E=1, E=5) and the "
+                         "config-4 shape at 1 BLAS thread and at the fastest thread count; JSON lines")
     args = ap.parse_args()
+    if args.cpu_table:
+        return cpu_table()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,9 +132,9 @@ def main():
     # candidate actions resident in HBM: buffer 0 = the reference's seed-0 draw of THIS rank's
     # shard (index check), buffers 1..3 = device-generated uniform candidates
     n_glob = N_CAND * world
-    from oracle.planner import sample_rs_actions
-    np.random.seed(0)
-    a0 = sample_rs_actions(env.action_space.low, env.action_space.high, n_glob, 1, HORIZON)
+    np.random.seed(0)                        # the draw of mpc_controller.py:67-69,114 for n_glob candidates
+    a0 = np.random.uniform(low=env.action_space.low, high=env.action_space.high,
+                           size=(HORIZON * n_glob, ACT_DIM)).reshape((HORIZON, n_glob, ACT_DIM))
     lo = rank * N_CAND
     bufs = [torch.from_numpy(np.ascontiguousarray(a0[:, lo:lo + N_CAND, :], dtype=np.float32)).to(dev)]
     gen = torch.Generator(device=dev)

@@ -305,9 +305,12 @@ class MPCController(Policy, Serializable):
         """CEM with sampling, clipping, elite selection and refit on the GPU (SURVEY.md section 8(f)
         rank 2): the five host synchronisations and 5 x n*m*h*act_dim host normals per plan step
         of the reference loop (``:84-104``) disappear; only the chosen action comes back.
-        Semantics are those of ``cem_mode='fixed'`` (clipped rollouts, true top-k elites per env,
-        env-major rows); numbers come from torch's Philox generator, so this mode is validated
-        against the host implementation with injected normals, not bit-for-bit against NumPy."""
+        ``cem_mode='reference'`` keeps the reference's semantics on the device - rollouts on the
+        UNCLIPPED samples, candidate-major rows (row = j*m + i read as env row // n), the rank-mask
+        "elites" of ``:101`` pooled over the envs; ``cem_mode='fixed'`` uses clipped rollouts,
+        env-major rows and true top-k elites per env.  Numbers come from torch's Philox generator, so
+        both are validated against the host loops with injected normals, not bit-for-bit against NumPy."""
+        reference = (self.cem_mode == "reference")
         n, m, h = self.n_candidates, len(observations), self.horizon
         act_dim = self.action_space.shape[0]
         D = h * act_dim
@@ -326,7 +329,12 @@ class MPCController(Policy, Serializable):
         cand = None
         for _ in range(self.num_cem_iters):
             z = self._cem_normal_device((n, m, D), dev)
-            cand = torch.clamp(mean + z * std, low, high).permute(1, 0, 2).contiguous()     # [m, n, D]
+            a = mean + z * std                                                                # [n, m, D]
+            a_clip = torch.clamp(a, low, high)
+            if reference:
+                cand = a.reshape(m, n, D)                  # the reference's reading of the same memory (:92-96)
+            else:
+                cand = a_clip.permute(1, 0, 2).contiguous()                                       # [m, n, D]
             seq = cand[:, lo:hi, :].reshape(m * n_local, h, act_dim).permute(1, 0, 2).contiguous()
             _, r_loc = self._rollout(observations, seq, n_local, lo, want_returns=True)
             if world > 1:
@@ -335,10 +343,18 @@ class MPCController(Policy, Serializable):
                 rets = torch.cat(parts, dim=1)
             else:
                 rets = r_loc
-            top = torch.topk(rets, num_elites, dim=1).indices                                 # [m, k]
-            elites = torch.gather(cand, 1, top.unsqueeze(-1).expand(m, num_elites, D))        # [m, k, D]
-            mean = mean * self.alpha + (1 - self.alpha) * elites.mean(dim=1)
-            std = elites.std(dim=1, unbiased=False)
+            if reference:
+                # :101-104: positions of the descending argsort whose VALUE is < num_elites, used as a
+                # mask over candidates, pooled over envs; mean / std broadcast back to every env
+                mask = (torch.argsort(rets, dim=1, descending=True, stable=True) < num_elites).t()   # [n, m]
+                elites = a_clip[mask]                                                         # [m*k, D]
+                mean = mean * self.alpha + (1 - self.alpha) * elites.mean(dim=0)
+                std = elites.std(dim=0, unbiased=False).expand(m, D)
+            else:
+                top = torch.topk(rets, num_elites, dim=1).indices                             # [m, k]
+                elites = torch.gather(cand, 1, top.unsqueeze(-1).expand(m, num_elites, D))    # [m, k, D]
+                mean = mean * self.alpha + (1 - self.alpha) * elites.mean(dim=1)
+                std = elites.std(dim=1, unbiased=False)
         idx = torch.argmax(rets, dim=1)                                                       # [m]
         first = cand[torch.arange(m, device=dev), idx, :act_dim]
         out = first.cpu().numpy().astype(np.float64)

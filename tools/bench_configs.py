@@ -140,15 +140,16 @@ def main():
     report("config 5: CEM rollout kernel, one iteration (n=4000)", one, env, k_ms,
            cem_plan_step_ms_end_to_end_host_rng=round(ms, 2), cem_iters=5,
            note="end-to-end includes 5 x np.random.normal(720k) + clip + elite statistics on the host")
-    ctrl = cases.product_controller(case, rng="device")
-    ctrl.get_actions(gold["obs0"])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
+    for cem_mode in ("reference", "fixed"):
+        ctrl = cases.product_controller(case, rng="device", cem_mode=cem_mode)
         ctrl.get_actions(gold["obs0"])
-    torch.cuda.synchronize()
-    print(json.dumps(dict(config="config 5: CEM plan step end to end, rng=device (sampling / top-k / refit on the GPU)",
-                          ms_per_call=round(1e3 * (time.perf_counter() - t0) / 10, 3))), flush=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ctrl.get_actions(gold["obs0"])
+        torch.cuda.synchronize()
+        print(json.dumps(dict(config="config 5: CEM plan step end to end, rng=device, cem_mode=%s (sampling / elites / refit on the GPU)" % cem_mode,
+                              ms_per_call=round(1e3 * (time.perf_counter() - t0) / 10, 3))), flush=True)
     # host<->device inclusive: get_actions through the controller (parity mode: host MT19937 + H2D per step)
     case = C["c2_hc_rs_n2000_h30_e5"]
     for mode in ("numpy", "device"):
