@@ -78,6 +78,34 @@ def make_adapted_sets(env, hidden_sizes, n_blocks, bias_std=0.05, scale=1e-3):
     return sets, norm
 
 
+def make_lstm_set(obs_dim, act_dim, units, seed, bias_std=0.05):
+    """Single-layer LSTM + output layer in the reference's variable order
+    (``dynamics/core/utils.py:192-236``): ``rnn/lstm_cell/kernel [in + units, 4 units]`` (gate
+    order i, j, f, o), ``rnn/lstm_cell/bias``, ``output/kernel [units, obs_dim]``, ``output/bias``.
+    Glorot-uniform kernels (TF's default for ``LSTMCell`` and the ``w_init`` of the output layer)."""
+    rs = np.random.RandomState(seed)
+    k_in = obs_dim + act_dim + units
+    lim = np.sqrt(6.0 / (k_in + 4 * units))
+    kernel = rs.uniform(-lim, lim, size=(k_in, 4 * units)).astype(np.float32)
+    bias = (bias_std * rs.randn(4 * units)).astype(np.float32)
+    lim = np.sqrt(6.0 / (units + obs_dim))
+    wout = rs.uniform(-lim, lim, size=(units, obs_dim)).astype(np.float32)
+    bout = (bias_std * rs.randn(obs_dim)).astype(np.float32)
+    return [kernel, bias, wout, bout]
+
+
+def named_lstm_params(params):
+    out = OrderedDict()
+    for name, p in zip(("rnn/lstm_cell/kernel", "rnn/lstm_cell/bias", "output/kernel", "output/bias"), params):
+        out[name] = p
+    return out
+
+
+def make_obs_sequence(m, obs_dim, steps):
+    """Observations of ``steps`` consecutive controller steps (recurrent planner cases)."""
+    return [np.random.RandomState(1 + k).randn(m, obs_dim) for k in range(steps)]
+
+
 def make_obs0(m, obs_dim):
     return np.random.RandomState(1).randn(m, obs_dim)
 

@@ -29,8 +29,16 @@ Parity status
   (``dynamics/core/utils.py:111-142``, ``:264-296``) - dense = ``x @ W + b``,
   kernels ``[in, out]`` - and is cross-checked against float64 NumPy and
   torch CPU fp32 in ``tests/test_oracle.py``.
+* recurrent planner (``oracle/rnn_planner.py``): PINNED against the real
+  ``RNNMPCController`` (``policies/rnn_mpc_controller.py``) the same way.
+* LSTM cell arithmetic (``oracle/rnn_dynamics.py``): unpinned at the
+  TensorFlow boundary (``tf.nn.rnn_cell.LSTMCell`` of tensorflow==1.13.1),
+  restated from its published algorithm; cross-checked against
+  ``torch.nn.LSTMCell`` in ``tests/test_oracle.py``.
 """
 
 from .dynamics import OracleMLPDynamics, mlp_forward_f32  # noqa: F401
 from .rewards import make_reward  # noqa: F401
 from .planner import rs_plan, cem_plan  # noqa: F401
+from .rnn_dynamics import OracleLSTMDynamics, LSTMStateTuple, lstm_step_f32  # noqa: F401
+from .rnn_planner import rnn_rs_plan, rnn_cem_plan, repeat_hidden  # noqa: F401

@@ -21,12 +21,35 @@ def case_ids(planner=None, max_work=None):
     for c in CASES.values():
         if planner is not None and c["planner"] != planner:
             continue
+        if planner is None and c["planner"].startswith("rnn"):
+            continue            # recurrent cases have their own tests (rnn_case_ids)
         work = c["n"] * c["h"] * c["m"] * (c["E"] if c["mode"] == "mean" else 1) * c.get("num_cem_iters", 1)
         if max_work is not None and work > max_work:
             continue
         for s in c["seeds"]:
             out.append("%s_s%d" % (c["name"], s))
     return out
+
+
+def rnn_case_ids():
+    return ["%s_s%d" % (c["name"], s) for c in CASES.values() if c["planner"].startswith("rnn")
+            for s in c["seeds"]]
+
+
+def rnn_recipe(case):
+    """(env, params, norm) of a recurrent case (single-layer LSTM + output layer)."""
+    env = SyntheticEnv(case["env"])
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    params = synthetic.make_lstm_set(od, ad, case["units"], 1000)
+    norm = synthetic.make_norm(od, ad, env.action_space.low, env.action_space.high, 2000)
+    return env, params, norm
+
+
+def oracle_rnn_dynamics(case):
+    from oracle import OracleLSTMDynamics
+    env, params, norm = rnn_recipe(case)
+    return OracleLSTMDynamics(env.observation_space.shape[0], env.action_space.shape[0], params, norm,
+                              hidden_nonlinearity=case.get("activation", "tanh"))
 
 
 def split_id(cid):
