@@ -23,6 +23,7 @@ extern "C" {
 
 typedef struct l2a_ctx l2a_ctx;
 typedef struct l2a_model l2a_model;
+typedef struct l2a_lstm l2a_lstm;
 
 /* ---- error codes --------------------------------------------------------------------- */
 #define L2A_OK 0
@@ -163,6 +164,49 @@ int l2a_predict(l2a_model* model, const float* obs, const float* act, int rows, 
  *   only collective of a plan step.                                                          */
 unsigned long long l2a_key_encode(float ret, int index);
 void l2a_key_decode(unsigned long long key, float* ret, int* index);
+
+/* ---- recurrent planner (ReBAL) --------------------------------------------------------------
+ * Single-layer LSTM dynamics model: `RNNDynamicsModel` (dynamics/rnn_dynamics.py:11-100) built by
+ * `create_rnn` (dynamics/core/utils.py:192-236) with cell_type='lstm' - the configuration of
+ * run_scripts/run_rebal.py:98-99.  `cell_act` is the cell's `activation` (hidden_nonlinearity,
+ * default tanh, rnn_dynamics.py:20), `output_act` the output layer's nonlinearity.
+ * Fused MFMA kernel for units in {128, 256, 512}, obs_dim <= 64, act_dim <= 16; generic VALU
+ * kernel otherwise (l2a_set_kernel applies).                                                    */
+int l2a_lstm_create(l2a_ctx* ctx, int obs_dim, int act_dim, int units, int cell_act, int output_act,
+                    l2a_lstm** out);
+void l2a_lstm_destroy(l2a_lstm* model);
+
+/* Upload the four trainable variables in the reference's order (rnn.get_params(),
+ * dynamics/core/layers.py:219-221): rnn/lstm_cell/kernel [obs_dim + act_dim + units, 4 * units]
+ * (TF gate order i, j, f, o), rnn/lstm_cell/bias [4 * units], output/kernel [units, obs_dim],
+ * output/bias [obs_dim]; fp32 device pointers, row-major.  Replaces `Layer.set_params`
+ * (core/layers.py:81-94).                                                                        */
+int l2a_lstm_set_weights(l2a_lstm* model, const void* const* device_ptrs, void* stream);
+
+/* `self.normalization` of RNNDynamicsModel (rnn_dynamics.py:295-307; host float64 vectors, eps 1e-10
+ * applied inside as in :329-334); all NULL = identity.                                           */
+int l2a_lstm_set_norm(l2a_lstm* model, const double* mean_obs, const double* std_obs,
+                      const double* mean_act, const double* std_act, const double* mean_delta,
+                      const double* std_delta, void* stream);
+
+/* One recurrent plan step = the loop of RNNMPCController.get_rs_action
+ * (policies/rnn_mpc_controller.py:112-134; also the rollout of one CEM iteration, :92-104):
+ * `repeat_hidden` (:165-187) of the per-env LSTM state (c0, h0: device fp32 [m, units]) to the n
+ * candidates of each env, h x `dynamics_model.predict(obs, a[t], hidden)` + `env.reward` + return
+ * accumulation + arg-max.  Other arguments as l2a_plan_rs.                                       */
+int l2a_lstm_plan_rs(l2a_lstm* model, const float* obs0, const float* c0, const float* h0,
+                     const float* actions, int m, int n, int h, float discount, const l2a_reward* reward,
+                     int cand_offset, float* returns_out, unsigned long long* best_key, void* stream);
+
+/* RNNDynamicsModel.predict (rnn_dynamics.py:233-252): one step for `rows` independent rows, each
+ * with its own LSTM state.  obs [rows, obs_dim], act [rows, act_dim], c / h [rows, units] ->
+ * next_obs_out [rows, obs_dim], c_out / h_out [rows, units] (all device fp32).  Used by
+ * RNNMPCController.get_actions (:63) to advance the controller's hidden state with the chosen action. */
+int l2a_lstm_predict(l2a_lstm* model, const float* obs, const float* act, const float* c, const float* h,
+                     int rows, float* next_obs_out, float* c_out, float* h_out, void* stream);
+
+/* 1 when (obs_dim, act_dim, units) is eligible for the MFMA LSTM kernel, else 0.                 */
+int l2a_lstm_mfma_eligible(int obs_dim, int act_dim, int units);
 
 /* ---- introspection used by tests (no GPU needed) ------------------------------------------ */
 /* 1 when (obs_dim, act_dim, hidden[]) is eligible for the MFMA kernel, else 0.               */

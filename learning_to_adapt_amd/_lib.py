@@ -26,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_norm",
     "l2a_plan_rs", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
     "l2a_packed_layer_floats", "l2a_pack_layer_host",
+    "l2a_lstm_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs",
+    "l2a_lstm_predict", "l2a_lstm_mfma_eligible",
 )
 
 
@@ -87,6 +89,20 @@ def load():
     lib.l2a_packed_layer_floats.restype = c.c_longlong
     lib.l2a_pack_layer_host.argtypes = [c.POINTER(f32), i32, i32, c.POINTER(f32)]
     lib.l2a_pack_layer_host.restype = i32
+    lib.l2a_lstm_create.argtypes = [vp, i32, i32, i32, i32, i32, c.POINTER(vp)]
+    lib.l2a_lstm_create.restype = i32
+    lib.l2a_lstm_destroy.argtypes = [vp]
+    lib.l2a_lstm_destroy.restype = None
+    lib.l2a_lstm_set_weights.argtypes = [vp, c.POINTER(vp), vp]
+    lib.l2a_lstm_set_weights.restype = i32
+    lib.l2a_lstm_set_norm.argtypes = [vp, dp, dp, dp, dp, dp, dp, vp]
+    lib.l2a_lstm_set_norm.restype = i32
+    lib.l2a_lstm_plan_rs.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, c.POINTER(RewardSpec), i32, vp, vp, vp]
+    lib.l2a_lstm_plan_rs.restype = i32
+    lib.l2a_lstm_predict.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.l2a_lstm_predict.restype = i32
+    lib.l2a_lstm_mfma_eligible.argtypes = [i32, i32, i32]
+    lib.l2a_lstm_mfma_eligible.restype = i32
     _lib = lib
     return lib
 

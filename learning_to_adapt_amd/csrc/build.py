@@ -2,8 +2,8 @@
 
     python learning_to_adapt_amd/csrc/build.py [--force]
 
-The MFMA kernel template is instantiated in six translation units (one per (NT, TPW) pair), which
-are compiled in parallel and linked with the API unit.
+The MFMA kernel template is instantiated in six translation units (one per (NT, TPW) pair), the
+LSTM kernel in three (one per units / 64); all are compiled in parallel and linked with the two API units.
 """
 
 import os
@@ -16,9 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libl2a_hip.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
-HEADERS = ["l2a_kernels.h", "l2a_valu.h", "l2a_mfma.h", "l2a_mfma_launch.h", os.path.join("..", "..", "include", "l2a.h")]
-SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip"]
+HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_mfma.h", "l2a_mfma_launch.h", "l2a_lstm.h",
+           "l2a_lstm_valu.h", "l2a_lstm_launch.h", os.path.join("..", "..", "include", "l2a.h")]
+SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8)]
+LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -52,7 +54,10 @@ def build(force=False, verbose=True, only=None):
             print("[l2a] %s is up to date" % OUT)
         return OUT
     os.makedirs(OBJ_DIR, exist_ok=True)
-    jobs = [("l2a_api.hip", os.path.join(OBJ_DIR, "l2a_api.o"), [])]
+    jobs = [("l2a_api.hip", os.path.join(OBJ_DIR, "l2a_api.o"), []),
+            ("l2a_lstm_api.hip", os.path.join(OBJ_DIR, "l2a_lstm_api.o"), [])]
+    for utw in LSTM_INSTANCES:
+        jobs.append(("l2a_lstm_inst.hip", os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % utw), ["-DL2A_INST_UTW=%d" % utw]))
     for nt, tpw in INSTANCES:
         obj = os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % (nt, tpw))
         if only is not None and (nt, tpw) not in only and os.path.exists(obj):
@@ -63,7 +68,9 @@ def build(force=False, verbose=True, only=None):
               % (" ".join(FLAGS), len(jobs), min(len(jobs), os.cpu_count() or 1)))
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
         list(pool.map(_compile, jobs))
-    objs = [os.path.join(OBJ_DIR, "l2a_api.o")] + [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
+    objs = [os.path.join(OBJ_DIR, "l2a_api.o"), os.path.join(OBJ_DIR, "l2a_lstm_api.o")]
+    objs += [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
+    objs += [os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % u) for u in LSTM_INSTANCES]
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
     return OUT
 

@@ -4,6 +4,7 @@
 // holding raw + MFMA-packed weights and the padded normalisation vectors) and the launch logic
 // of the fused rollout kernels in l2a_kernels.h.  Everything is enqueued on the caller's stream.
 
+#include "l2a_host.h"
 #include "l2a_kernels.h"
 #include "l2a_valu.h"
 #include "l2a_mfma_launch.h"
@@ -21,20 +22,10 @@ std::string g_init_error;
 
 }  // namespace
 
-struct l2a_ctx {
-    int device = 0;
-    int kernel_kind = L2A_KERNEL_AUTO;
-    int split_policy = 1;                 // 1 = split members over two workgroups when it fills the chip
-    unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
-    unsigned int* status_dev = nullptr;
-    unsigned long long* dbg = nullptr;    // optional timeline buffer (l2a_set_debug_buffer)
-    int num_cu = 0;
-    int lds_per_block = 0;
-    int clock_khz = 0;
-    std::string arch;
-    std::string name;
-    mutable std::string err;
-};
+int l2a_fail(const l2a_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_init_error = msg;
+    return code;
+}
 
 struct l2a_model {
     l2a_ctx* ctx = nullptr;
@@ -61,17 +52,7 @@ namespace {
 
 inline bool fast_act(int a) { return a == L2A_ACT_RELU || a == L2A_ACT_IDENTITY; }
 
-int fail(const l2a_ctx* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg; else g_init_error = msg;
-    return code;
-}
-
-#define L2A_HIP(ctx, call)                                                                     \
-    do {                                                                                       \
-        hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail((ctx), L2A_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
-    } while (0)
+inline int fail(const l2a_ctx* ctx, int code, const std::string& msg) { return l2a_fail(ctx, code, msg); }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

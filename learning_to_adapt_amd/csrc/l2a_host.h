@@ -1,0 +1,36 @@
+// l2a_host.h - host-side definitions shared by the translation units of libl2a_hip.so
+// (l2a_api.hip: MLP models; l2a_lstm.hip: recurrent models).  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/l2a.h"
+
+struct l2a_ctx {
+    int device = 0;
+    int kernel_kind = L2A_KERNEL_AUTO;
+    int split_policy = 1;                 // 1 = split members over two workgroups when it fills the chip
+    unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
+    unsigned int* status_dev = nullptr;
+    unsigned long long* dbg = nullptr;    // optional timeline buffer (l2a_set_debug_buffer)
+    int num_cu = 0;
+    int lds_per_block = 0;
+    int clock_khz = 0;
+    std::string arch;
+    std::string name;
+    mutable std::string err;
+};
+
+// Records `msg` on the context (or as the init error when ctx is null) and returns `code`.
+int l2a_fail(const l2a_ctx* ctx, int code, const std::string& msg);
+
+#define L2A_HIP(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return l2a_fail((ctx), L2A_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+inline int l2a_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,487 @@
+// l2a_lstm.h - fused rollout of the RECURRENT planner (gfx950 / CDNA4 only).
+//
+// One launch = the loop body of `RNNMPCController.get_rs_action`
+// (reference policies/rnn_mpc_controller.py:112-134): every candidate action sequence is rolled
+// through a single-layer LSTM dynamics model (`RNNDynamicsModel.predict`,
+// dynamics/rnn_dynamics.py:233-252; cell = tf.nn.rnn_cell.LSTMCell, dynamics/core/utils.py:192-236)
+// over the whole horizon, with the env's hidden state repeated to its candidates
+// (`repeat_hidden`, :165-187), the closed-form reward accumulated and the arg-max reduced.
+//
+// Per (candidate, step):
+//     z = [norm(obs) | norm(act) | h] @ kernel + bias          kernel [in + U, 4 U], gates i j f o
+//     c = sigmoid(f + 1) * c + sigmoid(i) * act(j);   h = sigmoid(o) * act(c)
+//     obs += denorm(h @ Wout + bout)
+//
+// Two kernels:
+//  * l2a_lstm_mfma_k  - fp32 MFMA path for U = 128 / 256 / 512 (same fragment scheme as
+//                       l2a_mfma.h: D = W^T-tile x activations, the D fragment of the gate GEMM is the
+//                       B fragment of the next step's h k-groups and of the output layer).
+//                       Workgroup = 4 waves, NT tiles of 16 candidates.  Wave w owns unit tiles
+//                       [w UTW, (w+1) UTW) for ALL FOUR gates (16 UTW accumulator registers), so the
+//                       gate arithmetic is register-local and the cell state c never leaves registers;
+//                       h travels through a double-buffered LDS region; ONE barrier per step.
+//  * l2a_lstm_valu_k  - generic fp32 VALU path (any U); baseline + fallback.
+#pragma once
+
+#include "l2a_kernels.h"
+#include "l2a_mfma.h"
+
+struct L2ALstmParams {
+    // ---- model -------------------------------------------------------------------------
+    const float* wblk;
+    long long raw_wk, raw_bk;   // TF kernel [in + U, 4U] row-major, bias [4U]
+    long long raw_wo, raw_bo;   // output layer [U, obs_dim], [obs_dim]
+    long long pk_wg;            // packed gate matrix [4 UT tiles][KG0 + UT k-groups][64][4]
+    long long pk_wout;          // packed output layer [OT][UT][64][4]
+    long long pk_bout;          // output bias padded to 16 OT
+    long long nm_off;           // [in_mu 16 KG0][in_inv 16 KG0][out_mu 16 OT][out_sd 16 OT]
+    int obs_dim, act_dim, in_dim, units;
+    int cell_act, output_act;
+    int KG0, OT;
+    // ---- launch ------------------------------------------------------------------------
+    const float* obs0;          // [m, obs_dim] (or [R, obs_dim] when obs_per_row)
+    const float* c0;            // [m, U] (or [R, U] when hid_per_row)
+    const float* h0;
+    const float* actions;       // [h, m*n, act_dim]
+    float* returns_out;         // [m, n] or null
+    unsigned long long* best_key;
+    float* state_out;           // [m*n, obs_dim] or null
+    float* c_out;               // [m*n, U] or null
+    float* h_out;
+    int obs_per_row, hid_per_row;
+    int m, n, h;
+    int tiles_per_env;
+    int cand_offset;
+    float discount;
+    l2a_reward rw;
+    unsigned long long* dbg;
+};
+
+// Gate-matrix tile order: tile T = w * (4 UTW) + q * UTW + uu  <->  gate q (i, j, f, o) of unit tile
+// u = w * UTW + uu.  k order: the KG0 input k-groups (in_dim padded to 16 KG0), then the UT k-groups of h.
+__host__ __device__ inline void l2a_lstm_pack_decode(long long idx, int KG0, int UT, int in_dim, int* k_tf, int* col_tf) {
+    const int KG = KG0 + UT;
+    const int UTW = UT / L2A_NW;
+    const int U = 16 * UT;
+    const int ii = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    const long long rest = idx >> 8;
+    const int g = (int)(rest % KG);
+    const int T = (int)(rest / KG);
+    const int w = T / (4 * UTW);
+    const int q = (T - w * 4 * UTW) / UTW;
+    const int uu = T - w * 4 * UTW - q * UTW;
+    const int k = 16 * g + 4 * (lane >> 4) + ii;
+    if (k < 16 * KG0) *k_tf = (k < in_dim) ? k : -1;
+    else *k_tf = in_dim + (k - 16 * KG0);
+    *col_tf = q * U + 16 * (w * UTW + uu) + (lane & 15);
+}
+
+__device__ __forceinline__ float l2a_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+// h-part of the gate GEMM for TW of this wave's gate tiles: acc += Wg[:, h k-groups] x h.
+// Same 4-buffer / distance-2 software pipeline as l2a_hidden_gemm (l2a_mfma.h); aA / aB arrive
+// preloaded with h k-groups 0 / 1; `tail2` / `tail3` run in the last two refill slots (they fetch the
+// next phase's first operands instead of reloading the final k-group).
+// ------------------------------------------------------------------------------------------
+template <int NT, int TW, int HT, class F2, class F3>
+__device__ __forceinline__ void l2a_lstm_gemm(__amdgpu_buffer_rsrc_t rs, const int (&voff)[TW], const f32x4* hin,
+                                              f32x4 (&aA)[TW], f32x4 (&aB)[TW], f32x4 (&acc)[NT][TW], int lane,
+                                              F2 tail2, F3 tail3) {
+    static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
+    f32x4 aC[TW], aD[TW], bA[NT], bB[NT], bC[NT], bD[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bA[nt] = hin[(nt * HT + 0) * 64 + lane];
+        bB[nt] = hin[(nt * HT + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { L2A_OPAQUE(bA[nt]); L2A_OPAQUE(bB[nt]); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int g = 0; g < HT - 4; g += 4) {
+        const int soff = (g + 2) * 1024;
+        L2A_STAGE(aA, bA, aC, bC, soff, 0, g + 2)
+        L2A_STAGE(aB, bB, aD, bD, soff, 1024, g + 3)
+        L2A_STAGE(aC, bC, aA, bA, soff, 2048, g + 4)
+        L2A_STAGE(aD, bD, aB, bB, soff, 3072, g + 5)
+    }
+    L2A_STAGE(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2)
+    L2A_STAGE(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1)
+    {
+        tail2();
+        L2A_STAGE_MFMA(aC, bC)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        tail3();
+        L2A_STAGE_MFMA(aD, bD)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NT, int UTW, int OT, int KG0>
+__global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmParams p) {
+    static_assert(UTW % 2 == 0, "a wave's 4 UTW gate tiles are processed in passes of 8");
+    constexpr int UT = L2A_NW * UTW;            // unit tiles = h k-groups
+    constexpr int U = 16 * UT;
+    constexpr int KG = KG0 + UT;                // k-groups of the gate matrix
+    constexpr int GTW = 4 * UTW;                // gate tiles per wave
+    constexpr int TW = 8;                       // gate tiles per pass
+    constexpr int NP = GTW / TW;                // passes
+    constexpr int HT = UT;                      // (name used by the L2A_STAGE macros: LDS stride)
+    // LDS: h fragments, double buffered; output-layer chunk partials, double buffered; constants
+    constexpr int HB = NT * UT * 64;            // f32x4 per h buffer
+    constexpr int PB = 2 * L2A_NW * NT * OT * 64;
+    constexpr int CST_BOUT = 32 * KG0 + 32 * OT;
+    constexpr int CST_BG = CST_BOUT + 16 * OT;  // gate bias [4 U], TF order
+    extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
+    f32x4* hbuf = reinterpret_cast<f32x4*>(l2a_smem);
+    f32x4* pbuf = hbuf + 2 * HB;
+    float* nrm = reinterpret_cast<float*>(pbuf + 2 * PB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jc = lane & 15;
+    const int qq = lane >> 4;
+    const int u0 = wave * UTW;                  // first unit tile of this wave
+
+    const int bid = l2a_logical_wg(blockIdx.x, gridDim.x);
+    const int env = bid / p.tiles_per_env;
+    const int tb = bid - env * p.tiles_per_env;
+    const int R = p.m * p.n;
+    const int obs_dim = p.obs_dim, act_dim = p.act_dim;
+
+    int cand[NT], row[NT];
+    bool valid[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        cand[nt] = tb * (16 * NT) + nt * 16 + jc;
+        valid[nt] = cand[nt] < p.n;
+        row[nt] = env * p.n + (valid[nt] ? cand[nt] : p.n - 1);
+    }
+
+    for (int i = tid; i < CST_BG + 4 * U; i += 64 * L2A_NW) {
+        float v;
+        if (i < CST_BOUT) v = p.wblk[p.nm_off + i];
+        else if (i < CST_BG) v = p.wblk[p.pk_bout + (i - CST_BOUT)];
+        else v = p.wblk[p.raw_bk + (i - CST_BG)];
+        nrm[i] = v;
+    }
+
+    // ---- state, cell state (registers) and h (LDS buffer 0) ----------------------------------
+    f32x4 st[NT][OT], creg[NT][UTW];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float* orow = p.obs0 + (p.obs_per_row ? (long long)row[nt] : (long long)env) * obs_dim;
+#pragma unroll
+        for (int c = 0; c < OT; ++c)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int dim = 16 * c + 4 * qq + ii;
+                const float v = orow[dim < obs_dim ? dim : obs_dim - 1];
+                st[nt][c][ii] = (dim < obs_dim) ? v : 0.0f;
+            }
+        const long long hrow = (p.hid_per_row ? (long long)row[nt] : (long long)env) * U;
+#pragma unroll
+        for (int uu = 0; uu < UTW; ++uu) {
+            creg[nt][uu] = *reinterpret_cast<const f32x4*>(p.c0 + hrow + 16 * (u0 + uu) + 4 * qq);
+            hbuf[(nt * UT + u0 + uu) * 64 + lane] = *reinterpret_cast<const f32x4*>(p.h0 + hrow + 16 * (u0 + uu) + 4 * qq);
+        }
+    }
+    __syncthreads();
+
+    const int ga0 = obs_dim >> 4;
+    f32x4 av_next[NT][2];
+    auto load_actions = [&](int t, f32x4 (&dst)[NT][2]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float* arow = p.actions + ((long long)t * R + row[nt]) * act_dim;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+                    const bool in = (ka >= 0) && (ka < act_dim);
+                    const float v = arow[in ? ka : 0];
+                    dst[nt][s][ii] = in ? v : 0.0f;
+                }
+        }
+    };
+    load_actions(0, av_next);
+
+    float ret[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ret[nt] = 0.0f;
+    double disc_pow = 1.0;
+
+    const long long wg_bytes = (long long)4 * UT * KG * 1024, wo_bytes = (long long)OT * UT * 1024;
+    const __amdgpu_buffer_rsrc_t rs = l2a_rsrc(p.wblk + p.pk_wg, wg_bytes);
+    const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(p.wblk + p.pk_wout, wo_bytes);
+    // byte offset of this lane in gate tile (pass, tt): x k-groups start at +0, h k-groups at +KG0 KiB
+    int voffx[NP][TW], voffh[NP][TW];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int tt = 0; tt < TW; ++tt) {
+            voffx[ps][tt] = lane * 16 + (wave * GTW + ps * TW + tt) * KG * 1024;
+            voffh[ps][tt] = voffx[ps][tt] + KG0 * 1024;
+        }
+    f32x4 pfA[TW], pfB[TW];         // h k-groups 0 / 1 of the upcoming pass
+    f32x4 pfO[UTW][OT];             // output-layer A fragments of this wave's unit tiles
+    f32x4 hreg[NT][UTW];
+
+    for (int t = 0; t < p.h; ++t) {
+        const f32x4* hcur = hbuf + (t & 1) * HB;
+        f32x4* hnext = hbuf + ((t + 1) & 1) * HB;
+        f32x4* pb = pbuf + (t & 1) * PB;
+        f32x4 av[NT][2];
+        float asq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            av[nt][0] = av_next[nt][0];
+            av[nt][1] = av_next[nt][1];
+            float s = 0.0f;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                s = fmaf(av[nt][0][ii], av[nt][0][ii], s);
+                s = fmaf(av[nt][1][ii], av[nt][1][ii], s);
+            }
+            asq[nt] = s;
+        }
+        load_actions((t + 1 < p.h) ? t + 1 : t, av_next);
+
+        // ---- x part of the gate GEMM: B = normalised [obs | act] from registers ---------------
+        f32x4 x[KG0][NT];
+#pragma unroll
+        for (int g = 0; g < KG0; ++g) {
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(nrm + 16 * g + 4 * qq);
+            const f32x4 iv = *reinterpret_cast<const f32x4*>(nrm + 16 * KG0 + 16 * g + 4 * qq);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (g < OT) sv = st[nt][g < OT ? g : 0];
+                f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (g == ga0) aa = av[nt][0];
+                if (g == ga0 + 1) aa = av[nt][1];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int k = 16 * g + 4 * qq + ii;
+                    const float v = (k < obs_dim) ? sv[ii] : aa[ii];
+                    x[g][nt][ii] = (v - mu[ii]) * iv[ii];
+                }
+            }
+        }
+        f32x4 acc[NP][NT][TW];
+#pragma unroll
+        for (int tt = 0; tt < TW; ++tt) {       // first operands of pass 0's h part
+            pfA[tt] = l2a_ldw(rs, voffh[0][tt], 0);
+            pfB[tt] = l2a_ldw(rs, voffh[0][tt] + 1024, 0);
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            f32x4 a[KG0][TW];
+#pragma unroll
+            for (int g = 0; g < KG0; ++g)
+#pragma unroll
+                for (int tt = 0; tt < TW; ++tt) a[g][tt] = l2a_ldw(rs, voffx[ps][tt] + g * 1024, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int tt = 0; tt < TW; ++tt) acc[ps][nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < KG0; ++g)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int tt = 0; tt < TW; ++tt)
+                            acc[ps][nt][tt] = L2A_MFMA(a[g][tt][ii], x[g][nt][ii], acc[ps][nt][tt]);
+        }
+
+        // ---- h part, pass by pass; each pass fetches the next one's first operands in its tail ----
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            if (ps + 1 < NP) {
+                const int pn = (ps + 1 < NP) ? ps + 1 : ps;
+                l2a_lstm_gemm<NT, TW, HT>(rs, voffh[ps], hcur, pfA, pfB, acc[ps], lane,
+                    [&]() {
+#pragma unroll
+                        for (int tt = 0; tt < TW; ++tt) pfA[tt] = l2a_ldw(rs, voffh[pn][tt], 0);
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int tt = 0; tt < TW; ++tt) pfB[tt] = l2a_ldw(rs, voffh[pn][tt] + 1024, 0);
+                    });
+            } else {
+                l2a_lstm_gemm<NT, TW, HT>(rs, voffh[ps], hcur, pfA, pfB, acc[ps], lane,
+                    [&]() {
+#pragma unroll
+                        for (int uu = 0; uu < UTW; ++uu)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+                                if (((uu * OT + c) & 1) == 0)
+                                    pfO[uu][c] = l2a_ldw(rs_out, lane * 16 + (u0 + uu) * 1024, c * UT * 1024);
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int uu = 0; uu < UTW; ++uu)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+                                if (((uu * OT + c) & 1) == 1)
+                                    pfO[uu][c] = l2a_ldw(rs_out, lane * 16 + (u0 + uu) * 1024, c * UT * 1024);
+                    });
+            }
+        }
+
+        // ---- gate arithmetic (register local) -> c, h ------------------------------------------
+#pragma unroll
+        for (int uu = 0; uu < UTW; ++uu) {
+            f32x4 bias[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bias[q] = *reinterpret_cast<const f32x4*>(nrm + CST_BG + q * U + 16 * (u0 + uu) + 4 * qq);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 z[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int lt = q * UTW + uu;
+                    z[q] = acc[lt / TW][nt][lt % TW] + bias[q];
+                }
+                f32x4 cn, hn;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const float ig = l2a_sigmoid(z[0][ii]);
+                    const float jg = l2a_act1(z[1][ii], p.cell_act);
+                    const float fg = l2a_sigmoid(z[2][ii] + 1.0f);          // forget_bias = 1
+                    const float og = l2a_sigmoid(z[3][ii]);
+                    cn[ii] = fg * creg[nt][uu][ii] + ig * jg;
+                    hn[ii] = og * l2a_act1(cn[ii], p.cell_act);
+                }
+                creg[nt][uu] = cn;
+                hreg[nt][uu] = hn;
+                hnext[(nt * UT + u0 + uu) * 64 + lane] = hn;
+            }
+        }
+
+        // ---- output layer: this wave's unit tiles are its k-groups; chunk partials -> LDS -------
+        {
+            constexpr int CS = UTW / 2;
+            f32x4 oacc[2][NT][OT];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) oacc[ch][nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t2 = 0; t2 < CS; ++t2)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+                                oacc[ch][nt][c] = L2A_MFMA(pfO[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], oacc[ch][nt][c]);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) pb[(((2 * wave + ch) * NT + nt) * OT + c) * 64 + lane] = oacc[ch][nt][c];
+        }
+        __syncthreads();
+
+        // ---- every wave sums the 8 chunk partials in the canonical order, then reward / state ----
+        const float disc_t = (float)disc_pow;
+        disc_pow *= (double)p.discount;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[nt];
+            float psq = 0.0f;
+#pragma unroll
+            for (int c = 0; c < OT; ++c) {
+                f32x4 s = pb[((0 * NT + nt) * OT + c) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < L2A_NW; ++w) s += pb[((w * NT + nt) * OT + c) * 64 + lane];
+                f32x4 s2 = pb[((L2A_NW * NT + nt) * OT + c) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < L2A_NW; ++w) s2 += pb[(((L2A_NW + w) * NT + nt) * OT + c) * 64 + lane];
+                s += s2;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(nrm + CST_BOUT + 16 * c + 4 * qq);
+                const f32x4 omu = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * c + 4 * qq);
+                const f32x4 osd = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
+                s = l2a_act4(s + bias, p.output_act);
+                const f32x4 d = s * osd + omu;
+                const f32x4 nx = st[nt][c] + d;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int dim = 16 * c + 4 * qq + ii;
+                    if (dim == p.rw.vel_index) plin += p.rw.w_vel * d[ii] * p.rw.inv_dt;
+                    const bool in_dist = (p.rw.dist_coef != 0.0f) && (dim >= p.rw.dist_index) &&
+                                         (dim < p.rw.dist_index + 3) && (dim < obs_dim);
+                    psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
+                }
+                st[nt][c] = nx;
+            }
+            plin += __shfl_xor(plin, 16);
+            plin += __shfl_xor(plin, 32);
+            psq += __shfl_xor(psq, 16);
+            psq += __shfl_xor(psq, 32);
+            float r = plin;
+            if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
+            ret[nt] = fmaf(disc_t, r, ret[nt]);
+        }
+    }
+
+    // ---- results ----------------------------------------------------------------------------
+    if (p.c_out || p.h_out) {       // every wave writes its own unit tiles (predict)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (valid[nt]) {
+                const long long orow = ((long long)env * p.n + cand[nt]) * U;
+#pragma unroll
+                for (int uu = 0; uu < UTW; ++uu) {
+                    if (p.c_out) *reinterpret_cast<f32x4*>(p.c_out + orow + 16 * (u0 + uu) + 4 * qq) = creg[nt][uu];
+                    if (p.h_out) *reinterpret_cast<f32x4*>(p.h_out + orow + 16 * (u0 + uu) + 4 * qq) = hreg[nt][uu];
+                }
+            }
+    }
+    if (wave == 0) {
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (valid[nt] && qq == 0) {
+                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[nt]] = ret[nt];
+                const unsigned long long k = l2a_key_pack(ret[nt], p.cand_offset + cand[nt]);
+                key = (k > key) ? k : key;
+            }
+            if (p.state_out && valid[nt]) {
+                float* srow = p.state_out + ((long long)env * p.n + cand[nt]) * obs_dim;
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int dim = 16 * c + 4 * qq + ii;
+                        if (dim < obs_dim) srow[dim] = st[nt][c][ii];
+                    }
+            }
+        }
+        if (p.best_key) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const unsigned int hi = __shfl_xor((unsigned int)(key >> 32), off);
+                const unsigned int lo = __shfl_xor((unsigned int)(key & 0xffffffffu), off);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key = (other > key) ? other : key;
+            }
+            if (lane == 0 && key != 0ull) atomicMax(p.best_key + env, key);
+        }
+    }
+}

@@ -1,0 +1,105 @@
+"""Python handle on an ``l2a_lstm`` (C ABI: ``include/l2a.h``, recurrent planner section).
+
+Like ``native_model.NativeModel``: no numerics of its own, PyTorch-ROCm tensors are storage, the
+fused kernels run on torch's current HIP stream, ``L2AError`` on any failure, no CPU fallback.
+"""
+
+import ctypes
+
+import torch
+
+from .. import _lib
+from ..envs.reward_spec import RewardSpec
+from .native_model import _dvec, _ptr, _stream_ptr
+
+
+class NativeLSTM(object):
+    def __init__(self, obs_dim, act_dim, units, cell_act="tanh", output_act=None, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.L2AError("no MI355X visible to PyTorch-ROCm: the rollout path is HIP-only "
+                                "(there is no CPU fallback)")
+        self.ctx = _lib.Context.get(device)
+        self.lib = self.ctx.lib
+        self.device = torch.device("cuda", device)
+        self.obs_dim, self.act_dim, self.units = int(obs_dim), int(act_dim), int(units)
+        if cell_act not in _lib.ACT_CODES or output_act not in _lib.ACT_CODES:
+            raise _lib.L2AError("nonlinearity %r / %r is not supported by the HIP kernels" % (cell_act, output_act))
+        handle = ctypes.c_void_p()
+        rc = self.lib.l2a_lstm_create(self.ctx.handle, self.obs_dim, self.act_dim, self.units,
+                                      _lib.ACT_CODES[cell_act], _lib.ACT_CODES[output_act], ctypes.byref(handle))
+        self.ctx.check(rc, "l2a_lstm_create")
+        self.handle = handle
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.l2a_lstm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, params):
+        """``params``: [kernel [in + U, 4U], bias [4U], output kernel [U, obs_dim], output bias]."""
+        U, k_in = self.units, self.obs_dim + self.act_dim + self.units
+        shapes = [(k_in, 4 * U), (4 * U,), (U, self.obs_dim), (self.obs_dim,)]
+        assert len(params) == 4, "expected 4 parameter arrays"
+        dev = []
+        for p, shp in zip(params, shapes):
+            t = torch.as_tensor(p) if not torch.is_tensor(p) else p
+            t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            assert tuple(t.shape) == shp, "LSTM parameter has shape %s, expected %s" % (tuple(t.shape), shp)
+            dev.append(t)
+        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in dev])
+        self.ctx.check(self.lib.l2a_lstm_set_weights(self.handle, ptrs, _stream_ptr()), "l2a_lstm_set_weights")
+        self._keep["w"] = dev
+
+    def set_norm(self, norm):
+        if norm is None:
+            null = ctypes.POINTER(ctypes.c_double)()
+            rc = self.lib.l2a_lstm_set_norm(self.handle, null, null, null, null, null, null, _stream_ptr())
+        else:
+            keep, args = [], []
+            for key in ("obs", "act", "delta"):
+                for j in (0, 1):
+                    arr, p = _dvec(norm[key][j])
+                    expect = self.act_dim if key == "act" else self.obs_dim
+                    assert arr.shape == (expect,), "normalization[%r] has shape %s" % (key, arr.shape)
+                    keep.append(arr)
+                    args.append(p)
+            rc = self.lib.l2a_lstm_set_norm(self.handle, *args, _stream_ptr())
+        self.ctx.check(rc, "l2a_lstm_set_norm")
+
+    def plan_rs(self, obs0, c0, h0, actions, m, n, h, discount, reward, cand_offset=0, returns_out=None,
+                best_key=None):
+        for t in (obs0, c0, h0, actions):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        assert obs0.numel() == m * self.obs_dim and actions.numel() == h * m * n * self.act_dim
+        assert c0.numel() == m * self.units and h0.numel() == m * self.units
+        if returns_out is not None:
+            assert returns_out.is_cuda and returns_out.dtype == torch.float32 and returns_out.numel() == m * n
+        if best_key is not None:
+            assert best_key.is_cuda and best_key.dtype == torch.int64 and best_key.numel() == m
+        assert isinstance(reward, RewardSpec)
+        rc = self.lib.l2a_lstm_plan_rs(self.handle, _ptr(obs0), _ptr(c0), _ptr(h0), _ptr(actions), int(m), int(n),
+                                       int(h), float(discount), ctypes.byref(reward), int(cand_offset),
+                                       _ptr(returns_out), _ptr(best_key), _stream_ptr())
+        self.ctx.check(rc, "l2a_lstm_plan_rs")
+
+    def predict(self, obs, act, c, h):
+        """One step for independent rows.  Returns ``(next_obs, c_out, h_out)`` CUDA tensors."""
+        for t in (obs, act, c, h):
+            assert t.is_cuda and t.dtype == torch.float32
+        rows = obs.shape[0]
+        assert c.shape == (rows, self.units) and h.shape == (rows, self.units)
+        nxt = torch.empty((rows, self.obs_dim), dtype=torch.float32, device=self.device)
+        c_out = torch.empty((rows, self.units), dtype=torch.float32, device=self.device)
+        h_out = torch.empty((rows, self.units), dtype=torch.float32, device=self.device)
+        rc = self.lib.l2a_lstm_predict(self.handle, _ptr(obs.contiguous()), _ptr(act.contiguous()),
+                                       _ptr(c.contiguous()), _ptr(h.contiguous()), int(rows), _ptr(nxt),
+                                       _ptr(c_out), _ptr(h_out), _stream_ptr())
+        self.ctx.check(rc, "l2a_lstm_predict")
+        return nxt, c_out, h_out

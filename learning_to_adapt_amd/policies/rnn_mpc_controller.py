@@ -1,0 +1,126 @@
+"""``RNNMPCController`` - drop-in for ``learning_to_adapt/policies/rnn_mpc_controller.py:7-195`` (ReBAL).
+
+Same constructor (``run_scripts/run_rebal.py:34-43``; note ``percent_elites=0.05`` and no ``alpha``
+here, ``:19``), same ``get_action`` / ``get_actions`` / ``reset(dones)`` / ``repeat_hidden`` surface
+and the same consumption of NumPy's global RNG as the reference.  The controller owns the model's
+hidden state (one LSTM state row per env): ``reset`` zeroes the rows of finished envs
+(``:136-163``), ``get_actions`` plans from it and then advances it with the chosen actions
+(``:57-65``).
+
+Underneath, the horizon loop with its per-step ``dynamics_model.predict(obs, a[t], hidden)``
+(``:121-131`` / ``:97-104``) is ONE launch of the fused recurrent rollout (``l2a_lstm_plan_rs``):
+the env's state is broadcast to its candidates inside the kernel (``repeat_hidden`` never
+materialises), cell states stay in registers.  Candidate sharding over ``torch.distributed`` ranks,
+the device RNG mode and CEM work as in ``MPCController`` (whose helpers are reused).
+"""
+
+import numpy as np
+import torch
+
+from ..utils.serializable import Serializable
+from .mpc_controller import MPCController
+
+
+class RNNMPCController(MPCController):
+    def __init__(
+            self,
+            name,
+            env,
+            dynamics_model,
+            reward_model=None,
+            discount=1,
+            use_cem=False,
+            n_candidates=1024,
+            horizon=10,
+            num_cem_iters=8,
+            percent_elites=0.05,
+            use_reward_model=False,
+            rng="numpy",
+            cem_mode="reference",
+            shard_candidates=True,
+    ):
+        Serializable.quick_init(self, locals())
+        # alpha = 0 makes the shared CEM update `mean * alpha + (1 - alpha) * mean(elites)` the
+        # reference's plain `np.mean(elites)` (:107), bit for bit.
+        MPCController.__init__(self, name=name, env=env, dynamics_model=dynamics_model,
+                               reward_model=reward_model, discount=discount, use_cem=use_cem,
+                               n_candidates=n_candidates, horizon=horizon, num_cem_iters=num_cem_iters,
+                               percent_elites=percent_elites, use_reward_model=use_reward_model, alpha=0.0,
+                               rng=rng, cem_mode=cem_mode, shard_candidates=shard_candidates)
+        self._hidden_state = None
+
+    # ------------------------------------------------------------------ reference API
+    def get_action(self, observation):
+        if observation.ndim == 1:
+            observation = observation[None]
+        action = self.get_actions(observation)[0]
+        return action, dict()
+
+    def get_actions(self, observations):
+        if self._hidden_state is None:
+            self.reset(dones=[True] * len(observations))
+        if self.use_cem:
+            actions = self.get_cem_action(observations)
+        else:
+            actions = self.get_rs_action(observations)
+        # advance the controller's own hidden state with the chosen actions (:63)
+        _, self._hidden_state = self.dynamics_model.predict(np.array(observations), actions, self._hidden_state)
+        return actions, dict()
+
+    def reset(self, dones=None):
+        if dones is None:
+            dones = [True]
+        if self._hidden_state is None:
+            self._hidden_state = self.dynamics_model.get_initial_hidden(batch_size=len(dones))
+        zero = self.dynamics_model.get_initial_hidden(batch_size=1)
+        dones = np.asarray(dones, dtype=bool)
+        for state, z in zip(self._hidden_state, zero):          # LSTM state: (c, h)
+            state[dones] = z
+
+    def repeat_hidden(self, hidden, n):
+        """``:165-187``: every row n times (env-major).  Only the unfused path materialises this."""
+        if isinstance(hidden, (list, tuple)):
+            rep = [self.repeat_hidden(part, n) for part in hidden]
+            return type(hidden)(*rep) if hasattr(hidden, "_fields") else rep
+        return np.repeat(hidden, n, axis=0)
+
+    # ------------------------------------------------------------------ fused rollout with the env's LSTM state
+    def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns):
+        native = self.dynamics_model.planner_model()
+        m = len(observations)
+        dev = native.device
+        c, h = self._hidden_state
+        assert c.shape == (m, native.units), "hidden state holds %d rows, %d observations were passed" % (
+            c.shape[0], m)
+        obs0 = self._buf("obs0", (m, native.obs_dim), torch.float32, dev)
+        obs0.copy_(torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32)))
+        c0 = self._buf("c0", (m, native.units), torch.float32, dev)
+        h0 = self._buf("h0", (m, native.units), torch.float32, dev)
+        c0.copy_(torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)))
+        h0.copy_(torch.from_numpy(np.ascontiguousarray(h, dtype=np.float32)))
+        best = self._buf("best", (m,), torch.int64, dev)
+        rets = self._buf("rets", (m, n_local), torch.float32, dev) if want_returns else None
+        native.plan_rs(obs0, c0, h0, actions_local, m, n_local, self.horizon, self.discount, self._reward_spec,
+                       cand_offset=cand_offset, returns_out=rets, best_key=best)
+        return best, rets
+
+    def _get_rs_action_unfused(self, observations):
+        """Custom env reward / reward model: the reference's loop shape (:112-134); the LSTM step
+        still runs on the GPU through ``dynamics_model.predict``."""
+        n, m, h = self.n_candidates, len(observations), self.horizon
+        returns = np.zeros((n * m,))
+        a = self.get_random_action(h * n * m).reshape((h, n * m, -1))
+        cand_a = a[0].reshape((m, n, -1))
+        observation = np.repeat(observations, n, axis=0)
+        hidden_state = self.repeat_hidden(self._hidden_state, n)
+        for t in range(h):
+            next_observation, hidden_state = self.dynamics_model.predict(observation, a[t], hidden_state)
+            if self.use_reward_model:
+                assert self.reward_model is not None
+                rewards = self.reward_model.predict(observation, a[t], next_observation)
+            else:
+                rewards = self.unwrapped_env.reward(observation, a[t], next_observation)
+            returns += self.discount ** t * rewards
+            observation = next_observation
+        returns = returns.reshape(m, n)
+        return cand_a[range(m), np.argmax(returns, axis=1)]

@@ -44,3 +44,39 @@ def install(controller, case):
     controller._upload = _upload
     controller._rollout = _rollout
     return controller
+
+
+def install_rnn(controller, case):
+    """Recurrent twin of ``install``: the fused recurrent rollout AND the model's ``predict`` (used by
+    ``get_actions`` to advance the hidden state) are computed by the oracle."""
+    from oracle import LSTMStateTuple
+    from oracle.rnn_planner import rnn_rollout_returns
+    lib = _lib.load()
+    env, _, _ = cases.rnn_recipe(case)
+    dyn = cases.oracle_rnn_dynamics(case)
+    reward = make_reward(case["env"], env.dt)
+    cpu = torch.device("cpu")
+
+    def _rollout(observations, actions_local, n_local, cand_offset, want_returns):
+        m = len(observations)
+        acts = actions_local.numpy().astype(np.float64)
+        c, h = controller._hidden_state
+        rets = rnn_rollout_returns(dyn, reward, observations, LSTMStateTuple(c, h), acts, n_local,
+                                   controller.discount)
+        rets = rets.reshape(m, n_local).astype(np.float32)
+        keys = np.zeros(m, dtype=np.int64)
+        for i in range(m):
+            keys[i] = max(lib.l2a_key_encode(ctypes.c_float(float(rets[i, j])), cand_offset + j)
+                          for j in range(n_local))
+        return torch.from_numpy(keys), (torch.from_numpy(rets) if want_returns else None)
+
+    def predict(obs, act, hidden):
+        nxt, hid = dyn.predict(obs, act, hidden)
+        return nxt, type(controller._hidden_state)(hid.c, hid.h)
+
+    controller._check_status = lambda: None
+    controller._device = lambda: cpu
+    controller._upload = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    controller._rollout = _rollout
+    controller.dynamics_model.predict = predict
+    return controller

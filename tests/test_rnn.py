@@ -1,0 +1,268 @@
+"""Recurrent planner (ReBAL): oracle vs the golden vectors of the real
+``RNNMPCController``, the LSTM restatement vs an independent implementation, host logic of the drop-in
+classes on CPU (launch replaced by the oracle) and - marked ``gpu`` - parity of the fused recurrent
+rollout through the C ABI."""
+
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle_backend
+from oracle import (LSTMStateTuple, OracleLSTMDynamics, lstm_step_f32, make_reward, rnn_cem_plan, rnn_rs_plan)
+
+RNN_IDS = cases.rnn_case_ids()
+
+
+def _replay(case, gold, plan_step, reset_hook):
+    """Drive ``plan_step(k, obs) -> (chosen, hidden_after)`` over the recorded controller steps."""
+    resets = {int(k): v for k, v in case.get("reset_after", {}).items()}
+    out = []
+    for k in range(case["steps"]):
+        out.append(plan_step(k, gold["obs"][k]))
+        if k in resets:
+            reset_hook(np.array(resets[k], dtype=bool))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ oracle (CPU)
+@pytest.mark.parametrize("cid", RNN_IDS)
+def test_oracle_reproduces_reference_rnn_controller(cid):
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    env, _, _ = cases.rnn_recipe(case)
+    dyn = cases.oracle_rnn_dynamics(case)
+    reward = make_reward(case["env"], env.dt)
+    state = {"hid": dyn.get_initial_hidden(case["m"])}
+    np.random.seed(seed)
+
+    def step(k, obs):
+        args = (dyn, reward, obs, state["hid"], env.action_space.low, env.action_space.high, case["n"], case["h"],
+                case.get("discount", 1.0))
+        if case["planner"] == "rnn_cem":
+            chosen, best, returns, hid = rnn_cem_plan(*args, num_cem_iters=case["num_cem_iters"])
+        else:
+            chosen, best, returns, hid = rnn_rs_plan(*args)
+        state["hid"] = hid
+        assert np.array_equal(returns, gold["returns_%d" % k])
+        assert np.array_equal(best, gold["best_%d" % k])
+        assert np.array_equal(chosen, gold["chosen_%d" % k])
+        assert np.array_equal(hid.c, gold["hidden_c_%d" % k]) and np.array_equal(hid.h, gold["hidden_h_%d" % k])
+
+    def reset(dones):
+        zero = dyn.get_initial_hidden(1)
+        state["hid"].c[dones] = zero.c
+        state["hid"].h[dones] = zero.h
+
+    _replay(case, gold, step, reset)
+    assert np.random.uniform() == float(gold["rng_next"])        # RNG consumption
+
+
+def test_lstm_restatement_matches_torch_lstm_cell():
+    """Independent check of the cell arithmetic: torch.nn.LSTMCell (gate order i, f, g, o; no forget
+    bias) fed with the re-ordered TF-layout weights and the forget bias folded into b_f."""
+    rs = np.random.RandomState(0)
+    n_in, U, B = 26, 64, 9
+    kernel = (0.2 * rs.randn(n_in + U, 4 * U)).astype(np.float32)
+    bias = (0.1 * rs.randn(4 * U)).astype(np.float32)
+    x = rs.randn(B, n_in).astype(np.float32)
+    c0 = rs.randn(B, U).astype(np.float32)
+    h0 = np.tanh(rs.randn(B, U)).astype(np.float32)
+    c1, h1 = lstm_step_f32(x, c0, h0, kernel, bias)
+    cell = torch.nn.LSTMCell(n_in, U)
+    i, j, f, o = np.split(kernel, 4, axis=1)
+    bi, bj, bf, bo = np.split(bias, 4)
+    w = np.concatenate([i, f, j, o], axis=1)                      # torch order: i, f, g(=j), o
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.from_numpy(w[:n_in].T.copy()))
+        cell.weight_hh.copy_(torch.from_numpy(w[n_in:].T.copy()))
+        cell.bias_ih.copy_(torch.from_numpy(np.concatenate([bi, bf + 1.0, bj, bo])))
+        cell.bias_hh.zero_()
+        h_t, c_t = cell(torch.from_numpy(x), (torch.from_numpy(h0), torch.from_numpy(c0)))
+    np.testing.assert_allclose(c1, c_t.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(h1, h_t.numpy(), rtol=2e-5, atol=2e-6)
+    c64, h64 = lstm_step_f32(x, c0, h0, kernel, bias, dtype=np.float64)
+    np.testing.assert_allclose(c1, c64, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ host logic (CPU)
+@pytest.mark.parametrize("cid", [c for c in RNN_IDS if "c6_" not in c])
+def test_rnn_controller_host_logic_matches_golden(cid):
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    ctrl = oracle_backend.install_rnn(cases.product_rnn_controller(case), case)
+    ctrl.reset(dones=[True] * case["m"])
+    np.random.seed(seed)
+
+    def step(k, obs):
+        chosen, info = ctrl.get_actions(obs)
+        assert info == {}
+        assert np.array_equal(ctrl.last_plan["best_index"], gold["best_%d" % k])
+        assert np.array_equal(chosen, gold["chosen_%d" % k])
+        assert np.array_equal(ctrl._hidden_state.c, gold["hidden_c_%d" % k])
+
+    _replay(case, gold, step, lambda dones: ctrl.reset(dones=dones))
+    assert np.random.uniform() == float(gold["rng_next"])
+
+
+def test_rnn_model_surface_and_pickling():
+    case = cases.CASES["hc_rnn_rs_u128_n40_h3"]
+    env, model = cases.product_rnn_model(case)
+    assert model.recurrent is True
+    hid = model.get_initial_hidden(3)
+    assert isinstance(hid, tuple) and hid.c.shape == (3, 128) and hid.h.dtype == np.float32 and not hid.c.any()
+    twin = pickle.loads(pickle.dumps(model))
+    for a, b in zip(model.get_param_values().values(), twin.get_param_values().values()):
+        assert np.array_equal(a, b)
+    assert list(twin.get_param_values()) == ["rnn/lstm_cell/kernel", "rnn/lstm_cell/bias", "output/kernel",
+                                             "output/bias"]
+    assert np.array_equal(twin.normalization["obs"][0], model.normalization["obs"][0])
+    ctrl = cases.product_rnn_controller(case, model=model, env=env)
+    ctrl2 = pickle.loads(pickle.dumps(ctrl))
+    assert ctrl2.n_candidates == case["n"] and ctrl2.percent_elites == 0.05 and ctrl2._hidden_state is None
+    with pytest.raises(NotImplementedError):
+        type(model)(name="x", env=env, hidden_sizes=(64,), cell_type="gru")
+    with pytest.raises(NotImplementedError):
+        type(model)(name="x", env=env, hidden_sizes=(64, 64))
+
+
+def test_rnn_fit_reduces_loss_on_a_learnable_sequence():
+    """Truncated-BPTT training (stock PyTorch): a linear system with memory is learnt."""
+    from learning_to_adapt_amd.dynamics import RNNDynamicsModel
+    from learning_to_adapt_amd.envs import SyntheticEnv
+    env = SyntheticEnv("half_cheetah")
+    od, ad = 20, 6
+    rs = np.random.RandomState(0)
+    paths, T = 12, 24
+    act = rs.uniform(-1, 1, (paths, T, ad))
+    obs = np.zeros((paths, T + 1, od))
+    obs[:, 0] = rs.randn(paths, od)
+    A = 0.1 * rs.randn(ad, od)
+    for t in range(T):
+        obs[:, t + 1] = 0.95 * obs[:, t] + act[:, t] @ A
+    model = RNNDynamicsModel(name="dyn", env=env, hidden_sizes=(32,), learning_rate=1e-2, batch_size=4,
+                             backprop_steps=8, init_seed=0)
+    np.random.seed(0)
+    torch.manual_seed(0)
+
+    def valid_loss():
+        from learning_to_adapt_amd.dynamics import core
+        from learning_to_adapt_amd.dynamics.rnn_dynamics import lstm_forward
+        nm = model.normalization
+        x = np.concatenate([core.normalize(obs[:, :-1], *nm["obs"]), core.normalize(act, *nm["act"])], axis=2)
+        y = core.normalize(obs[:, 1:] - obs[:, :-1], *nm["delta"])
+        dev = core.training_device()
+        z = torch.zeros((paths, 32), device=dev)
+        with torch.no_grad():
+            pred, _, _ = lstm_forward(torch.as_tensor(x, dtype=torch.float32, device=dev), z, z,
+                                      [p.to(dev) for p in model._params], "tanh", None)
+        return float(np.mean((pred.cpu().numpy() - y) ** 2))
+
+    model.fit(obs[:, :-1], act, obs[:, 1:], epochs=1, valid_split_ratio=0.2)
+    first = valid_loss()
+    stats = model.fit(obs[:, :-1], act, obs[:, 1:], epochs=30, valid_split_ratio=0.2, compute_normalization=False)
+    assert valid_loss() < 0.6 * first
+    assert set(stats) == {"AvgModelEpochTime", "Epochs"}
+
+
+# ------------------------------------------------------------------------------------------ GPU parity
+def _tol_returns(got, want):
+    scale = max(1.0, float(np.max(np.abs(want))))
+    return float(np.max(np.abs(got - want))) / scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["auto", "valu"])
+@pytest.mark.parametrize("cid", RNN_IDS)
+def test_gpu_rnn_controller_matches_golden(cid, kernel):
+    """The drop-in controller over several consecutive steps (hidden state carried, one reset): chosen
+    index bit-exact, chosen action bit-exact, hidden state and returns within fp32 tolerance."""
+    from learning_to_adapt_amd import _lib
+    case, seed = cases.split_id(cid)
+    if kernel == "valu" and case["n"] * case["h"] * case["m"] > 6000:
+        pytest.skip("VALU kernel: small cases only")
+    gold = cases.load_golden(cid)
+    ctrl = cases.product_rnn_controller(case)
+    ctx = _lib.Context.get(0)
+    ctx.set_kernel(kernel)
+    try:
+        ctrl.reset(dones=[True] * case["m"])
+        np.random.seed(seed)
+
+        def step(k, obs):
+            chosen, _ = ctrl.get_actions(obs)
+            margin = gold["margin_%d" % k]
+            safe = margin > 1e-4 * np.maximum(1.0, np.abs(gold["returns_%d" % k]).max(axis=1))
+            assert np.array_equal(ctrl.last_plan["best_index"][safe], gold["best_%d" % k][safe])
+            assert np.array_equal(chosen[safe], gold["chosen_%d" % k][safe])
+            if "best_return" in ctrl.last_plan:
+                want = gold["returns_%d" % k][np.arange(case["m"]), gold["best_%d" % k]]
+                np.testing.assert_allclose(ctrl.last_plan["best_return"][safe], want[safe], rtol=1e-4, atol=1e-4)
+            if safe.all():
+                np.testing.assert_allclose(ctrl._hidden_state.c, gold["hidden_c_%d" % k], rtol=1e-4, atol=2e-5)
+                np.testing.assert_allclose(ctrl._hidden_state.h, gold["hidden_h_%d" % k], rtol=1e-4, atol=2e-5)
+
+        _replay(case, gold, step, lambda dones: ctrl.reset(dones=dones))
+        if case["planner"] == "rnn_rs":
+            assert np.random.uniform() == float(gold["rng_next"])
+    finally:
+        ctx.set_kernel("auto")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+@pytest.mark.parametrize("name", ["hc_rnn_rs_m2_n64_h4_reset", "hc_rnn_rs_u128_n40_h3", "ant_rnn_rs_n100_h5_m2"])
+def test_gpu_rnn_returns_table_matches_oracle(name, kernel):
+    """Every candidate's return of one recurrent plan step, from a NON-zero hidden state."""
+    from learning_to_adapt_amd import _lib
+    from oracle.rnn_planner import rnn_rollout_returns
+    case = cases.CASES[name]
+    env, model = cases.product_rnn_model(case)
+    dyn = cases.oracle_rnn_dynamics(case)
+    reward = make_reward(case["env"], env.dt)
+    rs = np.random.RandomState(5)
+    m, n, h, U = case["m"], case["n"], case["h"], case["units"]
+    obs0 = rs.randn(m, env.observation_space.shape[0])
+    hid = LSTMStateTuple(rs.randn(m, U).astype(np.float32), np.tanh(rs.randn(m, U)).astype(np.float32))
+    acts = rs.uniform(env.action_space.low, env.action_space.high, (h, m * n, env.action_space.shape[0]))
+    want = rnn_rollout_returns(dyn, reward, obs0, hid, acts, n, case.get("discount", 1.0)).reshape(m, n)
+    ctx = _lib.Context.get(0)
+    ctx.set_kernel(kernel)
+    try:
+        native = model.planner_model()
+        dev = native.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+        rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+        best = torch.zeros((m,), dtype=torch.int64, device=dev)
+        native.plan_rs(up(obs0), up(hid.c), up(hid.h), up(acts), m, n, h, case.get("discount", 1.0),
+                       env.reward_spec, returns_out=rets, best_key=best)
+        got = rets.cpu().numpy()
+        assert _tol_returns(got, want) < 1e-4
+        keys = best.cpu().numpy()
+        for i in range(m):
+            ret, idx = _lib.key_decode(keys[i])
+            assert idx == int(np.argmax(got[i])) and ret == got[i, idx]
+    finally:
+        ctx.set_kernel("auto")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("units", [128, 256, 512, 200])
+def test_gpu_rnn_predict_matches_oracle(units):
+    """``RNNDynamicsModel.predict``: per-row hidden states, ragged row count."""
+    case = dict(cases.CASES["hc_rnn_rs_u128_n40_h3"], units=units)
+    env, model = cases.product_rnn_model(case)
+    dyn = cases.oracle_rnn_dynamics(case)
+    rs = np.random.RandomState(2)
+    rows = 37
+    obs = rs.randn(rows, 20)
+    act = rs.uniform(-1, 1, (rows, 6))
+    hid = LSTMStateTuple(rs.randn(rows, units).astype(np.float32), np.tanh(rs.randn(rows, units)).astype(np.float32))
+    want, whid = dyn.predict(obs, act, hid)
+    got, ghid = model.predict(obs, act, hid)
+    assert got.dtype == np.float64 and ghid.c.shape == (rows, units)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ghid.c, whid.c, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ghid.h, whid.h, rtol=1e-5, atol=2e-6)
