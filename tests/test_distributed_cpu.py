@@ -95,3 +95,49 @@ def test_device_rng_ranks_draw_different_candidates_and_agree(tmp_path):
         owner = 0 if idx < outs[0]["shard"][1] else 1
         lo = int(outs[owner]["shard"][0])
         np.testing.assert_allclose(outs[0]["actions"][i], outs[owner]["first"][i, idx - lo], rtol=1e-6)
+
+
+def _worker_rnn(rank, world, port, cid, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        import oracle_backend
+        case, seed = cases.split_id(cid)
+        gold = cases.load_golden(cid)
+        ctrl = oracle_backend.install_rnn(cases.product_rnn_controller(case), case)
+        ctrl.reset(dones=[True] * case["m"])
+        np.random.seed(seed)
+        resets = {int(k): v for k, v in case.get("reset_after", {}).items()}
+        rec = {}
+        for k in range(case["steps"]):
+            actions, _ = ctrl.get_actions(gold["obs"][k])
+            rec["actions_%d" % k] = actions
+            rec["best_%d" % k] = np.asarray(ctrl.last_plan["best_index"])
+            rec["c_%d" % k] = ctrl._hidden_state.c.copy()
+            if k in resets:
+                ctrl.reset(dones=np.array(resets[k], dtype=bool))
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **rec)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cid", ["hc_rnn_rs_m2_n64_h4_reset_s0", "hc_rnn_cem_n200_h5_m2_s0"])
+def test_two_rank_recurrent_plan_equals_single_process_plan(cid, tmp_path):
+    """Recurrent planner over 2 ranks: candidates sharded, hidden state replicated and advanced
+    identically on every rank, over several consecutive controller steps."""
+    world = 2
+    mp.spawn(_worker_rnn, args=(world, _free_port(), cid, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import cases
+    case, _ = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        for k in range(case["steps"]):
+            assert np.array_equal(o["best_%d" % k], gold["best_%d" % k])
+            np.testing.assert_array_equal(o["actions_%d" % k], gold["chosen_%d" % k])
+            np.testing.assert_array_equal(o["c_%d" % k], gold["hidden_c_%d" % k])

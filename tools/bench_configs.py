@@ -122,6 +122,55 @@ def main():
         print(json.dumps(dict(config="GrBAL controller step (adapt 5 envs + plan config 3 / 3x512), rng=" + mode,
                               adapt_and_upload_ms=round(1e3 * float(np.median(t_adapt)), 3), step_ms=round(1e3 * float(np.median(t_all)), 3),
                               step_ms_mean=round(1e3 * float(np.mean(t_all)), 3), step_ms_max=round(1e3 * float(np.max(t_all)), 3))), flush=True)
+    # recurrent planner (ReBAL, run_scripts/run_rebal.py defaults: LSTM(256), n=500, h=10, 5 envs) + larger plans
+    for label, over in (("c6 ReBAL default (LSTM 256, n=500, h=10, m=5)", {}),
+                        ("ReBAL, LSTM 256, n=2000, h=30, m=1", {"n": 2000, "h": 30, "m": 1}),
+                        ("ReBAL, LSTM 256, n=4096, h=30, m=1 (256 tiles)", {"n": 4096, "h": 30, "m": 1}),
+                        ("ReBAL, LSTM 512, n=4096, h=20, m=1", {"n": 4096, "h": 20, "m": 1, "units": 512})):
+        case = dict(C["c6_hc_rnn_rs_n500_h10_m5"], **over)
+        env, model = cases.product_rnn_model(case)
+        native = model.planner_model()
+        dev = native.device
+        m, n, h, U = case["m"], case["n"], case["h"], case["units"]
+        obs0 = torch.randn((m, 20), device=dev)
+        c0 = torch.randn((m, U), device=dev)
+        h0 = torch.tanh(torch.randn((m, U), device=dev))
+        a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
+        best = torch.zeros((m,), dtype=torch.int64, device=dev)
+        for kernel in ("mfma", "valu"):
+            if kernel == "valu" and n * m * h > 30000:
+                continue
+            _lib.Context.get(0).set_kernel(kernel)
+            for _ in range(3):
+                native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
+            torch.cuda.synchronize()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            for s_, e_ in evs:
+                s_.record()
+                native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
+                e_.record()
+            torch.cuda.synchronize()
+            ms = float(np.median([s_.elapsed_time(e_) for s_, e_ in evs]))
+            fl = 2.0 * ((26 + U) * 4 * U + U * 20) * n * m * h
+            print(json.dumps(dict(config=label + ", " + kernel + " kernel", n=n, h=h, m=m, units=U,
+                                  kernel_ms=round(ms, 4), tflops=round(fl / ms / 1e9, 2),
+                                  frac_fp32_peak=round(fl / ms / 1e9 / PEAK, 4),
+                                  lstm_steps_per_ms=round(n * m * h / ms, 1))), flush=True)
+        _lib.Context.get(0).set_kernel("auto")
+    case = C["c6_hc_rnn_rs_n500_h10_m5"]
+    for mode in ("numpy", "device"):
+        ctrl = cases.product_rnn_controller(case, rng=mode)
+        obs = np.random.RandomState(0).randn(5, 20)
+        ctrl.reset(dones=[True] * 5)
+        ctrl.get_actions(obs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            ctrl.get_actions(obs)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 30
+        print(json.dumps(dict(config="c6 ReBAL controller step end to end (plan + hidden-state advance), rng=" + mode,
+                              ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1))), flush=True)
     # config 5: one CEM plan step (5 iterations x 4000 candidates) through the drop-in controller
     case = C["c5_hc_cem_n4000_h30_e5"]
     ctrl = cases.product_controller(case)
