@@ -77,7 +77,28 @@ __host__ __device__ inline void l2a_lstm_pack_decode(long long idx, int KG0, int
     *col_tf = q * U + 16 * (w * UTW + uu) + (lane & 15);
 }
 
+// Phase timeline for tools/timeline_lstm.py: the waves of workgroup 0 stamp the shader clock,
+// dbg[((t * 4 + wave) * 16 + slot].  One uniform branch per stamp, pinned by scheduling barriers.
+#define L2A_LTS(slot)                                                                       \
+    if (p.dbg && bid == 0) {                                                                \
+        unsigned long long ts_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (lane == 0) p.dbg[((long long)t * 4 + wave) * 16 + (slot)] = ts_;                \
+    }
+
 __device__ __forceinline__ float l2a_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Gate transcendentals of the MFMA kernel: one v_exp_f32 + one v_rcp_f32 each (both ~1 ulp), i.e.
+// ~1e-7 ABSOLUTE error on values in [-1, 1] - the libm forms cost ~900 cycles per (unit, candidate)
+// and made the gate phase 24 % of a step (tools/timeline_lstm.py).  Saturate correctly: exp2 -> 0 / inf.
+__device__ __forceinline__ float l2a_fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float l2a_fast_tanh(float x) {
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
+}
 
 // ------------------------------------------------------------------------------------------
 // h-part of the gate GEMM for TW of this wave's gate tiles: acc += Wg[:, h k-groups] x h.
@@ -229,6 +250,11 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             voffx[ps][tt] = lane * 16 + (wave * GTW + ps * TW + tt) * KG * 1024;
             voffh[ps][tt] = voffx[ps][tt] + KG0 * 1024;
         }
+    f32x4 pfX[KG0][TW];             // x k-groups of pass 0 of the upcoming step (fetched across the barrier)
+#pragma unroll
+    for (int g = 0; g < KG0; ++g)
+#pragma unroll
+        for (int tt = 0; tt < TW; ++tt) pfX[g][tt] = l2a_ldw(rs, voffx[0][tt] + g * 1024, 0);
     f32x4 pfA[TW], pfB[TW];         // h k-groups 0 / 1 of the upcoming pass
     f32x4 pfO[UTW][OT];             // output-layer A fragments of this wave's unit tiles
     f32x4 hreg[NT][UTW];
@@ -252,6 +278,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             asq[nt] = s;
         }
         load_actions((t + 1 < p.h) ? t + 1 : t, av_next);
+        L2A_LTS(0)
 
         // ---- x part of the gate GEMM: B = normalised [obs | act] from registers ---------------
         f32x4 x[KG0][NT];
@@ -286,7 +313,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
             for (int g = 0; g < KG0; ++g)
 #pragma unroll
-                for (int tt = 0; tt < TW; ++tt) a[g][tt] = l2a_ldw(rs, voffx[ps][tt] + g * 1024, 0);
+                for (int tt = 0; tt < TW; ++tt)
+                    a[g][tt] = (ps == 0) ? pfX[g][tt] : l2a_ldw(rs, voffx[ps][tt] + g * 1024, 0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -302,6 +330,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                             acc[ps][nt][tt] = L2A_MFMA(a[g][tt][ii], x[g][nt][ii], acc[ps][nt][tt]);
         }
 
+        L2A_LTS(1)
         // ---- h part, pass by pass; each pass fetches the next one's first operands in its tail ----
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
@@ -337,6 +366,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             }
         }
 
+        L2A_LTS(2)
         // ---- gate arithmetic (register local) -> c, h ------------------------------------------
 #pragma unroll
         for (int uu = 0; uu < UTW; ++uu) {
@@ -353,14 +383,26 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                     z[q] = acc[lt / TW][nt][lt % TW] + bias[q];
                 }
                 f32x4 cn, hn;
+                if (p.cell_act == L2A_ACT_TANH) {       // wave-uniform; the reference default (rnn_dynamics.py:20)
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const float ig = l2a_sigmoid(z[0][ii]);
-                    const float jg = l2a_act1(z[1][ii], p.cell_act);
-                    const float fg = l2a_sigmoid(z[2][ii] + 1.0f);          // forget_bias = 1
-                    const float og = l2a_sigmoid(z[3][ii]);
-                    cn[ii] = fg * creg[nt][uu][ii] + ig * jg;
-                    hn[ii] = og * l2a_act1(cn[ii], p.cell_act);
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const float ig = l2a_fast_sigmoid(z[0][ii]);
+                        const float jg = l2a_fast_tanh(z[1][ii]);
+                        const float fg = l2a_fast_sigmoid(z[2][ii] + 1.0f);     // forget_bias = 1
+                        const float og = l2a_fast_sigmoid(z[3][ii]);
+                        cn[ii] = fmaf(fg, creg[nt][uu][ii], ig * jg);
+                        hn[ii] = og * l2a_fast_tanh(cn[ii]);
+                    }
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const float ig = l2a_fast_sigmoid(z[0][ii]);
+                        const float jg = l2a_act1(z[1][ii], p.cell_act);
+                        const float fg = l2a_fast_sigmoid(z[2][ii] + 1.0f);
+                        const float og = l2a_fast_sigmoid(z[3][ii]);
+                        cn[ii] = fmaf(fg, creg[nt][uu][ii], ig * jg);
+                        hn[ii] = og * l2a_act1(cn[ii], p.cell_act);
+                    }
                 }
                 creg[nt][uu] = cn;
                 hreg[nt][uu] = hn;
@@ -368,6 +410,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             }
         }
 
+        L2A_LTS(3)
         // ---- output layer: this wave's unit tiles are its k-groups; chunk partials -> LDS -------
         {
             constexpr int CS = UTW / 2;
@@ -396,7 +439,13 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
                     for (int c = 0; c < OT; ++c) pb[(((2 * wave + ch) * NT + nt) * OT + c) * 64 + lane] = oacc[ch][nt][c];
         }
+        L2A_LTS(4)
+#pragma unroll
+        for (int g = 0; g < KG0; ++g)       // next step's first operands, in flight across the barrier and the reduce
+#pragma unroll
+            for (int tt = 0; tt < TW; ++tt) pfX[g][tt] = l2a_ldw(rs, voffx[0][tt] + g * 1024, 0);
         __syncthreads();
+        L2A_LTS(5)
 
         // ---- every wave sums the 8 chunk partials in the canonical order, then reward / state ----
         const float disc_t = (float)disc_pow;
@@ -438,6 +487,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
             ret[nt] = fmaf(disc_t, r, ret[nt]);
         }
+        L2A_LTS(6)
     }
 
     // ---- results ----------------------------------------------------------------------------

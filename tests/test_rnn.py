@@ -213,12 +213,17 @@ def test_gpu_rnn_controller_matches_golden(cid, kernel):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["mfma", "valu"])
-@pytest.mark.parametrize("name", ["hc_rnn_rs_m2_n64_h4_reset", "hc_rnn_rs_u128_n40_h3", "ant_rnn_rs_n100_h5_m2"])
+@pytest.mark.parametrize("name", ["hc_rnn_rs_m2_n64_h4_reset", "hc_rnn_rs_u128_n40_h3", "ant_rnn_rs_n100_h5_m2",
+                                  "hc_rnn_rs_m2_n64_h4_reset:relu", "hc_rnn_rs_u128_n40_h3:swish"])
 def test_gpu_rnn_returns_table_matches_oracle(name, kernel):
-    """Every candidate's return of one recurrent plan step, from a NON-zero hidden state."""
+    """Every candidate's return of one recurrent plan step, from a NON-zero hidden state (also with
+    other cell activations than the default tanh)."""
     from learning_to_adapt_amd import _lib
     from oracle.rnn_planner import rnn_rollout_returns
-    case = cases.CASES[name]
+    name, _, act = name.partition(":")
+    case = dict(cases.CASES[name])
+    if act:
+        case["activation"] = act
     env, model = cases.product_rnn_model(case)
     dyn = cases.oracle_rnn_dynamics(case)
     reward = make_reward(case["env"], env.dt)
@@ -266,3 +271,124 @@ def test_gpu_rnn_predict_matches_oracle(units):
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(ghid.c, whid.c, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(ghid.h, whid.h, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_rnn_full_size_properties():
+    """ReBAL default size (LSTM 256, n = 500, h = 10, 5 envs) and a chip-filling plan: determinism,
+    sharding invariance (max of shard keys == key of the full plan, bit for bit), ragged prefix
+    (the first n' candidates of a plan return the same bits whatever follows them), n = 1 / h = 1."""
+    from learning_to_adapt_amd import _lib
+    case = cases.CASES["c6_hc_rnn_rs_n500_h10_m5"]
+    env, model = cases.product_rnn_model(case)
+    native = model.planner_model()
+    dev = native.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    for m, n, h in ((5, 500, 10), (1, 4096, 12), (2, 1, 1)):
+        obs0 = torch.randn((m, 20), generator=gen, device=dev)
+        c0 = torch.randn((m, 256), generator=gen, device=dev)
+        h0 = torch.tanh(torch.randn((m, 256), generator=gen, device=dev))
+        a = torch.rand((h, m * n, 6), generator=gen, device=dev) * 2 - 1
+
+        def plan(acts, n_, off=0):
+            rets = torch.empty((m, n_), dtype=torch.float32, device=dev)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(obs0, c0, h0, acts.contiguous(), m, n_, h, 0.97, env.reward_spec, cand_offset=off,
+                           returns_out=rets, best_key=best)
+            return rets.cpu().numpy(), best.cpu().numpy()
+
+        r1, k1 = plan(a, n)
+        r2, k2 = plan(a, n)
+        assert np.array_equal(r1, r2) and np.array_equal(k1, k2)            # deterministic
+        assert np.all(np.isfinite(r1))
+        for i in range(m):
+            ret, idx = _lib.key_decode(k1[i])
+            assert idx == int(np.argmax(r1[i])) and ret == r1[i, idx]
+        if n >= 64:
+            a4 = a.reshape(h, m, n, 6)
+            shards = 4
+            keys = []
+            for s in range(shards):
+                lo, hi = s * n // shards, (s + 1) * n // shards
+                rs_, ks = plan(a4[:, :, lo:hi].reshape(h, m * (hi - lo), 6), hi - lo, off=lo)
+                assert np.array_equal(rs_, r1[:, lo:hi])
+                keys.append(ks)
+            assert np.array_equal(np.max(np.stack(keys), axis=0), k1)
+            npre = 37
+            rp, _ = plan(a4[:, :, :npre].reshape(h, m * npre, 6), npre)
+            assert np.array_equal(rp, r1[:, :npre])
+
+
+@pytest.mark.gpu
+def test_gpu_rnn_invalid_calls_are_rejected():
+    from learning_to_adapt_amd import _lib
+    from learning_to_adapt_amd.dynamics.native_lstm import NativeLSTM
+    from learning_to_adapt_amd.envs import RewardSpec
+    nat = NativeLSTM(20, 6, 256)
+    dev = nat.device
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+    best = torch.zeros((1,), dtype=torch.int64, device=dev)
+    spec = RewardSpec.half_cheetah(20, 0.01)
+    with pytest.raises(_lib.L2AError, match="never set"):
+        nat.plan_rs(z(1, 20), z(1, 256), z(1, 256), z(2, 16, 6), 1, 16, 2, 1.0, spec, best_key=best)
+    case = cases.CASES["hc_rnn_rs_m2_n64_h4_reset"]
+    _, params, norm = cases.rnn_recipe(case)
+    nat.set_weights(params)
+    with pytest.raises(_lib.L2AError, match="normalisation"):
+        nat.plan_rs(z(1, 20), z(1, 256), z(1, 256), z(2, 16, 6), 1, 16, 2, 1.0, spec, best_key=best)
+    nat.set_norm(norm)
+    nat.plan_rs(z(1, 20), z(1, 256), z(1, 256), z(2, 16, 6), 1, 16, 2, 1.0, spec, best_key=best)
+    with pytest.raises(_lib.L2AError, match="nothing to write"):
+        nat.plan_rs(z(1, 20), z(1, 256), z(1, 256), z(2, 16, 6), 1, 16, 2, 1.0, spec)
+    bad = RewardSpec.make(w_vel=1.0, dt=1.0, vel_index=99)
+    with pytest.raises(_lib.L2AError, match="vel_index"):
+        nat.plan_rs(z(1, 20), z(1, 256), z(1, 256), z(2, 16, 6), 1, 16, 2, 1.0, bad, best_key=best)
+    with pytest.raises(AssertionError):
+        nat.set_weights(params[:3])
+    ctx = _lib.Context.get(0)
+    odd = NativeLSTM(20, 6, 200)
+    odd.set_weights(synthetic_lstm(200))
+    odd.set_norm(norm)
+    ctx.set_kernel("mfma")
+    try:
+        with pytest.raises(_lib.L2AError, match="not eligible"):
+            odd.plan_rs(z(1, 20), z(1, 200), z(1, 200), z(2, 16, 6), 1, 16, 2, 1.0, spec, best_key=best)
+    finally:
+        ctx.set_kernel("auto")
+    assert _lib.load().l2a_lstm_mfma_eligible(20, 6, 256) == 1 and _lib.load().l2a_lstm_mfma_eligible(20, 6, 200) == 0
+
+
+def synthetic_lstm(units):
+    from learning_to_adapt_amd.utils import synthetic
+    return synthetic.make_lstm_set(20, 6, units, 1000)
+
+
+@pytest.mark.gpu
+def test_gpu_rnn_unfused_path_matches_fused():
+    """An env whose reward has no closed-form spec goes through the reference's loop shape with the LSTM
+    step on the GPU (`dynamics_model.predict`); same decision as the fused kernel."""
+    case = cases.CASES["hc_rnn_rs_m2_n64_h4_reset"]
+    gold = cases.load_golden("hc_rnn_rs_m2_n64_h4_reset_s0")
+    env, model = cases.product_rnn_model(case)
+    fused = cases.product_rnn_controller(case, model=model, env=env)
+    fused.reset(dones=[True, True])
+    np.random.seed(0)
+    a_fused, _ = fused.get_actions(gold["obs"][0])
+
+    class OpaqueEnv(object):
+        def __init__(self, inner):
+            self.inner = inner
+            self.action_space, self.observation_space, self.dt = inner.action_space, inner.observation_space, inner.dt
+
+        def reward(self, obs, act, nxt):
+            return self.inner.reward(obs, act, nxt)
+
+    plain = cases.product_rnn_controller(case, model=model, env=OpaqueEnv(env))
+    assert not plain._fusable()
+    plain.reset(dones=[True, True])
+    np.random.seed(0)
+    a_plain, _ = plain.get_actions(gold["obs"][0])
+    np.testing.assert_array_equal(a_plain, a_fused)
+    np.testing.assert_array_equal(a_plain, gold["chosen_0"])
+    np.testing.assert_allclose(plain._hidden_state.c, fused._hidden_state.c, rtol=1e-6, atol=1e-7)
