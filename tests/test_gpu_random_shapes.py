@@ -1,0 +1,132 @@
+"""Randomised shape sweep on the GPU: model shapes, ensemble modes, plan sizes, discounts and reward
+kinds drawn from a seeded generator; every candidate's return is compared with the oracle (rel 1e-4)
+and the arg-max key with the returns the kernel itself wrote (bit exact).  Covers the corners between
+the hand-picked golden cases: obs/act dims that straddle 16-feature tiles, every MFMA-eligible hidden
+width and depth, odd ensembles under all tile-split policies, ragged candidate counts."""
+
+import numpy as np
+import pytest
+import torch
+
+from learning_to_adapt_amd import _lib
+from learning_to_adapt_amd.dynamics.native_lstm import NativeLSTM
+from learning_to_adapt_amd.dynamics.native_model import NativeModel
+from learning_to_adapt_amd.envs import RewardSpec
+from learning_to_adapt_amd.utils import synthetic
+from oracle import LSTMStateTuple, OracleLSTMDynamics, OracleMLPDynamics
+from oracle.planner import rollout_returns
+from oracle.rnn_planner import rnn_rollout_returns
+
+pytestmark = pytest.mark.gpu
+
+
+def _reward(rs, obs_dim, act_dim):
+    kind = rs.randint(3)
+    if kind == 0:       # velocity + control cost (half-cheetah form), random index / coefficients
+        spec = RewardSpec.make(w_vel=float(rs.uniform(0.5, 2.0)), dt=float(rs.choice([0.01, 0.02, 0.05])),
+                               ctrl_coef=float(rs.uniform(0.0, 0.1)), vel_index=int(rs.randint(obs_dim)))
+    elif kind == 1:     # velocity + alive bonus (ant form)
+        spec = RewardSpec.make(w_vel=1.0, dt=0.02, alive=0.05, vel_index=obs_dim - 1)
+    else:               # distance + control cost (arm form)
+        spec = RewardSpec.make(dist_coef=1.0, ctrl_coef=0.005, dist_index=int(rs.randint(max(obs_dim - 2, 1))))
+    return spec
+
+
+def _norm(rs, obs_dim, act_dim, low, high):
+    return synthetic.make_norm(obs_dim, act_dim, low, high, int(rs.randint(1 << 30)))
+
+
+def _check(got, want, keys, n, offset):
+    scale = max(1.0, float(np.max(np.abs(want))))
+    assert float(np.max(np.abs(got - want))) / scale < 1e-4
+    for i in range(got.shape[0]):
+        ret, idx = _lib.key_decode(keys[i])
+        assert idx - offset == int(np.argmax(got[i])) and ret == got[i, idx - offset]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_mlp_shapes_match_oracle(seed):
+    rs = np.random.RandomState(100 + seed)
+    obs_dim = int(rs.choice([3, 15, 16, 17, 20, 31, 33, 41, 48, 64]))
+    act_dim = int(rs.choice([1, 6, 8, 12, 16]))
+    if obs_dim + act_dim > 80:
+        act_dim = 80 - obs_dim
+    width = int(rs.choice([128, 256, 512, 96]))
+    depth = int(rs.choice([1, 2, 3]))
+    hidden = [width] * depth
+    mode = str(rs.choice(["single", "mean", "per_block"]))
+    E = 1 if mode == "single" else int(rs.choice([2, 3, 5]))
+    m = E if mode == "per_block" else int(rs.choice([1, 2, 3]))
+    n = int(rs.choice([1, 15, 16, 17, 47, 100, 260]))
+    h = int(rs.choice([1, 2, 5, 9]))
+    discount = float(rs.choice([1.0, 0.9]))
+    act = str(rs.choice(["relu", "relu", "tanh"]))
+    low, high = -np.ones(act_dim) * 2.0, np.ones(act_dim) * 2.0
+    sets = [synthetic.make_weight_set(obs_dim, act_dim, hidden, int(rs.randint(1 << 30))) for _ in range(E)]
+    norms = [_norm(rs, obs_dim, act_dim, low, high) for _ in range(E)]
+    if mode == "per_block":
+        norms = [norms[0]] * E
+    spec = _reward(rs, obs_dim, act_dim)
+    dyn = OracleMLPDynamics(obs_dim, act_dim, sets, norms, mode=mode, hidden_nonlinearity=act)
+    obs0 = rs.randn(m, obs_dim)
+    acts = rs.uniform(low, high, (h, m * n, act_dim))
+    want = rollout_returns(dyn, spec.evaluate, obs0, acts, n, discount).reshape(m, n)
+
+    native = NativeModel(obs_dim, act_dim, hidden, act, None, E, mode)
+    for e in range(E):
+        native.set_weights(e, sets[e])
+        native.set_norm(e, norms[e])
+    dev = native.device
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    offset = int(rs.choice([0, 1000]))
+    results = []
+    ctx = _lib.Context.get(0)
+    try:
+        for split in (1, 0, 2):
+            ctx.set_split(split)
+            rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(up(obs0), up(acts), m, n, h, discount, spec, cand_offset=offset, returns_out=rets,
+                           best_key=best)
+            got, keys = rets.cpu().numpy(), best.cpu().numpy()
+            ctx.launch_status()
+            _check(got, want, keys, n, offset)
+            results.append(got)
+    finally:
+        ctx.set_split(1)
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+    native.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_lstm_shapes_match_oracle(seed):
+    rs = np.random.RandomState(200 + seed)
+    obs_dim = int(rs.choice([3, 16, 17, 20, 33, 41, 64]))
+    act_dim = int(rs.choice([1, 6, 8, 16]))
+    units = int(rs.choice([128, 256, 512, 72]))
+    m = int(rs.choice([1, 2, 4]))
+    n = int(rs.choice([1, 16, 17, 50, 130]))
+    h = int(rs.choice([1, 2, 4, 7]))
+    discount = float(rs.choice([1.0, 0.95]))
+    act = str(rs.choice(["tanh", "tanh", "relu"]))
+    low, high = -np.ones(act_dim), np.ones(act_dim)
+    params = synthetic.make_lstm_set(obs_dim, act_dim, units, int(rs.randint(1 << 30)))
+    norm = _norm(rs, obs_dim, act_dim, low, high)
+    spec = _reward(rs, obs_dim, act_dim)
+    dyn = OracleLSTMDynamics(obs_dim, act_dim, params, norm, hidden_nonlinearity=act)
+    obs0 = rs.randn(m, obs_dim)
+    hid = LSTMStateTuple(rs.randn(m, units).astype(np.float32), np.tanh(rs.randn(m, units)).astype(np.float32))
+    acts = rs.uniform(low, high, (h, m * n, act_dim))
+    want = rnn_rollout_returns(dyn, spec.evaluate, obs0, hid, acts, n, discount).reshape(m, n)
+
+    native = NativeLSTM(obs_dim, act_dim, units, act, None)
+    native.set_weights(params)
+    native.set_norm(norm)
+    dev = native.device
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    native.plan_rs(up(obs0), up(hid.c), up(hid.h), up(acts), m, n, h, discount, spec, cand_offset=7,
+                   returns_out=rets, best_key=best)
+    _check(rets.cpu().numpy(), want, best.cpu().numpy(), n, 7)
+    native.close()
