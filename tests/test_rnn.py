@@ -392,3 +392,34 @@ def test_gpu_rnn_unfused_path_matches_fused():
     np.testing.assert_array_equal(a_plain, a_fused)
     np.testing.assert_array_equal(a_plain, gold["chosen_0"])
     np.testing.assert_allclose(plain._hidden_state.c, fused._hidden_state.c, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cem_mode", ["reference", "fixed"])
+def test_gpu_rnn_device_cem_matches_host_loop_with_injected_normals(cem_mode):
+    """Recurrent CEM with sampling / elites / refit on the GPU vs the host loop on the same normals."""
+    case = dict(cases.CASES["hc_rnn_cem_n200_h5_m2"])
+    gold = cases.load_golden("hc_rnn_cem_n200_h5_m2_s0")
+    n, m, D = case["n"], case["m"], case["h"] * 6
+    zs = [np.random.RandomState(300 + i).normal(size=(n, m, D)) for i in range(case["num_cem_iters"])]
+    env, model = cases.product_rnn_model(case)
+    host = cases.product_rnn_controller(case, model=model, env=env, cem_mode=cem_mode)
+    host.reset(dones=[True] * m)
+    it = iter(zs)
+    orig = np.random.normal
+    try:
+        np.random.normal = lambda size=None: next(it)
+        a_host, _ = host.get_actions(gold["obs"][0])
+    finally:
+        np.random.normal = orig
+    dev = cases.product_rnn_controller(case, model=model, env=env, rng="device", cem_mode=cem_mode)
+    dev.reset(dones=[True] * m)
+    it2 = iter(zs)
+    dev._cem_normal_device = lambda shape, device: torch.from_numpy(next(it2).astype(np.float32)).to(device)
+    a_dev, _ = dev.get_actions(gold["obs"][0])
+    tr = host.last_plan["cem_trace"][-1]
+    np.testing.assert_allclose(dev.last_plan["cem_mean"], np.broadcast_to(tr["mean"], (m, D)), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(dev.last_plan["cem_std"], np.broadcast_to(tr["std"], (m, D)), rtol=1e-3, atol=1e-3)
+    assert np.array_equal(dev.last_plan["best_index"], host.last_plan["best_index"])
+    np.testing.assert_allclose(a_dev, a_host, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dev._hidden_state.c, host._hidden_state.c, rtol=1e-5, atol=1e-6)
