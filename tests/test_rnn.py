@@ -11,7 +11,7 @@ import torch
 
 import cases
 import oracle_backend
-from oracle import (LSTMStateTuple, OracleLSTMDynamics, lstm_step_f32, make_reward, rnn_cem_plan, rnn_rs_plan)
+from oracle import LSTMStateTuple, lstm_step_f32, make_reward, rnn_cem_plan, rnn_rs_plan
 
 RNN_IDS = cases.rnn_case_ids()
 

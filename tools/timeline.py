@@ -16,7 +16,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
-from learning_to_adapt_amd import _lib  # noqa: E402
 
 case = cases.CASES["c2_hc_rs_n2000_h30_e5"]
 env, model = cases.product_model(case)
