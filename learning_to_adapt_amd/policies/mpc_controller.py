@@ -215,11 +215,12 @@ class MPCController(Policy, Serializable):
         if cand_a is not None:
             return cand_a[range(m), idx]
         # device RNG: the winning first action lives on the rank that owns the candidate
-        out = torch.zeros((m, act_dim), dtype=torch.float32, device=a_dev.device)
         first = a_dev[0].reshape(m, n_local, act_dim)
-        for i in range(m):
-            if lo <= idx[i] < hi:
-                out[i] = first[i, idx[i] - lo]
+        gidx = torch.from_numpy(idx).to(a_dev.device)
+        own = ((gidx >= lo) & (gidx < hi)).to(torch.float32).unsqueeze(1)
+        loc = (gidx - lo).clamp(0, max(n_local - 1, 0))
+        out = first[torch.arange(m, device=a_dev.device), loc] * own if n_local > 0 else \
+            torch.zeros((m, act_dim), dtype=torch.float32, device=a_dev.device)
         if world > 1:
             torch.distributed.all_reduce(out, op=torch.distributed.ReduceOp.SUM)
         return out.cpu().numpy().astype(np.float64)

@@ -22,6 +22,10 @@ from .mpc_controller import MPCController
 
 
 class RNNMPCController(MPCController):
+    _hid_host = None        # LSTMStateTuple of NumPy arrays (the reference's `_hidden_state`)
+    _hid_dev = None         # (c, h) CUDA tensors
+    _hid_stale = None       # which copy is out of date: None | "host" | "dev"
+
     def __init__(
             self,
             name,
@@ -49,6 +53,34 @@ class RNNMPCController(MPCController):
                                rng=rng, cem_mode=cem_mode, shard_candidates=shard_candidates)
         self._hidden_state = None
 
+    # ------------------------------------------------------------------ hidden state: host view + device copy
+    # The reference keeps `_hidden_state` as NumPy arrays (:30, :136-163) and so does this class for
+    # everyone who looks at it.  The planner however consumes and produces the state on the GPU, so a
+    # device copy is carried between controller steps and the host arrays are refreshed only when somebody
+    # reads them (`reset` of a finished env, tests, pickling): no per-step round trip of 2 x [m, units].
+    @property
+    def _hidden_state(self):
+        if self._hid_stale == "host":
+            c, h = self._hid_dev
+            self._hid_host = type(self.dynamics_model.get_initial_hidden(1))(c.cpu().numpy(), h.cpu().numpy())
+            self._hid_stale = None
+        return self._hid_host
+
+    @_hidden_state.setter
+    def _hidden_state(self, value):
+        self._hid_host = value
+        self._hid_dev = None
+        self._hid_stale = None if value is None else "dev"
+
+    def _device_hidden(self, device):
+        """(c, h) CUDA tensors [m, units] of the current hidden state."""
+        if self._hid_dev is None or self._hid_stale == "dev":
+            c, h = self._hid_host
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
+            self._hid_dev = (up(c), up(h))
+            self._hid_stale = None
+        return self._hid_dev
+
     # ------------------------------------------------------------------ reference API
     def get_action(self, observation):
         if observation.ndim == 1:
@@ -57,25 +89,41 @@ class RNNMPCController(MPCController):
         return action, dict()
 
     def get_actions(self, observations):
-        if self._hidden_state is None:
+        if self._hid_host is None and self._hid_dev is None:
             self.reset(dones=[True] * len(observations))
         if self.use_cem:
             actions = self.get_cem_action(observations)
         else:
             actions = self.get_rs_action(observations)
         # advance the controller's own hidden state with the chosen actions (:63)
-        _, self._hidden_state = self.dynamics_model.predict(np.array(observations), actions, self._hidden_state)
+        self._advance_hidden(observations, actions)
         return actions, dict()
+
+    def _advance_hidden(self, observations, actions):
+        if not self._fusable():
+            _, self._hidden_state = self.dynamics_model.predict(np.array(observations), actions, self._hidden_state)
+            return
+        native = self.dynamics_model.planner_model()
+        dev = native.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+        c, h = self._device_hidden(dev)
+        _, c_out, h_out = native.predict(up(observations), up(actions), c, h)
+        self._hid_dev = (c_out, h_out)
+        self._hid_stale = "host"
 
     def reset(self, dones=None):
         if dones is None:
             dones = [True]
-        if self._hidden_state is None:
-            self._hidden_state = self.dynamics_model.get_initial_hidden(batch_size=len(dones))
-        zero = self.dynamics_model.get_initial_hidden(batch_size=1)
         dones = np.asarray(dones, dtype=bool)
-        for state, z in zip(self._hidden_state, zero):          # LSTM state: (c, h)
-            state[dones] = z
+        if self._hid_host is None and self._hid_dev is None:
+            self._hidden_state = self.dynamics_model.get_initial_hidden(batch_size=len(dones))
+        if not dones.any():
+            return                                              # nothing to zero: no host round trip
+        zero = self.dynamics_model.get_initial_hidden(batch_size=1)
+        state = self._hidden_state                              # refreshes the host arrays if needed
+        for part, z in zip(state, zero):                        # LSTM state: (c, h)
+            part[dones] = z
+        self._hidden_state = state                              # device copy is stale now
 
     def repeat_hidden(self, hidden, n):
         """``:165-187``: every row n times (env-major).  Only the unfused path materialises this."""
@@ -89,15 +137,11 @@ class RNNMPCController(MPCController):
         native = self.dynamics_model.planner_model()
         m = len(observations)
         dev = native.device
-        c, h = self._hidden_state
-        assert c.shape == (m, native.units), "hidden state holds %d rows, %d observations were passed" % (
-            c.shape[0], m)
+        c0, h0 = self._device_hidden(dev)
+        assert tuple(c0.shape) == (m, native.units), "hidden state holds %d rows, %d observations were passed" % (
+            c0.shape[0], m)
         obs0 = self._buf("obs0", (m, native.obs_dim), torch.float32, dev)
         obs0.copy_(torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32)))
-        c0 = self._buf("c0", (m, native.units), torch.float32, dev)
-        h0 = self._buf("h0", (m, native.units), torch.float32, dev)
-        c0.copy_(torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)))
-        h0.copy_(torch.from_numpy(np.ascontiguousarray(h, dtype=np.float32)))
         best = self._buf("best", (m,), torch.int64, dev)
         rets = self._buf("rets", (m, n_local), torch.float32, dev) if want_returns else None
         native.plan_rs(obs0, c0, h0, actions_local, m, n_local, self.horizon, self.discount, self._reward_spec,

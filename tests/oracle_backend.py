@@ -77,6 +77,10 @@ def install_rnn(controller, case):
     controller._check_status = lambda: None
     controller._device = lambda: cpu
     controller._upload = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    def _advance_hidden(observations, actions):
+        _, controller._hidden_state = predict(np.array(observations), actions, controller._hidden_state)
+
     controller._rollout = _rollout
+    controller._advance_hidden = _advance_hidden
     controller.dynamics_model.predict = predict
     return controller
