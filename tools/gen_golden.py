@@ -102,6 +102,14 @@ CASES = [
          mode="single", E=1, hidden=[512, 512], seeds=[0, 1], num_cem_iters=3),
     dict(name="hc_cem_m2_n100_h4", env="half_cheetah", planner="cem", n=100, h=4, m=2,
          mode="single", E=1, hidden=[512, 512], seeds=[0], num_cem_iters=3),
+    dict(name="ant_cem_m2_n120_h4_pb2", env="ant", planner="cem", n=120, h=4, m=2,
+         mode="per_block", E=2, hidden=[512, 512], seeds=[1], num_cem_iters=2),
+    dict(name="arm_cem_n160_h5_e3", env="arm_7dof", planner="cem", n=160, h=5, m=1,
+         mode="mean", E=3, hidden=[256, 256], seeds=[0], num_cem_iters=2),
+    dict(name="hc_rs_sigmoid_3x128", env="half_cheetah", planner="rs", n=90, h=5, m=2,
+         mode="single", E=1, hidden=[128, 128, 128], seeds=[0], activation="sigmoid"),
+    dict(name="ant_rs_4x256_e2", env="ant", planner="rs", n=70, h=4, m=1,
+         mode="mean", E=2, hidden=[256, 256, 256, 256], seeds=[0], discount=0.99),
     # recurrent planner (ReBAL, run_scripts/run_rebal.py:77-99: LSTM(256), n=500, h=10, 5 rollouts)
     dict(name="c6_hc_rnn_rs_n500_h10_m5", env="half_cheetah", planner="rnn_rs", n=500, h=10, m=5,
          units=256, steps=3, seeds=[0]),
@@ -115,6 +123,10 @@ CASES = [
          units=256, steps=2, discount=0.95, seeds=[0]),
     dict(name="hc_rnn_cem_n200_h5_m2", env="half_cheetah", planner="rnn_cem", n=200, h=5, m=2,
          units=256, steps=2, num_cem_iters=3, seeds=[0]),
+    dict(name="arm_rnn_rs_u512_n48_h4", env="arm_7dof", planner="rnn_rs", n=48, h=4, m=2,
+         units=512, steps=2, seeds=[0]),
+    dict(name="hc_rnn_rs_relu_u128_n33_h3", env="half_cheetah", planner="rnn_rs", n=33, h=3, m=3,
+         units=128, steps=3, activation="relu", reset_after={"0": [True, False, False]}, seeds=[0]),
 ]
 
 
