@@ -185,8 +185,6 @@ class MPCController(Policy, Serializable):
             a_dev = self._upload(a_loc)
         else:
             dev = self._device()
-            low = torch.as_tensor(self.action_space.low, dtype=torch.float32, device=dev)
-            high = torch.as_tensor(self.action_space.high, dtype=torch.float32, device=dev)
             a_dev = self._buf("a_dev", (h, m * n_local, act_dim), torch.float32, dev)
             gen = self._bufs.get("rs_gen")
             if gen is None or gen.device != dev:
@@ -194,8 +192,14 @@ class MPCController(Policy, Serializable):
                 gen = torch.Generator(device=dev)
                 gen.manual_seed((int(torch.initial_seed()) + 7919 * rank) & 0x7FFFFFFF)
                 self._bufs["rs_gen"] = gen
-            a_dev.uniform_(0.0, 1.0, generator=gen)
-            a_dev.mul_(high - low).add_(low)
+            lo_np, hi_np = np.asarray(self.action_space.low), np.asarray(self.action_space.high)
+            if np.all(lo_np == lo_np[0]) and np.all(hi_np == hi_np[0]):
+                a_dev.uniform_(float(lo_np[0]), float(hi_np[0]), generator=gen)     # one launch (the usual +-bound box)
+            else:
+                low = torch.as_tensor(lo_np, dtype=torch.float32, device=dev)
+                high = torch.as_tensor(hi_np, dtype=torch.float32, device=dev)
+                a_dev.uniform_(0.0, 1.0, generator=gen)
+                a_dev.mul_(high - low).add_(low)
             cand_a = None
 
         if n_local > 0:
@@ -215,14 +219,16 @@ class MPCController(Policy, Serializable):
         if cand_a is not None:
             return cand_a[range(m), idx]
         # device RNG: the winning first action lives on the rank that owns the candidate
+        if world == 1:
+            rows = torch.from_numpy(np.arange(m, dtype=np.int64) * n_local + (idx - lo)).to(a_dev.device)
+            return a_dev[0].index_select(0, rows).cpu().numpy().astype(np.float64)
         first = a_dev[0].reshape(m, n_local, act_dim)
         gidx = torch.from_numpy(idx).to(a_dev.device)
         own = ((gidx >= lo) & (gidx < hi)).to(torch.float32).unsqueeze(1)
         loc = (gidx - lo).clamp(0, max(n_local - 1, 0))
         out = first[torch.arange(m, device=a_dev.device), loc] * own if n_local > 0 else \
             torch.zeros((m, act_dim), dtype=torch.float32, device=a_dev.device)
-        if world > 1:
-            torch.distributed.all_reduce(out, op=torch.distributed.ReduceOp.SUM)
+        torch.distributed.all_reduce(out, op=torch.distributed.ReduceOp.SUM)
         return out.cpu().numpy().astype(np.float64)
 
     def _get_rs_action_unfused(self, observations):
