@@ -99,9 +99,41 @@ class MPCController(Policy, Serializable):
             actions = self.get_rs_action(observations)
         return actions, dict()
 
+    _fast_uniform = None        # class-wide: does the vectorised draw reproduce np.random.uniform bit for bit here?
+
     def get_random_action(self, n):
-        return np.random.uniform(low=self.action_space.low,
-                                 high=self.action_space.high, size=(n,) + self.action_space.low.shape)
+        """``np.random.uniform(low, high, (n, act_dim))`` (reference ``:67-69``) - same values, same
+        consumption of the global MT19937 stream.  NumPy's legacy ``uniform`` with array bounds walks a
+        broadcast iterator per element (measured 2.6x the cost of the raw doubles); ``low + (high - low) *
+        random_sample()`` is the same arithmetic (``random_uniform``: ``lower + range * next_double``, two
+        roundings) vectorised.  Verified once per process against the real call on a saved RNG state; if
+        the platform's NumPy ever differed, the reference call is used."""
+        low, high = self.action_space.low, self.action_space.high
+        shape = (n,) + low.shape
+        cls = MPCController
+        if cls._fast_uniform is None:
+            state = np.random.get_state()
+            want = np.random.uniform(low=low, high=high, size=(257,) + low.shape)
+            np.random.set_state(state)
+            got = np.random.random_sample((257,) + low.shape)
+            got *= (high - low)
+            got += low
+            np.random.set_state(state)
+            cls._fast_uniform = bool(np.array_equal(want, got))
+        if not cls._fast_uniform:
+            return np.random.uniform(low=low, high=high, size=shape)
+        u = np.random.random_sample(shape)
+        # full-size (contiguous) scale / offset arrays: broadcasting a length-act_dim vector over the last
+        # axis makes NumPy run act_dim-element inner loops, slower than the draw itself
+        key = ("uniform_affine", shape)
+        aff = self._bufs.get(key)
+        if aff is None:
+            aff = (np.ascontiguousarray(np.broadcast_to(high - low, shape)),
+                   np.ascontiguousarray(np.broadcast_to(low, shape)))
+            self._bufs[key] = aff
+        u *= aff[0]
+        u += aff[1]
+        return u
 
     def get_params_internal(self, **tags):
         return []
@@ -135,8 +167,19 @@ class MPCController(Policy, Serializable):
         return self.dynamics_model.planner_model().device
 
     def _upload(self, actions_local):
-        """Host fp32 ``[h, m * n_local, act_dim]`` -> device tensor (one H2D copy per plan step)."""
-        return torch.from_numpy(np.ascontiguousarray(actions_local, dtype=np.float32)).to(self._device())
+        """Host ``[h, m * n_local, act_dim]`` (any float dtype) -> fp32 device tensor: cast straight into a
+        pinned staging buffer, one asynchronous H2D copy per plan step (the caller reads the plan's result
+        back before it can call again, so the staging buffer is never overwritten in flight)."""
+        dev = self._device()
+        shape = tuple(actions_local.shape)
+        pin = self._bufs.get("a_pin")
+        if pin is None or tuple(pin.shape) != shape:
+            pin = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+            self._bufs["a_pin"] = pin
+        np.copyto(pin.numpy(), actions_local, casting="same_kind")
+        a_dev = self._buf("a_up", shape, torch.float32, dev)
+        a_dev.copy_(pin, non_blocking=True)
+        return a_dev
 
     def _check_status(self):
         """After a device->host read-back (= stream sync): raise if a launch flagged a problem."""
@@ -181,8 +224,9 @@ class MPCController(Policy, Serializable):
             # identical draw and layout to the reference (:114): [h, n*m, act_dim], row = i*n + j
             a = self.get_random_action(h * n * m).reshape((h, n * m, -1))
             cand_a = a[0].reshape((m, n, -1))
-            a_loc = a.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32).reshape(h, m * n_local, act_dim)
-            a_dev = self._upload(a_loc)
+            a_loc = a.reshape(h, m, n, act_dim)[:, :, lo:hi, :]
+            a_dev = self._upload(a_loc if world > 1 else a).view(h, m * n_local, act_dim) if n_local > 0 else \
+                self._upload(np.zeros((h, 0, act_dim), dtype=np.float32))
         else:
             dev = self._device()
             a_dev = self._buf("a_dev", (h, m * n_local, act_dim), torch.float32, dev)
