@@ -1,0 +1,95 @@
+/*
+ * abi_demo.c - libl2a_hip.so driven from plain C (no Python, no torch): the binding a non-Python host of
+ * the reference's planner would write against include/l2a.h.  Test infrastructure (tests/test_c_abi.py
+ * compiles it with gcc and runs it on the GPU box).
+ *
+ * usage: abi_demo <case.bin> ; the file is written by the test:
+ *   int32 header[8] = {obs_dim, act_dim, n_hidden, hidden0, m, n, h, vel_index}
+ *   float  dt, ctrl_coef
+ *   per layer: kernel [in, out] fp32, bias [out] fp32          (reference parameter order)
+ *   double norm[6][...]: mean_obs, std_obs, mean_act, std_act, mean_delta, std_delta
+ *   float  obs0[m * obs_dim], actions[h * m * n * act_dim]
+ * prints: one line per env "env <i> index <idx> return <ret>"
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "l2a.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define CHECK_L2A(ctx, x) do { int rc_ = (x); if (rc_ != L2A_OK) { \
+    fprintf(stderr, "%s failed (%d): %s\n", #x, rc_, l2a_last_error(ctx)); return 3; } } while (0)
+
+static void* rd(FILE* f, size_t bytes) {
+    void* p = malloc(bytes ? bytes : 1);
+    if (fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "short read\n"); exit(4); }
+    return p;
+}
+
+static void* to_device(const void* host, size_t bytes) {
+    void* d = NULL;
+    if (hipMalloc(&d, bytes) != hipSuccess || hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        fprintf(stderr, "device upload failed\n");
+        exit(5);
+    }
+    return d;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s case.bin\n", argv[0]); return 1; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 1; }
+    int* hd = (int*)rd(f, 8 * sizeof(int));
+    const int obs_dim = hd[0], act_dim = hd[1], n_hidden = hd[2], width = hd[3], m = hd[4], n = hd[5], h = hd[6];
+    float* rw_par = (float*)rd(f, 2 * sizeof(float));
+
+    l2a_ctx* ctx = NULL;
+    if (l2a_init(0, &ctx) != L2A_OK) { fprintf(stderr, "l2a_init: %s\n", l2a_last_error(NULL)); return 3; }
+    int hidden[8];
+    for (int i = 0; i < n_hidden; ++i) hidden[i] = width;
+    l2a_model* model = NULL;
+    CHECK_L2A(ctx, l2a_model_create(ctx, obs_dim, act_dim, n_hidden, hidden, L2A_ACT_RELU, L2A_ACT_IDENTITY, 1,
+                                    L2A_MODE_SINGLE, &model));
+
+    const void* ptrs[2 * 9];
+    int k_in = obs_dim + act_dim;
+    for (int l = 0; l <= n_hidden; ++l) {
+        const int n_out = (l < n_hidden) ? width : obs_dim;
+        float* w = (float*)rd(f, sizeof(float) * (size_t)k_in * n_out);
+        float* b = (float*)rd(f, sizeof(float) * (size_t)n_out);
+        ptrs[2 * l] = to_device(w, sizeof(float) * (size_t)k_in * n_out);
+        ptrs[2 * l + 1] = to_device(b, sizeof(float) * (size_t)n_out);
+        free(w); free(b);
+        k_in = n_out;
+    }
+    CHECK_L2A(ctx, l2a_model_set_weights(model, 0, ptrs, NULL));
+    double* nm[6];
+    for (int i = 0; i < 6; ++i) nm[i] = (double*)rd(f, sizeof(double) * (size_t)((i == 2 || i == 3) ? act_dim : obs_dim));
+    CHECK_L2A(ctx, l2a_model_set_norm(model, 0, nm[0], nm[1], nm[2], nm[3], nm[4], nm[5], NULL));
+
+    float* obs0 = (float*)rd(f, sizeof(float) * (size_t)m * obs_dim);
+    float* acts = (float*)rd(f, sizeof(float) * (size_t)h * m * n * act_dim);
+    fclose(f);
+    float* d_obs0 = (float*)to_device(obs0, sizeof(float) * (size_t)m * obs_dim);
+    float* d_acts = (float*)to_device(acts, sizeof(float) * (size_t)h * m * n * act_dim);
+    unsigned long long* d_key = NULL;
+    CHECK_HIP(hipMalloc((void**)&d_key, sizeof(unsigned long long) * (size_t)m));
+
+    l2a_reward rw = {1.0f, 1.0f / rw_par[0], 0.0f, rw_par[1], 0.0f, hd[7], 0, 0};      /* half_cheetah_env.py:58-65 */
+    CHECK_L2A(ctx, l2a_plan_rs(model, d_obs0, d_acts, m, n, h, 1.0f, &rw, 0, NULL, d_key, NULL));
+    unsigned long long* key = (unsigned long long*)malloc(sizeof(unsigned long long) * (size_t)m);
+    CHECK_HIP(hipMemcpy(key, d_key, sizeof(unsigned long long) * (size_t)m, hipMemcpyDeviceToHost));   /* = the sync */
+    int status = 0;
+    CHECK_L2A(ctx, l2a_launch_status(ctx, &status));
+    if (status != 0) { fprintf(stderr, "launch status 0x%x\n", status); return 6; }
+    for (int i = 0; i < m; ++i) {
+        float ret; int idx;
+        l2a_key_decode(key[i], &ret, &idx);
+        printf("env %d index %d return %.9g\n", i, idx, ret);
+    }
+    l2a_model_destroy(model);
+    l2a_destroy(ctx);
+    return 0;
+}

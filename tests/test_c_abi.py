@@ -1,0 +1,66 @@
+"""The C ABI from plain C: ``tests/c/abi_demo.c`` is compiled with gcc against ``include/l2a.h`` and
+``libl2a_hip.so`` (no Python, no torch in that process), fed a golden case through a binary file and must
+pick the reference planner's candidates."""
+
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+ROCM = "/opt/rocm"
+
+
+def _build(tmp_path):
+    exe = os.path.join(str(tmp_path), "abi_demo")
+    pkg = os.path.join(ROOT, "learning_to_adapt_amd")
+    cmd = [shutil.which("gcc") or "gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROCM, "include"),
+           os.path.join(HERE, "c", "abi_demo.c"), "-o", exe,
+           "-L", pkg, "-l:libl2a_hip.so", "-L", os.path.join(ROCM, "lib"), "-lamdhip64",
+           "-Wl,-rpath," + pkg, "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_c_demo_compiles_against_the_header(tmp_path):
+    """CPU box: the demo must compile and link against include/l2a.h + the built library (no run)."""
+    if not os.path.exists(os.path.join(ROOT, "learning_to_adapt_amd", "libl2a_hip.so")):
+        pytest.skip("library not built")
+    assert os.path.exists(_build(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_demo_picks_the_reference_candidates(tmp_path):
+    cid = "hc_rs_m3_n64_h5_s0"
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    env, sets, norms = cases.recipe(case)
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    np.random.seed(seed)
+    a = np.random.uniform(env.action_space.low, env.action_space.high,
+                          (case["h"] * case["n"] * case["m"], ad)).reshape(case["h"], case["n"] * case["m"], ad)
+    path = os.path.join(str(tmp_path), "case.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("8i", od, ad, len(case["hidden"]), case["hidden"][0], case["m"], case["n"], case["h"], od - 3))
+        f.write(struct.pack("2f", env.dt, 0.05))
+        for p in sets[0]:
+            f.write(np.ascontiguousarray(p, dtype=np.float32).tobytes())
+        nm = norms[0]
+        for key in ("obs", "act", "delta"):
+            for j in (0, 1):
+                f.write(np.ascontiguousarray(nm[key][j], dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(gold["obs0"], dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+    out = subprocess.check_output([_build(tmp_path), path], timeout=120).decode().strip().splitlines()
+    assert len(out) == case["m"]
+    for i, line in enumerate(out):
+        tok = line.split()
+        assert int(tok[1]) == i and int(tok[3]) == int(gold["best"][i])
+        assert abs(float(tok[5]) - float(gold["returns"][i, gold["best"][i]])) <= 1e-4 * max(1.0, abs(float(tok[5])))
