@@ -185,7 +185,14 @@ class MPCController(Policy, Serializable):
         """After a device->host read-back (= stream sync): raise if a launch flagged a problem."""
         self.dynamics_model.planner_model().ctx.launch_status()
 
-    def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns):
+    def _upload_obs(self, observations):
+        """``[m, obs_dim]`` host observations -> the fp32 device buffer the rollout reads."""
+        native = self.dynamics_model.planner_model()
+        obs0 = self._buf("obs0", (len(observations), native.obs_dim), torch.float32, native.device)
+        obs0.copy_(torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32)), non_blocking=False)
+        return obs0
+
+    def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
         """Launch the fused kernel on this rank's shard.
 
         ``actions_local``: fp32 CUDA tensor ``[h, m * n_local, act_dim]`` (row = env * n_local + j).
@@ -198,8 +205,7 @@ class MPCController(Policy, Serializable):
             raise _lib.L2AError("the dynamics model holds %d adapted weight sets but %d observations "
                                 "were passed" % (blocks, m))
         dev = native.device
-        obs0 = self._buf("obs0", (m, native.obs_dim), torch.float32, dev)
-        obs0.copy_(torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32)), non_blocking=False)
+        obs0 = obs_dev if obs_dev is not None else self._upload_obs(observations)
         best = self._buf("best", (m,), torch.int64, dev)
         rets = self._buf("rets", (m, n_local), torch.float32, dev) if want_returns else None
         native.plan_rs(obs0, actions_local, m, n_local, self.horizon, self.discount, self._reward_spec,
@@ -378,6 +384,7 @@ class MPCController(Policy, Serializable):
             raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
         rets = None
         cand = None
+        obs_dev = self._upload_obs(observations)             # once per plan step, not once per CEM iteration
         for _ in range(self.num_cem_iters):
             z = self._cem_normal_device((n, m, D), dev)
             a = mean + z * std                                                                # [n, m, D]
@@ -387,7 +394,7 @@ class MPCController(Policy, Serializable):
             else:
                 cand = a_clip.permute(1, 0, 2).contiguous()                                       # [m, n, D]
             seq = cand[:, lo:hi, :].reshape(m * n_local, h, act_dim).permute(1, 0, 2).contiguous()
-            _, r_loc = self._rollout(observations, seq, n_local, lo, want_returns=True)
+            _, r_loc = self._rollout(observations, seq, n_local, lo, want_returns=True, obs_dev=obs_dev)
             if world > 1:
                 parts = [torch.empty_like(r_loc) for _ in range(world)]
                 torch.distributed.all_gather(parts, r_loc)
@@ -398,9 +405,14 @@ class MPCController(Policy, Serializable):
                 # :101-104: positions of the descending argsort whose VALUE is < num_elites, used as a
                 # mask over candidates, pooled over envs; mean / std broadcast back to every env
                 mask = (torch.argsort(rets, dim=1, descending=True, stable=True) < num_elites).t()   # [n, m]
-                elites = a_clip[mask]                                                         # [m*k, D]
-                mean = mean * self.alpha + (1 - self.alpha) * elites.mean(dim=0)
-                std = elites.std(dim=0, unbiased=False).expand(m, D)
+                # masked moments instead of `a_clip[mask]`: boolean indexing needs the element count on the
+                # host (a sync per iteration); the mask always selects exactly m * num_elites samples
+                w = mask.to(torch.float32).unsqueeze(-1)                                      # [n, m, 1]
+                cnt = float(m * num_elites)
+                e_mean = (a_clip * w).sum(dim=(0, 1)) / cnt                                   # [D]
+                e_var = (((a_clip - e_mean) ** 2) * w).sum(dim=(0, 1)) / cnt
+                mean = mean * self.alpha + (1 - self.alpha) * e_mean
+                std = torch.sqrt(e_var).expand(m, D)
             else:
                 top = torch.topk(rets, num_elites, dim=1).indices                             # [m, k]
                 elites = torch.gather(cand, 1, top.unsqueeze(-1).expand(m, num_elites, D))    # [m, k, D]

@@ -133,15 +133,14 @@ class RNNMPCController(MPCController):
         return np.repeat(hidden, n, axis=0)
 
     # ------------------------------------------------------------------ fused rollout with the env's LSTM state
-    def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns):
+    def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
         native = self.dynamics_model.planner_model()
         m = len(observations)
         dev = native.device
         c0, h0 = self._device_hidden(dev)
         assert tuple(c0.shape) == (m, native.units), "hidden state holds %d rows, %d observations were passed" % (
             c0.shape[0], m)
-        obs0 = self._buf("obs0", (m, native.obs_dim), torch.float32, dev)
-        obs0.copy_(torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32)))
+        obs0 = obs_dev if obs_dev is not None else self._upload_obs(observations)
         best = self._buf("best", (m,), torch.int64, dev)
         rets = self._buf("rets", (m, n_local), torch.float32, dev) if want_returns else None
         native.plan_rs(obs0, c0, h0, actions_local, m, n_local, self.horizon, self.discount, self._reward_spec,

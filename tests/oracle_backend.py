@@ -27,7 +27,7 @@ def install(controller, case):
     def _upload(actions_local):
         return torch.from_numpy(np.ascontiguousarray(actions_local, dtype=np.float32))
 
-    def _rollout(observations, actions_local, n_local, cand_offset, want_returns):
+    def _rollout(observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
         m = len(observations)
         acts = actions_local.numpy().astype(np.float64)
         rets = rollout_returns(dyn, reward, observations, acts, n_local, controller.discount)
@@ -40,6 +40,7 @@ def install(controller, case):
         return torch.from_numpy(keys), (torch.from_numpy(rets) if want_returns else None)
 
     controller._check_status = lambda: None
+    controller._upload_obs = lambda observations: None
     controller._device = _device
     controller._upload = _upload
     controller._rollout = _rollout
@@ -57,7 +58,7 @@ def install_rnn(controller, case):
     reward = make_reward(case["env"], env.dt)
     cpu = torch.device("cpu")
 
-    def _rollout(observations, actions_local, n_local, cand_offset, want_returns):
+    def _rollout(observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
         m = len(observations)
         acts = actions_local.numpy().astype(np.float64)
         c, h = controller._hidden_state
@@ -75,6 +76,7 @@ def install_rnn(controller, case):
         return nxt, type(controller._hidden_state)(hid.c, hid.h)
 
     controller._check_status = lambda: None
+    controller._upload_obs = lambda observations: None
     controller._device = lambda: cpu
     controller._upload = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
     def _advance_hidden(observations, actions):
