@@ -105,13 +105,21 @@ def main():
         raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the rollout path is HIP-only)"
+    # Developer hook (tools/gpu_round.sh): L2A_BENCH_SHARE_GPU=1 runs every rank on GPU 0 over gloo so that
+    # the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver; numbers are meaningless.
+    share = os.environ.get("L2A_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from learning_to_adapt_amd import _lib
     from learning_to_adapt_amd.dynamics.native_model import NativeModel
