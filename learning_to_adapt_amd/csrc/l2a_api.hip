@@ -133,12 +133,26 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         // set of a lone model) is shared: each workgroup runs the last hidden layer and the output
         // layer for one half of its hidden tiles (needs >= 2 hidden layers).
         p.split = 0;
-        if (ctx->split_policy != 0 && nt == 1 && 2 * pairs <= cus && p.h < 4096) {
-            if ((e_loop & 1) && md->n_hidden >= 2 && ctx->split_policy == 1) p.split = 2;
-            else if (e_loop >= 2) p.split = 1;
+        p.split_from = -1;
+        long long split_pairs = 0;          // tiles shared by two workgroups
+        auto split_mode = [&]() {
+            if ((e_loop & 1) && md->n_hidden >= 2 && ctx->split_policy == 1) return 2;
+            return (e_loop >= 2) ? 1 : 0;
+        };
+        if (ctx->split_policy != 0 && nt == 1 && p.h < 4096) {
+            if (2 * pairs <= cus) {
+                p.split = split_mode();
+                split_pairs = p.split ? pairs : 0;
+            } else if (pairs > cus && pairs % cus != 0 && 2 * (pairs % cus) <= cus && split_mode() != 0) {
+                // Tail split: a multi-round plan whose last round would fill less than half of the chip -
+                // the left-over tiles are shared by two workgroups each (dispatched last, see l2a_mfma.h).
+                p.split = split_mode();
+                split_pairs = pairs % cus;
+                p.split_from = (int)(pairs - split_pairs);
+            }
         }
         if (p.split) {
-            const long long need = pairs * 2 * 2 * 2 * (long long)(nt * md->OT * 2 * 64 * 16) / 8;   // in 8-byte units
+            const long long need = split_pairs * 2 * 2 * 2 * (long long)(nt * md->OT * 2 * 64 * 16) / 8;   // in 8-byte units
             if (need > md->xbuf_granules) {
                 if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
                 L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));
@@ -156,7 +170,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             p.status = ctx->status_dev;
         }
         p.dbg = ctx->dbg;
-        const dim3 grid((unsigned)(pairs * (p.split ? 2 : 1))), block(64 * L2A_NW);
+        const dim3 grid((unsigned)(pairs + (p.split ? split_pairs : 0))), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
         int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, &p, grid.x, smem, stream);
         if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");

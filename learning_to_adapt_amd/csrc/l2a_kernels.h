@@ -60,7 +60,9 @@ struct L2AKParams {
     float discount;
     l2a_reward rw;
     // ---- member split (MFMA kernel, mean mode): two workgroups share one candidate tile ----
-    int split;                  // 0: one workgroup runs all members; 1: group A | group B
+    int split;                  // 0: one workgroup runs all members; 1: group A | group B; 2: + shared set
+    int split_from;             // -1: `split` applies to every tile; >= 0: tail split - hardware workgroups
+                                // [0, split_from) run whole tiles, the rest are pairs sharing tiles split_from ..
     unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1
     unsigned long long* xbuf;   // exchange granules [pair][group][slot][NT*OT*4][64]
     unsigned int* status;       // host-visible word; bit 0 set = exchange timed out

@@ -38,6 +38,8 @@
 // travel through 16-byte self-validating {tag, v, tag, v} granules in global memory: write-through
 // (sc1) stores, sc1 loads, no flag and no fence (cdna_hip_programming.md G16 recipe R2); the group
 // sums are published before the half member starts.  Spins are bounded (status word, never a hang).
+// Tail split (p.split_from >= 0): in a multi-round plan whose last round would fill under half of the
+// chip only the left-over tiles are shared; their workgroup pairs are dispatched last, back to back.
 //
 // Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave (hidden
 // width = 16 * L2A_NW * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16), GACT =
@@ -296,10 +298,29 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const int qq = lane >> 4;
     const int c0 = wave * TPW;
 
-    const int bid = l2a_logical_wg(blockIdx.x, gridDim.x);
-    const int n_pairs = p.m * p.tiles_per_env;
-    const int grp = p.split ? (bid / n_pairs) : 0;          // which of the two workgroups of a tile
-    const int pairid = bid - grp * n_pairs;
+    // Geometry.  Uniform launches (p.split_from < 0): every tile is run by 1 (split 0) or 2 workgroups, ids
+    // remapped XCD-aware.  Tail split (p.split_from >= 0): the first split_from hardware workgroups run whole
+    // tiles, the remaining ones - dispatched last - are pairs that share the left-over tiles of a multi-round
+    // plan (e.g. 625 tiles on 256 CUs: 512 whole + 113 shared instead of a third, 44 %-filled round).
+    const int tail = p.split_from >= 0;
+    const int in_tail = tail && (int)blockIdx.x >= p.split_from;
+    const int split = tail ? (in_tail ? p.split : 0) : p.split;        // this workgroup's split mode
+    const int n_tiles = p.m * p.tiles_per_env;
+    const int n_pairs = tail ? n_tiles - p.split_from : n_tiles;       // tiles that are shared by two workgroups
+    int bid, grp, lpair, pairid;
+    if (!tail) {
+        bid = l2a_logical_wg(blockIdx.x, gridDim.x);
+        grp = split ? (bid / n_pairs) : 0;                  // which of the two workgroups of a tile
+        lpair = bid - grp * n_pairs;
+        pairid = lpair;
+    } else if (!in_tail) {
+        bid = l2a_logical_wg(blockIdx.x, p.split_from);
+        grp = 0; lpair = 0; pairid = bid;
+    } else {
+        bid = (int)blockIdx.x - p.split_from;
+        grp = bid & 1; lpair = bid >> 1;                    // partners are dispatched back to back
+        pairid = p.split_from + lpair;
+    }
     const int env = pairid / p.tiles_per_env;
     const int tb = pairid - env * p.tiles_per_env;
     const int R = p.m * p.n;
@@ -379,19 +400,19 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const float e_count = (float)e_loop;
     double disc_pow = 1.0;      // discount ** t, carried in float64 like the reference (:126)
 
-    // Which sets this workgroup runs (p.split: 0 = all; 1 = group A | group B; 2 = as 1, but the
+    // Which sets this workgroup runs (split: 0 = all; 1 = group A | group B; 2 = as 1, but the
     // last set of group A is SHARED: both workgroups run it as a "half member" - layer 0 and the
     // inner hidden layers in full, the last hidden layer and the output layer for one half of the
     // hidden tiles each - which balances odd ensembles and lets a single model use two CUs).
     // Both workgroups run their full sets first and the shared one last, so the group sums of
     // the full sets can be published (and travel) while the half set is still being computed.
-    const int e_shared = (p.split == 2) ? e_half - 1 : -1;
-    const int n_full = !p.split ? e_loop : (grp == 0 ? e_half - (p.split == 2 ? 1 : 0) : e_loop - e_half);
-    const int n_seq = n_full + (p.split == 2 ? 1 : 0);
-    const int full0 = (p.split && grp == 1) ? e_half : 0;       // first full set of this workgroup
+    const int e_shared = (split == 2) ? e_half - 1 : -1;
+    const int n_full = !split ? e_loop : (grp == 0 ? e_half - (split == 2 ? 1 : 0) : e_loop - e_half);
+    const int n_seq = n_full + (split == 2 ? 1 : 0);
+    const int full0 = (split && grp == 1) ? e_half : 0;       // first full set of this workgroup
     auto seq = [&](int i) { return (i < n_full) ? full0 + i : e_shared; };
     auto set_base = [&](int e) { return p.wblk + (long long)(per_block ? env : e) * p.set_stride; };
-    const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, p.split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
+    const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
     // barrier that separates them, so a phase never starts with an exposed L2 round trip).
@@ -450,7 +471,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         // no flag and no fence - a granule is accepted when its tags match (G16 recipe R2).
         const unsigned int xtag = p.xtag + (unsigned int)(t + 1);
         constexpr int XREG = NT * OT * 2 * 64 * 16;             // bytes per region
-        auto xbase = [&](int g, int region) { return (((pairid * 2 + g) * 2 + (t & 1)) * 2 + region) * XREG + lane * 16; };
+        auto xbase = [&](int g, int region) { return (((lpair * 2 + g) * 2 + (t & 1)) * 2 + region) * XREG + lane * 16; };
         auto xput = [&](int region, const f32x4 (&v)[NT][OT]) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -483,7 +504,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
         for (int i = 0; i < n_seq; ++i) {
             const int e = seq(i);
-            if (e == e_half && !p.split) {      // group A complete: park it, start group B
+            if (e == e_half && !split) {      // group A complete: park it, start group B
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -695,15 +716,15 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             // finished these reads by then).  n_hidden == 1: there is no layer-0 barrier, the next
             // partial sums would land in `hoth` while slow waves still read it -> alternate regions.
             if (n_hidden == 1) { f32x4* tmp = hcur; hcur = hoth; hoth = tmp; }
-            if (p.split == 2 && i == n_full - 1 && wave == 0) xput(0, dgrp);   // travels under the half set
+            if (split == 2 && i == n_full - 1 && wave == 0) xput(0, dgrp);   // travels under the half set
             L2A_TS(6)
         }
 
         // ---- combine the two workgroups of a tile ---------------------------------------------
         { const int e = 7; L2A_TS(9) }
-        if (p.split) {
+        if (split) {
             if (wave == 0) {
-                if (p.split == 2) xput(1, qsh);
+                if (split == 2) xput(1, qsh);
                 else xput(0, dgrp);
                 { const int e = 7; L2A_TS(11) }
                 f32x4 oth[2][NT][OT];
@@ -715,12 +736,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         oth[1][nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                 // single model (E == 1): there are no full sets, region 0 is never written - skip it
-                const bool want0 = (p.split == 1) || (e_loop > 1);
+                const bool want0 = (split == 1) || (e_loop > 1);
                 unsigned int spins = 0;
                 while (true) {
                     // both regions in ONE round trip (an sc1 load sweep costs ~3k cycles whatever its size)
                     bool ok = true;
-                    if (p.split == 2) ok = xget(1, oth[1]);
+                    if (split == 2) ok = xget(1, oth[1]);
                     if (want0) ok = xget(0, oth[0]) && ok;
                     if (__all(ok)) break;
                     if (++spins > (1u << 22)) {     // partner never arrived: flag it, do not hang
@@ -752,7 +773,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     const f32x4 og = xlds[((0 * NT + nt) * OT + c) * 64 + lane];      // partner's group sum
                     f32x4 ga = (grp == 0) ? dgrp[nt][c] : og;                          // group A (without the shared set)
                     const f32x4 gb = (grp == 0) ? og : dgrp[nt][c];                    // group B
-                    if (p.split == 2) {
+                    if (split == 2) {
                         f32x4 s = qsh[nt][c] + xlds[((1 * NT + nt) * OT + c) * 64 + lane];   // S1 + S2
                         s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
                         ga += s * osd + omu;        // the shared set is the last member of group A

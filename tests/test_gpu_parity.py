@@ -179,6 +179,10 @@ SPLIT_CASES = [
     ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128, 128], E=1, n=150, h=4)),
     ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128, 128], E=2, n=150, h=4, activation="tanh")),
     ("c2_hc_rs_n2000_h30_e5", dict(hidden=[256, 256, 256, 256], E=1, n=90, h=3)),
+    # tail split: multi-round plans whose last round fills under half of the chip (l2a_api.hip)
+    ("c3_ant_rs_n2000_h20_pb5", dict(h=3)),                 # 625 tiles = 512 whole + 113 shared (per-block sets)
+    ("c2_hc_rs_n2000_h30_e5", dict(n=4800, h=2)),           # 300 tiles = 256 + 44, E = 5 (groups + shared middle set)
+    ("hc_rs_m2_n100_h7_e2", dict(n=2600, h=2)),             # m = 2, 326 tiles = 256 + 70, E = 2 (whole-set split)
 ]
 
 
