@@ -79,13 +79,25 @@ int allow_big_lds(const l2a_ctx* ctx, K kernel, int bytes) {
     return L2A_OK;
 }
 
-// Launch geometry of the MFMA kernel for (m, n): NT candidate tiles per workgroup.
-int choose_nt(const l2a_model* md, int m, int n, int sa_bytes_nt2, int other_bytes_nt2) {
+// Which tile-split flavour a model / policy allows: 2 = groups + shared middle (or only) set, 1 = whole
+// sets, 0 = none.
+int split_mode_for(const l2a_model* md, int e_loop) {
+    const int policy = md->ctx->split_policy;
+    if (policy == 0) return 0;
+    if ((e_loop & 1) && md->n_hidden >= 2 && policy == 1) return 2;
+    return (e_loop >= 2) ? 1 : 0;
+}
+
+// Launch geometry of the MFMA kernel for (m, n): NT candidate tiles per workgroup.  Costs in units of
+// "one workgroup running one tile for the whole horizon": NT = 2 costs 1.9, a shared tail round ~0.8.
+int choose_nt(const l2a_model* md, int m, int n, int e_loop, int sa_bytes_nt2, int other_bytes_nt2) {
     const int cus = md->ctx->num_cu > 0 ? md->ctx->num_cu : 256;
     if (2 * sa_bytes_nt2 + other_bytes_nt2 > md->ctx->lds_per_block) return 1;
     const long long wg1 = (long long)m * ceil_div(n, 16);
     const long long wg2 = (long long)m * ceil_div(n, 32);
-    const double cost1 = (double)((wg1 + cus - 1) / cus) * 1.0;
+    const long long t = wg1 % cus;
+    double cost1 = (double)((wg1 + cus - 1) / cus);
+    if (wg1 > cus && t != 0 && 2 * t <= cus && split_mode_for(md, e_loop) != 0) cost1 = (double)(wg1 / cus) + 0.8;
     const double cost2 = (double)((wg2 + cus - 1) / cus) * 1.9;
     return (cost2 < cost1) ? 2 : 1;
 }
@@ -117,7 +129,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     if (kind == L2A_KERNEL_MFMA) {
         const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
         const int cst_bytes = e_loop0 * (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4;
-        const int nt = choose_nt(md, p.m, p.n, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16);
+        const int nt = choose_nt(md, p.m, p.n, e_loop0, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16);
         p.sa_elems = sa_elems_for(md, nt);
         p.tiles_per_env = ceil_div(p.n, 16 * nt);
         const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
@@ -135,10 +147,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         p.split = 0;
         p.split_from = -1;
         long long split_pairs = 0;          // tiles shared by two workgroups
-        auto split_mode = [&]() {
-            if ((e_loop & 1) && md->n_hidden >= 2 && ctx->split_policy == 1) return 2;
-            return (e_loop >= 2) ? 1 : 0;
-        };
+        auto split_mode = [&]() { return split_mode_for(md, e_loop); };
         if (ctx->split_policy != 0 && nt == 1 && p.h < 4096) {
             if (2 * pairs <= cus) {
                 p.split = split_mode();
