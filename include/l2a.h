@@ -165,6 +165,15 @@ int l2a_predict(l2a_model* model, const float* obs, const float* act, int rows, 
 unsigned long long l2a_key_encode(float ret, int index);
 void l2a_key_decode(unsigned long long key, float* ret, int* index);
 
+/* Batched form of l2a_model_set_weights for `count` consecutive weight sets first_set .. first_set+count-1
+ * whose parameters are stacked along a leading axis: device_ptrs[i] points at parameter i of set first_set
+ * and set_strides[i] (in floats) is the distance to the same parameter of the next set.  This is the shape
+ * GrBAL's inner adaptation produces (`_adapted_param_values`, meta_mlp_dynamics.py:344,429-432: one dict of
+ * arrays per task) when all tasks are adapted in one batched step; 2 * (n_hidden + 1) strided copies and
+ * n_hidden + 1 pack launches in total instead of per set.                                              */
+int l2a_model_set_weights_strided(l2a_model* model, int first_set, int count, const void* const* device_ptrs,
+                                  const long long* set_strides, void* stream);
+
 /* ---- recurrent planner (ReBAL) --------------------------------------------------------------
  * Single-layer LSTM dynamics model: `RNNDynamicsModel` (dynamics/rnn_dynamics.py:11-100) built by
  * `create_rnn` (dynamics/core/utils.py:192-236) with cell_type='lstm' - the configuration of

@@ -422,23 +422,34 @@ void l2a_model_destroy(l2a_model* md) {
     delete md;
 }
 
-int l2a_model_set_weights(l2a_model* md, int e, const void* const* device_ptrs, void* stream_v) {
+int l2a_model_set_weights_strided(l2a_model* md, int first_set, int count, const void* const* device_ptrs,
+                                  const long long* set_strides, void* stream_v) {
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
-    if (e < 0 || e >= md->n_sets) return fail(ctx, L2A_EINVAL, "weight set index out of range");
+    if (count < 1 || first_set < 0 || first_set + count > md->n_sets)
+        return fail(ctx, L2A_EINVAL, "weight set range out of bounds");
     if (!device_ptrs) return fail(ctx, L2A_EINVAL, "device_ptrs is null");
+    if (count > 1 && !set_strides) return fail(ctx, L2A_EINVAL, "set_strides is null");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-    float* blk = md->wblk + (long long)e * md->set_stride;
+    float* blk = md->wblk + (long long)first_set * md->set_stride;
+    const size_t dpitch = sizeof(float) * (size_t)md->set_stride;
+    // One strided device-to-device copy of `n` floats per set (hipMemcpy2DAsync: `count` rows).
+    auto copy_sets = [&](float* dst, const float* src, long long src_stride, size_t n) -> hipError_t {
+        if (count == 1) return hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, stream);
+        return hipMemcpy2DAsync(dst, dpitch, src, sizeof(float) * (size_t)src_stride, sizeof(float) * n,
+                                (size_t)count, hipMemcpyDeviceToDevice, stream);
+    };
     int k_in = md->in_dim;
     for (int l = 0; l <= md->n_hidden; ++l) {
         const int n_out = (l < md->n_hidden) ? md->hidden[l] : md->obs_dim;
         const float* w = static_cast<const float*>(device_ptrs[2 * l]);
         const float* b = static_cast<const float*>(device_ptrs[2 * l + 1]);
         if (!w || !b) return fail(ctx, L2A_EINVAL, "null parameter pointer for layer " + std::to_string(l));
-        L2A_HIP(ctx, hipMemcpyAsync(blk + md->raw_w[l], w, sizeof(float) * (size_t)k_in * n_out,
-                                    hipMemcpyDeviceToDevice, stream));
-        L2A_HIP(ctx, hipMemcpyAsync(blk + md->raw_b[l], b, sizeof(float) * (size_t)n_out,
-                                    hipMemcpyDeviceToDevice, stream));
+        const long long ws = (count > 1) ? set_strides[2 * l] : 0, bs = (count > 1) ? set_strides[2 * l + 1] : 0;
+        if (count > 1 && (ws < (long long)k_in * n_out || bs < n_out))
+            return fail(ctx, L2A_EINVAL, "set stride smaller than the parameter of layer " + std::to_string(l));
+        L2A_HIP(ctx, copy_sets(blk + md->raw_w[l], w, ws, (size_t)k_in * n_out));
+        L2A_HIP(ctx, copy_sets(blk + md->raw_b[l], b, bs, (size_t)n_out));
         if (md->mfma_ok) {
             float* dst;
             if (l == 0) dst = blk + md->pk_w0;
@@ -446,19 +457,21 @@ int l2a_model_set_weights(l2a_model* md, int e, const void* const* device_ptrs, 
             else dst = blk + md->pk_wout;
             const long long total = packed_floats(k_in, n_out);
             const int KG = ceil_div(k_in, 16);
-            const unsigned blocks = (unsigned)((total + 255) / 256);
-            hipLaunchKernelGGL(l2a_pack_layer_k, dim3(blocks), dim3(256), 0, stream, w, k_in, n_out, KG, total, dst);
+            const dim3 grid((unsigned)((total + 255) / 256), (unsigned)count);
+            hipLaunchKernelGGL(l2a_pack_layer_k, grid, dim3(256), 0, stream, w, ws, k_in, n_out, KG, total, dst,
+                               md->set_stride);
             L2A_HIP(ctx, hipGetLastError());
         }
-        if (l == md->n_hidden) {
-            // padded copy of the output bias (the tail beyond obs_dim stays zero from model_create)
-            L2A_HIP(ctx, hipMemcpyAsync(blk + md->pk_bout, b, sizeof(float) * (size_t)n_out,
-                                        hipMemcpyDeviceToDevice, stream));
-        }
+        if (l == md->n_hidden)      // padded copy of the output bias (the tail beyond obs_dim stays zero)
+            L2A_HIP(ctx, copy_sets(blk + md->pk_bout, b, bs, (size_t)n_out));
         k_in = n_out;
     }
-    md->weights_set[e] = 1;
+    for (int e = first_set; e < first_set + count; ++e) md->weights_set[e] = 1;
     return L2A_OK;
+}
+
+int l2a_model_set_weights(l2a_model* md, int e, const void* const* device_ptrs, void* stream_v) {
+    return l2a_model_set_weights_strided(md, e, 1, device_ptrs, nullptr, stream_v);
 }
 
 int l2a_model_set_norm(l2a_model* md, int e, const double* mean_obs, const double* std_obs,

@@ -3,10 +3,13 @@
 
 #include "l2a_kernels.h"
 
-__global__ void l2a_pack_layer_k(const float* __restrict__ w, int k_in, int n_out, int KG,
-                                 long long total, float* __restrict__ out) {
+// blockIdx.y = weight set: source / destination advance by w_stride / out_stride floats per set.
+__global__ void l2a_pack_layer_k(const float* __restrict__ w, long long w_stride, int k_in, int n_out, int KG,
+                                 long long total, float* __restrict__ out, long long out_stride) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
+    w += (long long)blockIdx.y * w_stride;
+    out += (long long)blockIdx.y * out_stride;
     int k, u;
     l2a_pack_decode(idx, KG, &k, &u);
     out[idx] = (k < k_in && u < n_out) ? w[(long long)k * n_out + u] : 0.0f;

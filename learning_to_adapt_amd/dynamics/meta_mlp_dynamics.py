@@ -57,6 +57,8 @@ class MetaMLPDynamicsModel(Serializable):
         self._dataset_test = None
         self._prev_params = None
         self._params_dev = None          # (list identity, device, device copies) of self._params
+        self._adapted_stacked = None     # adapted sets stacked along a leading axis (batched adapt)
+        self._adapted_norm_of = None     # (native model, normalization) whose vectors are already uploaded
         self._adapted_param_values = None
         self._num_adapted_models = 0
 
@@ -92,6 +94,7 @@ class MetaMLPDynamicsModel(Serializable):
     def set_adapted_params(self, param_sets):
         """Install externally computed adapted weight sets (list of OrderedDict / flat lists)."""
         self._adapted_param_values = [core.as_param_list(p, len(self.hidden_sizes)) for p in param_sets]
+        self._adapted_stacked = None
         self._num_adapted_models = len(param_sets)
         self._adapted_dirty = True
 
@@ -130,9 +133,16 @@ class MetaMLPDynamicsModel(Serializable):
                                                    self.output_nonlinearity, k, "per_block")
                 self._adapted_dirty = True
             if self._adapted_dirty:
-                for i in range(k):
-                    self._native_adapted.set_weights(i, self._adapted_param_values[i])
-                    self._native_adapted.set_norm(i, self._norm())
+                if self._adapted_stacked is not None:            # batched adapt(): all sets in one strided call
+                    self._native_adapted.set_weights_stacked(0, self._adapted_stacked)
+                else:
+                    for i in range(k):
+                        self._native_adapted.set_weights(i, self._adapted_param_values[i])
+                c = self._adapted_norm_of       # normalisation vectors change only with fit / set_normalization
+                if c is None or c[0] is not self._native_adapted or c[1] is not self.normalization:
+                    for i in range(k):
+                        self._native_adapted.set_norm(i, self._norm())
+                    self._adapted_norm_of = (self._native_adapted, self.normalization)
                 self._adapted_dirty = False
             return self._native_adapted
         if self._native_base is None:
@@ -202,7 +212,9 @@ class MetaMLPDynamicsModel(Serializable):
             grads = torch.autograd.grad(loss, params)
             stacked = [(p - self.inner_learning_rate * g).detach() for p, g in zip(params, grads)]
             adapted = [[q[i] for q in stacked] for i in range(m)]
+            self._adapted_stacked = stacked
         else:
+            self._adapted_stacked = None
             base = self._device_params(dev)
             adapted = []
             for x_np, y_np in zip(xs, ys):

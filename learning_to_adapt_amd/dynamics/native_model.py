@@ -79,6 +79,25 @@ class NativeModel(object):
         self.ctx.check(rc, "l2a_model_set_weights")
         self._keep[("w", e)] = dev
 
+    def set_weights_stacked(self, first_set, stacked):
+        """``stacked``: [W0, b0, ..., Wout, bout] with a leading set axis (``[count, in, out]`` / ``[count, out]``
+        CUDA tensors) - all ``count`` sets go up in one strided call (``l2a_model_set_weights_strided``)."""
+        sizes = (self.obs_dim + self.act_dim,) + self.hidden_sizes + (self.obs_dim,)
+        assert len(stacked) == 2 * (len(sizes) - 1)
+        count = int(stacked[0].shape[0])
+        dev = []
+        for i, t in enumerate(stacked):
+            t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            li = i // 2
+            expect = (count, sizes[li], sizes[li + 1]) if i % 2 == 0 else (count, sizes[li + 1])
+            assert tuple(t.shape) == expect, "stacked parameter %d has shape %s, expected %s" % (i, tuple(t.shape), expect)
+            dev.append(t)
+        ptrs = (ctypes.c_void_p * len(dev))(*[t.data_ptr() for t in dev])
+        strides = (ctypes.c_longlong * len(dev))(*[int(t.stride(0)) for t in dev])
+        rc = self.lib.l2a_model_set_weights_strided(self.handle, int(first_set), count, ptrs, strides, _stream_ptr())
+        self.ctx.check(rc, "l2a_model_set_weights_strided")
+        self._keep[("w_stacked", first_set)] = dev
+
     def set_norm(self, e, norm):
         """``norm``: the reference's ``normalization`` dict (``'obs'/'act'/'delta' -> (mean, std)``)
         or ``None`` for identity."""
