@@ -174,6 +174,23 @@ void l2a_key_decode(unsigned long long key, float* ret, int* index);
 int l2a_model_set_weights_strided(l2a_model* model, int first_set, int count, const void* const* device_ptrs,
                                   const long long* set_strides, void* stream);
 
+/* GrBAL's inner adaptation on the device: for every task i < m one SGD step
+ *   theta_i = theta - lr * grad mean((f_theta(x_i) - y_i)^2)
+ * (MetaMLPDynamicsModel.adapt / _adapt_sym, dynamics/meta_mlp_dynamics.py:321-345,409-421; loss :118), written
+ * straight into weight sets 0 .. m-1 of `model` (L2A_MODE_PER_BLOCK) in both the reference layout and the
+ * kernel's packed layout - replaces the sess.run + host round trip of the adapted parameters (:344) and their
+ * re-feed on every later predict (:429-432).  base_ptrs: the pre-update parameters theta in the order of
+ * l2a_model_set_weights (device fp32).  x [m, rows, obs_dim + act_dim] and y [m, rows, obs_dim] (device fp32):
+ * the NORMALISED inputs and target deltas of each task's adaptation batch (:324-326; rows <= 16 =
+ * adapt_batch_size of run_scripts/run_grbal.py).  Requires an identity output layer and a relu / tanh /
+ * sigmoid / identity hidden nonlinearity.                                                             */
+int l2a_model_adapt_sgd(l2a_model* model, const void* const* base_ptrs, const float* x, const float* y, int m,
+                        int rows, float lr, void* stream);
+
+/* Copy weight set `e` out of the model in the reference's parameter order and layout (device fp32 buffers of
+ * the sizes l2a_model_set_weights takes) - e.g. to read back adapted sets (`_adapted_param_values`).    */
+int l2a_model_get_weights(l2a_model* model, int e, void* const* device_ptrs_out, void* stream);
+
 /* ---- recurrent planner (ReBAL) --------------------------------------------------------------
  * Single-layer LSTM dynamics model: `RNNDynamicsModel` (dynamics/rnn_dynamics.py:11-100) built by
  * `create_rnn` (dynamics/core/utils.py:192-236) with cell_type='lstm' - the configuration of

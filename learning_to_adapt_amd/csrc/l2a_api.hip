@@ -7,6 +7,7 @@
 #include "l2a_host.h"
 #include "l2a_kernels.h"
 #include "l2a_valu.h"
+#include "l2a_adapt.h"
 #include "l2a_mfma_launch.h"
 
 #include <cmath>
@@ -46,6 +47,8 @@ struct l2a_model {
     unsigned long long* xbuf = nullptr;           // member-split exchange granules
     long long xbuf_granules = 0;
     unsigned int launch_nonce = 0;
+    float* adapt_scratch = nullptr;               // l2a_model_adapt_sgd: layer inputs and dZ of every task
+    long long adapt_scratch_floats = 0;
 };
 
 namespace {
@@ -419,6 +422,7 @@ void l2a_model_destroy(l2a_model* md) {
         (void)hipFree(md->wblk);
     }
     if (md->xbuf) (void)hipFree(md->xbuf);
+    if (md->adapt_scratch) (void)hipFree(md->adapt_scratch);
     delete md;
 }
 
@@ -472,6 +476,96 @@ int l2a_model_set_weights_strided(l2a_model* md, int first_set, int count, const
 
 int l2a_model_set_weights(l2a_model* md, int e, const void* const* device_ptrs, void* stream_v) {
     return l2a_model_set_weights_strided(md, e, 1, device_ptrs, nullptr, stream_v);
+}
+
+int l2a_model_adapt_sgd(l2a_model* md, const void* const* base_ptrs, const float* x, const float* y, int m,
+                        int rows, float lr, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!base_ptrs || !x || !y) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd: null pointer");
+    if (md->mode != L2A_MODE_PER_BLOCK) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd needs a per-block model");
+    if (m < 1 || m > md->n_sets) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd: m must be in [1, n_sets]");
+    if (rows < 1 || rows > L2A_AR)
+        return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd: rows must be in [1, " + std::to_string(L2A_AR) + "]");
+    if (md->output_act != L2A_ACT_IDENTITY || md->hidden_act == L2A_ACT_SWISH)
+        return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd: needs an identity output layer and a relu / tanh / "
+                                     "sigmoid / identity hidden nonlinearity");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    L2AAdaptParams ap;
+    std::memset(&ap, 0, sizeof(ap));
+    const int L = md->n_hidden + 1;
+    ap.n_layers = L;
+    ap.dims[0] = md->in_dim;
+    for (int l = 0; l < md->n_hidden; ++l) ap.dims[l + 1] = md->hidden[l];
+    ap.dims[L] = md->obs_dim;
+    long long off = 0;
+    int hmax = 0;
+    for (int l = 0; l <= L; ++l) hmax = ap.dims[l] > hmax ? ap.dims[l] : hmax;
+    for (int l = 0; l < L; ++l) { ap.a_off[l] = off; off += (long long)ap.dims[l] * L2A_AR; }
+    for (int l = 1; l <= L; ++l) { ap.z_off[l] = off; off += (long long)ap.dims[l] * L2A_AR; }
+    ap.scratch_stride = off;
+    ap.hmax = hmax;
+    for (int l = 0; l < L; ++l) {
+        ap.w[l] = static_cast<const float*>(base_ptrs[2 * l]);
+        ap.b[l] = static_cast<const float*>(base_ptrs[2 * l + 1]);
+        if (!ap.w[l] || !ap.b[l]) return fail(ctx, L2A_EINVAL, "null base parameter pointer for layer " + std::to_string(l));
+    }
+    ap.hidden_act = md->hidden_act;
+    ap.rows = rows;
+    ap.x = x; ap.y = y;
+    const long long need = off * md->n_sets;
+    if (need > md->adapt_scratch_floats) {
+        if (md->adapt_scratch) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->adapt_scratch)); md->adapt_scratch = nullptr; }
+        L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->adapt_scratch), (size_t)need * sizeof(float)));
+        md->adapt_scratch_floats = need;
+    }
+    ap.scratch = md->adapt_scratch;
+    hipLaunchKernelGGL(l2a_adapt_prep_k, dim3((unsigned)((ap.dims[0] * L2A_AR + 255) / 256), (unsigned)m), dim3(256), 0,
+                       stream, ap);
+    for (int l = 0; l < L; ++l)
+        hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3((unsigned)((ap.dims[l + 1] + 63) / 64), (unsigned)m), dim3(256), 0,
+                           stream, ap, l);
+    for (int l = L - 1; l >= 1; --l)
+        hipLaunchKernelGGL(l2a_adapt_bwd_k, dim3((unsigned)((ap.dims[l] + 63) / 64), (unsigned)m), dim3(256), 0,
+                           stream, ap, l);
+    L2A_HIP(ctx, hipGetLastError());
+    for (int l = 0; l < L; ++l) {
+        const long long total = (long long)ap.dims[l] * ap.dims[l + 1];
+        long long pk = 0;
+        if (md->mfma_ok) {
+            if (l == 0) pk = md->pk_w0;
+            else if (l < md->n_hidden) pk = md->pk_wmid + (long long)(l - 1) * md->pk_wmid_stride;
+            else pk = md->pk_wout;
+        }
+        const dim3 grid((unsigned)((total + 255) / 256), (unsigned)m);
+        hipLaunchKernelGGL(l2a_adapt_update_k, grid, dim3(256), 0, stream, ap, l, lr, md->wblk, md->set_stride,
+                           md->raw_w[l], md->raw_b[l], pk, md->mfma_ok ? 1 : 0, md->pk_bout, (l == L - 1) ? 1 : 0);
+        L2A_HIP(ctx, hipGetLastError());
+    }
+    for (int e = 0; e < m; ++e) md->weights_set[e] = 1;
+    return L2A_OK;
+}
+
+int l2a_model_get_weights(l2a_model* md, int e, void* const* device_ptrs_out, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (e < 0 || e >= md->n_sets) return fail(ctx, L2A_EINVAL, "weight set index out of range");
+    if (!device_ptrs_out) return fail(ctx, L2A_EINVAL, "device_ptrs_out is null");
+    if (!md->weights_set[e]) return fail(ctx, L2A_ESTATE, "weight set " + std::to_string(e) + " was never set");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const float* blk = md->wblk + (long long)e * md->set_stride;
+    int k_in = md->in_dim;
+    for (int l = 0; l <= md->n_hidden; ++l) {
+        const int n_out = (l < md->n_hidden) ? md->hidden[l] : md->obs_dim;
+        if (!device_ptrs_out[2 * l] || !device_ptrs_out[2 * l + 1])
+            return fail(ctx, L2A_EINVAL, "null output pointer for layer " + std::to_string(l));
+        L2A_HIP(ctx, hipMemcpyAsync(device_ptrs_out[2 * l], blk + md->raw_w[l], sizeof(float) * (size_t)k_in * n_out,
+                                    hipMemcpyDeviceToDevice, stream));
+        L2A_HIP(ctx, hipMemcpyAsync(device_ptrs_out[2 * l + 1], blk + md->raw_b[l], sizeof(float) * (size_t)n_out,
+                                    hipMemcpyDeviceToDevice, stream));
+        k_in = n_out;
+    }
+    return L2A_OK;
 }
 
 int l2a_model_set_norm(l2a_model* md, int e, const double* mean_obs, const double* std_obs,

@@ -23,6 +23,28 @@ from ..utils.serializable import Serializable
 from . import core
 
 
+class _ResidentSets(object):
+    """``_adapted_param_values`` when the adapted sets were produced on the device by
+    ``l2a_model_adapt_sgd``: they live in the planner's model already; parameter tensors are copied out
+    only if somebody asks for them (the reference keeps host dicts, ``meta_mlp_dynamics.py:344``)."""
+
+    def __init__(self, native, count):
+        self._native, self._count, self._cache = native, count, {}
+
+    def __len__(self):
+        return self._count
+
+    def __getitem__(self, i):
+        if not 0 <= i < self._count:
+            raise IndexError(i)
+        if i not in self._cache:
+            self._cache[i] = self._native.get_weights(i)
+        return self._cache[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(self._count))
+
+
 class MetaMLPDynamicsModel(Serializable):
     _activations = core.ACTIVATION_NAMES
 
@@ -58,6 +80,7 @@ class MetaMLPDynamicsModel(Serializable):
         self._prev_params = None
         self._params_dev = None          # (list identity, device, device copies) of self._params
         self._adapted_stacked = None     # adapted sets stacked along a leading axis (batched adapt)
+        self.use_native_adapt = True     # False: inner step with stock PyTorch autograd even on the GPU
         self._adapted_norm_of = None     # (native model, normalization) whose vectors are already uploaded
         self._adapted_param_values = None
         self._num_adapted_models = 0
@@ -132,12 +155,15 @@ class MetaMLPDynamicsModel(Serializable):
                                                    self.hidden_sizes, self.hidden_nonlinearity,
                                                    self.output_nonlinearity, k, "per_block")
                 self._adapted_dirty = True
-            if self._adapted_dirty:
+            if self._adapted_dirty and isinstance(self._adapted_param_values, _ResidentSets):
+                pass                                             # written in place by l2a_model_adapt_sgd
+            elif self._adapted_dirty:
                 if self._adapted_stacked is not None:            # batched adapt(): all sets in one strided call
                     self._native_adapted.set_weights_stacked(0, self._adapted_stacked)
                 else:
                     for i in range(k):
                         self._native_adapted.set_weights(i, self._adapted_param_values[i])
+            if self._adapted_dirty:
                 c = self._adapted_norm_of       # normalisation vectors change only with fit / set_normalization
                 if c is None or c[0] is not self._native_adapted or c[1] is not self.normalization:
                     for i in range(k):
@@ -194,7 +220,23 @@ class MetaMLPDynamicsModel(Serializable):
             ys.append(d_n)
         # Only the real rows enter the pre-update loss: the reference pads each task with an equal
         # number of zero rows and then splits the task batch in two, pre = real half (:324-326, :99-103).
-        if len({x.shape[0] for x in xs}) == 1:
+        if self._native_adapt_ok(xs):
+            # on the GPU: two kernels that write the adapted sets straight into the planner's per-block model
+            from .native_model import NativeModel
+            m = len(xs)
+            if self._native_adapted is None or self._native_adapted.n_sets != m:
+                if self._native_adapted is not None:
+                    self._native_adapted.close()
+                self._native_adapted = NativeModel(self.obs_space_dims, self.action_space_dims,
+                                                   self.hidden_sizes, self.hidden_nonlinearity,
+                                                   self.output_nonlinearity, m, "per_block")
+            native = self._native_adapted
+            x = torch.from_numpy(np.stack(xs).astype(np.float32)).to(native.device)
+            y = torch.from_numpy(np.stack(ys).astype(np.float32)).to(native.device)
+            native.adapt_sgd(self._device_params(native.device), x, y, self.inner_learning_rate)
+            self._adapted_stacked = None
+            adapted = _ResidentSets(native, m)
+        elif len({x.shape[0] for x in xs}) == 1:
             # all envs in ONE batched forward/backward: every env gets its own copy of theta, so the
             # gradient of sum_i L_i w.r.t. copy i is exactly grad L_i (:409-421)
             m = len(xs)
@@ -228,6 +270,16 @@ class MetaMLPDynamicsModel(Serializable):
         self._prev_params = self._params      # parameter tensors are never modified in place
         self._adapted_param_values = adapted
         self._adapted_dirty = True
+
+    def _native_adapt_ok(self, xs):
+        """The fused device path needs a GPU, equal batches of at most 16 rows, an identity output layer
+        and a hidden nonlinearity whose derivative follows from its output."""
+        if not (self.use_native_adapt and torch.cuda.is_available()):
+            return False
+        rows = {x.shape[0] for x in xs}
+        return (len(rows) == 1 and 1 <= next(iter(rows)) <= 16
+                and self.output_nonlinearity in (None, "identity")
+                and self.hidden_nonlinearity in (None, "identity", "relu", "tanh", "sigmoid"))
 
     def switch_to_pre_adapt(self):
         if self._prev_params is not None:

@@ -98,6 +98,32 @@ class NativeModel(object):
         self.ctx.check(rc, "l2a_model_set_weights_strided")
         self._keep[("w_stacked", first_set)] = dev
 
+    def adapt_sgd(self, base_params, x, y, lr):
+        """One SGD step per task on the device, written straight into weight sets ``0 .. m-1``
+        (``l2a_model_adapt_sgd``).  ``base_params``: pre-update [W0, b0, ...] CUDA tensors; ``x`` /
+        ``y``: fp32 CUDA ``[m, rows, in_dim]`` / ``[m, rows, obs_dim]`` (normalised)."""
+        m, rows = int(x.shape[0]), int(x.shape[1])
+        assert x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32
+        assert tuple(x.shape) == (m, rows, self.obs_dim + self.act_dim) and tuple(y.shape) == (m, rows, self.obs_dim)
+        base = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in base_params]
+        ptrs = (ctypes.c_void_p * len(base))(*[t.data_ptr() for t in base])
+        x, y = x.contiguous(), y.contiguous()
+        rc = self.lib.l2a_model_adapt_sgd(self.handle, ptrs, _ptr(x), _ptr(y), m, rows, float(lr), _stream_ptr())
+        self.ctx.check(rc, "l2a_model_adapt_sgd")
+        self._keep["adapt"] = (base, x, y)
+
+    def get_weights(self, e):
+        """Weight set ``e`` as fresh CUDA tensors in the reference's order and layout."""
+        sizes = (self.obs_dim + self.act_dim,) + self.hidden_sizes + (self.obs_dim,)
+        out = []
+        for li in range(len(sizes) - 1):
+            out.append(torch.empty((sizes[li], sizes[li + 1]), dtype=torch.float32, device=self.device))
+            out.append(torch.empty((sizes[li + 1],), dtype=torch.float32, device=self.device))
+        ptrs = (ctypes.c_void_p * len(out))(*[t.data_ptr() for t in out])
+        rc = self.lib.l2a_model_get_weights(self.handle, int(e), ptrs, _stream_ptr())
+        self.ctx.check(rc, "l2a_model_get_weights")
+        return out
+
     def set_norm(self, e, norm):
         """``norm``: the reference's ``normalization`` dict (``'obs'/'act'/'delta' -> (mean, std)``)
         or ``None`` for identity."""
