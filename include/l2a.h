@@ -149,6 +149,21 @@ int l2a_plan_rs(l2a_model* model, const float* obs0, const float* actions, int m
                 float discount, const l2a_reward* reward, int cand_offset, float* returns_out,
                 unsigned long long* best_key, void* stream);
 
+/* A plan step cut along the horizon: launch k covers horizon steps t0 .. t0 + h_chunk - 1 of
+ * get_rs_action's loop (policies/mpc_controller.py:116-127) and hands the per-candidate state and the
+ * accumulated returns to launch k + 1.  Lets the host draw / upload the NEXT chunk of candidate actions (the
+ * reference's `get_random_action`, :67-69,114, consumes its RNG stream horizon-major) while the GPU rolls out the
+ * current one; the chain is bit-identical to one l2a_plan_rs over the whole horizon.
+ *   state:       t0 == 0: obs0 [m, obs_dim] (state_per_row = 0) ; t0 > 0: state_out of the previous chunk
+ *                [m * n, obs_dim] (state_per_row = 1)
+ *   actions:     [h_chunk, m * n, act_dim] - the rows of this chunk only
+ *   returns_in:  returns_out of the previous chunk (ignored when t0 == 0); returns_out [m, n] is required
+ *   state_out:   [m * n, obs_dim] or NULL (last chunk); best_key: [m] or NULL (give it on the last chunk)   */
+int l2a_plan_rs_chunk(l2a_model* model, const float* state, int state_per_row, const float* actions, int m, int n,
+                      int h_chunk, int t0, float discount, const l2a_reward* reward, int cand_offset,
+                      const float* returns_in, float* returns_out, float* state_out, unsigned long long* best_key,
+                      void* stream);
+
 /* One-step batched prediction: MLPDynamicsModel.predict / MetaMLPDynamicsModel.predict
  * (mlp_dynamics.py:204-222, meta_mlp_dynamics.py:276-294).
  *   obs device fp32 [R, obs_dim], act device fp32 [R, act_dim] -> next_obs device fp32 [R, obs_dim]

@@ -625,7 +625,39 @@ int l2a_plan_rs(l2a_model* md, const float* obs0, const float* actions, int m, i
     fill_model_params(md, p);
     p.obs0 = obs0; p.actions = actions; p.returns_out = returns_out; p.best_key = best_key;
     p.state_out = nullptr; p.obs_per_row = 0;
+    p.ret_in = nullptr; p.disc0 = 1.0;
     p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
+    return launch_rollout(md, p, stream_v);
+}
+
+int l2a_plan_rs_chunk(l2a_model* md, const float* state, int state_per_row, const float* actions, int m, int n,
+                      int h_chunk, int t0, float discount, const l2a_reward* reward, int cand_offset,
+                      const float* returns_in, float* returns_out, float* state_out, unsigned long long* best_key,
+                      void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!state || !actions || !reward) return fail(ctx, L2A_EINVAL, "l2a_plan_rs_chunk: null state/actions/reward");
+    if (!returns_out) return fail(ctx, L2A_EINVAL, "l2a_plan_rs_chunk: returns_out is required");
+    if (m < 1 || n < 1 || h_chunk < 1 || t0 < 0) return fail(ctx, L2A_EINVAL, "l2a_plan_rs_chunk: bad m / n / h_chunk / t0");
+    if (t0 > 0 && (!returns_in || !state_per_row))
+        return fail(ctx, L2A_EINVAL, "l2a_plan_rs_chunk: a continuation needs returns_in and per-row states");
+    if ((long long)m * n > 0x3fffffffLL || cand_offset < 0 || (long long)cand_offset + n > 0x7fffffffLL)
+        return fail(ctx, L2A_EINVAL, "l2a_plan_rs_chunk: too many candidates");
+    if (reward->w_vel != 0.0f && (reward->vel_index < 0 || reward->vel_index >= md->obs_dim))
+        return fail(ctx, L2A_EINVAL, "reward.vel_index out of range");
+    if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
+        return fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (best_key) L2A_HIP(ctx, hipMemsetAsync(best_key, 0, sizeof(unsigned long long) * (size_t)m, stream));
+    L2AKParams p;
+    fill_model_params(md, p);
+    p.obs0 = state; p.obs_per_row = state_per_row ? 1 : 0;
+    p.actions = actions; p.returns_out = returns_out; p.best_key = best_key; p.state_out = state_out;
+    p.ret_in = (t0 > 0) ? returns_in : nullptr;
+    double d0 = 1.0;    // discount ** t0 by the kernel's own recurrence (bit-identical continuation)
+    for (int t = 0; t < t0; ++t) d0 *= (double)discount;
+    p.disc0 = d0;
+    p.m = m; p.n = n; p.h = h_chunk; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
     return launch_rollout(md, p, stream_v);
 }
 
@@ -642,6 +674,7 @@ int l2a_predict(l2a_model* md, const float* obs, const float* act, int rows, int
     fill_model_params(md, p);
     p.obs0 = obs; p.actions = act; p.returns_out = nullptr; p.best_key = nullptr;
     p.state_out = next_obs_out; p.obs_per_row = 1;
+    p.ret_in = nullptr; p.disc0 = 1.0;
     p.m = n_blocks; p.n = rows / n_blocks; p.h = 1; p.cand_offset = 0; p.discount = 1.0f;
     std::memset(&p.rw, 0, sizeof(p.rw));
     return launch_rollout(md, p, stream_v);

@@ -52,7 +52,9 @@ struct L2AKParams {
     const float* actions;       // [h, m*n, act_dim]
     float* returns_out;         // [m, n] or null
     unsigned long long* best_key;  // [m] or null
-    float* state_out;           // [m*n, obs_dim] or null (final state; used by predict)
+    float* state_out;           // [m*n, obs_dim] or null (final state; used by predict and chunked plans)
+    const float* ret_in;        // [m, n] returns accumulated by earlier horizon chunks, or null (= 0)
+    double disc0;               // discount ** (first horizon step of this launch); 1.0 for a whole plan
     int obs_per_row;
     int m, n, h;
     int tiles_per_env;

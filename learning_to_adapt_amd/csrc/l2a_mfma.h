@@ -393,12 +393,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
     float ret[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) ret[nt] = 0.0f;
+    for (int nt = 0; nt < NT; ++nt) ret[nt] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[nt] ? cand[nt] : p.n - 1)] : 0.0f;
 
     f32x4* hcur = buf0;
     f32x4* hoth = buf1;
     const float e_count = (float)e_loop;
-    double disc_pow = 1.0;      // discount ** t, carried in float64 like the reference (:126)
+    double disc_pow = p.disc0;  // discount ** t, carried in float64 like the reference (:126)
 
     // Which sets this workgroup runs (split: 0 = all; 1 = group A | group B; 2 = as 1, but the
     // last set of group A is SHARED: both workgroups run it as a "half member" - layer 0 and the

@@ -79,10 +79,10 @@ __global__ void __launch_bounds__(256) l2a_rollout_valu_k(const L2AKParams p) {
         st[i] = p.obs0[orow * obs_dim + d];
         ds[i] = 0.0f;
     }
-    if (tid < L2A_VT) rets[tid] = 0.0f;
+    if (tid < L2A_VT) rets[tid] = p.ret_in ? p.ret_in[row_of(tid)] : 0.0f;
     __syncthreads();
 
-    double disc_pow = 1.0;
+    double disc_pow = p.disc0;
     for (int t = 0; t < p.h; ++t) {
         for (int i = tid; i < act_dim * L2A_VT; i += 256) {
             const int k = i / L2A_VT, c = i - k * L2A_VT;

@@ -160,6 +160,20 @@ class NativeModel(object):
                                   _ptr(returns_out), _ptr(best_key), _stream_ptr())
         self.ctx.check(rc, "l2a_plan_rs")
 
+    def plan_rs_chunk(self, state, state_per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
+                      returns_in=None, returns_out=None, state_out=None, best_key=None):
+        """Horizon steps ``t0 .. t0 + h_chunk - 1`` of a plan (``l2a_plan_rs_chunk``); all tensors fp32 CUDA."""
+        assert state.is_cuda and actions.is_cuda and state.is_contiguous() and actions.is_contiguous()
+        assert actions.numel() == h_chunk * m * n * self.act_dim
+        assert state.numel() == (m * n if state_per_row else m) * self.obs_dim
+        assert returns_out is not None and returns_out.numel() == m * n
+        assert isinstance(reward, RewardSpec)
+        rc = self.lib.l2a_plan_rs_chunk(self.handle, _ptr(state), 1 if state_per_row else 0, _ptr(actions), int(m), int(n),
+                                        int(h_chunk), int(t0), float(discount), ctypes.byref(reward), int(cand_offset),
+                                        _ptr(returns_in), _ptr(returns_out), _ptr(state_out), _ptr(best_key),
+                                        _stream_ptr())
+        self.ctx.check(rc, "l2a_plan_rs_chunk")
+
     def predict(self, obs, act, n_blocks=1, out=None):
         assert obs.is_cuda and act.is_cuda and obs.dtype == torch.float32 and act.dtype == torch.float32
         rows = obs.shape[0]

@@ -18,7 +18,9 @@ Extra keyword arguments (all optional, defaults reproduce the reference):
 drawn on the GPU with torch's Philox generator - statistically equivalent, not bit-identical),
 ``cem_mode`` (``'reference'`` keeps the reference's three CEM quirks, SURVEY.md section 3.3;
 ``'fixed'`` = clipped rollouts, true top-k elites, env-consistent row order),
-``shard_candidates`` (use torch.distributed when initialised).
+``shard_candidates`` (use torch.distributed when initialised), ``pipeline_chunks`` (parity mode: the
+plan step is cut into this many horizon chunks so that the host draws / uploads chunk k + 1 while the
+GPU rolls out chunk k - same RNG stream, bit-identical result; 1 = one launch).
 """
 
 import numpy as np
@@ -48,6 +50,7 @@ class MPCController(Policy, Serializable):
             rng="numpy",
             cem_mode="reference",
             shard_candidates=True,
+            pipeline_chunks=5,
     ):
         self.dynamics_model = dynamics_model
         self.reward_model = reward_model
@@ -65,6 +68,7 @@ class MPCController(Policy, Serializable):
         self.rng = rng
         self.cem_mode = cem_mode
         self.shard_candidates = shard_candidates
+        self.pipeline_chunks = int(pipeline_chunks)
 
         self.unwrapped_env = innermost_env(env)
 
@@ -226,7 +230,10 @@ class MPCController(Policy, Serializable):
         n_local = hi - lo
         act_dim = self.action_space.shape[0]
 
-        if self.rng == "numpy":
+        pipelined = self.rng == "numpy" and self._can_pipeline(h, n_local)
+        if pipelined:
+            best, cand_a = self._plan_pipelined(observations, n, m, h, lo, hi, world)
+        elif self.rng == "numpy":
             # identical draw and layout to the reference (:114): [h, n*m, act_dim], row = i*n + j
             a = self.get_random_action(h * n * m).reshape((h, n * m, -1))
             cand_a = a[0].reshape((m, n, -1))
@@ -252,7 +259,9 @@ class MPCController(Policy, Serializable):
                 a_dev.mul_(high - low).add_(low)
             cand_a = None
 
-        if n_local > 0:
+        if pipelined:
+            pass                            # already planned, chunk by chunk
+        elif n_local > 0:
             best, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=False)
         else:   # more ranks than candidates: this rank contributes the neutral key
             best = torch.zeros((m,), dtype=torch.int64, device=a_dev.device)
@@ -280,6 +289,52 @@ class MPCController(Policy, Serializable):
             torch.zeros((m, act_dim), dtype=torch.float32, device=a_dev.device)
         torch.distributed.all_reduce(out, op=torch.distributed.ReduceOp.SUM)
         return out.cpu().numpy().astype(np.float64)
+
+    # ------------------------------------------------------------------ parity mode, pipelined over the horizon
+    def _can_pipeline(self, h, n_local):
+        return (self.pipeline_chunks > 1 and h >= 6 and n_local > 0
+                and hasattr(self.dynamics_model.planner_model(), "plan_rs_chunk"))
+
+    def _plan_pipelined(self, observations, n, m, h, lo, hi, world):
+        """The reference draws its ``h*n*m`` candidate rows horizon-major (``:114``), so the first rows of the
+        stream are the first horizon steps: draw chunk k + 1 on the host while the GPU rolls out chunk k
+        (``l2a_plan_rs_chunk`` carries per-candidate state and returns between launches).  Same RNG
+        consumption, bit-identical returns and arg-max as the single launch."""
+        native = self.dynamics_model.planner_model()
+        dev = native.device
+        blocks = self.dynamics_model.planner_blocks(m)
+        if blocks != 1 and blocks != m:
+            raise _lib.L2AError("the dynamics model holds %d adapted weight sets but %d observations "
+                                "were passed" % (blocks, m))
+        act_dim = self.action_space.shape[0]
+        n_local = hi - lo
+        K = max(2, min(self.pipeline_chunks, h // 2))      # at least two horizon steps per launch
+        bounds = [(h * c) // K for c in range(K + 1)]
+        obs0 = self._upload_obs(observations)
+        best = self._buf("best", (m,), torch.int64, dev)
+        rets = [self._buf("pipe_ret%d" % i, (m, n_local), torch.float32, dev) for i in (0, 1)]
+        state = [self._buf("pipe_state%d" % i, (m * n_local, native.obs_dim), torch.float32, dev) for i in (0, 1)]
+        cand_a = None
+        for c in range(K):
+            t0, hc = bounds[c], bounds[c + 1] - bounds[c]
+            a = self.get_random_action(hc * n * m).reshape((hc, n * m, -1))
+            if c == 0:
+                cand_a = a[0].reshape((m, n, -1))
+            src = a if world == 1 else a.reshape(hc, m, n, act_dim)[:, :, lo:hi, :]
+            shape = (hc, m * n_local, act_dim)
+            pin = self._bufs.get(("pipe_pin", c))
+            if pin is None or tuple(pin.shape) != shape:
+                pin = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+                self._bufs[("pipe_pin", c)] = pin
+            np.copyto(pin.numpy().reshape(src.shape), src, casting="same_kind")
+            a_dev = self._buf(("pipe_dev", c), shape, torch.float32, dev)
+            a_dev.copy_(pin, non_blocking=True)
+            last = (c == K - 1)
+            native.plan_rs_chunk(obs0 if c == 0 else state[(c + 1) % 2], c > 0, a_dev, m, n_local, hc, t0,
+                                 self.discount, self._reward_spec, cand_offset=lo,
+                                 returns_in=rets[(c + 1) % 2] if c > 0 else None, returns_out=rets[c % 2],
+                                 state_out=None if last else state[c % 2], best_key=best if last else None)
+        return best, cand_a
 
     def _get_rs_action_unfused(self, observations):
         """No closed-form reward available (custom env reward or ``use_reward_model``): keep the

@@ -50,7 +50,8 @@ class RNNMPCController(MPCController):
                                reward_model=reward_model, discount=discount, use_cem=use_cem,
                                n_candidates=n_candidates, horizon=horizon, num_cem_iters=num_cem_iters,
                                percent_elites=percent_elites, use_reward_model=use_reward_model, alpha=0.0,
-                               rng=rng, cem_mode=cem_mode, shard_candidates=shard_candidates)
+                               rng=rng, cem_mode=cem_mode, shard_candidates=shard_candidates,
+                               pipeline_chunks=1)          # the recurrent kernel has no continuation entry point
         self._hidden_state = None
 
     # ------------------------------------------------------------------ hidden state: host view + device copy

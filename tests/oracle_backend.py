@@ -40,6 +40,7 @@ def install(controller, case):
         return torch.from_numpy(keys), (torch.from_numpy(rets) if want_returns else None)
 
     controller._check_status = lambda: None
+    controller.pipeline_chunks = 1            # the chunked launches bypass `_rollout`; the harness replaces that
     controller._upload_obs = lambda observations: None
     controller._device = _device
     controller._upload = _upload

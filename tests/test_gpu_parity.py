@@ -502,6 +502,68 @@ def test_device_adapt_matches_autograd(hidden, act, rows):
     np.testing.assert_allclose(picks[0][2], picks[1][2], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kernel", ["auto", "valu"])
+@pytest.mark.parametrize("name,over", [("c2_hc_rs_n2000_h30_e5", dict(h=9)), ("hc_rs_m3_n64_h5", dict(h=7)),
+                                        ("c3_ant_rs_n2000_h20_pb5", dict(n=300, h=6)),
+                                        ("hc_rs_discount", dict(h=10)), ("c2_hc_rs_n2000_h30_e5", dict(n=4800, h=4))])
+def test_horizon_chunks_are_bit_identical_to_one_launch(name, over, kernel):
+    """`l2a_plan_rs_chunk` chains (state + returns handed from launch to launch) against one `l2a_plan_rs`:
+    returns and arg-max key bit for bit, for uneven chunkings, both kernels, every split flavour."""
+    case = dict(cases.CASES[name], **over)
+    if kernel == "valu" and case["n"] * case["m"] * case["h"] > 20000:
+        pytest.skip("VALU kernel: small cases only")
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    m, n, h = case["m"], case["n"], case["h"]
+    a = _rs_actions(case, 2, env)
+    obs0 = np.random.RandomState(12).randn(m, env.observation_space.shape[0])
+    ctx = _lib.Context.get(0)
+    ctx.set_kernel(kernel)
+    try:
+        want_r, want_k = _plan_returns(native, case, env, obs0, a)
+        a_dev = torch.from_numpy(a.astype(np.float32)).to(dev)
+        obs_dev = torch.from_numpy(obs0.astype(np.float32)).to(dev)
+        disc = case.get("discount", 1.0)
+        for bounds in ([0, h // 3, h], [0, 1, 2, h], [0, h - 1, h]):
+            rets = [torch.empty((m, n), dtype=torch.float32, device=dev) for _ in (0, 1)]
+            state = [torch.empty((m * n, native.obs_dim), dtype=torch.float32, device=dev) for _ in (0, 1)]
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            K = len(bounds) - 1
+            for c in range(K):
+                t0, t1 = bounds[c], bounds[c + 1]
+                last = c == K - 1
+                native.plan_rs_chunk(obs_dev if c == 0 else state[(c + 1) % 2], c > 0, a_dev[t0:t1].contiguous(), m, n,
+                                     t1 - t0, t0, disc, env.reward_spec,
+                                     returns_in=rets[(c + 1) % 2] if c > 0 else None, returns_out=rets[c % 2],
+                                     state_out=None if last else state[c % 2], best_key=best if last else None)
+            got_r, got_k = rets[(K - 1) % 2].cpu().numpy(), best.cpu().numpy()
+            ctx.launch_status()
+            assert np.array_equal(got_r, want_r), bounds
+            assert np.array_equal(got_k, want_k), bounds
+    finally:
+        ctx.set_kernel("auto")
+
+
+@pytest.mark.parametrize("cid", ["c2_hc_rs_n2000_h30_e5_s0", "c3_ant_rs_n2000_h20_pb5_s0", "hc_rs_discount_s0"])
+def test_pipelined_controller_equals_single_launch_controller(cid):
+    """Parity mode with the horizon pipeline (draw chunk k + 1 while chunk k rolls out) vs one launch: same RNG
+    consumption, same action, same return bits; and the golden vector."""
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    env, model = cases.product_model(case)
+    out = []
+    for chunks in (3, 1, 5):
+        ctrl = cases.product_controller(case, model=model, env=env, pipeline_chunks=chunks)
+        np.random.seed(seed)
+        a, _ = ctrl.get_actions(gold["obs0"])
+        assert np.random.uniform() == float(gold["rng_next"])
+        out.append((a, ctrl.last_plan["best_index"].copy(), ctrl.last_plan["best_return"].copy()))
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2])
+    np.testing.assert_array_equal(out[0][0], gold["chosen"])
+
+
 def test_invalid_plans_are_rejected():
     case = cases.CASES["c1_hc_rs_n500_h10_e1"]
     env, model = cases.product_model(case)
