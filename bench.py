@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the informational end-to-end get_actions modes (profiling runs: keeps the kernel "
+                         "statistics to the timed plan launches only)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps to time (0 = auto, ~10-30 s)")
     ap.add_argument("--cpu-table", action="store_true",
                     help="no GPU work: time the oracle (CPU restatement) on configs 1, 2 (E=1, E=5) and the "
@@ -203,7 +206,7 @@ def main():
 
     # ---- end-to-end modes through the drop-in MPCController (informational) --------------------
     modes = {}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_e2e:
         for mode in ("numpy", "device"):
             ctrl = cases.product_controller(case, model=model, env=env, rng=mode)
             np.random.seed(0)
