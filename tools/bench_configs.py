@@ -203,14 +203,15 @@ def main():
     case = C["c2_hc_rs_n2000_h30_e5"]
     for mode in ("numpy", "device"):
         ctrl = cases.product_controller(case, rng=mode)
-        gold = cases.load_golden("c2_hc_rs_n2000_h30_e5_s0")
-        ctrl.get_actions(gold["obs0"])
+        obs_np = np.array(cases.load_golden("c2_hc_rs_n2000_h30_e5_s0")["obs0"])
+        for _ in range(3):
+            ctrl.get_actions(obs_np)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(30):
-            ctrl.get_actions(gold["obs0"])
+        for _ in range(50):
+            ctrl.get_actions(obs_np)
         torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / 30
+        ms = 1e3 * (time.perf_counter() - t0) / 50
         print(json.dumps(dict(config="config 2 end to end through MPCController.get_actions, rng=" + mode,
                               ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1))), flush=True)
 
