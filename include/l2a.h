@@ -239,6 +239,16 @@ int l2a_lstm_plan_rs(l2a_lstm* model, const float* obs0, const float* c0, const 
                      const float* actions, int m, int n, int h, float discount, const l2a_reward* reward,
                      int cand_offset, float* returns_out, unsigned long long* best_key, void* stream);
 
+/* l2a_lstm_plan_rs cut along the horizon (see l2a_plan_rs_chunk): launch k covers steps t0 .. t0 + h_chunk - 1
+ * and hands per-candidate observation, LSTM state and accumulated returns to launch k + 1; the chain is
+ * bit-identical to one launch.  t0 == 0: state [m, obs_dim], c / h [m, units] (per_row = 0); t0 > 0: the
+ * state_out / c_out / h_out of the previous chunk, [m * n, ...] (per_row = 1).  state_out, c_out, h_out: all
+ * three or none (last chunk); best_key on the last chunk.                                               */
+int l2a_lstm_plan_rs_chunk(l2a_lstm* model, const float* state, const float* c, const float* h, int per_row,
+                           const float* actions, int m, int n, int h_chunk, int t0, float discount,
+                           const l2a_reward* reward, int cand_offset, const float* returns_in, float* returns_out,
+                           float* state_out, float* c_out, float* h_out, unsigned long long* best_key, void* stream);
+
 /* RNNDynamicsModel.predict (rnn_dynamics.py:233-252): one step for `rows` independent rows, each
  * with its own LSTM state.  obs [rows, obs_dim], act [rows, act_dim], c / h [rows, units] ->
  * next_obs_out [rows, obs_dim], c_out / h_out [rows, units] (all device fp32).  Used by

@@ -48,6 +48,8 @@ struct L2ALstmParams {
     float* state_out;           // [m*n, obs_dim] or null
     float* c_out;               // [m*n, U] or null
     float* h_out;
+    const float* ret_in;        // [m, n] returns of earlier horizon chunks, or null (= 0)
+    double disc0;               // discount ** (first horizon step of this launch)
     int obs_per_row, hid_per_row;
     int m, n, h;
     int tiles_per_env;
@@ -235,8 +237,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 
     float ret[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) ret[nt] = 0.0f;
-    double disc_pow = 1.0;
+    for (int nt = 0; nt < NT; ++nt) ret[nt] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[nt] ? cand[nt] : p.n - 1)] : 0.0f;
+    double disc_pow = p.disc0;
 
     const long long wg_bytes = (long long)4 * UT * KG * 1024, wo_bytes = (long long)OT * UT * 1024;
     const __amdgpu_buffer_rsrc_t rs = l2a_rsrc(p.wblk + p.pk_wg, wg_bytes);

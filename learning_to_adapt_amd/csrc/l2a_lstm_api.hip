@@ -43,6 +43,7 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
     p.obs_dim = md->obs_dim; p.act_dim = md->act_dim; p.in_dim = md->in_dim; p.units = md->units;
     p.cell_act = md->cell_act; p.output_act = md->output_act;
     p.KG0 = md->KG0; p.OT = md->OT;
+    p.disc0 = 1.0;
 }
 
 int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v) {
@@ -231,6 +232,43 @@ int l2a_lstm_plan_rs(l2a_lstm* md, const float* obs0, const float* c0, const flo
     p.obs0 = obs0; p.c0 = c0; p.h0 = h0; p.actions = actions;
     p.returns_out = returns_out; p.best_key = best_key;
     p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
+    return launch(md, p, stream_v);
+}
+
+int l2a_lstm_plan_rs_chunk(l2a_lstm* md, const float* state, const float* c, const float* h, int per_row,
+                           const float* actions, int m, int n, int h_chunk, int t0, float discount,
+                           const l2a_reward* reward, int cand_offset, const float* returns_in, float* returns_out,
+                           float* state_out, float* c_out, float* h_out, unsigned long long* best_key, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!state || !c || !h || !actions || !reward)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_chunk: null state/c/h/actions/reward");
+    if (!returns_out) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_chunk: returns_out is required");
+    if (m < 1 || n < 1 || h_chunk < 1 || t0 < 0)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_chunk: bad m / n / h_chunk / t0");
+    if (t0 > 0 && (!returns_in || !per_row))
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_chunk: a continuation needs returns_in and per-row states");
+    if ((!state_out) != (!c_out) || (!state_out) != (!h_out))
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_chunk: pass state_out, c_out and h_out together");
+    if ((long long)m * n > 0x3fffffffLL || cand_offset < 0 || (long long)cand_offset + n > 0x7fffffffLL)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_chunk: too many candidates");
+    if (reward->w_vel != 0.0f && (reward->vel_index < 0 || reward->vel_index >= md->obs_dim))
+        return l2a_fail(ctx, L2A_EINVAL, "reward.vel_index out of range");
+    if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
+        return l2a_fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (best_key) L2A_HIP(ctx, hipMemsetAsync(best_key, 0, sizeof(unsigned long long) * (size_t)m, stream));
+    L2ALstmParams p;
+    fill(md, p);
+    p.obs0 = state; p.c0 = c; p.h0 = h; p.actions = actions;
+    p.obs_per_row = per_row ? 1 : 0; p.hid_per_row = per_row ? 1 : 0;
+    p.returns_out = returns_out; p.best_key = best_key;
+    p.state_out = state_out; p.c_out = c_out; p.h_out = h_out;
+    p.ret_in = (t0 > 0) ? returns_in : nullptr;
+    double d0 = 1.0;
+    for (int t = 0; t < t0; ++t) d0 *= (double)discount;
+    p.disc0 = d0;
+    p.m = m; p.n = n; p.h = h_chunk; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
     return launch(md, p, stream_v);
 }
 

@@ -63,10 +63,10 @@ __global__ void __launch_bounds__(256) l2a_lstm_valu_k(const L2ALstmParams p) {
     }
     const float* orow = p.obs0 + (p.obs_per_row ? (long long)row : (long long)env) * obs_dim;
     for (int d = s; d < obs_dim; d += 16) ss[j * obs_dim + d] = orow[d];
-    if (s == 0) rs_[j] = 0.0f;
+    if (s == 0) rs_[j] = p.ret_in ? p.ret_in[row] : 0.0f;
     __syncthreads();
 
-    double disc_pow = 1.0;
+    double disc_pow = p.disc0;
     for (int t = 0; t < p.h; ++t) {
         float* hc = hs + (t & 1) * L2A_LVT * U;
         float* hn = hs + ((t + 1) & 1) * L2A_LVT * U;

@@ -89,6 +89,21 @@ class NativeLSTM(object):
                                        _ptr(returns_out), _ptr(best_key), _stream_ptr())
         self.ctx.check(rc, "l2a_lstm_plan_rs")
 
+    def plan_rs_chunk(self, state, c, h, per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
+                      returns_in=None, returns_out=None, state_out=None, c_out=None, h_out=None, best_key=None):
+        """Horizon steps ``t0 .. t0 + h_chunk - 1`` of a recurrent plan (``l2a_lstm_plan_rs_chunk``)."""
+        for t in (state, c, h, actions):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        rows = m * n if per_row else m
+        assert state.numel() == rows * self.obs_dim and c.numel() == rows * self.units and h.numel() == rows * self.units
+        assert actions.numel() == h_chunk * m * n * self.act_dim and returns_out.numel() == m * n
+        assert isinstance(reward, RewardSpec)
+        rc = self.lib.l2a_lstm_plan_rs_chunk(self.handle, _ptr(state), _ptr(c), _ptr(h), 1 if per_row else 0, _ptr(actions),
+                                             int(m), int(n), int(h_chunk), int(t0), float(discount), ctypes.byref(reward),
+                                             int(cand_offset), _ptr(returns_in), _ptr(returns_out), _ptr(state_out),
+                                             _ptr(c_out), _ptr(h_out), _ptr(best_key), _stream_ptr())
+        self.ctx.check(rc, "l2a_lstm_plan_rs_chunk")
+
     def predict(self, obs, act, c, h):
         """One step for independent rows.  Returns ``(next_obs, c_out, h_out)`` CUDA tensors."""
         for t in (obs, act, c, h):

@@ -151,6 +151,10 @@ class RNNDynamicsModel(Serializable):
             self._native_dirty = False
         return self._native
 
+    def planner_blocks(self, m):
+        """One shared weight set for every env (the planner interface of the MLP models)."""
+        return 1
+
     # ------------------------------------------------------------------ hidden state (reference :273-293)
     def get_initial_hidden(self, batch_size):
         z = np.zeros((batch_size, self.units), dtype=np.float32)

@@ -312,8 +312,6 @@ class MPCController(Policy, Serializable):
         bounds = [(h * c) // K for c in range(K + 1)]
         obs0 = self._upload_obs(observations)
         best = self._buf("best", (m,), torch.int64, dev)
-        rets = [self._buf("pipe_ret%d" % i, (m, n_local), torch.float32, dev) for i in (0, 1)]
-        state = [self._buf("pipe_state%d" % i, (m * n_local, native.obs_dim), torch.float32, dev) for i in (0, 1)]
         cand_a = None
         for c in range(K):
             t0, hc = bounds[c], bounds[c + 1] - bounds[c]
@@ -329,12 +327,18 @@ class MPCController(Policy, Serializable):
             np.copyto(pin.numpy().reshape(src.shape), src, casting="same_kind")
             a_dev = self._buf(("pipe_dev", c), shape, torch.float32, dev)
             a_dev.copy_(pin, non_blocking=True)
-            last = (c == K - 1)
-            native.plan_rs_chunk(obs0 if c == 0 else state[(c + 1) % 2], c > 0, a_dev, m, n_local, hc, t0,
-                                 self.discount, self._reward_spec, cand_offset=lo,
-                                 returns_in=rets[(c + 1) % 2] if c > 0 else None, returns_out=rets[c % 2],
-                                 state_out=None if last else state[c % 2], best_key=best if last else None)
+            self._launch_chunk(native, c, c == K - 1, obs0, a_dev, m, n_local, hc, t0, lo, best)
         return best, cand_a
+
+    def _launch_chunk(self, native, c, last, obs0, a_dev, m, n_local, hc, t0, lo, best):
+        """Chunk ``c`` of a pipelined plan: state and returns ping-pong between two buffer pairs."""
+        dev = native.device
+        rets = [self._buf("pipe_ret%d" % i, (m, n_local), torch.float32, dev) for i in (0, 1)]
+        state = [self._buf("pipe_state%d" % i, (m * n_local, native.obs_dim), torch.float32, dev) for i in (0, 1)]
+        native.plan_rs_chunk(obs0 if c == 0 else state[(c + 1) % 2], c > 0, a_dev, m, n_local, hc, t0,
+                             self.discount, self._reward_spec, cand_offset=lo,
+                             returns_in=rets[(c + 1) % 2] if c > 0 else None, returns_out=rets[c % 2],
+                             state_out=None if last else state[c % 2], best_key=best if last else None)
 
     def _get_rs_action_unfused(self, observations):
         """No closed-form reward available (custom env reward or ``use_reward_model``): keep the

@@ -42,6 +42,7 @@ class RNNMPCController(MPCController):
             rng="numpy",
             cem_mode="reference",
             shard_candidates=True,
+            pipeline_chunks=3,
     ):
         Serializable.quick_init(self, locals())
         # alpha = 0 makes the shared CEM update `mean * alpha + (1 - alpha) * mean(elites)` the
@@ -51,7 +52,7 @@ class RNNMPCController(MPCController):
                                n_candidates=n_candidates, horizon=horizon, num_cem_iters=num_cem_iters,
                                percent_elites=percent_elites, use_reward_model=use_reward_model, alpha=0.0,
                                rng=rng, cem_mode=cem_mode, shard_candidates=shard_candidates,
-                               pipeline_chunks=1)          # the recurrent kernel has no continuation entry point
+                               pipeline_chunks=pipeline_chunks)
         self._hidden_state = None
 
     # ------------------------------------------------------------------ hidden state: host view + device copy
@@ -147,6 +148,22 @@ class RNNMPCController(MPCController):
         native.plan_rs(obs0, c0, h0, actions_local, m, n_local, self.horizon, self.discount, self._reward_spec,
                        cand_offset=cand_offset, returns_out=rets, best_key=best)
         return best, rets
+
+    def _launch_chunk(self, native, c, last, obs0, a_dev, m, n_local, hc, t0, lo, best):
+        """Recurrent chunk: observation, LSTM state and returns ping-pong between two buffer sets."""
+        dev = native.device
+        rows, U = m * n_local, native.units
+        rets = [self._buf("pipe_ret%d" % i, (m, n_local), torch.float32, dev) for i in (0, 1)]
+        state = [self._buf("pipe_state%d" % i, (rows, native.obs_dim), torch.float32, dev) for i in (0, 1)]
+        cs = [self._buf("pipe_c%d" % i, (rows, U), torch.float32, dev) for i in (0, 1)]
+        hs = [self._buf("pipe_h%d" % i, (rows, U), torch.float32, dev) for i in (0, 1)]
+        c0, h0 = self._device_hidden(dev)
+        src, dst = (c + 1) % 2, c % 2
+        native.plan_rs_chunk(obs0 if c == 0 else state[src], c0 if c == 0 else cs[src], h0 if c == 0 else hs[src],
+                             c > 0, a_dev, m, n_local, hc, t0, self.discount, self._reward_spec, cand_offset=lo,
+                             returns_in=rets[src] if c > 0 else None, returns_out=rets[dst],
+                             state_out=None if last else state[dst], c_out=None if last else cs[dst],
+                             h_out=None if last else hs[dst], best_key=best if last else None)
 
     def _get_rs_action_unfused(self, observations):
         """Custom env reward / reward model: the reference's loop shape (:112-134); the LSTM step

@@ -423,3 +423,31 @@ def test_gpu_rnn_device_cem_matches_host_loop_with_injected_normals(cem_mode):
     assert np.array_equal(dev.last_plan["best_index"], host.last_plan["best_index"])
     np.testing.assert_allclose(a_dev, a_host, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(dev._hidden_state.c, host._hidden_state.c, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", ["c6_hc_rnn_rs_n500_h10_m5_s0", "ant_rnn_rs_n100_h5_m2_s0", "hc_rnn_rs_u200_n40_h3_s0"])
+def test_gpu_rnn_pipelined_controller_equals_single_launch(cid):
+    """Recurrent parity mode pipelined over the horizon (observation, LSTM state and returns handed from launch
+    to launch) vs one launch per plan step: same RNG consumption, same actions, same return bits, same hidden
+    state - over consecutive controller steps."""
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    env, model = cases.product_rnn_model(case)
+    runs = []
+    for chunks in (3, 1, 2):
+        ctrl = cases.product_rnn_controller(case, model=model, env=env, pipeline_chunks=chunks)
+        ctrl.reset(dones=[True] * case["m"])
+        np.random.seed(seed)
+        rec = []
+        for k in range(case["steps"]):
+            a, _ = ctrl.get_actions(gold["obs"][k])
+            rec.append((a, ctrl.last_plan["best_index"].copy(), ctrl.last_plan["best_return"].copy(),
+                        ctrl._hidden_state.c.copy()))
+        runs.append(rec)
+    for rec in runs[1:]:
+        for got, want in zip(rec, runs[0]):
+            for x, y in zip(got, want):
+                assert np.array_equal(x, y)
+    if case["h"] >= 6:
+        assert np.array_equal(runs[0][0][1], gold["best_0"])
