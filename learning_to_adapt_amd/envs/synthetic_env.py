@@ -64,7 +64,35 @@ class SyntheticEnv(object):
         return self.reward_spec.evaluate(obs, action, next_obs)
 
     def reset(self):
-        return np.zeros(self._obs_space.shape)
+        self._state = np.zeros(self._obs_space.shape)
+        return self._state.copy()
+
+    # A toy transition function so that closed-loop tests and demos can run the whole fit -> plan -> act cycle
+    # without MuJoCo: a damped linear system whose velocity coordinate (the one the reward reads) is driven by a
+    # fixed random mix of the actions.  Not a physics model.
+    def _toy_matrices(self):
+        if getattr(self, "_toy", None) is None:
+            rs = np.random.RandomState(7)
+            od, ad = self._obs_space.shape[0], self._act_space.shape[0]
+            a = 0.9 * np.eye(od) + 0.02 * rs.randn(od, od)
+            b = 0.05 * rs.randn(ad, od) / np.maximum(np.abs(self._act_space.high), 1e-6)[:, None]
+            self._toy = (a, b)
+        return self._toy
+
+    def toy_dynamics(self, obs, act):
+        """Vectorised ``next_obs = obs @ A + clip(act) @ B`` (float64)."""
+        a, b = self._toy_matrices()
+        act = np.clip(act, self._act_space.low, self._act_space.high)
+        return np.asarray(obs, dtype=np.float64) @ a + act @ b
+
+    def step(self, action):
+        obs = getattr(self, "_state", None)
+        if obs is None:
+            obs = self.reset()
+        nxt = self.toy_dynamics(obs[None], np.asarray(action, dtype=np.float64)[None])[0]
+        rew = float(self.reward(obs[None], np.asarray(action, dtype=np.float64)[None], nxt[None])[0])
+        self._state = nxt
+        return nxt.copy(), rew, False, {}
 
     def log_diagnostics(self, paths, prefix=""):
         pass
