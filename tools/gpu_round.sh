@@ -31,6 +31,11 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 done
 python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
 fi
+echo "== configs / parity report / timelines"
+timeout 600 python tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err; echo "configs rc=$?"
+timeout 300 python tools/parity_report.py > $OUT/parity_report.txt 2> $OUT/parity.err; echo "parity rc=$?"
+timeout 120 python tools/timeline.py > $OUT/timeline.txt 2>&1; echo "timeline rc=$?"
+timeout 120 python tools/timeline_lstm.py 256 4096 > $OUT/timeline_lstm.txt 2>&1; echo "timeline_lstm rc=$?"
 # keep the merged-back payload small
 find $OUT/prof -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $OUT
