@@ -4,6 +4,8 @@ and the arg-max key with the returns the kernel itself wrote (bit exact).  Cover
 the hand-picked golden cases: obs/act dims that straddle 16-feature tiles, every MFMA-eligible hidden
 width and depth, odd ensembles under all tile-split policies, ragged candidate counts."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -18,6 +20,9 @@ from oracle.planner import rollout_returns
 from oracle.rnn_planner import rnn_rollout_returns
 
 pytestmark = pytest.mark.gpu
+
+# more seeds for a one-off sweep: L2A_RANDOM_SEEDS=100 python -m pytest tests/test_gpu_random_shapes.py -m gpu
+_EXTRA = int(os.environ.get("L2A_RANDOM_SEEDS", "0"))
 
 
 def _reward(rs, obs_dim, act_dim):
@@ -44,7 +49,7 @@ def _check(got, want, keys, n, offset):
         assert idx - offset == int(np.argmax(got[i])) and ret == got[i, idx - offset]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(max(12, _EXTRA)))
 def test_random_mlp_shapes_match_oracle(seed):
     rs = np.random.RandomState(100 + seed)
     obs_dim = int(rs.choice([3, 15, 16, 17, 20, 31, 33, 41, 48, 64]))
@@ -98,7 +103,7 @@ def test_random_mlp_shapes_match_oracle(seed):
     native.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(max(8, _EXTRA)))
 def test_random_lstm_shapes_match_oracle(seed):
     rs = np.random.RandomState(200 + seed)
     obs_dim = int(rs.choice([3, 16, 17, 20, 33, 41, 64]))
