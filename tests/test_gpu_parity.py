@@ -355,6 +355,30 @@ def test_unfused_path_agrees_with_fused_choice():
     np.testing.assert_array_equal(actions, gold["chosen"])
 
 
+def test_reward_model_path_agrees_with_fused_choice():
+    """`use_reward_model=True` (reference `mpc_controller.py:122-124`): rewards come from
+    `reward_model.predict(obs, act, next_obs)` on the host, dynamics from the GPU `predict`."""
+    from learning_to_adapt_amd.policies import MPCController
+    case = cases.CASES["hc_rs_m3_n64_h5"]
+    gold = cases.load_golden("hc_rs_m3_n64_h5_s0")
+    env, model = cases.product_model(case)
+
+    class RewardModel(object):
+        calls = 0
+
+        def predict(self, obs, act, nxt):
+            RewardModel.calls += 1
+            return env.reward(obs, act, nxt)
+
+    ctrl = MPCController(name="policy", env=env, dynamics_model=model, reward_model=RewardModel(),
+                         use_reward_model=True, n_candidates=case["n"], horizon=case["h"])
+    assert not ctrl._fusable()
+    np.random.seed(0)
+    actions, _ = ctrl.get_actions(gold["obs0"])
+    assert RewardModel.calls == case["h"]
+    np.testing.assert_array_equal(actions, gold["chosen"])
+
+
 def test_device_rng_mode_plans_within_bounds():
     case = cases.CASES["c1_hc_rs_n500_h10_e1"]
     gold = cases.load_golden("c1_hc_rs_n500_h10_e1_s0")
