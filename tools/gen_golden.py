@@ -66,11 +66,11 @@ from learning_to_adapt_amd.utils import synthetic  # noqa: E402
 CASES = [
     # BASELINE.json configs
     dict(name="c1_hc_rs_n500_h10_e1", env="half_cheetah", planner="rs", n=500, h=10, m=1,
-         mode="single", E=1, hidden=[512, 512], seeds=[0, 1, 2]),
+         mode="single", E=1, hidden=[512, 512], seeds=[0, 1, 2, 3, 4, 5]),
     dict(name="c2_hc_rs_n2000_h30_e5", env="half_cheetah", planner="rs", n=2000, h=30, m=1,
-         mode="mean", E=5, hidden=[512, 512], seeds=[0, 1]),
+         mode="mean", E=5, hidden=[512, 512], seeds=[0, 1, 2, 3, 4, 5]),
     dict(name="c3_ant_rs_n2000_h20_pb5", env="ant", planner="rs", n=2000, h=20, m=5,
-         mode="per_block", E=5, hidden=[512, 512], seeds=[0]),
+         mode="per_block", E=5, hidden=[512, 512], seeds=[0, 1]),
     dict(name="c3b_ant_rs_n500_h10_pb5_3x512", env="ant", planner="rs", n=500, h=10, m=5,
          mode="per_block", E=5, hidden=[512, 512, 512], seeds=[0]),
     dict(name="c4_hc_rs_n16000_h30_e5", env="half_cheetah", planner="rs", n=16000, h=30, m=1,
