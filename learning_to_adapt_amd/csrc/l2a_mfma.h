@@ -534,6 +534,37 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     for (int tt = 0; tt < TPW; ++tt)
                         a[g][tt] = (g == 0) ? pfL0[tt] : l2a_ldw(r0, voff0[tt] + g * 1024, 0);
                 L2A_TS(8)
+                // normalised inputs of every k-group up front: all 2 KG0 constant reads are issued together (the
+                // register-starved scheduler otherwise puts each LDS round trip right in front of its MFMAs)
+                constexpr bool XPRE = (KG0 <= 2);       // wider inputs: no registers to spare, per k-group as before
+                auto norm_in = [&](int g, const f32x4& mu, const f32x4& iv, f32x4 (&x)[NT]) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (g < OT) sv = st[nt][g < OT ? g : 0];
+                        f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (g == ga0) aa = av[nt][0];
+                        if (g == ga0 + 1) aa = av[nt][1];
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const int k = 16 * g + 4 * qq + ii;
+                            const float v = (k < obs_dim) ? sv[ii] : aa[ii];
+                            x[nt][ii] = (v - mu[ii]) * iv[ii];
+                        }
+                    }
+                };
+                f32x4 xin[XPRE ? KG0 : 1][NT];
+                if (XPRE) {
+                    f32x4 mu[KG0], iv[KG0];
+#pragma unroll
+                    for (int g = 0; g < KG0; ++g) {
+                        mu[g] = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
+                        iv[g] = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < KG0; ++g) norm_in(g, mu[g], iv[g], xin[XPRE ? g : 0]);
+                }
                 f32x4 acc[NT][TPW];
                 // layer-0 MFMAs; called from both branches below so that each branch's operand
                 // prefetch shares a basic block with them and can be interleaved (NPF loads)
@@ -545,22 +576,14 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         for (int tt = 0; tt < TPW; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int g = 0; g < KG0; ++g) {
-                        const f32x4 mu = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
-                        const f32x4 iv = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
-                        f32x4 x[NT];
+                        f32x4 xg[NT];
+                        if (XPRE) {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (g < OT) sv = st[nt][g < OT ? g : 0];
-                            f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (g == ga0) aa = av[nt][0];
-                            if (g == ga0 + 1) aa = av[nt][1];
-#pragma unroll
-                            for (int ii = 0; ii < 4; ++ii) {
-                                const int k = 16 * g + 4 * qq + ii;
-                                const float v = (k < obs_dim) ? sv[ii] : aa[ii];
-                                x[nt][ii] = (v - mu[ii]) * iv[ii];
-                            }
+                            for (int nt = 0; nt < NT; ++nt) xg[nt] = xin[XPRE ? g : 0][nt];
+                        } else {
+                            const f32x4 mu = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
+                            const f32x4 iv = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
+                            norm_in(g, mu, iv, xg);
                         }
 #pragma unroll
                         for (int ii = 0; ii < 4; ++ii)
@@ -568,7 +591,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                                 for (int tt = 0; tt < TPW; ++tt)
-                                    acc[nt][tt] = L2A_MFMA(a[g][tt][ii], x[nt][ii], acc[nt][tt]);
+                                    acc[nt][tt] = L2A_MFMA(a[g][tt][ii], xg[nt][ii], acc[nt][tt]);
                     }
                     // hint: the a[g >= 1] loads first, then one prefetch load per few MFMAs
                     constexpr int NM = KG0 * 4 * NT * TPW;
@@ -687,23 +710,33 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 // Sum the chunk partials in the canonical order ((c0+c1)+c2)+c3 [+ ((c4+c5)+c6)+c7].
                 // A half member holds only its own four chunks; the other four arrive at the end of
                 // the step from the partner workgroup.
+                // All LDS reads of an obs tile are issued before the first add: left to itself the compiler,
+                // which is out of registers kernel-wide, serialises them read-wait-add (~120 cycles each, 22 of
+                // them: the reduce measured 1.4k cycles per set in tools/timeline.py).  The half member's
+                // unwritten upper chunks are read too (branch-free) and simply not used.
 #pragma unroll
                 for (int c = 0; c < OT; ++c) {
+                    f32x4 part[2 * L2A_NW][NT];
+#pragma unroll
+                    for (int ch = 0; ch < 2 * L2A_NW; ++ch)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) part[ch][nt] = hoth[((ch * NT + nt) * OT + c) * 64 + lane];
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BOUT + 16 * c + 4 * qq);
+                    const f32x4 omu = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * c + 4 * qq);
+                    const f32x4 osd = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        f32x4 s = hoth[((0 * NT + nt) * OT + c) * 64 + lane];
+                        f32x4 s = part[0][nt];
 #pragma unroll
-                        for (int w = 1; w < L2A_NW; ++w) s += hoth[((w * NT + nt) * OT + c) * 64 + lane];
+                        for (int w = 1; w < L2A_NW; ++w) s += part[w][nt];
                         if (is_half) {
                             qsh[nt][c] = s;
                         } else {
-                            f32x4 s2 = hoth[((L2A_NW * NT + nt) * OT + c) * 64 + lane];
+                            f32x4 s2 = part[L2A_NW][nt];
 #pragma unroll
-                            for (int w = 1; w < L2A_NW; ++w) s2 += hoth[(((L2A_NW + w) * NT + nt) * OT + c) * 64 + lane];
+                            for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w][nt];
                             s += s2;
-                            const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BOUT + 16 * c + 4 * qq);
-                            const f32x4 omu = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * c + 4 * qq);
-                            const f32x4 osd = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
                             s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
                             dgrp[nt][c] += s * osd + omu;
                         }
@@ -763,24 +796,34 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             __syncthreads();
             { const int e = 7; L2A_TS(13) }
             const float* nrs = nrm + (e_shared < 0 ? 0 : e_shared) * NRM_SET;
+            {   // every LDS read of the combine first, then the arithmetic (one exposed round trip, not four)
+                f32x4 cb[OT], cm[OT], cs[OT], og[NT][OT], oq[NT][OT];
 #pragma unroll
-            for (int c = 0; c < OT; ++c) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(nrs + CST_BOUT + 16 * c + 4 * qq);
-                const f32x4 omu = *reinterpret_cast<const f32x4*>(nrs + 32 * KG0 + 16 * c + 4 * qq);
-                const f32x4 osd = *reinterpret_cast<const f32x4*>(nrs + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
+                for (int c = 0; c < OT; ++c) {
+                    cb[c] = *reinterpret_cast<const f32x4*>(nrs + CST_BOUT + 16 * c + 4 * qq);
+                    cm[c] = *reinterpret_cast<const f32x4*>(nrs + 32 * KG0 + 16 * c + 4 * qq);
+                    cs[c] = *reinterpret_cast<const f32x4*>(nrs + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4 og = xlds[((0 * NT + nt) * OT + c) * 64 + lane];      // partner's group sum
-                    f32x4 ga = (grp == 0) ? dgrp[nt][c] : og;                          // group A (without the shared set)
-                    const f32x4 gb = (grp == 0) ? og : dgrp[nt][c];                    // group B
-                    if (split == 2) {
-                        f32x4 s = qsh[nt][c] + xlds[((1 * NT + nt) * OT + c) * 64 + lane];   // S1 + S2
-                        s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
-                        ga += s * osd + omu;        // the shared set is the last member of group A
+                    for (int nt = 0; nt < NT; ++nt) {
+                        og[nt][c] = xlds[((0 * NT + nt) * OT + c) * 64 + lane];       // partner's group sum
+                        oq[nt][c] = xlds[((1 * NT + nt) * OT + c) * 64 + lane];       // partner's half of the shared set
                     }
-                    dsum[nt][c] = ga;
-                    dgrp[nt][c] = gb;
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 ga = (grp == 0) ? dgrp[nt][c] : og[nt][c];               // group A (without the shared set)
+                        const f32x4 gb = (grp == 0) ? og[nt][c] : dgrp[nt][c];         // group B
+                        if (split == 2) {
+                            f32x4 s = qsh[nt][c] + oq[nt][c];                          // S1 + S2
+                            s = l2a_actv<GACT>(s + cb[c], p.output_act, p.out_floor);
+                            ga += s * cs[c] + cm[c];        // the shared set is the last member of group A
+                        }
+                        dsum[nt][c] = ga;
+                        dgrp[nt][c] = gb;
+                    }
             }
         }
 #pragma unroll
