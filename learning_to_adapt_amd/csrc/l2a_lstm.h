@@ -458,16 +458,21 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             float psq = 0.0f;
 #pragma unroll
             for (int c = 0; c < OT; ++c) {
-                f32x4 s = pb[((0 * NT + nt) * OT + c) * 64 + lane];
+                // all LDS reads of this obs tile first (left alone the scheduler serialises read-wait-add)
+                f32x4 part[2 * L2A_NW];
 #pragma unroll
-                for (int w = 1; w < L2A_NW; ++w) s += pb[((w * NT + nt) * OT + c) * 64 + lane];
-                f32x4 s2 = pb[((L2A_NW * NT + nt) * OT + c) * 64 + lane];
-#pragma unroll
-                for (int w = 1; w < L2A_NW; ++w) s2 += pb[(((L2A_NW + w) * NT + nt) * OT + c) * 64 + lane];
-                s += s2;
+                for (int ch = 0; ch < 2 * L2A_NW; ++ch) part[ch] = pb[((ch * NT + nt) * OT + c) * 64 + lane];
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(nrm + CST_BOUT + 16 * c + 4 * qq);
                 const f32x4 omu = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * c + 4 * qq);
                 const f32x4 osd = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 s = part[0];
+#pragma unroll
+                for (int w = 1; w < L2A_NW; ++w) s += part[w];
+                f32x4 s2 = part[L2A_NW];
+#pragma unroll
+                for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w];
+                s += s2;
                 s = l2a_act4(s + bias, p.output_act);
                 const f32x4 d = s * osd + omu;
                 const f32x4 nx = st[nt][c] + d;
