@@ -14,10 +14,12 @@ from .native_model import _dvec, _ptr, _stream_ptr
 
 
 class NativeLSTM(object):
-    def __init__(self, obs_dim, act_dim, units, cell_act="tanh", output_act=None, device=0):
+    def __init__(self, obs_dim, act_dim, units, cell_act="tanh", output_act=None, device=None):
         if not torch.cuda.is_available():
             raise _lib.L2AError("no MI355X visible to PyTorch-ROCm: the rollout path is HIP-only "
                                 "(there is no CPU fallback)")
+        if device is None:                  # one process per GPU: the process' current device (torch.cuda.set_device)
+            device = torch.cuda.current_device()
         self.ctx = _lib.Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device("cuda", device)
@@ -54,13 +56,13 @@ class NativeLSTM(object):
             assert tuple(t.shape) == shp, "LSTM parameter has shape %s, expected %s" % (tuple(t.shape), shp)
             dev.append(t)
         ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in dev])
-        self.ctx.check(self.lib.l2a_lstm_set_weights(self.handle, ptrs, _stream_ptr()), "l2a_lstm_set_weights")
+        self.ctx.check(self.lib.l2a_lstm_set_weights(self.handle, ptrs, _stream_ptr(self.device)), "l2a_lstm_set_weights")
         self._keep["w"] = dev
 
     def set_norm(self, norm):
         if norm is None:
             null = ctypes.POINTER(ctypes.c_double)()
-            rc = self.lib.l2a_lstm_set_norm(self.handle, null, null, null, null, null, null, _stream_ptr())
+            rc = self.lib.l2a_lstm_set_norm(self.handle, null, null, null, null, null, null, _stream_ptr(self.device))
         else:
             keep, args = [], []
             for key in ("obs", "act", "delta"):
@@ -70,7 +72,7 @@ class NativeLSTM(object):
                     assert arr.shape == (expect,), "normalization[%r] has shape %s" % (key, arr.shape)
                     keep.append(arr)
                     args.append(p)
-            rc = self.lib.l2a_lstm_set_norm(self.handle, *args, _stream_ptr())
+            rc = self.lib.l2a_lstm_set_norm(self.handle, *args, _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_lstm_set_norm")
 
     def plan_rs(self, obs0, c0, h0, actions, m, n, h, discount, reward, cand_offset=0, returns_out=None,
@@ -86,7 +88,7 @@ class NativeLSTM(object):
         assert isinstance(reward, RewardSpec)
         rc = self.lib.l2a_lstm_plan_rs(self.handle, _ptr(obs0), _ptr(c0), _ptr(h0), _ptr(actions), int(m), int(n),
                                        int(h), float(discount), ctypes.byref(reward), int(cand_offset),
-                                       _ptr(returns_out), _ptr(best_key), _stream_ptr())
+                                       _ptr(returns_out), _ptr(best_key), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_lstm_plan_rs")
 
     def plan_rs_chunk(self, state, c, h, per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
@@ -101,7 +103,7 @@ class NativeLSTM(object):
         rc = self.lib.l2a_lstm_plan_rs_chunk(self.handle, _ptr(state), _ptr(c), _ptr(h), 1 if per_row else 0, _ptr(actions),
                                              int(m), int(n), int(h_chunk), int(t0), float(discount), ctypes.byref(reward),
                                              int(cand_offset), _ptr(returns_in), _ptr(returns_out), _ptr(state_out),
-                                             _ptr(c_out), _ptr(h_out), _ptr(best_key), _stream_ptr())
+                                             _ptr(c_out), _ptr(h_out), _ptr(best_key), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_lstm_plan_rs_chunk")
 
     def predict(self, obs, act, c, h):
@@ -115,6 +117,6 @@ class NativeLSTM(object):
         h_out = torch.empty((rows, self.units), dtype=torch.float32, device=self.device)
         rc = self.lib.l2a_lstm_predict(self.handle, _ptr(obs.contiguous()), _ptr(act.contiguous()),
                                        _ptr(c.contiguous()), _ptr(h.contiguous()), int(rows), _ptr(nxt),
-                                       _ptr(c_out), _ptr(h_out), _stream_ptr())
+                                       _ptr(c_out), _ptr(h_out), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_lstm_predict")
         return nxt, c_out, h_out

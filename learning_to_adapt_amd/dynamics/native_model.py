@@ -14,8 +14,9 @@ from .. import _lib
 from ..envs.reward_spec import RewardSpec
 
 
-def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream_ptr(device=None):
+    """torch's current HIP stream on `device` (the model's GPU, not necessarily the process' current one)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t):
@@ -28,10 +29,12 @@ def _dvec(x):
 
 
 class NativeModel(object):
-    def __init__(self, obs_dim, act_dim, hidden_sizes, hidden_act, output_act, n_sets, mode, device=0):
+    def __init__(self, obs_dim, act_dim, hidden_sizes, hidden_act, output_act, n_sets, mode, device=None):
         if not torch.cuda.is_available():
             raise _lib.L2AError("no MI355X visible to PyTorch-ROCm: the rollout path is HIP-only "
                                 "(there is no CPU fallback)")
+        if device is None:                  # one process per GPU: the process' current device (torch.cuda.set_device)
+            device = torch.cuda.current_device()
         self.ctx = _lib.Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device("cuda", device)
@@ -75,7 +78,7 @@ class NativeModel(object):
                 "kernel %d has shape %s, expected %s" % (li, tuple(dev[2 * li].shape), (sizes[li], sizes[li + 1]))
             assert tuple(dev[2 * li + 1].shape) == (sizes[li + 1],)
         ptrs = (ctypes.c_void_p * len(dev))(*[t.data_ptr() for t in dev])
-        rc = self.lib.l2a_model_set_weights(self.handle, int(e), ptrs, _stream_ptr())
+        rc = self.lib.l2a_model_set_weights(self.handle, int(e), ptrs, _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_model_set_weights")
         self._keep[("w", e)] = dev
 
@@ -94,7 +97,7 @@ class NativeModel(object):
             dev.append(t)
         ptrs = (ctypes.c_void_p * len(dev))(*[t.data_ptr() for t in dev])
         strides = (ctypes.c_longlong * len(dev))(*[int(t.stride(0)) for t in dev])
-        rc = self.lib.l2a_model_set_weights_strided(self.handle, int(first_set), count, ptrs, strides, _stream_ptr())
+        rc = self.lib.l2a_model_set_weights_strided(self.handle, int(first_set), count, ptrs, strides, _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_model_set_weights_strided")
         self._keep[("w_stacked", first_set)] = dev
 
@@ -108,7 +111,7 @@ class NativeModel(object):
         base = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in base_params]
         ptrs = (ctypes.c_void_p * len(base))(*[t.data_ptr() for t in base])
         x, y = x.contiguous(), y.contiguous()
-        rc = self.lib.l2a_model_adapt_sgd(self.handle, ptrs, _ptr(x), _ptr(y), m, rows, float(lr), _stream_ptr())
+        rc = self.lib.l2a_model_adapt_sgd(self.handle, ptrs, _ptr(x), _ptr(y), m, rows, float(lr), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_model_adapt_sgd")
         self._keep["adapt"] = (base, x, y)
 
@@ -120,7 +123,7 @@ class NativeModel(object):
             out.append(torch.empty((sizes[li], sizes[li + 1]), dtype=torch.float32, device=self.device))
             out.append(torch.empty((sizes[li + 1],), dtype=torch.float32, device=self.device))
         ptrs = (ctypes.c_void_p * len(out))(*[t.data_ptr() for t in out])
-        rc = self.lib.l2a_model_get_weights(self.handle, int(e), ptrs, _stream_ptr())
+        rc = self.lib.l2a_model_get_weights(self.handle, int(e), ptrs, _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_model_get_weights")
         return out
 
@@ -130,7 +133,7 @@ class NativeModel(object):
         if norm is None:
             null = ctypes.POINTER(ctypes.c_double)()
             rc = self.lib.l2a_model_set_norm(self.handle, int(e), null, null, null, null, null, null,
-                                             _stream_ptr())
+                                             _stream_ptr(self.device))
         else:
             keep, args = [], []
             for key in ("obs", "act", "delta"):
@@ -140,7 +143,7 @@ class NativeModel(object):
                     assert arr.shape == (expect,), "normalization[%r] has shape %s" % (key, arr.shape)
                     keep.append(arr)
                     args.append(p)
-            rc = self.lib.l2a_model_set_norm(self.handle, int(e), *args, _stream_ptr())
+            rc = self.lib.l2a_model_set_norm(self.handle, int(e), *args, _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_model_set_norm")
 
     # ---- launches -----------------------------------------------------------------------
@@ -157,7 +160,7 @@ class NativeModel(object):
         assert isinstance(reward, RewardSpec)
         rc = self.lib.l2a_plan_rs(self.handle, _ptr(obs0), _ptr(actions), int(m), int(n), int(h),
                                   float(discount), ctypes.byref(reward), int(cand_offset),
-                                  _ptr(returns_out), _ptr(best_key), _stream_ptr())
+                                  _ptr(returns_out), _ptr(best_key), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_plan_rs")
 
     def plan_rs_chunk(self, state, state_per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
@@ -171,7 +174,7 @@ class NativeModel(object):
         rc = self.lib.l2a_plan_rs_chunk(self.handle, _ptr(state), 1 if state_per_row else 0, _ptr(actions), int(m), int(n),
                                         int(h_chunk), int(t0), float(discount), ctypes.byref(reward), int(cand_offset),
                                         _ptr(returns_in), _ptr(returns_out), _ptr(state_out), _ptr(best_key),
-                                        _stream_ptr())
+                                        _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_plan_rs_chunk")
 
     def predict(self, obs, act, n_blocks=1, out=None):
@@ -180,6 +183,6 @@ class NativeModel(object):
         if out is None:
             out = torch.empty((rows, self.obs_dim), dtype=torch.float32, device=self.device)
         rc = self.lib.l2a_predict(self.handle, _ptr(obs.contiguous()), _ptr(act.contiguous()), int(rows),
-                                  int(n_blocks), _ptr(out), _stream_ptr())
+                                  int(n_blocks), _ptr(out), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_predict")
         return out
