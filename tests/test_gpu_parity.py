@@ -588,6 +588,43 @@ def test_pipelined_controller_equals_single_launch_controller(cid):
     np.testing.assert_array_equal(out[0][0], gold["chosen"])
 
 
+def test_weight_upload_round_trips_and_strided_equals_per_set():
+    """`l2a_model_get_weights` returns what `l2a_model_set_weights` stored; the strided batch upload of stacked
+    sets plans exactly like per-set uploads (same packed copies); bad strides are rejected."""
+    from learning_to_adapt_amd.dynamics.native_model import NativeModel
+    case = cases.CASES["c3b_ant_rs_n500_h10_pb5_3x512"]
+    env, sets, norms = cases.recipe(case)
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    a = NativeModel(od, ad, case["hidden"], "relu", None, case["E"], "per_block")
+    b = NativeModel(od, ad, case["hidden"], "relu", None, case["E"], "per_block")
+    for e in range(case["E"]):
+        a.set_weights(e, sets[e])
+        a.set_norm(e, norms[e])
+        b.set_norm(e, norms[e])
+    stacked = [torch.from_numpy(np.stack([sets[e][i] for e in range(case["E"])])).to(b.device) for i in range(len(sets[0]))]
+    b.set_weights_stacked(0, stacked)
+    for e in range(case["E"]):
+        for got_a, got_b, want in zip(a.get_weights(e), b.get_weights(e), sets[e]):
+            assert np.array_equal(got_a.cpu().numpy(), want) and np.array_equal(got_b.cpu().numpy(), want)
+    rs = np.random.RandomState(0)
+    m, n, h = case["m"], 100, 3
+    obs0 = torch.from_numpy(rs.randn(m, od).astype(np.float32)).to(a.device)
+    acts = torch.from_numpy(rs.uniform(-150, 150, (h, m * n, ad)).astype(np.float32)).to(a.device)
+    outs = []
+    for nat in (a, b):
+        rets = torch.empty((m, n), dtype=torch.float32, device=nat.device)
+        best = torch.zeros((m,), dtype=torch.int64, device=nat.device)
+        nat.plan_rs(obs0, acts, m, n, h, 1.0, env.reward_spec, returns_out=rets, best_key=best)
+        outs.append((rets.cpu().numpy(), best.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ptrs = (ctypes.c_void_p * len(stacked))(*[t.data_ptr() for t in stacked])
+    bad = (ctypes.c_longlong * len(stacked))(*([1] * len(stacked)))
+    rc = b.lib.l2a_model_set_weights_strided(b.handle, 0, case["E"], ptrs, bad, None)
+    assert rc < 0 and b"stride" in b.lib.l2a_last_error(b.ctx.handle)
+    rc = b.lib.l2a_model_set_weights_strided(b.handle, 3, case["E"], ptrs, bad, None)
+    assert rc < 0 and b"range" in b.lib.l2a_last_error(b.ctx.handle)
+
+
 def test_invalid_plans_are_rejected():
     case = cases.CASES["c1_hc_rs_n500_h10_e1"]
     env, model = cases.product_model(case)
