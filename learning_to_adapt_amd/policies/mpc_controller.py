@@ -371,6 +371,12 @@ class MPCController(Policy, Serializable):
         act_dim = self.action_space.shape[0]
         n_local = hi - lo
         reference = (self.cem_mode == "reference")
+        if self._can_pipeline_cem(m, world, n):
+            a, a_stacked, returns = self._cem_rollout_pipelined(observations, mean, std, clip_low, clip_high,
+                                                                reference)
+            cand_a = a.reshape((n, h, act_dim))[:, 0, :].reshape((1, n, act_dim)) if reference else \
+                a_stacked.reshape((n, h, act_dim))[:, 0, :].reshape((1, n, act_dim))
+            return self._cem_refit(mean, a_stacked, returns, num_elites, reference) + (returns, cand_a)
         z = np.random.normal(size=(n, m, h * act_dim))
         a = mean + z * std
         a_stacked = np.clip(a, clip_low, clip_high)
@@ -393,6 +399,12 @@ class MPCController(Policy, Serializable):
             rets = torch.cat(parts, dim=1)
         returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
         self._check_status()
+        mean, std = self._cem_refit(mean, a_stacked, returns, num_elites, reference)
+        return mean, std, returns, cand_a
+
+    def _cem_refit(self, mean, a_stacked, returns, num_elites, reference):
+        """Elite statistics of one iteration (reference ``:101-104``)."""
+        m = returns.shape[0]
         if reference:
             elites_idx = ((-returns).argsort(axis=-1) < num_elites).T                # :101
             elites = a_stacked[elites_idx]
@@ -403,7 +415,50 @@ class MPCController(Policy, Serializable):
             elites = np.stack([a_stacked[order[i], i] for i in range(m)], axis=0)     # [m, k, h*act]
             mean = mean * self.alpha + (1 - self.alpha) * np.mean(elites, axis=1)
             std = np.std(elites, axis=1)
-        return mean, std, returns, cand_a
+        return mean, std
+
+    def _can_pipeline_cem(self, m, world, n):
+        """Single env, single rank: rows are candidates, the stream is candidate-major - chunks of candidates can be
+        drawn while earlier chunks roll out."""
+        return (self.pipeline_chunks > 1 and m == 1 and world == 1 and n >= 64 * self.pipeline_chunks
+                and hasattr(self.dynamics_model.planner_model(), "plan_rs_chunk"))
+
+    def _cem_rollout_pipelined(self, observations, mean, std, clip_low, clip_high, reference):
+        """One CEM iteration's sampling + rollout for m == 1, pipelined over candidate chunks: ``np.random.normal``
+        consumes its stream candidate-major (``:85``; chunked draws continue the legacy generator exactly, cached
+        Gaussian included), so chunk k + 1 is drawn and clipped on the host while the GPU rolls out chunk k into
+        its slice of the returns.  Returns ``(a [n, 1, D], a_stacked, returns [1, n] float64)``."""
+        native = self.dynamics_model.planner_model()
+        dev = native.device
+        n, h = self.n_candidates, self.horizon
+        act_dim = self.action_space.shape[0]
+        D = h * act_dim
+        K = self.pipeline_chunks
+        bounds = [(n * c) // K for c in range(K + 1)]
+        obs0 = self._upload_obs(observations)
+        rets = self._buf("rets", (1, n), torch.float32, dev)
+        a = np.empty((n, 1, D))
+        a_stacked = np.empty((n, 1, D))
+        for c in range(K):
+            j0, j1 = bounds[c], bounds[c + 1]
+            nc = j1 - j0
+            z = np.random.normal(size=(nc, 1, D))
+            a[j0:j1] = mean + z * std
+            np.clip(a[j0:j1], clip_low, clip_high, out=a_stacked[j0:j1])
+            src = (a if reference else a_stacked)[j0:j1].reshape(nc, h, act_dim)
+            shape = (h, nc, act_dim)
+            pin = self._bufs.get(("cem_pin", c))
+            if pin is None or tuple(pin.shape) != shape:
+                pin = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+                self._bufs[("cem_pin", c)] = pin
+            np.copyto(pin.numpy(), np.transpose(src, (1, 0, 2)), casting="same_kind")
+            a_dev = self._buf(("cem_dev", c), shape, torch.float32, dev)
+            a_dev.copy_(pin, non_blocking=True)
+            native.plan_rs(obs0, a_dev, 1, nc, h, self.discount, self._reward_spec, cand_offset=j0,
+                           returns_out=rets[0, j0:j1])
+        returns = rets.cpu().numpy().astype(np.float64).reshape(1, n)
+        self._check_status()
+        return a, a_stacked, returns
 
     # ------------------------------------------------------------------ CEM (reference :71-106)
     def _cem_normal_device(self, shape, device):

@@ -165,6 +165,9 @@ class RNNMPCController(MPCController):
                              state_out=None if last else state[dst], c_out=None if last else cs[dst],
                              h_out=None if last else hs[dst], best_key=best if last else None)
 
+    def _can_pipeline_cem(self, m, world, n):
+        return False            # the candidate-chunked CEM rollout is wired for the feed-forward launch only
+
     def _get_rs_action_unfused(self, observations):
         """Custom env reward / reward model: the reference's loop shape (:112-134); the LSTM step
         still runs on the GPU through ``dynamics_model.predict``."""

@@ -401,7 +401,7 @@ def test_device_cem_matches_host_loop_with_injected_normals(name, cem_mode):
     obs0 = cases.load_golden(name + "_s0")["obs0"]
     n, m, D = case["n"], case["m"], case["h"] * 6
     zs = [np.random.RandomState(100 + i).normal(size=(n, m, D)) for i in range(case["num_cem_iters"])]
-    host = cases.product_controller(case, cem_mode=cem_mode)
+    host = cases.product_controller(case, cem_mode=cem_mode, pipeline_chunks=1)   # whole-iteration draws are injected
     it = iter(zs)
     orig = np.random.normal
     try:
