@@ -625,6 +625,34 @@ def test_weight_upload_round_trips_and_strided_equals_per_set():
     assert rc < 0 and b"range" in b.lib.l2a_last_error(b.ctx.handle)
 
 
+def test_pipelined_plan_of_candidate_shards_combines_to_the_full_plan():
+    """The N > 1 flavour of the pipelined parity mode on one GPU: every "rank" draws the full candidate stream
+    chunk by chunk and rolls out only its shard (global indices through cand_offset); the MAX of the shard keys
+    is the key of the unsharded single-launch plan, bit for bit."""
+    case = cases.CASES["hc_rs_m3_n64_h5"]
+    case = dict(case, h=8)
+    env, model = cases.product_model(case)
+    obs0 = np.random.RandomState(3).randn(case["m"], env.observation_space.shape[0])
+    full = cases.product_controller(case, model=model, env=env, pipeline_chunks=1)
+    np.random.seed(5)
+    a_full, _ = full.get_actions(obs0)
+    want_idx, want_ret = full.last_plan["best_index"], full.last_plan["best_return"]
+    n, m, h = case["n"], case["m"], case["h"]
+    keys = []
+    for rank in range(3):
+        ctrl = cases.product_controller(case, model=model, env=env, pipeline_chunks=4)
+        lo, hi = ctrl._shard_range(n, rank, 3)
+        np.random.seed(5)
+        best, cand_a = ctrl._plan_pipelined(obs0, n, m, h, lo, hi, 3)
+        keys.append(best.cpu().numpy().copy())
+        assert cand_a.shape == (m, n, env.action_space.shape[0])
+    key = np.max(np.stack(keys), axis=0)
+    for i in range(m):
+        ret, idx = _lib.key_decode(key[i])
+        assert idx == int(want_idx[i]) and np.float32(ret) == np.float32(want_ret[i])
+    np.testing.assert_array_equal(cand_a[np.arange(m), want_idx], a_full)
+
+
 def test_invalid_plans_are_rejected():
     case = cases.CASES["c1_hc_rs_n500_h10_e1"]
     env, model = cases.product_model(case)
