@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libl2a_hip.so (built artefacts are git-ignored): build it once with hipcc
+    (cross-compiles without a GPU) instead of failing every test that loads the C ABI."""
+    lib = os.path.join(ROOT, "learning_to_adapt_amd", "libl2a_hip.so")
+    if not os.path.exists(lib):
+        try:
+            from learning_to_adapt_amd.csrc import build as l2a_build
+            l2a_build.build(force=False)
+        except Exception as exc:            # leave the failure to the tests, with the reason visible
+            sys.stderr.write("[conftest] could not build libl2a_hip.so: %r\n" % (exc,))
+
+
 def _gpu_available():
     try:
         import torch
