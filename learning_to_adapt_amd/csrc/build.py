@@ -15,10 +15,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libl2a_hip.so")
+RNG_OUT = os.path.join(PKG, "libl2a_rng.so")        # host-only helper (gcc), see l2a_rng.c
 OBJ_DIR = os.path.join(HERE, "_obj")
 HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_mfma.h", "l2a_mfma_launch.h", "l2a_lstm.h",
            "l2a_lstm_valu.h", "l2a_lstm_launch.h", os.path.join("..", "..", "include", "l2a.h")]
-SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip"]
+SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_rng.c"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -31,8 +32,19 @@ def _hipcc():
     return exe
 
 
+def build_rng(verbose=True):
+    """The host RNG helper: plain C, built with gcc.  Optional - without it parity mode uses NumPy's own loop."""
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        if verbose:
+            print("[l2a] gcc not found: skipping libl2a_rng.so (parity mode falls back to np.random.random_sample)")
+        return None
+    subprocess.check_call([gcc, "-O3", "-fPIC", "-shared", os.path.join(HERE, "l2a_rng.c"), "-o", RNG_OUT])
+    return RNG_OUT
+
+
 def up_to_date():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or (shutil.which("gcc") and not os.path.exists(RNG_OUT)):
         return False
     t = os.path.getmtime(OUT)
     deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -72,6 +84,7 @@ def build(force=False, verbose=True, only=None):
     objs += [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
     objs += [os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % u) for u in LSTM_INSTANCES]
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, cwd=HERE)
+    build_rng(verbose)
     return OUT
 
 

@@ -28,6 +28,7 @@ import torch
 
 from .. import _lib
 from ..envs.reward_spec import reward_spec_for_env
+from ..utils import fast_rng
 from ..utils.serializable import Serializable
 from .policy import Policy, innermost_env
 
@@ -126,7 +127,7 @@ class MPCController(Policy, Serializable):
             cls._fast_uniform = bool(np.array_equal(want, got))
         if not cls._fast_uniform:
             return np.random.uniform(low=low, high=high, size=shape)
-        u = np.random.random_sample(shape)
+        u = fast_rng.random_sample(shape)            # same stream, vectorised generator (utils/fast_rng.py)
         # full-size (contiguous) scale / offset arrays: broadcasting a length-act_dim vector over the last
         # axis makes NumPy run act_dim-element inner loops, slower than the draw itself
         key = ("uniform_affine", shape)

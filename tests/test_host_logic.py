@@ -161,3 +161,29 @@ def test_device_cem_matches_host_loop_with_injected_normals(cem_mode):
     np.testing.assert_allclose(dev.last_plan["cem_std"], np.broadcast_to(tr["std"], (m, D)), rtol=1e-3, atol=1e-4)
     assert np.array_equal(dev.last_plan["best_index"], host.last_plan["best_index"])
     np.testing.assert_allclose(a_dev, a_host, rtol=1e-5, atol=1e-6)
+
+
+def test_fast_rng_reproduces_numpy_global_stream():
+    """`utils/fast_rng.random_sample` (vectorised MT19937 helper, csrc/l2a_rng.c) against
+    `np.random.random_sample`: same doubles, same generator state afterwards (cached Gaussian included),
+    for sizes that start / end inside a 624-word state block."""
+    from learning_to_adapt_amd.utils import fast_rng
+    if not fast_rng.available():
+        pytest.skip("libl2a_rng.so not built (no gcc) - the controller then uses np.random.random_sample itself")
+    for seed in range(4):
+        for sizes in ([2048], [4097, 2049, 3000], [(700, 6), (1, 4096)], [312 * 7 + 1, 5000]):
+            np.random.seed(seed)
+            np.random.normal(size=3)                      # odd stream position + a cached Gaussian
+            want = [np.random.random_sample(s) for s in sizes]
+            tail_want = (np.random.normal(), np.random.uniform())
+            np.random.seed(seed)
+            np.random.normal(size=3)
+            got = [fast_rng.random_sample(s) for s in sizes]
+            tail_got = (np.random.normal(), np.random.uniform())
+            for a, b in zip(want, got):
+                assert a.shape == b.shape and np.array_equal(a, b)
+            assert tail_want == tail_got
+    np.random.seed(0)
+    small = fast_rng.random_sample((3, 2))                # below the threshold: NumPy's own call
+    np.random.seed(0)
+    assert np.array_equal(small, np.random.random_sample((3, 2)))
