@@ -97,6 +97,9 @@ int l2a_set_split(l2a_ctx* ctx, int policy);
  * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch
  * with l2a_set_split(ctx, 0)).  Reading clears it.                                            */
 int l2a_launch_status(l2a_ctx* ctx, int* status_out);
+/* How many polls a split workgroup may spend waiting for its partner, per launch, before it gives up and sets
+ * status bit 0 (0 = default 2^18, about half a second).  Tests use a tiny value to force the condition. */
+int l2a_set_spin_limit(l2a_ctx* ctx, unsigned int polls);
 /* Developer aid (tools/timeline.py): when `device_ptr` is non-NULL the MFMA kernel's first
  * candidate tile stamps the shader clock at its phase boundaries into it as u64
  * [group 2][step h][set 8][slot 8].  NULL (default) disables it.                               */
@@ -144,9 +147,11 @@ int l2a_model_set_norm(l2a_model* model, int e, const double* mean_obs, const do
  *                                             zeroes it on `stream` before the launch.
  *   cand_offset                               global index of local candidate 0 (multi-GPU
  *                                             sharding: indices in best_key are global)
- * Rows whose env index is i use weight set i in L2A_MODE_PER_BLOCK (needs n_sets >= m).      */
+ * Rows whose env index is i use weight set i in L2A_MODE_PER_BLOCK (needs n_sets >= m).
+ * `discount` is float64 like the reference's `self.discount ** t` (:126); the kernel carries the power in
+ * float64 by repeated multiplication and rounds it to fp32 once per step, where it meets the fp32 reward. */
 int l2a_plan_rs(l2a_model* model, const float* obs0, const float* actions, int m, int n, int h,
-                float discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
                 unsigned long long* best_key, void* stream);
 
 /* A plan step cut along the horizon: launch k covers horizon steps t0 .. t0 + h_chunk - 1 of
@@ -160,7 +165,7 @@ int l2a_plan_rs(l2a_model* model, const float* obs0, const float* actions, int m
  *   returns_in:  returns_out of the previous chunk (ignored when t0 == 0); returns_out [m, n] is required
  *   state_out:   [m * n, obs_dim] or NULL (last chunk); best_key: [m] or NULL (give it on the last chunk)   */
 int l2a_plan_rs_chunk(l2a_model* model, const float* state, int state_per_row, const float* actions, int m, int n,
-                      int h_chunk, int t0, float discount, const l2a_reward* reward, int cand_offset,
+                      int h_chunk, int t0, double discount, const l2a_reward* reward, int cand_offset,
                       const float* returns_in, float* returns_out, float* state_out, unsigned long long* best_key,
                       void* stream);
 
@@ -236,7 +241,7 @@ int l2a_lstm_set_norm(l2a_lstm* model, const double* mean_obs, const double* std
  * candidates of each env, h x `dynamics_model.predict(obs, a[t], hidden)` + `env.reward` + return
  * accumulation + arg-max.  Other arguments as l2a_plan_rs.                                       */
 int l2a_lstm_plan_rs(l2a_lstm* model, const float* obs0, const float* c0, const float* h0,
-                     const float* actions, int m, int n, int h, float discount, const l2a_reward* reward,
+                     const float* actions, int m, int n, int h, double discount, const l2a_reward* reward,
                      int cand_offset, float* returns_out, unsigned long long* best_key, void* stream);
 
 /* l2a_lstm_plan_rs cut along the horizon (see l2a_plan_rs_chunk): launch k covers steps t0 .. t0 + h_chunk - 1
@@ -245,7 +250,7 @@ int l2a_lstm_plan_rs(l2a_lstm* model, const float* obs0, const float* c0, const 
  * state_out / c_out / h_out of the previous chunk, [m * n, ...] (per_row = 1).  state_out, c_out, h_out: all
  * three or none (last chunk); best_key on the last chunk.                                               */
 int l2a_lstm_plan_rs_chunk(l2a_lstm* model, const float* state, const float* c, const float* h, int per_row,
-                           const float* actions, int m, int n, int h_chunk, int t0, float discount,
+                           const float* actions, int m, int n, int h_chunk, int t0, double discount,
                            const l2a_reward* reward, int cand_offset, const float* returns_in, float* returns_out,
                            float* state_out, float* c_out, float* h_out, unsigned long long* best_key, void* stream);
 

@@ -22,7 +22,7 @@ KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
 
 EXPORTED_SYMBOLS = (
     "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split",
-    "l2a_launch_status", "l2a_set_debug_buffer",
+    "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_get_weights",
     "l2a_plan_rs", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
@@ -67,6 +67,8 @@ def load():
     lib.l2a_launch_status.restype = i32
     lib.l2a_set_debug_buffer.argtypes = [vp, vp]
     lib.l2a_set_debug_buffer.restype = i32
+    lib.l2a_set_spin_limit.argtypes = [vp, c.c_uint]
+    lib.l2a_set_spin_limit.restype = i32
     lib.l2a_model_create.argtypes = [vp, i32, i32, i32, c.POINTER(i32), i32, i32, i32, i32, c.POINTER(vp)]
     lib.l2a_model_create.restype = i32
     lib.l2a_model_destroy.argtypes = [vp]
@@ -82,9 +84,9 @@ def load():
     dp = c.POINTER(c.c_double)
     lib.l2a_model_set_norm.argtypes = [vp, i32, dp, dp, dp, dp, dp, dp, vp]
     lib.l2a_model_set_norm.restype = i32
-    lib.l2a_plan_rs.argtypes = [vp, vp, vp, i32, i32, i32, f32, c.POINTER(RewardSpec), i32, vp, vp, vp]
+    lib.l2a_plan_rs.argtypes = [vp, vp, vp, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32, vp, vp, vp]
     lib.l2a_plan_rs.restype = i32
-    lib.l2a_plan_rs_chunk.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, f32, c.POINTER(RewardSpec), i32, vp, vp, vp, vp, vp]
+    lib.l2a_plan_rs_chunk.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32, vp, vp, vp, vp, vp]
     lib.l2a_plan_rs_chunk.restype = i32
     lib.l2a_predict.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.l2a_predict.restype = i32
@@ -106,9 +108,9 @@ def load():
     lib.l2a_lstm_set_weights.restype = i32
     lib.l2a_lstm_set_norm.argtypes = [vp, dp, dp, dp, dp, dp, dp, vp]
     lib.l2a_lstm_set_norm.restype = i32
-    lib.l2a_lstm_plan_rs.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, c.POINTER(RewardSpec), i32, vp, vp, vp]
+    lib.l2a_lstm_plan_rs.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32, vp, vp, vp]
     lib.l2a_lstm_plan_rs.restype = i32
-    lib.l2a_lstm_plan_rs_chunk.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, c.POINTER(RewardSpec), i32,
+    lib.l2a_lstm_plan_rs_chunk.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32,
                                            vp, vp, vp, vp, vp, vp, vp]
     lib.l2a_lstm_plan_rs_chunk.restype = i32
     lib.l2a_lstm_predict.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
@@ -172,12 +174,36 @@ class Context(object):
         """0 = never, 1 = auto (default; shares the middle set of odd ensembles), 2 = whole sets only."""
         self.check(self.lib.l2a_set_split(self.handle, int(policy)), "l2a_set_split")
 
+    def launch_status_value(self):
+        """Status word of the launches since the last call (stream must be synchronised); reading clears it."""
+        st = ctypes.c_int()
+        self.check(self.lib.l2a_launch_status(self.handle, ctypes.byref(st)), "l2a_launch_status")
+        return st.value
+
     def launch_status(self):
         """Status of the launches since the last call (stream must be synchronised).  Raises when a
         member-split exchange timed out - results of those launches are invalid."""
-        st = ctypes.c_int()
-        self.check(self.lib.l2a_launch_status(self.handle, ctypes.byref(st)), "l2a_launch_status")
-        if st.value != 0:
+        st = self.launch_status_value()
+        if st != 0:
             raise L2AError("rollout launch reported status 0x%x (member-split exchange timed out; "
-                           "set L2A_SPLIT=0 to disable the split)" % st.value)
-        return st.value
+                           "set L2A_SPLIT=0 to disable the split)" % st)
+        return st
+
+    def check_or_degrade(self):
+        """After a stream sync: True when every launch since the last check was fine.  A tile-split exchange
+        that timed out (the two workgroups of a tile were not co-resident, e.g. another process shares the GPU)
+        invalidates those launches: the context is switched to the unsplit launch geometry for good - same
+        bits, fewer busy CUs - and False is returned so that the caller relaunches.  Raises only when launches
+        fail although the split is already off."""
+        st = self.launch_status_value()
+        if st == 0:
+            return True
+        if getattr(self, "split_degraded", False):
+            raise L2AError("rollout launch reported status 0x%x with the tile split disabled" % st)
+        self.set_split(0)
+        self.split_degraded = True
+        return False
+
+    def set_spin_limit(self, polls):
+        """Developer / test knob: polls a split workgroup waits for its partner per launch (0 = default)."""
+        self.check(self.lib.l2a_set_spin_limit(self.handle, int(polls)), "l2a_set_spin_limit")

@@ -39,7 +39,9 @@ def build_rng(verbose=True):
         if verbose:
             print("[l2a] gcc not found: skipping libl2a_rng.so (parity mode falls back to np.random.random_sample)")
         return None
-    subprocess.check_call([gcc, "-O3", "-fPIC", "-shared", os.path.join(HERE, "l2a_rng.c"), "-o", RNG_OUT])
+    # -ffp-contract=off: NumPy's baseline build has no FMA; a contracted x1*x1 + x2*x2 would change bits
+    subprocess.check_call([gcc, "-O3", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
+                           os.path.join(HERE, "l2a_rng.c"), "-o", RNG_OUT, "-lm"])
     return RNG_OUT
 
 

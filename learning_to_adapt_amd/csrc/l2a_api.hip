@@ -114,6 +114,7 @@ int sa_elems_for(const l2a_model* md, int nt) {
 
 int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     l2a_ctx* ctx = md->ctx;
+    l2a_device_guard guard(ctx->device);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     const int sets_needed = (p.mode == L2A_MODE_PER_BLOCK) ? (p.m < md->n_sets ? p.m : md->n_sets) : md->n_sets;
     for (int e = 0; e < sets_needed; ++e) {
@@ -168,7 +169,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             if (need > md->xbuf_granules) {
                 if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
                 L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));
-                L2A_HIP(ctx, hipMemset(md->xbuf, 0, (size_t)need * 8));
+                L2A_HIP(ctx, hipMemsetAsync(md->xbuf, 0, (size_t)need * 8, stream));   // ordered before the launch
                 md->xbuf_granules = need;
                 md->launch_nonce = 0;
             }
@@ -180,6 +181,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             p.xtag = md->launch_nonce << 12;
             p.xbuf = md->xbuf;
             p.status = ctx->status_dev;
+            p.spin_limit = ctx->spin_limit;
         }
         p.dbg = ctx->dbg;
         const dim3 grid((unsigned)(pairs + (p.split ? split_pairs : 0))), block(64 * L2A_NW);
@@ -280,6 +282,12 @@ int l2a_set_split(l2a_ctx* ctx, int policy) {
     if (!ctx) return L2A_EINVAL;
     if (policy < 0 || policy > 2) return fail(ctx, L2A_EINVAL, "split policy must be 0, 1 or 2");
     ctx->split_policy = policy;
+    return L2A_OK;
+}
+
+int l2a_set_spin_limit(l2a_ctx* ctx, unsigned int polls) {
+    if (!ctx) return L2A_EINVAL;
+    ctx->spin_limit = polls ? polls : (1u << 18);
     return L2A_OK;
 }
 
@@ -417,6 +425,7 @@ int l2a_model_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_hidden, const
 
 void l2a_model_destroy(l2a_model* md) {
     if (!md) return;
+    l2a_device_guard guard(md->ctx->device);
     if (md->wblk) {
         (void)hipDeviceSynchronize();
         (void)hipFree(md->wblk);
@@ -435,6 +444,7 @@ int l2a_model_set_weights_strided(l2a_model* md, int first_set, int count, const
     if (!device_ptrs) return fail(ctx, L2A_EINVAL, "device_ptrs is null");
     if (count > 1 && !set_strides) return fail(ctx, L2A_EINVAL, "set_strides is null");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     float* blk = md->wblk + (long long)first_set * md->set_stride;
     const size_t dpitch = sizeof(float) * (size_t)md->set_stride;
     // One strided device-to-device copy of `n` floats per set (hipMemcpy2DAsync: `count` rows).
@@ -491,6 +501,7 @@ int l2a_model_adapt_sgd(l2a_model* md, const void* const* base_ptrs, const float
         return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd: needs an identity output layer and a relu / tanh / "
                                      "sigmoid / identity hidden nonlinearity");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     L2AAdaptParams ap;
     std::memset(&ap, 0, sizeof(ap));
     const int L = md->n_hidden + 1;
@@ -553,6 +564,7 @@ int l2a_model_get_weights(l2a_model* md, int e, void* const* device_ptrs_out, vo
     if (!device_ptrs_out) return fail(ctx, L2A_EINVAL, "device_ptrs_out is null");
     if (!md->weights_set[e]) return fail(ctx, L2A_ESTATE, "weight set " + std::to_string(e) + " was never set");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     const float* blk = md->wblk + (long long)e * md->set_stride;
     int k_in = md->in_dim;
     for (int l = 0; l <= md->n_hidden; ++l) {
@@ -578,6 +590,7 @@ int l2a_model_set_norm(l2a_model* md, int e, const double* mean_obs, const doubl
     if (n_null != 0 && n_null != 6)
         return fail(ctx, L2A_EINVAL, "pass all six normalisation vectors, or none for identity");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     const int KG0 = md->KG0, OT = md->OT;
     std::vector<float>& st = md->norm_stage[e];
     // a previous async copy from this staging buffer must have drained before we overwrite it
@@ -606,7 +619,7 @@ int l2a_model_set_norm(l2a_model* md, int e, const double* mean_obs, const doubl
 }
 
 int l2a_plan_rs(l2a_model* md, const float* obs0, const float* actions, int m, int n, int h,
-                float discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
                 unsigned long long* best_key, void* stream_v) {
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
@@ -620,6 +633,7 @@ int l2a_plan_rs(l2a_model* md, const float* obs0, const float* actions, int m, i
     if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
         return fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     if (best_key) L2A_HIP(ctx, hipMemsetAsync(best_key, 0, sizeof(unsigned long long) * (size_t)m, stream));
     L2AKParams p;
     fill_model_params(md, p);
@@ -631,7 +645,7 @@ int l2a_plan_rs(l2a_model* md, const float* obs0, const float* actions, int m, i
 }
 
 int l2a_plan_rs_chunk(l2a_model* md, const float* state, int state_per_row, const float* actions, int m, int n,
-                      int h_chunk, int t0, float discount, const l2a_reward* reward, int cand_offset,
+                      int h_chunk, int t0, double discount, const l2a_reward* reward, int cand_offset,
                       const float* returns_in, float* returns_out, float* state_out, unsigned long long* best_key,
                       void* stream_v) {
     if (!md) return L2A_EINVAL;
@@ -648,6 +662,7 @@ int l2a_plan_rs_chunk(l2a_model* md, const float* state, int state_per_row, cons
     if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
         return fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     if (best_key) L2A_HIP(ctx, hipMemsetAsync(best_key, 0, sizeof(unsigned long long) * (size_t)m, stream));
     L2AKParams p;
     fill_model_params(md, p);
@@ -655,7 +670,7 @@ int l2a_plan_rs_chunk(l2a_model* md, const float* state, int state_per_row, cons
     p.actions = actions; p.returns_out = returns_out; p.best_key = best_key; p.state_out = state_out;
     p.ret_in = (t0 > 0) ? returns_in : nullptr;
     double d0 = 1.0;    // discount ** t0 by the kernel's own recurrence (bit-identical continuation)
-    for (int t = 0; t < t0; ++t) d0 *= (double)discount;
+    for (int t = 0; t < t0; ++t) d0 *= discount;
     p.disc0 = d0;
     p.m = m; p.n = n; p.h = h_chunk; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
     return launch_rollout(md, p, stream_v);
@@ -675,7 +690,7 @@ int l2a_predict(l2a_model* md, const float* obs, const float* act, int rows, int
     p.obs0 = obs; p.actions = act; p.returns_out = nullptr; p.best_key = nullptr;
     p.state_out = next_obs_out; p.obs_per_row = 1;
     p.ret_in = nullptr; p.disc0 = 1.0;
-    p.m = n_blocks; p.n = rows / n_blocks; p.h = 1; p.cand_offset = 0; p.discount = 1.0f;
+    p.m = n_blocks; p.n = rows / n_blocks; p.h = 1; p.cand_offset = 0; p.discount = 1.0;
     std::memset(&p.rw, 0, sizeof(p.rw));
     return launch_rollout(md, p, stream_v);
 }

@@ -15,6 +15,7 @@ struct l2a_ctx {
     unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
     unsigned int* status_dev = nullptr;
     unsigned long long* dbg = nullptr;    // optional timeline buffer (l2a_set_debug_buffer)
+    unsigned int spin_limit = 1u << 18;   // exchange polls per workgroup and launch before it gives up (~0.5 s)
     int num_cu = 0;
     int lds_per_block = 0;
     int clock_khz = 0;
@@ -34,3 +35,15 @@ int l2a_fail(const l2a_ctx* ctx, int code, const std::string& msg);
     } while (0)
 
 inline int l2a_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Makes the context's device current for the duration of an entry point and restores the caller's (a process
+// driving several GPUs, or a torch thread whose current device differs from the model's).
+struct l2a_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit l2a_device_guard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+    }
+    ~l2a_device_guard() { if (switched) (void)hipSetDevice(prev); }
+};
+

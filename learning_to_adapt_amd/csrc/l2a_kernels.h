@@ -59,7 +59,7 @@ struct L2AKParams {
     int m, n, h;
     int tiles_per_env;
     int cand_offset;
-    float discount;
+    double discount;            // float64 like the reference's `self.discount ** t` (:126)
     l2a_reward rw;
     // ---- member split (MFMA kernel, mean mode): two workgroups share one candidate tile ----
     int split;                  // 0: one workgroup runs all members; 1: group A | group B; 2: + shared set
@@ -68,6 +68,7 @@ struct L2AKParams {
     unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1
     unsigned long long* xbuf;   // exchange granules [pair][group][slot][NT*OT*4][64]
     unsigned int* status;       // host-visible word; bit 0 set = exchange timed out
+    unsigned int spin_limit;    // polls one workgroup may spend waiting for its partner, per launch
     unsigned long long* dbg;    // optional phase timeline (tools/timeline.py); null in production
 };
 

@@ -54,7 +54,7 @@ struct L2ALstmParams {
     int m, n, h;
     int tiles_per_env;
     int cand_offset;
-    float discount;
+    double discount;
     l2a_reward rw;
     unsigned long long* dbg;
 };
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 
         // ---- every wave sums the 8 chunk partials in the canonical order, then reward / state ----
         const float disc_t = (float)disc_pow;
-        disc_pow *= (double)p.discount;
+        disc_pow *= p.discount;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[nt];

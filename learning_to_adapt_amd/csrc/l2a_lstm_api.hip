@@ -49,6 +49,7 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
 int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v) {
     l2a_ctx* ctx = md->ctx;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     if (!md->weights_set) return l2a_fail(ctx, L2A_ESTATE, "LSTM weights were never set");
     if (!md->norm_set) return l2a_fail(ctx, L2A_ESTATE, "LSTM normalisation was never set");
     int kind = ctx->kernel_kind;
@@ -149,6 +150,7 @@ int l2a_lstm_set_weights(l2a_lstm* md, const void* const* device_ptrs, void* str
     for (int i = 0; i < 4; ++i)
         if (!device_ptrs[i]) return l2a_fail(ctx, L2A_EINVAL, "null LSTM parameter pointer " + std::to_string(i));
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     const int U = md->units;
     const float* wk = static_cast<const float*>(device_ptrs[0]);
     const float* wo = static_cast<const float*>(device_ptrs[2]);
@@ -185,6 +187,7 @@ int l2a_lstm_set_norm(l2a_lstm* md, const double* mean_obs, const double* std_ob
     if (n_null != 0 && n_null != 6)
         return l2a_fail(ctx, L2A_EINVAL, "pass all six normalisation vectors, or none for identity");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     const int KG0 = md->KG0, OT = md->OT;
     std::vector<float>& st = md->norm_stage;
     if (!st.empty()) L2A_HIP(ctx, hipStreamSynchronize(stream));
@@ -211,7 +214,7 @@ int l2a_lstm_set_norm(l2a_lstm* md, const double* mean_obs, const double* std_ob
 }
 
 int l2a_lstm_plan_rs(l2a_lstm* md, const float* obs0, const float* c0, const float* h0, const float* actions,
-                     int m, int n, int h, float discount, const l2a_reward* reward, int cand_offset,
+                     int m, int n, int h, double discount, const l2a_reward* reward, int cand_offset,
                      float* returns_out, unsigned long long* best_key, void* stream_v) {
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
@@ -226,6 +229,7 @@ int l2a_lstm_plan_rs(l2a_lstm* md, const float* obs0, const float* c0, const flo
     if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
         return l2a_fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     if (best_key) L2A_HIP(ctx, hipMemsetAsync(best_key, 0, sizeof(unsigned long long) * (size_t)m, stream));
     L2ALstmParams p;
     fill(md, p);
@@ -236,7 +240,7 @@ int l2a_lstm_plan_rs(l2a_lstm* md, const float* obs0, const float* c0, const flo
 }
 
 int l2a_lstm_plan_rs_chunk(l2a_lstm* md, const float* state, const float* c, const float* h, int per_row,
-                           const float* actions, int m, int n, int h_chunk, int t0, float discount,
+                           const float* actions, int m, int n, int h_chunk, int t0, double discount,
                            const l2a_reward* reward, int cand_offset, const float* returns_in, float* returns_out,
                            float* state_out, float* c_out, float* h_out, unsigned long long* best_key, void* stream_v) {
     if (!md) return L2A_EINVAL;
@@ -257,6 +261,7 @@ int l2a_lstm_plan_rs_chunk(l2a_lstm* md, const float* state, const float* c, con
     if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
         return l2a_fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
     if (best_key) L2A_HIP(ctx, hipMemsetAsync(best_key, 0, sizeof(unsigned long long) * (size_t)m, stream));
     L2ALstmParams p;
     fill(md, p);
@@ -266,7 +271,7 @@ int l2a_lstm_plan_rs_chunk(l2a_lstm* md, const float* state, const float* c, con
     p.state_out = state_out; p.c_out = c_out; p.h_out = h_out;
     p.ret_in = (t0 > 0) ? returns_in : nullptr;
     double d0 = 1.0;
-    for (int t = 0; t < t0; ++t) d0 *= (double)discount;
+    for (int t = 0; t < t0; ++t) d0 *= discount;
     p.disc0 = d0;
     p.m = m; p.n = n; p.h = h_chunk; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
     return launch(md, p, stream_v);
@@ -284,7 +289,7 @@ int l2a_lstm_predict(l2a_lstm* md, const float* obs, const float* act, const flo
     p.obs0 = obs; p.c0 = c; p.h0 = h; p.actions = act;
     p.state_out = next_obs_out; p.c_out = c_out; p.h_out = h_out;
     p.obs_per_row = 1; p.hid_per_row = 1;
-    p.m = 1; p.n = rows; p.h = 1; p.discount = 1.0f;
+    p.m = 1; p.n = rows; p.h = 1; p.discount = 1.0;
     return launch(md, p, stream_v);
 }
 

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) l2a_lstm_valu_k(const L2ALstmParams p) {
             }
             rs_[j] = fmaf((float)disc_pow, r, rs_[j]);
         }
-        disc_pow *= (double)p.discount;
+        disc_pow *= p.discount;
         __syncthreads();
         for (int d = s; d < obs_dim; d += 16) ss[j * obs_dim + d] += ds[j * obs_dim + d];
         __syncthreads();

@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     f32x4* hoth = buf1;
     const float e_count = (float)e_loop;
     double disc_pow = p.disc0;  // discount ** t, carried in float64 like the reference (:126)
+    unsigned int spin_left = p.spin_limit;      // exchange polls this workgroup may still spend (whole launch)
 
     // Which sets this workgroup runs (split: 0 = all; 1 = group A | group B; 2 = as 1, but the
     // last set of group A is SHARED: both workgroups run it as a "half member" - layer 0 and the
@@ -777,10 +778,13 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     if (split == 2) ok = xget(1, oth[1]);
                     if (want0) ok = xget(0, oth[0]) && ok;
                     if (__all(ok)) break;
-                    if (++spins > (1u << 22)) {     // partner never arrived: flag it, do not hang
+                    ++spins;
+                    if (spin_left == 0) {           // partner never arrived: flag it, do not hang; the budget is per
+                                                    // launch, so the remaining steps give up after one poll each
                         if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
+                    --spin_left;
                     __builtin_amdgcn_s_sleep(4);
                 }
 #pragma unroll
@@ -833,7 +837,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
         // ---- ensemble mean, reward, state update -------------------------------------------
         const float disc_t = (float)disc_pow;
-        disc_pow *= (double)p.discount;
+        disc_pow *= p.discount;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[nt];

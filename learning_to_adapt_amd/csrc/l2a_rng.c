@@ -1,18 +1,39 @@
 /*
- * l2a_rng.c - host helper (plain C, no GPU): the double stream of NumPy's legacy global generator, faster.
+ * l2a_rng.c - host helper (plain C, no GPU): NumPy's legacy global generator, faster and on several threads.
  *
- * Parity mode draws its candidate actions from `np.random` exactly as the reference does
- * (policies/mpc_controller.py:67-69).  The legacy `RandomState.random_sample` produces
- *     (a * 67108864 + b) / 9007199254740992,  a = next32() >> 5,  b = next32() >> 6
- * from the MT19937 sequence (Matsumoto & Nishimura's reference generator, as in
- * numpy/random/src/mt19937/mt19937.c); this file restates that generator with the two state-update loops and
- * the tempering written so that gcc vectorises them (dependency distances are 227 / 397 words), ~3x the
- * speed of the scalar loop.  The Python side (`learning_to_adapt_amd/utils/fast_rng.py`) takes the state out of
- * `np.random.get_state()`, calls `l2a_mt19937_fill_double` and puts the advanced state back, and verifies the
- * stream against `np.random.random_sample` once per process before trusting it.
+ * Parity mode draws its candidate actions from `np.random` exactly as the reference does:
+ *   random shooting  np.random.uniform(low, high, (h*n*m, act_dim))        policies/mpc_controller.py:67-69,114
+ *   CEM              np.random.normal(size=(n, m, h*act_dim))              policies/mpc_controller.py:85
+ * Both consume the MT19937 word stream of the legacy `RandomState` (Matsumoto & Nishimura's reference
+ * generator, numpy/random/src/mt19937/mt19937.c):
+ *   random_sample :  (a * 67108864 + b) / 9007199254740992,  a = next32() >> 5,  b = next32() >> 6
+ *   uniform       :  low + (high - low) * random_sample           (two roundings, no FMA)
+ *   legacy_gauss  :  polar method on pairs x = 2 * random_sample - 1, r2 = x1*x1 + x2*x2, rejected when
+ *                    r2 >= 1 or r2 == 0; f = sqrt(-2 log(r2) / r2); returns f*x2, caches f*x1 for the next call
+ *                    (numpy/random/src/legacy/legacy-distributions.c)
+ * This file restates them so that
+ *   - the state-update loops and the tempering vectorise (dependency distances 227 / 397 words),
+ *   - T threads generate DISJOINT SLICES OF THE SAME STREAM: a slice's start state is reached by fast-forwarding
+ *     a copy of the state (state updates only, no tempering / conversion: ~0.1 ns per word, an order of magnitude
+ *     cheaper than producing the numbers), or, for long distances, by `l2a_mt19937_jump` (polynomial jump-ahead),
+ *   - the Gaussian's rejection loop becomes a data-parallel compaction: every attempt consumes exactly one pair of
+ *     doubles, so attempt k always reads doubles 2k, 2k+1 of the stream whatever happened to attempts < k,
+ *   - the float64 -> fp32 cast, the rank's candidate slice and the [h, rows, act] transposition of the CEM
+ *     samples are fused into the draw (the planner's pinned staging buffer is written directly).
+ * The Python side (`learning_to_adapt_amd/utils/fast_rng.py`) moves the state out of `np.random.get_state()`, calls
+ * in here and puts the advanced state back; it trusts each entry point only after it has reproduced NumPy's own
+ * call on the running machine (libm's `log` is the same shared object NumPy calls).
+ *
+ * Built with -ffp-contract=off: NumPy's baseline build has no FMA, a fused x1*x1 + x2*x2 would change bits.
  */
-#include <stdint.h>
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
 #include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 #define MT_N 624
 #define MT_M 397
@@ -20,9 +41,11 @@
 #define MT_UP 0x80000000U
 #define MT_LO 0x7fffffffU
 
-/* runtime dispatch: the AVX2 clone is picked on CPUs that have it (the library is built on one machine and
- * runs on another, so no -march=native) */
+/* runtime dispatch: the AVX2 / AVX-512 clone is picked on CPUs that have it (the library is built on one machine
+ * and runs on another, so no -march=native) */
 #define L2A_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+
+typedef struct { uint32_t key[MT_N]; int pos; } mt_t;
 
 L2A_CLONES static void mt_regen(uint32_t* mt) {
     int kk;
@@ -50,18 +73,25 @@ static inline uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-/* Fill out[0..n) with the next n doubles of the stream; key[624] and *pos are NumPy's legacy state and are
- * advanced in place.  Returns 0, or -1 on a bad argument. */
-L2A_CLONES int l2a_mt19937_fill_double(uint32_t* key, int* pos, double* out, long long n) {
-    if (!key || !pos || !out || n < 0 || *pos < 0 || *pos > MT_N) return -1;
+/* Advance the state by `words` 32-bit outputs without producing them. */
+static void mt_skip(mt_t* s, long long words) {
+    while (words > 0) {
+        if (s->pos >= MT_N) { mt_regen(s->key); s->pos = 0; }
+        long long take = MT_N - s->pos;
+        if (take > words) take = words;
+        s->pos += (int)take;
+        words -= take;
+    }
+}
+
+/* The next n doubles of the stream. */
+L2A_CLONES static void mt_fill_double(mt_t* s, double* out, long long n) {
     long long i = 0;
-    int p = *pos;
+    int p = s->pos;
+    uint32_t* key = s->key;
     uint32_t t[MT_N];
     while (i < n) {
-        if (p >= MT_N) {
-            mt_regen(key);
-            p = 0;
-        }
+        if (p >= MT_N) { mt_regen(key); p = 0; }
         /* temper the rest of this block at once, then pair the words up */
         const int avail = MT_N - p;
         int k;
@@ -82,6 +112,413 @@ L2A_CLONES int l2a_mt19937_fill_double(uint32_t* key, int* pos, double* out, lon
             p = 1;
         }
     }
-    *pos = p;
+    s->pos = p;
+}
+
+/* ---- a small persistent thread pool ------------------------------------------------------------------------
+ * Jobs are fork-join; the caller runs slice 0.  Workers sleep on a condition variable between jobs.  If the
+ * process forked after the pool was created (the reference forks its env workers, samplers/sampler.py:37), the
+ * child has no worker threads: the pid check rebuilds the pool there. */
+#define L2A_MAXT 32
+typedef void (*job_fn)(void* arg, int tid, int nthreads);
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_start, cv_done;
+    pthread_t th[L2A_MAXT];
+    int n_workers;
+    pid_t pid;
+    job_fn fn;
+    void* arg;
+    int nthreads;       /* participants of the current job (incl. the caller) */
+    unsigned gen;       /* job generation */
+    int pending;
+    unsigned seen0[L2A_MAXT];   /* generation each worker starts from (set by its creator) */
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, {0}};
+static pthread_mutex_t g_call_mu = PTHREAD_MUTEX_INITIALIZER;      /* one parallel job at a time */
+
+static void* pool_worker(void* idp) {
+    const int id = (int)(intptr_t)idp;      /* 1 .. n_workers */
+    pthread_mutex_lock(&g_pool.mu);
+    unsigned seen = g_pool.seen0[id];
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.cv_start, &g_pool.mu);
+        seen = g_pool.gen;
+        if (id < g_pool.nthreads) {
+            job_fn fn = g_pool.fn;
+            void* arg = g_pool.arg;
+            const int nt = g_pool.nthreads;
+            pthread_mutex_unlock(&g_pool.mu);
+            fn(arg, id, nt);
+            pthread_mutex_lock(&g_pool.mu);
+            if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+        }
+    }
+    return NULL;
+}
+
+static void pool_atfork_child(void) {        /* the child owns no worker threads and no held locks */
+    pthread_mutex_init(&g_call_mu, NULL);
+    g_pool.pid = 0;
+}
+
+static void pool_register_atfork(void) { pthread_atfork(NULL, NULL, pool_atfork_child); }
+
+static void run_parallel(job_fn fn, void* arg, int nthreads) {
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    if (nthreads > L2A_MAXT) nthreads = L2A_MAXT;
+    if (nthreads <= 1) { fn(arg, 0, 1); return; }
+    pthread_once(&once, pool_register_atfork);
+    pthread_mutex_lock(&g_call_mu);
+    if (g_pool.pid != getpid()) {           /* first use, or a forked child */
+        pthread_mutex_init(&g_pool.mu, NULL);
+        pthread_cond_init(&g_pool.cv_start, NULL);
+        pthread_cond_init(&g_pool.cv_done, NULL);
+        g_pool.n_workers = 0;
+        g_pool.gen = 0;
+        g_pool.pid = getpid();
+    }
+    while (g_pool.n_workers < nthreads - 1) {
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        const int id = g_pool.n_workers + 1;
+        g_pool.seen0[id] = g_pool.gen;      /* jobs are only posted below, under g_call_mu */
+        if (pthread_create(&g_pool.th[id], &at, pool_worker, (void*)(intptr_t)id) != 0) {
+            pthread_attr_destroy(&at);
+            nthreads = g_pool.n_workers + 1;            /* make do with what we have */
+            break;
+        }
+        pthread_attr_destroy(&at);
+        g_pool.n_workers = id;
+    }
+    if (nthreads <= 1) { pthread_mutex_unlock(&g_call_mu); fn(arg, 0, 1); return; }
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.fn = fn; g_pool.arg = arg; g_pool.nthreads = nthreads; g_pool.pending = nthreads - 1;
+    g_pool.gen += 1;
+    pthread_cond_broadcast(&g_pool.cv_start);
+    pthread_mutex_unlock(&g_pool.mu);
+    fn(arg, 0, nthreads);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.pending != 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_call_mu);
+}
+
+static inline long long slice_lo(long long n, int tid, int nt) { return n * tid / nt; }
+
+/* ---- plain doubles ----------------------------------------------------------------------------------------- */
+typedef struct { const mt_t* s0; double* out; long long n; mt_t end; } fill_job;
+
+static void fill_slice(void* argp, int tid, int nt) {
+    fill_job* j = (fill_job*)argp;
+    const long long lo = slice_lo(j->n, tid, nt), hi = slice_lo(j->n, tid + 1, nt);
+    mt_t s = *j->s0;
+    mt_skip(&s, 2 * lo);
+    mt_fill_double(&s, j->out + lo, hi - lo);
+    if (tid == nt - 1) j->end = s;
+}
+
+/* Fill out[0..n) with the next n doubles of the stream; key[624] and *pos are NumPy's legacy state and are
+ * advanced in place.  Returns 0, or -1 on a bad argument. */
+int l2a_mt19937_fill_double_mt(uint32_t* key, int* pos, double* out, long long n, int nthreads) {
+    if (!key || !pos || !out || n < 0 || *pos < 0 || *pos > MT_N) return -1;
+    mt_t s0;
+    memcpy(s0.key, key, sizeof(s0.key));
+    s0.pos = *pos;
+    if (n < 65536) nthreads = 1;
+    fill_job j = {&s0, out, n, s0};
+    if (n > 0) run_parallel(fill_slice, &j, nthreads);
+    memcpy(key, j.end.key, sizeof(s0.key));
+    *pos = j.end.pos;
     return 0;
 }
+
+int l2a_mt19937_fill_double(uint32_t* key, int* pos, double* out, long long n) {
+    return l2a_mt19937_fill_double_mt(key, pos, out, n, 1);
+}
+
+/* Advance the state by `words` 32-bit outputs (a double consumes two). */
+int l2a_mt19937_skip(uint32_t* key, int* pos, long long words) {
+    if (!key || !pos || words < 0 || *pos < 0 || *pos > MT_N) return -1;
+    mt_t s;
+    memcpy(s.key, key, sizeof(s.key));
+    s.pos = *pos;
+    mt_skip(&s, words);
+    memcpy(key, s.key, sizeof(s.key));
+    *pos = s.pos;
+    return 0;
+}
+
+/* ---- the random-shooting draw, fused -------------------------------------------------------------------------
+ * `get_random_action(h*n*m)` + `.reshape(h, n*m, act_dim)` (policies/mpc_controller.py:67-69,114): rows of act_dim
+ * doubles, value = low[k] + (high[k] - low[k]) * u.  Row r of the stream belongs to candidate j = r % period
+ * (period = n); rows with sel_lo <= j < sel_hi (this rank's shard) are cast to fp32 and written compactly to
+ * out_f32 (row-major, the layout l2a_plan_rs reads).  The first rows64 rows are also kept in float64 (out_f64):
+ * `cand_a = a[0]`, whose winner the controller returns (:118,129).  Consumes rows * act_dim doubles. */
+typedef struct {
+    const mt_t* s0; mt_t end;
+    long long rows; int act_dim; const double* low; const double* range;
+    long long period, sel_lo, sel_hi; float* out_f32;
+    long long rows64; double* out_f64;
+} uni_job;
+
+L2A_CLONES static void uniform_rows(const uni_job* j, mt_t* s, long long r0, long long r1) {
+    enum { BLK = 1024 };
+    const int ad = j->act_dim;
+    const long long nsel = j->sel_hi - j->sel_lo;
+    double u[BLK * 16], rng_t[BLK * 16], low_t[BLK * 16];
+    const long long rows_per_blk = (BLK * 16) / ad;
+    for (long long q = 0; q < rows_per_blk; ++q)        /* bounds tiled over a block: the affine map vectorises */
+        for (int k = 0; k < ad; ++k) { rng_t[q * ad + k] = j->range[k]; low_t[q * ad + k] = j->low[k]; }
+    for (long long r = r0; r < r1; r += rows_per_blk) {
+        const long long nr = (r1 - r < rows_per_blk) ? r1 - r : rows_per_blk;
+        mt_fill_double(s, u, nr * ad);
+        for (long long e = 0; e < nr * ad; ++e) {
+            const double v = u[e] * rng_t[e];
+            u[e] = v + low_t[e];
+        }
+        if (j->out_f64 && r < j->rows64) {
+            const long long n64 = (j->rows64 - r < nr) ? j->rows64 - r : nr;
+            memcpy(j->out_f64 + r * ad, u, sizeof(double) * (size_t)(n64 * ad));
+        }
+        if (j->out_f32) {
+            long long q = 0;
+            while (q < nr) {
+                const long long row = r + q;
+                const long long cand = row % j->period, blk = row / j->period;
+                if (cand >= j->sel_hi) { q += j->period - cand; continue; }
+                if (cand < j->sel_lo) { q += j->sel_lo - cand; continue; }
+                long long run = j->sel_hi - cand;           /* consecutive selected rows */
+                if (run > nr - q) run = nr - q;
+                float* dst = j->out_f32 + (blk * nsel + (cand - j->sel_lo)) * ad;
+                const double* src = u + q * ad;
+                for (long long e = 0; e < run * ad; ++e) dst[e] = (float)src[e];
+                q += run;
+            }
+        }
+    }
+}
+
+static void uniform_slice(void* argp, int tid, int nt) {
+    uni_job* j = (uni_job*)argp;
+    const long long lo = slice_lo(j->rows, tid, nt), hi = slice_lo(j->rows, tid + 1, nt);
+    mt_t s = *j->s0;
+    mt_skip(&s, 2 * lo * j->act_dim);
+    uniform_rows(j, &s, lo, hi);
+    if (tid == nt - 1) j->end = s;
+}
+
+int l2a_mt19937_uniform_rows(uint32_t* key, int* pos, long long rows, int act_dim, const double* low,
+                             const double* high, long long period, long long sel_lo, long long sel_hi,
+                             float* out_f32, long long rows64, double* out_f64, int nthreads) {
+    if (!key || !pos || !low || !high || rows < 0 || act_dim < 1 || act_dim > 16 || *pos < 0 || *pos > MT_N) return -1;
+    if (period < 1 || sel_lo < 0 || sel_hi < sel_lo || sel_hi > period || rows64 < 0 || rows64 > rows) return -1;
+    double range[16];
+    for (int k = 0; k < act_dim; ++k) range[k] = high[k] - low[k];
+    mt_t s0;
+    memcpy(s0.key, key, sizeof(s0.key));
+    s0.pos = *pos;
+    uni_job j = {&s0, s0, rows, act_dim, low, range, period, sel_lo, sel_hi, (sel_hi > sel_lo) ? out_f32 : NULL,
+                 rows64, out_f64};
+    if (rows * act_dim < 65536) nthreads = 1;
+    if (rows > 0) run_parallel(uniform_slice, &j, nthreads);
+    memcpy(key, j.end.key, sizeof(s0.key));
+    *pos = j.end.pos;
+    return 0;
+}
+
+/* ---- legacy Gaussian ----------------------------------------------------------------------------------------- */
+typedef struct {
+    const mt_t* s0;
+    long long attempts;         /* attempts of this round, split over the threads */
+    double* tmp;                /* [attempts][2] accepted values, thread slices at 2 * slice_lo */
+    int* tmp_idx;               /* [attempts] attempt index of every accepted pair */
+    long long count[L2A_MAXT];
+    /* phase 2 */
+    double* out; long long out_pairs; long long prefix[L2A_MAXT + 1];
+} gauss_job;
+
+L2A_CLONES static long long gauss_attempts(mt_t* s, long long a0, long long a1, double* vals, int* idx) {
+    enum { BLK = 2048 };
+    double u[2 * BLK], r2v[BLK], c1[BLK], c2[BLK], cr[BLK], lg[BLK];
+    long long c = 0;
+    for (long long a = a0; a < a1; a += BLK) {
+        const int na = (int)((a1 - a < BLK) ? a1 - a : BLK);
+        mt_fill_double(s, u, 2 * (long long)na);
+        for (int k = 0; k < na; ++k) {
+            const double x1 = 2.0 * u[2 * k] - 1.0, x2 = 2.0 * u[2 * k + 1] - 1.0;
+            u[2 * k] = x1; u[2 * k + 1] = x2;
+            r2v[k] = x1 * x1 + x2 * x2;
+        }
+        /* branch-free compaction of the accepted attempts, then the transcendental on a dense array */
+        int nc = 0;
+        for (int k = 0; k < na; ++k) {
+            const double r2 = r2v[k];
+            c1[nc] = u[2 * k]; c2[nc] = u[2 * k + 1]; cr[nc] = r2;
+            idx[c + nc] = (int)(a + k - a0);
+            nc += (int)((r2 < 1.0) & (r2 != 0.0));
+        }
+        for (int k = 0; k < nc; ++k) lg[k] = log(cr[k]);
+        for (int k = 0; k < nc; ++k) {
+            const double f = sqrt(-2.0 * lg[k] / cr[k]);
+            vals[2 * (c + k)] = f * c2[k];          /* returned first */
+            vals[2 * (c + k) + 1] = f * c1[k];      /* cached, returned by the next call */
+        }
+        c += nc;
+    }
+    return c;
+}
+
+static void gauss_phase1(void* argp, int tid, int nt) {
+    gauss_job* j = (gauss_job*)argp;
+    const long long lo = slice_lo(j->attempts, tid, nt), hi = slice_lo(j->attempts, tid + 1, nt);
+    mt_t s = *j->s0;
+    mt_skip(&s, 4 * lo);
+    j->count[tid] = gauss_attempts(&s, lo, hi, j->tmp + 2 * lo, j->tmp_idx + lo);
+}
+
+static void gauss_phase2(void* argp, int tid, int nt) {
+    gauss_job* j = (gauss_job*)argp;
+    const long long lo = slice_lo(j->attempts, tid, nt);
+    long long from = j->prefix[tid], to = j->prefix[tid + 1];
+    if (to > j->out_pairs) to = j->out_pairs;
+    if (to > from) memcpy(j->out + 2 * from, j->tmp + 2 * lo, sizeof(double) * 2 * (size_t)(to - from));
+}
+
+/* out[0..n) = the next n values of `np.random.normal()` / `standard_normal()` of the legacy generator (loc 0,
+ * scale 1); key / pos / has_gauss / gauss are the legacy state (np.random.get_state()) and are advanced. */
+int l2a_mt19937_fill_gauss(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, long long n,
+                           int nthreads) {
+    if (!key || !pos || !has_gauss || !gauss || !out || n < 0 || *pos < 0 || *pos > MT_N) return -1;
+    long long i = 0;
+    if (n > 0 && *has_gauss) { out[i++] = *gauss; *has_gauss = 0; *gauss = 0.0; }
+    long long pairs = (n - i + 1) / 2;             /* accepted attempts still needed */
+    if (pairs == 0) return 0;
+    const int odd = (int)((n - i) & 1);
+    mt_t s;
+    memcpy(s.key, key, sizeof(s.key));
+    s.pos = *pos;
+    double last_cached = 0.0;
+    while (pairs > 0) {
+        long long attempts = (long long)((double)pairs * 1.2742 * 1.01) + 64;     /* 4/pi, + margin */
+        if (attempts > 0x7fffff00LL) attempts = 0x7fffff00LL;
+        int nt = (attempts < 16384) ? 1 : nthreads;
+        if (nt > L2A_MAXT) nt = L2A_MAXT;
+        if (nt < 1) nt = 1;
+        gauss_job j;
+        memset(&j, 0, sizeof(j));
+        j.s0 = &s; j.attempts = attempts;
+        j.tmp = (double*)malloc(sizeof(double) * 2 * (size_t)attempts);
+        j.tmp_idx = (int*)malloc(sizeof(int) * (size_t)attempts);
+        if (!j.tmp || !j.tmp_idx) { free(j.tmp); free(j.tmp_idx); return -2; }
+        /* run_parallel may fall back to fewer threads only when nt collapses to 1; slices are indexed by the
+         * nt actually used, which the job functions receive */
+        j.count[0] = -1;
+        for (int t = 0; t < L2A_MAXT; ++t) j.count[t] = -1;
+        run_parallel(gauss_phase1, &j, nt);
+        int used = 0;
+        while (used < L2A_MAXT && j.count[used] >= 0) ++used;
+        j.prefix[0] = 0;
+        for (int t = 0; t < used; ++t) j.prefix[t + 1] = j.prefix[t] + j.count[t];
+        const long long got = j.prefix[used];
+        const long long take = (got < pairs) ? got : pairs;
+        /* when n is odd the very last pair only contributes its first value */
+        const int ends_here = (take == pairs);
+        const long long full = (ends_here && odd) ? take - 1 : take;
+        j.out = out + i; j.out_pairs = full;
+        run_parallel(gauss_phase2, &j, used);
+        long long used_attempts = attempts;
+        if (ends_here) {
+            /* locate the last accepted pair: thread tl, local index ll */
+            int tl = 0;
+            while (j.prefix[tl + 1] < take) ++tl;
+            const long long ll = take - 1 - j.prefix[tl];
+            const long long lo = slice_lo(attempts, tl, used);
+            used_attempts = lo + j.tmp_idx[lo + ll] + 1;
+            if (odd) {
+                out[i + 2 * full] = j.tmp[2 * (lo + ll)];
+                last_cached = j.tmp[2 * (lo + ll) + 1];
+            }
+        }
+        i += 2 * full + ((ends_here && odd) ? 1 : 0);
+        pairs -= take;
+        mt_skip(&s, 4 * used_attempts);
+        free(j.tmp); free(j.tmp_idx);
+    }
+    memcpy(key, s.key, sizeof(s.key));
+    *pos = s.pos;
+    if (odd) { *has_gauss = 1; *gauss = last_cached; }
+    return 0;
+}
+
+/* ---- one CEM iteration's samples, fused ------------------------------------------------------------------------
+ * `rows` consecutive rows (global flat rows row_base .. row_base + rows - 1 of the n * m drawn by
+ * `np.random.normal(size=(n, m, D))`, D = h * act_dim, policies/mpc_controller.py:85; flat row g = j * m + i) whose
+ * standard normals are already in `z` [rows, D]:
+ *   a        = mean_i + z * std_i             (:86, float64, two roundings)      -> a_out [rows, D] (may alias z)
+ *   a_clip   = clip(a, low, high)             (:87)                              -> clip_out [rows, D] or NULL
+ *   seq_f32  fp32 [h, m * nsel, act_dim], the tensor l2a_plan_rs reads: row of the plan = g in the reference's
+ *            reading (it feeds the candidate-major rows as if they were env-major, :92-96) or i * n + j
+ *            (env_major); of those rows only candidates sel_lo <= row % n < sel_hi are written, compactly
+ *            (this rank's shard, or the candidate chunk being pipelined).  Values: the UNCLIPPED samples in the
+ *            reference (:92-96), the clipped ones when use_clipped.
+ * mean / std: [m, D]. */
+typedef struct {
+    const double* z; long long rows, row_base; int h, act_dim; const double* mean; const double* std; int m;
+    const double* low; const double* high; double* a_out; double* clip_out; float* seq;
+    long long n, sel_lo, sel_hi; int env_major, use_clipped;
+} cem_job;
+
+L2A_CLONES static void cem_slice(void* argp, int tid, int nt) {
+    cem_job* j = (cem_job*)argp;
+    const long long lo = slice_lo(j->rows, tid, nt), hi = slice_lo(j->rows, tid + 1, nt);
+    const int D = j->h * j->act_dim, ad = j->act_dim;
+    const long long nsel = j->sel_hi - j->sel_lo, seq_rows = (long long)j->m * nsel;
+    double av[4096], cv[4096];
+    for (long long r = lo; r < hi; ++r) {
+        const long long g = j->row_base + r;
+        const int env = (int)(g % j->m);
+        const double* zr = j->z + r * D;
+        const double* mu = j->mean + (long long)env * D;
+        const double* sd = j->std + (long long)env * D;
+        for (int t = 0; t < j->h; ++t)
+            for (int k = 0; k < ad; ++k) {
+                const int d = t * ad + k;
+                const double zs = zr[d] * sd[d];
+                const double v = mu[d] + zs;
+                double c = v;
+                if (c < j->low[k]) c = j->low[k];
+                if (c > j->high[k]) c = j->high[k];
+                av[d] = v; cv[d] = c;
+            }
+        memcpy(j->a_out + r * D, av, sizeof(double) * (size_t)D);
+        if (j->clip_out) memcpy(j->clip_out + r * D, cv, sizeof(double) * (size_t)D);
+        if (j->seq) {
+            const long long prow = j->env_major ? (long long)env * j->n + g / j->m : g;
+            const long long cand = prow % j->n, blk = prow / j->n;
+            if (cand >= j->sel_lo && cand < j->sel_hi) {
+                const long long srow = blk * nsel + (cand - j->sel_lo);
+                const double* src = j->use_clipped ? cv : av;
+                for (int t = 0; t < j->h; ++t)
+                    for (int k = 0; k < ad; ++k)
+                        j->seq[((long long)t * seq_rows + srow) * ad + k] = (float)src[t * ad + k];
+            }
+        }
+    }
+}
+
+int l2a_cem_samples(const double* z, long long rows, long long row_base, int h, int act_dim, const double* mean,
+                    const double* std, int m, const double* low, const double* high, double* a_out,
+                    double* clip_out, float* seq_f32, long long n, long long sel_lo, long long sel_hi,
+                    int env_major, int use_clipped, int nthreads) {
+    if (!z || !mean || !std || !low || !high || !a_out || rows < 0 || row_base < 0 || h < 1 || act_dim < 1 || m < 1)
+        return -1;
+    if (h * act_dim > 4096 || n < 1 || sel_lo < 0 || sel_hi < sel_lo || sel_hi > n || row_base + rows > n * m) return -1;
+    cem_job j = {z, rows, row_base, h, act_dim, mean, std, m, low, high, a_out, clip_out,
+                 (sel_hi > sel_lo) ? seq_f32 : NULL, n, sel_lo, sel_hi, env_major, use_clipped};
+    if (rows * h * act_dim < 65536) nthreads = 1;
+    if (rows > 0) run_parallel(cem_slice, &j, nthreads);
+    return 0;
+}
+
+int l2a_rng_version(void) { return 2; }

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) l2a_rollout_valu_k(const L2AKParams p) {
             __syncthreads();
         }
         const float disc_t = (float)disc_pow;
-        disc_pow *= (double)p.discount;
+        disc_pow *= p.discount;
         if (tid < L2A_VT) {
             const int c = tid;
             float asq = 0.0f;

@@ -1,0 +1,141 @@
+"""Draw the planner's NEXT random numbers while the GPU is still busy with the current plan - without changing
+a single bit of what the reference would compute.
+
+The reference draws its candidates from NumPy's global generator at the top of every controller step
+(``policies/mpc_controller.py:67-69,85,114``); the stream is a pure function of the generator state, so the draw
+of step k + 1 is known as soon as step k has consumed its numbers.  A ``DrawAhead`` chain keeps a PRIVATE copy of
+the state (``utils/fast_rng.State``) and a worker thread that produces the upcoming blocks from it (into pinned
+staging, uploading them on a side stream) while the caller waits for the GPU.  The global generator is never
+touched by the worker.  When the caller comes back it asks ``take(sig)``:
+
+* the chain was built for the same request shape AND the global generator is still exactly in the state the next
+  block started from (nobody else drew from ``np.random`` in between - compared word for word): the block is
+  adopted and the global state is set to the block's end state, i.e. precisely where the reference's own draw
+  would have left it;
+* otherwise the chain is dropped, ``take`` returns ``None`` and the caller draws synchronously as before.
+
+Either way the numbers, their order and the generator state seen by everybody else are those of the reference.
+"""
+
+import collections
+import os
+import threading
+
+from ..utils import fast_rng
+
+
+class _Block(object):
+    __slots__ = ("base", "end", "payload", "done", "error", "gen")
+
+    def __init__(self, base, gen):
+        self.base, self.end, self.payload, self.done, self.error, self.gen = base, None, None, False, None, gen
+
+
+class DrawAhead(object):
+    def __init__(self, depth=1):
+        self.depth = int(depth)
+        self.cv = threading.Condition()
+        self.blocks = collections.deque()
+        self.sig = None
+        self.producer = None
+        self.tail = None            # state after the last block handed to the worker
+        self.gen = 0                # bumped on every flush: in-flight work of older generations is discarded
+        self.slot = 0
+        self.thread = None
+        self.pid = None
+        self.misses = 0             # consecutive failed takes (somebody else is drawing from np.random)
+        self.hits = 0
+        self.cooldown = 0
+
+    @property
+    def n_slots(self):
+        return self.depth + 2
+
+    # ------------------------------------------------------------------ consumer side
+    def take(self, sig):
+        """Payload of the next block if it is valid for the current global generator state, else None."""
+        with self.cv:
+            if self.sig != sig or (self.producer is None and not self.blocks):
+                self._flush()
+                return None
+            while not self.blocks:          # the worker has been told to produce and is about to post the block
+                self.cv.wait()
+            blk = self.blocks[0]
+            while not blk.done:
+                self.cv.wait()
+            if blk.error is not None or not blk.base.same_as_global():
+                self._flush()
+                self.misses += 1
+                return None
+            self.blocks.popleft()
+            blk.end.to_global()
+            self.misses = 0
+            self.hits += 1
+            self.cv.notify_all()
+            return blk.payload
+
+    def start(self, sig, producer, depth=None):
+        """(Re)start the chain at the CURRENT global state (call it right after a synchronous draw).  Backs off
+        when takes keep failing (a consumer of ``np.random`` runs between controller steps)."""
+        if not fast_rng.available("double"):
+            return
+        with self.cv:
+            if self.sig == sig and self.blocks and self.producer is not None:
+                return                              # already running for this request
+            if self.misses >= 2:
+                self.cooldown += 1
+                if self.cooldown % 16 != 0:
+                    return
+            base = fast_rng.State.from_global()
+            if base is None:
+                return
+            self._flush()
+            if depth is not None:
+                self.depth = int(depth)
+            self.sig, self.producer, self.tail = sig, producer, base
+            self._ensure_thread()
+            self.cv.notify_all()
+
+    def stop(self):
+        with self.cv:
+            self._flush()
+
+    def _flush(self):
+        self.gen += 1
+        self.blocks.clear()
+        self.sig = None
+        self.producer = None
+        self.tail = None
+        self.cv.notify_all()
+
+    # ------------------------------------------------------------------ worker side
+    def _ensure_thread(self):
+        if self.thread is None or self.pid != os.getpid() or not self.thread.is_alive():
+            self.pid = os.getpid()
+            self.thread = threading.Thread(target=self._run, name="l2a-draw-ahead", daemon=True)
+            self.thread.start()
+
+    def _run(self):
+        while True:
+            with self.cv:
+                while self.producer is None or len(self.blocks) >= self.depth:
+                    self.cv.wait()
+                gen, producer = self.gen, self.producer
+                state = self.tail.copy()
+                blk = _Block(self.tail, gen)
+                self.blocks.append(blk)
+                slot = self.slot
+                self.slot = (self.slot + 1) % self.n_slots
+            payload, error = None, None
+            try:
+                payload = producer(state, slot)
+            except BaseException as exc:        # surfaces as a miss on the consumer side
+                error = exc
+            with self.cv:
+                if gen == self.gen:
+                    blk.payload, blk.error, blk.end = payload, error, state
+                    self.tail = state.copy()
+                    if error is not None:
+                        self.producer = None
+                blk.done = True
+                self.cv.notify_all()

@@ -20,8 +20,17 @@ drawn on the GPU with torch's Philox generator - statistically equivalent, not b
 ``'fixed'`` = clipped rollouts, true top-k elites, env-consistent row order),
 ``shard_candidates`` (use torch.distributed when initialised), ``pipeline_chunks`` (parity mode: the
 plan step is cut into this many horizon chunks so that the host draws / uploads chunk k + 1 while the
-GPU rolls out chunk k - same RNG stream, bit-identical result; 1 = one launch).
+GPU rolls out chunk k - same RNG stream, bit-identical result; 1 = one launch), ``draw_ahead`` (parity
+mode: the NEXT controller step's candidates are drawn on a private copy of the generator state while the
+GPU runs the current plan and adopted only if the global generator is still in exactly that state -
+``policies/draw_ahead.py``; numbers, order and the state left behind are the reference's).
+
+A tile-split launch whose exchange partner was not co-resident (another process on the GPU) flags a status
+word instead of hanging; the controller then switches the context to the unsplit geometry (bit-identical
+results) and relaunches the plan - it never raises mid-rollout for that.
 """
+
+import zlib
 
 import numpy as np
 import torch
@@ -30,6 +39,7 @@ from .. import _lib
 from ..envs.reward_spec import reward_spec_for_env
 from ..utils import fast_rng
 from ..utils.serializable import Serializable
+from .draw_ahead import DrawAhead
 from .policy import Policy, innermost_env
 
 
@@ -52,6 +62,7 @@ class MPCController(Policy, Serializable):
             cem_mode="reference",
             shard_candidates=True,
             pipeline_chunks=5,
+            draw_ahead=True,
     ):
         self.dynamics_model = dynamics_model
         self.reward_model = reward_model
@@ -70,6 +81,7 @@ class MPCController(Policy, Serializable):
         self.cem_mode = cem_mode
         self.shard_candidates = shard_candidates
         self.pipeline_chunks = int(pipeline_chunks)
+        self.draw_ahead = bool(draw_ahead)
 
         self.unwrapped_env = innermost_env(env)
 
@@ -81,6 +93,8 @@ class MPCController(Policy, Serializable):
 
         self._reward_spec = None if use_reward_model else reward_spec_for_env(env)
         self._bufs = {}
+        self._ahead = None          # DrawAhead chain (parity mode), created on first use
+        self._ranks_checked = False
         self.last_plan = None       # diagnostics of the latest fused plan (returns, keys, ...)
 
     @property
@@ -157,6 +171,28 @@ class MPCController(Policy, Serializable):
     def _shard_range(n, rank, world):
         return (rank * n) // world, ((rank + 1) * n) // world
 
+    def _check_ranks_agree(self, world):
+        """Sharded planning lets every rank draw the SAME candidate tensor and keep its slice (parity mode), or the
+        same CEM normals (device mode).  Ranks seeded differently (the common ``seed + rank``) would combine keys
+        and returns that refer to different actions - silently.  Once per controller: all-reduce a digest of the
+        generator state and refuse to plan if the ranks disagree."""
+        if world == 1 or self._ranks_checked:
+            return
+        if self.rng == "numpy":
+            st = np.random.get_state()
+            digest = (zlib.crc32(np.asarray(st[1]).tobytes()) ^ (int(st[2]) << 32)) & 0x7FFFFFFFFFFFFFFF
+            what = "np.random global state"
+        else:
+            digest = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            what = "torch.initial_seed()"
+        t = torch.tensor([digest, -digest], dtype=torch.int64, device=self._device())
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        lo_hi = t.cpu().numpy()
+        if int(lo_hi[0]) != -int(lo_hi[1]):
+            raise _lib.L2AError("candidate sharding needs identical %s on every rank (seed all ranks alike; "
+                                "the shards themselves are disjoint)" % what)
+        self._ranks_checked = True
+
     def _fusable(self):
         return (self._reward_spec is not None) and hasattr(self.dynamics_model, "planner_model")
 
@@ -166,6 +202,22 @@ class MPCController(Policy, Serializable):
             t = torch.empty(shape, dtype=dtype, device=device)
             self._bufs[key] = t
         return t
+
+    def _pinned(self, key, shape, dev=None):
+        """fp32 host staging tensor (page-locked when the planner runs on a GPU)."""
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            dev = dev if dev is not None else self._device()
+            t = torch.empty(tuple(shape), dtype=torch.float32, pin_memory=(dev.type == "cuda"))
+            self._bufs[key] = t
+        return t
+
+    def _host64(self, key, shape):
+        a = self._bufs.get(key)
+        if a is None or a.shape != tuple(shape):
+            a = np.empty(tuple(shape), dtype=np.float64)
+            self._bufs[key] = a
+        return a
 
     # ------------------------------------------------------------------ fused rollout of a candidate batch
     def _device(self):
@@ -186,9 +238,48 @@ class MPCController(Policy, Serializable):
         a_dev.copy_(pin, non_blocking=True)
         return a_dev
 
+    def _to_device(self, pin, key):
+        """Staging tensor -> device tensor ``key`` on the current stream (asynchronous)."""
+        dev = self._device()
+        if dev.type != "cuda":
+            return pin
+        a_dev = self._buf(key, tuple(pin.shape), torch.float32, dev)
+        a_dev.copy_(pin, non_blocking=True)
+        return a_dev
+
+    def _to_device_side(self, pin, key, dev):
+        """As ``_to_device`` but on a private copy stream (the draw-ahead worker's upload must not queue behind
+        the rollout that is running on the main stream).  Returns ``(tensor, event)``.  Runs on the worker
+        thread: it must not touch the dynamics model (``dev`` is captured by the caller)."""
+        if dev.type != "cuda":
+            return pin, None
+        side = self._bufs.get("side_stream")
+        if side is None:
+            side = torch.cuda.Stream(device=dev)
+            self._bufs["side_stream"] = side
+        a_dev = self._buf(key, tuple(pin.shape), torch.float32, dev)
+        with torch.cuda.stream(side):
+            a_dev.copy_(pin, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return a_dev, ev
+
+    def _sync(self):
+        dev = self._device()
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+
     def _check_status(self):
-        """After a device->host read-back (= stream sync): raise if a launch flagged a problem."""
-        self.dynamics_model.planner_model().ctx.launch_status()
+        """After a device->host read-back (= stream sync).  ``False``: a launch since the last check was invalid
+        (its tile-split partner was not co-resident); the context has been switched to the unsplit launch
+        geometry and the caller must relaunch.  Raises only if launches fail with the split already off."""
+        return self.dynamics_model.planner_model().ctx.check_or_degrade()
+
+    def _check_blocks(self, m):
+        blocks = self.dynamics_model.planner_blocks(m)
+        if blocks != 1 and blocks != m:
+            raise _lib.L2AError("the dynamics model holds %d adapted weight sets but %d observations "
+                                "were passed" % (blocks, m))
 
     def _upload_obs(self, observations):
         """``[m, obs_dim]`` host observations -> the fp32 device buffer the rollout reads."""
@@ -205,10 +296,7 @@ class MPCController(Policy, Serializable):
         """
         native = self.dynamics_model.planner_model()
         m = len(observations)
-        blocks = self.dynamics_model.planner_blocks(m)
-        if blocks != 1 and blocks != m:
-            raise _lib.L2AError("the dynamics model holds %d adapted weight sets but %d observations "
-                                "were passed" % (blocks, m))
+        self._check_blocks(m)
         dev = native.device
         obs0 = obs_dev if obs_dev is not None else self._upload_obs(observations)
         best = self._buf("best", (m,), torch.int64, dev)
@@ -216,6 +304,54 @@ class MPCController(Policy, Serializable):
         native.plan_rs(obs0, actions_local, m, n_local, self.horizon, self.discount, self._reward_spec,
                        cand_offset=cand_offset, returns_out=rets, best_key=best)
         return best, rets
+
+    # ------------------------------------------------------------------ parity-mode draws
+    def _draw_rows(self, rows, n, lo, hi, out_f32, rows64=0, out_f64=None):
+        """``rows`` rows of the reference's draw (``get_random_action``, ``:67-69``) from the GLOBAL generator:
+        candidates ``lo <= row % n < hi`` of every block of n rows as fp32 into ``out_f32`` (this rank's shard, the
+        layout ``l2a_plan_rs`` reads), the first ``rows64`` rows as float64 into ``out_f64``.  One threaded pass of
+        ``csrc/l2a_rng.c`` when the helper has proven itself on this machine, NumPy otherwise."""
+        low, high = self.action_space.low, self.action_space.high
+        if fast_rng.available("uniform"):
+            st = fast_rng.State.from_global()
+            if st is not None:
+                st.uniform_rows(rows, low, high, n, lo, hi, out_f32, rows64, out_f64)
+                st.to_global()
+                return
+        a = self.get_random_action(rows)
+        act_dim = a.shape[-1]
+        if out_f64 is not None and rows64:
+            out_f64.reshape(-1, act_dim)[:rows64] = a[:rows64]
+        if out_f32 is not None and hi > lo:
+            np.copyto(out_f32.reshape(-1, hi - lo, act_dim), a.reshape(-1, n, act_dim)[:, lo:hi, :], casting="same_kind")
+
+    def _use_draw_ahead(self, kind="uniform"):
+        return self.draw_ahead and self.rng == "numpy" and fast_rng.available(kind)
+
+    def _ahead_chain(self):
+        if self._ahead is None:
+            self._ahead = DrawAhead(depth=1)
+        return self._ahead
+
+    def _rs_producer(self, n, m, h, lo, hi):
+        """Producer of one controller step's candidates for the draw-ahead chain (runs on its worker thread)."""
+        low = np.array(self.action_space.low, dtype=np.float64)
+        high = np.array(self.action_space.high, dtype=np.float64)
+        act_dim = low.shape[0]
+        n_local = hi - lo
+        dev = self._device()
+
+        def produce(state, slot):
+            c64 = self._host64(("ahead_c64", slot), (m * n, act_dim))
+            if n_local > 0:
+                pin = self._pinned(("ahead_pin", slot), (h, m * n_local, act_dim), dev)
+                state.uniform_rows(h * n * m, low, high, n, lo, hi, pin.numpy(), n * m, c64)
+                a_dev, ev = self._to_device_side(pin, ("ahead_dev", slot), dev)
+            else:
+                state.uniform_rows(h * n * m, low, high, n, lo, hi, None, n * m, c64)
+                a_dev, ev = None, None
+            return dict(a_dev=a_dev, event=ev, cand_a=c64.reshape(m, n, act_dim))
+        return produce
 
     # ------------------------------------------------------------------ random shooting (reference :108-129)
     def get_rs_action(self, observations):
@@ -227,22 +363,17 @@ class MPCController(Policy, Serializable):
             return self._get_rs_action_unfused(observations)
 
         rank, world = self._dist()
+        self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         n_local = hi - lo
         act_dim = self.action_space.shape[0]
+        dev = self._device()
+        a_dev = None
 
-        pipelined = self.rng == "numpy" and self._can_pipeline(h, n_local)
-        if pipelined:
-            best, cand_a = self._plan_pipelined(observations, n, m, h, lo, hi, world)
-        elif self.rng == "numpy":
-            # identical draw and layout to the reference (:114): [h, n*m, act_dim], row = i*n + j
-            a = self.get_random_action(h * n * m).reshape((h, n * m, -1))
-            cand_a = a[0].reshape((m, n, -1))
-            a_loc = a.reshape(h, m, n, act_dim)[:, :, lo:hi, :]
-            a_dev = self._upload(a_loc if world > 1 else a).view(h, m * n_local, act_dim) if n_local > 0 else \
-                self._upload(np.zeros((h, 0, act_dim), dtype=np.float32))
+        if self.rng == "numpy":
+            best, cand_a, relaunch = self._rs_parity_plan(observations, n, m, h, lo, hi, world)
         else:
-            dev = self._device()
+            cand_a = None
             a_dev = self._buf("a_dev", (h, m * n_local, act_dim), torch.float32, dev)
             gen = self._bufs.get("rs_gen")
             if gen is None or gen.device != dev:
@@ -258,18 +389,14 @@ class MPCController(Policy, Serializable):
                 high = torch.as_tensor(hi_np, dtype=torch.float32, device=dev)
                 a_dev.uniform_(0.0, 1.0, generator=gen)
                 a_dev.mul_(high - low).add_(low)
-            cand_a = None
 
-        if pipelined:
-            pass                            # already planned, chunk by chunk
-        elif n_local > 0:
-            best, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=False)
-        else:   # more ranks than candidates: this rank contributes the neutral key
-            best = torch.zeros((m,), dtype=torch.int64, device=a_dev.device)
-        if world > 1:
-            torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MAX)
-        keys = best.cpu().numpy()
-        self._check_status()
+            def relaunch():
+                if n_local > 0:
+                    return self._rollout(observations, a_dev, n_local, lo, want_returns=False)[0]
+                return torch.zeros((m,), dtype=torch.int64, device=dev)     # neutral key
+            best = relaunch()
+
+        keys = self._combine_keys(best, relaunch, world)
         idx = np.empty(m, dtype=np.int64)
         best_ret = np.empty(m, dtype=np.float32)
         for i in range(m):
@@ -291,45 +418,108 @@ class MPCController(Policy, Serializable):
         torch.distributed.all_reduce(out, op=torch.distributed.ReduceOp.SUM)
         return out.cpu().numpy().astype(np.float64)
 
+    def _combine_keys(self, best, relaunch, world):
+        """Read the arg-max keys back (max all-reduce over the ranks first).  A launch flagged invalid (see
+        ``_check_status``) is repeated with the unsplit geometry - before the collective, so that a rank never
+        contributes a stale key."""
+        if world > 1:
+            self._sync()
+            if self._check_status() is False:
+                best = relaunch()
+                self._sync()
+                if self._check_status() is False:
+                    raise _lib.L2AError("rollout launch failed twice")
+            torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MAX)
+            return best.cpu().numpy()
+        keys = best.cpu().numpy()
+        if self._check_status() is False:
+            keys = relaunch().cpu().numpy()
+            if self._check_status() is False:
+                raise _lib.L2AError("rollout launch failed twice")
+        return keys
+
+    def _rs_parity_plan(self, observations, n, m, h, lo, hi, world):
+        """Parity mode: candidates from NumPy's global generator exactly as the reference draws them (``:114``:
+        ``[h, n*m, act_dim]``, row = i*n + j).  Returns ``(best_key, cand_a float64 [m, n, act], relaunch)``.
+
+        Three ways to the same bits, fastest first: (1) the block the draw-ahead chain prepared while the
+        previous plan ran (already in HBM); (2) the draw pipelined over horizon chunks under the rollout;
+        (3) one draw, one upload, one launch."""
+        n_local = hi - lo
+        act_dim = self.action_space.shape[0]
+        dev = self._device()
+        ahead = self._use_draw_ahead("uniform")
+        sig = ("rs", n, m, h, lo, hi)
+        blk = self._ahead_chain().take(sig) if ahead else None
+
+        def neutral():
+            return torch.zeros((m,), dtype=torch.int64, device=dev)     # more ranks than candidates
+
+        if blk is not None:
+            cand_a, a_dev = blk["cand_a"], blk["a_dev"]
+            if blk["event"] is not None:
+                torch.cuda.current_stream(dev).wait_event(blk["event"])
+
+            def relaunch():
+                return self._rollout(observations, a_dev, n_local, lo, want_returns=False)[0] if n_local > 0 \
+                    else neutral()
+            best = relaunch()
+        elif n_local > 0 and self._can_pipeline(h, n_local):
+            best, cand_a = self._plan_pipelined(observations, n, m, h, lo, hi, world)
+
+            def relaunch():
+                return self._plan_pipelined(observations, n, m, h, lo, hi, world, redraw=False)[0]
+        else:
+            c64 = self._host64("rs_c64", (m * n, act_dim))
+            if n_local > 0:
+                pin = self._pinned("rs_pin", (h, m * n_local, act_dim))
+                self._draw_rows(h * n * m, n, lo, hi, pin.numpy(), n * m, c64)
+                a_dev = self._to_device(pin, "rs_dev")
+            else:
+                self._draw_rows(h * n * m, n, lo, hi, None, n * m, c64)
+                a_dev = None
+            cand_a = c64.reshape(m, n, act_dim)
+
+            def relaunch():
+                return self._rollout(observations, a_dev, n_local, lo, want_returns=False)[0] if n_local > 0 \
+                    else neutral()
+            best = relaunch()
+        if ahead:       # the next controller step's candidates are drawn while this plan runs on the GPU
+            self._ahead_chain().start(sig, self._rs_producer(n, m, h, lo, hi), depth=1)
+        return best, cand_a, relaunch
+
     # ------------------------------------------------------------------ parity mode, pipelined over the horizon
     def _can_pipeline(self, h, n_local):
         return (self.pipeline_chunks > 1 and h >= 6 and n_local > 0
                 and hasattr(self.dynamics_model.planner_model(), "plan_rs_chunk"))
 
-    def _plan_pipelined(self, observations, n, m, h, lo, hi, world):
+    def _plan_pipelined(self, observations, n, m, h, lo, hi, world, redraw=True):
         """The reference draws its ``h*n*m`` candidate rows horizon-major (``:114``), so the first rows of the
         stream are the first horizon steps: draw chunk k + 1 on the host while the GPU rolls out chunk k
         (``l2a_plan_rs_chunk`` carries per-candidate state and returns between launches).  Same RNG
-        consumption, bit-identical returns and arg-max as the single launch."""
+        consumption, bit-identical returns and arg-max as the single launch.  ``redraw=False`` relaunches the
+        chunks already in HBM (after a launch was flagged invalid)."""
         native = self.dynamics_model.planner_model()
         dev = native.device
-        blocks = self.dynamics_model.planner_blocks(m)
-        if blocks != 1 and blocks != m:
-            raise _lib.L2AError("the dynamics model holds %d adapted weight sets but %d observations "
-                                "were passed" % (blocks, m))
+        self._check_blocks(m)
         act_dim = self.action_space.shape[0]
         n_local = hi - lo
         K = max(2, min(self.pipeline_chunks, h // 2))      # at least two horizon steps per launch
         bounds = [(h * c) // K for c in range(K + 1)]
         obs0 = self._upload_obs(observations)
         best = self._buf("best", (m,), torch.int64, dev)
-        cand_a = None
+        c64 = self._host64("pipe_c64", (m * n, act_dim))
         for c in range(K):
             t0, hc = bounds[c], bounds[c + 1] - bounds[c]
-            a = self.get_random_action(hc * n * m).reshape((hc, n * m, -1))
-            if c == 0:
-                cand_a = a[0].reshape((m, n, -1))
-            src = a if world == 1 else a.reshape(hc, m, n, act_dim)[:, :, lo:hi, :]
             shape = (hc, m * n_local, act_dim)
-            pin = self._bufs.get(("pipe_pin", c))
-            if pin is None or tuple(pin.shape) != shape:
-                pin = torch.empty(shape, dtype=torch.float32, pin_memory=True)
-                self._bufs[("pipe_pin", c)] = pin
-            np.copyto(pin.numpy().reshape(src.shape), src, casting="same_kind")
-            a_dev = self._buf(("pipe_dev", c), shape, torch.float32, dev)
-            a_dev.copy_(pin, non_blocking=True)
+            if redraw:
+                pin = self._pinned(("pipe_pin", c), shape)
+                self._draw_rows(hc * n * m, n, lo, hi, pin.numpy(), n * m if c == 0 else 0, c64 if c == 0 else None)
+                a_dev = self._to_device(pin, ("pipe_dev", c))
+            else:
+                a_dev = self._bufs[("pipe_dev", c)]
             self._launch_chunk(native, c, c == K - 1, obs0, a_dev, m, n_local, hc, t0, lo, best)
-        return best, cand_a
+        return best, c64.reshape(m, n, act_dim)
 
     def _launch_chunk(self, native, c, last, obs0, a_dev, m, n_local, hc, t0, lo, best):
         """Chunk ``c`` of a pipelined plan: state and returns ping-pong between two buffer pairs."""
@@ -363,6 +553,32 @@ class MPCController(Policy, Serializable):
         returns = returns.reshape(m, n)
         return cand_a[range(m), np.argmax(returns, axis=1)]
 
+    def _cem_draw(self, n, m, D):
+        """The iteration's standard normals ``np.random.normal(size=(n, m, D))`` (``:85``) as a ``[n * m, D]``
+        float64 array (flat row g = j * m + i): from the draw-ahead chain when it is valid (the z of upcoming
+        iterations - and of the next controller step - do not depend on mean / std, so they are drawn while
+        the GPU rolls out), else synchronously from the global generator (threaded helper or NumPy)."""
+        sig = ("cem", n, m, D)
+        if self._use_draw_ahead("normal"):
+            chain = self._ahead_chain()
+            z = chain.take(sig)
+            if z is None:
+                z = self._host64("cem_z_sync", (n * m, D))
+                st = fast_rng.State.from_global()
+                if st is not None:
+                    st.standard_normal(n * m * D, out=z.reshape(-1))
+                    st.to_global()
+                else:
+                    z[...] = np.random.normal(size=(n * m, D))
+
+                def produce(state, slot):
+                    buf = self._host64(("cem_z", slot), (n * m, D))
+                    state.standard_normal(n * m * D, out=buf.reshape(-1))
+                    return buf
+                chain.start(sig, produce, depth=max(1, int(self.num_cem_iters)))
+            return z
+        return fast_rng.standard_normal((n * m, D))
+
     def _cem_iteration(self, observations, mean, std, num_elites, clip_low, clip_high, lo, hi, world):
         """One CEM iteration (reference ``:85-104``): sample, roll out on the GPU, refit mean/std.
         Consumes ``n * m * h * act_dim`` normals of the global NumPy stream."""
@@ -370,38 +586,59 @@ class MPCController(Policy, Serializable):
         m = len(observations)
         h = self.horizon
         act_dim = self.action_space.shape[0]
+        D = h * act_dim
         n_local = hi - lo
         reference = (self.cem_mode == "reference")
-        if self._can_pipeline_cem(m, world, n):
-            a, a_stacked, returns = self._cem_rollout_pipelined(observations, mean, std, clip_low, clip_high,
-                                                                reference)
-            cand_a = a.reshape((n, h, act_dim))[:, 0, :].reshape((1, n, act_dim)) if reference else \
-                a_stacked.reshape((n, h, act_dim))[:, 0, :].reshape((1, n, act_dim))
-            return self._cem_refit(mean, a_stacked, returns, num_elites, reference) + (returns, cand_a)
-        z = np.random.normal(size=(n, m, h * act_dim))
-        a = mean + z * std
-        a_stacked = np.clip(a, clip_low, clip_high)
-        if reference:
-            # reference quirks: rollouts use the UNCLIPPED samples, and the flat row order is
-            # candidate-major (row = j*m + i) while observations are env-major (row // n).
-            seq = np.transpose(a.reshape((n * m, h, act_dim)), (1, 0, 2))          # [h, n*m, act]
+        z = self._cem_draw(n, m, D)                                         # [n*m, D], row g = j*m + i
+        mean2 = np.ascontiguousarray(np.broadcast_to(mean, (m, D)), dtype=np.float64)
+        std2 = np.ascontiguousarray(np.broadcast_to(std, (m, D)), dtype=np.float64)
+        a = self._host64("cem_a", (n * m, D))                               # :86 (unclipped)
+        a_st = self._host64("cem_clip", (n * m, D))                         # :87
+        low, high = self.action_space.low, self.action_space.high
+        fused = fast_rng.available("double")        # helper library present and trusted
+        if fused and n_local > 0 and self._can_pipeline_cem(m, world, n):
+            returns = self._cem_rollout_pipelined(observations, z, a, a_st, mean2, std2, reference)
         else:
-            seq = np.transpose(a_stacked.transpose(1, 0, 2).reshape((m * n, h, act_dim)), (1, 0, 2))
-        cand_a = seq[0].reshape((m, n, -1))
-        seq_loc = seq.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32)
-        a_dev = self._upload(seq_loc.reshape(h, m * n_local, act_dim))
-        _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
-        if world > 1:
-            if any(self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] != n_local
-                   for r in range(world)):
-                raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
-            parts = [torch.empty_like(rets) for _ in range(world)]
-            torch.distributed.all_gather(parts, rets)
-            rets = torch.cat(parts, dim=1)
-        returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
-        self._check_status()
-        mean, std = self._cem_refit(mean, a_stacked, returns, num_elites, reference)
-        return mean, std, returns, cand_a
+            if fused and n_local > 0 and D <= 4096:
+                pin = self._pinned("cem_pin_all", (h, m * n_local, act_dim))
+                fast_rng.cem_samples(z, 0, h, act_dim, mean2, std2, low, high, a, a_st, pin.numpy(), n, lo, hi,
+                                     env_major=not reference, use_clipped=not reference)
+                a_dev = self._to_device(pin, "cem_dev_all")
+            else:
+                a3 = mean2 + z.reshape(n, m, D) * std2
+                a[...] = a3.reshape(n * m, D)
+                a_st[...] = np.clip(a3, clip_low, clip_high).reshape(n * m, D)
+                if reference:
+                    # reference quirks: rollouts use the UNCLIPPED samples, and the flat row order is
+                    # candidate-major (row = j*m + i) while observations are env-major (row // n).
+                    seq = np.transpose(a.reshape((n * m, h, act_dim)), (1, 0, 2))          # [h, n*m, act]
+                else:
+                    seq = np.transpose(a_st.reshape(n, m, D).transpose(1, 0, 2).reshape((m * n, h, act_dim)), (1, 0, 2))
+                seq_loc = seq.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32)
+                a_dev = self._upload(seq_loc.reshape(h, m * n_local, act_dim))
+            _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+            if world > 1:
+                if any(self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] != n_local
+                       for r in range(world)):
+                    raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
+                self._sync()
+                if self._check_status() is False:
+                    _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+                parts = [torch.empty_like(rets) for _ in range(world)]
+                torch.distributed.all_gather(parts, rets)
+                rets = torch.cat(parts, dim=1)
+            returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
+            if world == 1 and self._check_status() is False:
+                _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+                returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
+                if self._check_status() is False:
+                    raise _lib.L2AError("rollout launch failed twice")
+        if reference:
+            cand_a = a[:, :act_dim].reshape(m, n, act_dim)                  # = seq[0].reshape(m, n, -1)
+        else:
+            cand_a = a_st.reshape(n, m, D)[:, :, :act_dim].transpose(1, 0, 2)
+        mean, std = self._cem_refit(mean, a_st.reshape(n, m, D), returns, num_elites, reference)
+        return mean, std, returns, np.array(cand_a)
 
     def _cem_refit(self, mean, a_stacked, returns, num_elites, reference):
         """Elite statistics of one iteration (reference ``:101-104``)."""
@@ -424,42 +661,40 @@ class MPCController(Policy, Serializable):
         return (self.pipeline_chunks > 1 and m == 1 and world == 1 and n >= 64 * self.pipeline_chunks
                 and hasattr(self.dynamics_model.planner_model(), "plan_rs_chunk"))
 
-    def _cem_rollout_pipelined(self, observations, mean, std, clip_low, clip_high, reference):
-        """One CEM iteration's sampling + rollout for m == 1, pipelined over candidate chunks: ``np.random.normal``
-        consumes its stream candidate-major (``:85``; chunked draws continue the legacy generator exactly, cached
-        Gaussian included), so chunk k + 1 is drawn and clipped on the host while the GPU rolls out chunk k into
-        its slice of the returns.  Returns ``(a [n, 1, D], a_stacked, returns [1, n] float64)``."""
+    def _cem_rollout_pipelined(self, observations, z, a, a_st, mean2, std2, reference, relaunch=False):
+        """One CEM iteration's rollout for m == 1, pipelined over candidate chunks: ``a = mean + z * std``, the
+        clip, the fp32 cast and the ``[h, rows, act]`` transposition of chunk k + 1 run on the host
+        (``l2a_cem_samples``, threaded) while the GPU rolls out chunk k into its slice of the returns.
+        Fills ``a`` / ``a_st`` ``[n, D]``; returns ``returns [1, n]`` float64."""
         native = self.dynamics_model.planner_model()
         dev = native.device
         n, h = self.n_candidates, self.horizon
         act_dim = self.action_space.shape[0]
-        D = h * act_dim
+        self._check_blocks(1)
         K = self.pipeline_chunks
         bounds = [(n * c) // K for c in range(K + 1)]
         obs0 = self._upload_obs(observations)
         rets = self._buf("rets", (1, n), torch.float32, dev)
-        a = np.empty((n, 1, D))
-        a_stacked = np.empty((n, 1, D))
+        low, high = self.action_space.low, self.action_space.high
         for c in range(K):
             j0, j1 = bounds[c], bounds[c + 1]
             nc = j1 - j0
-            z = np.random.normal(size=(nc, 1, D))
-            a[j0:j1] = mean + z * std
-            np.clip(a[j0:j1], clip_low, clip_high, out=a_stacked[j0:j1])
-            src = (a if reference else a_stacked)[j0:j1].reshape(nc, h, act_dim)
             shape = (h, nc, act_dim)
-            pin = self._bufs.get(("cem_pin", c))
-            if pin is None or tuple(pin.shape) != shape:
-                pin = torch.empty(shape, dtype=torch.float32, pin_memory=True)
-                self._bufs[("cem_pin", c)] = pin
-            np.copyto(pin.numpy(), np.transpose(src, (1, 0, 2)), casting="same_kind")
-            a_dev = self._buf(("cem_dev", c), shape, torch.float32, dev)
-            a_dev.copy_(pin, non_blocking=True)
+            if not relaunch:
+                pin = self._pinned(("cem_pin", c), shape)
+                fast_rng.cem_samples(z[j0:j1], j0, h, act_dim, mean2, std2, low, high, a[j0:j1], a_st[j0:j1],
+                                     pin.numpy(), n, j0, j1, env_major=False, use_clipped=not reference)
+                a_dev = self._to_device(pin, ("cem_dev", c))
+            else:
+                a_dev = self._bufs[("cem_dev", c)]
             native.plan_rs(obs0, a_dev, 1, nc, h, self.discount, self._reward_spec, cand_offset=j0,
                            returns_out=rets[0, j0:j1])
         returns = rets.cpu().numpy().astype(np.float64).reshape(1, n)
-        self._check_status()
-        return a, a_stacked, returns
+        if self._check_status() is False:
+            if relaunch:
+                raise _lib.L2AError("rollout launch failed twice")
+            return self._cem_rollout_pipelined(observations, z, a, a_st, mean2, std2, reference, relaunch=True)
+        return returns
 
     # ------------------------------------------------------------------ CEM (reference :71-106)
     def _cem_normal_device(self, shape, device):
@@ -473,7 +708,7 @@ class MPCController(Policy, Serializable):
             self._bufs["cem_gen"] = gen
         return torch.randn(shape, generator=gen, device=device, dtype=torch.float32)
 
-    def get_cem_action_device(self, observations):
+    def get_cem_action_device(self, observations, retry=False):
         """CEM with sampling, clipping, elite selection and refit on the GPU (SURVEY.md section 8(f)
         rank 2): the five host synchronisations and 5 x n*m*h*act_dim host normals per plan step
         of the reference loop (``:84-104``) disappear; only the chosen action comes back.
@@ -493,6 +728,7 @@ class MPCController(Policy, Serializable):
         mean = torch.zeros((m, D), dtype=torch.float32, device=dev)
         std = torch.ones((m, D), dtype=torch.float32, device=dev)
         rank, world = self._dist()
+        self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         n_local = hi - lo
         if world > 1 and n % world != 0:
@@ -500,6 +736,8 @@ class MPCController(Policy, Serializable):
         rets = None
         cand = None
         obs_dev = self._upload_obs(observations)             # once per plan step, not once per CEM iteration
+        gen0 = self._bufs.get("cem_gen")
+        gen_state = gen0.get_state() if gen0 is not None else None
         for _ in range(self.num_cem_iters):
             z = self._cem_normal_device((n, m, D), dev)
             a = mean + z * std                                                                # [n, m, D]
@@ -536,7 +774,18 @@ class MPCController(Policy, Serializable):
         idx = torch.argmax(rets, dim=1)                                                       # [m]
         first = cand[torch.arange(m, device=dev), idx, :act_dim]
         out = first.cpu().numpy().astype(np.float64)
-        self._check_status()
+        bad = self._check_status() is False     # a launch lost its tile-split partner: the context is unsplit now
+        if world > 1:                           # every rank gathered that rank's returns: all of them replay
+            flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            bad = bool(int(flag.cpu()[0]))
+        if bad:
+            if retry:
+                raise _lib.L2AError("rollout launch failed twice")
+            gen = self._bufs.get("cem_gen")
+            if gen is not None and gen_state is not None:
+                gen.set_state(gen_state)        # replay the same normals
+            return self.get_cem_action_device(observations, retry=True)
         self.last_plan = dict(best_index=idx.cpu().numpy(), best_return=rets.max(dim=1).values.cpu().numpy(),
                               cem_mean=mean.cpu().numpy(), cem_std=std.cpu().numpy())
         return out
@@ -557,6 +806,7 @@ class MPCController(Policy, Serializable):
         clip_high = np.concatenate([self.action_space.high] * h)
 
         rank, world = self._dist()
+        self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         trace = []
         cand_a = None

@@ -1,12 +1,20 @@
-"""``np.random.random_sample`` of the legacy global generator, ~4x faster, same stream.
+"""NumPy's legacy global generator (``np.random.random_sample`` / ``uniform`` / ``normal``), faster, same stream.
 
 Parity mode must consume NumPy's global MT19937 stream exactly as the reference does
-(``policies/mpc_controller.py:67-69``); its draw is the host-side cost of a controller step (1.6 M doubles per
-GrBAL step).  ``csrc/l2a_rng.c`` restates the generator with vectorisable loops; this module moves the state out
-of ``np.random.get_state()``, lets the helper fill the array and puts the advanced state back (the cached
-Gaussian of ``np.random.normal`` is preserved).  Trust is earned at run time: the first call compares the helper
-with ``np.random.random_sample`` on a saved state, across a state-block boundary; on any difference, or when
-``libl2a_rng.so`` is missing (no gcc at build time), NumPy's own call is used.
+(``policies/mpc_controller.py:67-69`` uniform, ``:85`` normal); the draw is the host-side cost of a controller step
+(360 k doubles per config-2 step, 2.88 M per config-4 step on every rank, 5 x 720 k normals per config-5 step).
+``csrc/l2a_rng.c`` restates the generator with vectorisable loops, a data-parallel form of the legacy Gaussian's
+rejection loop and a fork-join thread pool whose threads produce disjoint slices of the same stream; this module
+moves the state out of ``np.random.get_state()``, lets the helper fill the arrays and puts the advanced state back
+(position and cached Gaussian included).
+
+Trust is earned at run time, per entry point: the first use compares the helper with NumPy's own call on a saved
+state (across state-block boundaries, odd counts, a cached Gaussian); on any difference, or when ``libl2a_rng.so``
+is missing (no gcc at build time), NumPy's own call is used.
+
+A ``State`` is a private copy of the generator state: the planner uses it to draw the NEXT controller step's
+candidates ahead of time without touching the global generator (``MPCController`` adopts the result only if the
+global state is still the one the copy was taken from).
 """
 
 import ctypes
@@ -15,62 +23,232 @@ import os
 import numpy as np
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libl2a_rng.so")
-_state = {"lib": None, "ok": None}
+_state = {"lib": None, "ok": {}, "threads": None}
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def threads():
+    """Worker threads of the helper: ``L2A_RNG_THREADS``, else half of the CPUs this process may run on divided
+    by the ranks of a torch.distributed.run launch (``LOCAL_WORLD_SIZE``), at most 8."""
+    if _state["threads"] is None:
+        env = os.environ.get("L2A_RNG_THREADS")
+        if env:
+            t = max(1, int(env))
+        else:
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            t = max(1, min(8, ncpu // (2 * local)))
+        _state["threads"] = t
+    return _state["threads"]
+
+
+def set_threads(n):
+    _state["threads"] = max(1, int(n))
 
 
 def _load():
     if _state["lib"] is None and os.path.exists(_LIB_PATH):
         try:
             lib = ctypes.CDLL(_LIB_PATH)
-            lib.l2a_mt19937_fill_double.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
-                                                    ctypes.c_longlong]
-            lib.l2a_mt19937_fill_double.restype = ctypes.c_int
+            c = ctypes
+            vp, ll, i32 = c.c_void_p, c.c_longlong, c.c_int
+            ip = c.POINTER(i32)
+            if lib.l2a_rng_version() < 2:
+                return None
+            lib.l2a_mt19937_fill_double_mt.argtypes = [vp, ip, vp, ll, i32]
+            lib.l2a_mt19937_fill_double_mt.restype = i32
+            lib.l2a_mt19937_skip.argtypes = [vp, ip, ll]
+            lib.l2a_mt19937_skip.restype = i32
+            lib.l2a_mt19937_uniform_rows.argtypes = [vp, ip, ll, i32, vp, vp, ll, ll, ll, vp, ll, vp, i32]
+            lib.l2a_mt19937_uniform_rows.restype = i32
+            lib.l2a_mt19937_fill_gauss.argtypes = [vp, ip, ip, _dp, vp, ll, i32]
+            lib.l2a_mt19937_fill_gauss.restype = i32
+            lib.l2a_cem_samples.argtypes = [vp, ll, ll, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, ll, ll, ll, i32, i32,
+                                            i32]
+            lib.l2a_cem_samples.restype = i32
             _state["lib"] = lib
-        except OSError:
+        except (OSError, AttributeError):
             _state["lib"] = None
     return _state["lib"]
 
 
-def _fill(lib, n):
-    st = np.random.get_state()
-    if st[0] != "MT19937":
-        return None
-    key = np.array(st[1], dtype=np.uint32, copy=True)
-    pos = ctypes.c_int(int(st[2]))
-    out = np.empty(n, dtype=np.float64)
-    if lib.l2a_mt19937_fill_double(key.ctypes.data, ctypes.byref(pos), out.ctypes.data, n) != 0:
-        return None
-    np.random.set_state(("MT19937", key, pos.value, st[3], st[4]))
-    return out
+class State(object):
+    """A copy of a legacy MT19937 state: ``key`` (624 words), ``pos``, ``has_gauss``, ``gauss``."""
+
+    __slots__ = ("key", "pos", "has_gauss", "gauss")
+
+    def __init__(self, key, pos, has_gauss, gauss):
+        self.key = np.array(key, dtype=np.uint32, copy=True)
+        self.pos = ctypes.c_int(int(pos))
+        self.has_gauss = ctypes.c_int(int(has_gauss))
+        self.gauss = ctypes.c_double(float(gauss))
+
+    @classmethod
+    def from_global(cls):
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            return None
+        return cls(st[1], st[2], st[3], st[4])
+
+    def copy(self):
+        return State(self.key, self.pos.value, self.has_gauss.value, self.gauss.value)
+
+    def to_global(self):
+        np.random.set_state(("MT19937", self.key, self.pos.value, self.has_gauss.value, self.gauss.value))
+
+    def same_as_global(self):
+        """Is the global generator exactly in this state (nobody drew from it since the copy was taken)?"""
+        st = np.random.get_state()
+        return (st[0] == "MT19937" and st[2] == self.pos.value and st[3] == self.has_gauss.value
+                and (not st[3] or st[4] == self.gauss.value) and np.array_equal(st[1], self.key))
+
+    # ---- draws on this state (advance it) ------------------------------------------------------------------
+    def random_sample(self, n, out=None):
+        lib = _state["lib"]
+        if out is None:
+            out = np.empty(int(n), dtype=np.float64)
+        rc = lib.l2a_mt19937_fill_double_mt(self.key.ctypes.data, ctypes.byref(self.pos), out.ctypes.data, int(n),
+                                            threads())
+        if rc != 0:
+            raise RuntimeError("l2a_mt19937_fill_double_mt failed (%d)" % rc)
+        return out
+
+    def skip_doubles(self, n):
+        rc = _state["lib"].l2a_mt19937_skip(self.key.ctypes.data, ctypes.byref(self.pos), 2 * int(n))
+        if rc != 0:
+            raise RuntimeError("l2a_mt19937_skip failed (%d)" % rc)
+
+    def uniform_rows(self, rows, low, high, period, sel_lo, sel_hi, out_f32, rows64=0, out_f64=None):
+        """``rows`` rows of ``len(low)`` uniforms ``low + (high - low) * u`` (the reference's
+        ``get_random_action``); rows whose ``row % period`` lies in ``[sel_lo, sel_hi)`` go to ``out_f32``
+        (fp32, compact), the first ``rows64`` rows also to ``out_f64``."""
+        low = np.ascontiguousarray(low, dtype=np.float64)
+        high = np.ascontiguousarray(high, dtype=np.float64)
+        rc = _state["lib"].l2a_mt19937_uniform_rows(
+            self.key.ctypes.data, ctypes.byref(self.pos), int(rows), int(low.shape[0]), low.ctypes.data,
+            high.ctypes.data, int(period), int(sel_lo), int(sel_hi),
+            out_f32.ctypes.data if out_f32 is not None else None, int(rows64),
+            out_f64.ctypes.data if out_f64 is not None else None, threads())
+        if rc != 0:
+            raise RuntimeError("l2a_mt19937_uniform_rows failed (%d)" % rc)
+
+    def standard_normal(self, n, out=None):
+        if out is None:
+            out = np.empty(int(n), dtype=np.float64)
+        rc = _state["lib"].l2a_mt19937_fill_gauss(self.key.ctypes.data, ctypes.byref(self.pos),
+                                                  ctypes.byref(self.has_gauss), ctypes.byref(self.gauss),
+                                                  out.ctypes.data, int(n), threads())
+        if rc != 0:
+            raise RuntimeError("l2a_mt19937_fill_gauss failed (%d)" % rc)
+        return out
 
 
-def available():
-    """True when the helper is loaded and has reproduced NumPy's stream on this machine."""
-    if _state["ok"] is None:
-        lib = _load()
+def _verify(kind):
+    """Reproduce NumPy's own call with the helper on a saved state; restores the global state."""
+    lib = _load()
+    if lib is None:
+        return False
+    saved = np.random.get_state()
+    ok = False
+    try:
+        if kind == "double":
+            want = np.random.random_sample(70001)               # > 65536: the threaded path; odd block offsets
+            after = State.from_global()
+            np.random.set_state(saved)
+            st = State.from_global()
+            got = st.random_sample(70001)
+            ok = st is not None and np.array_equal(want, got) and _same(st, after)
+        elif kind == "uniform":
+            low, high = np.array([-1.0, -0.5, -150.0]), np.array([1.0, 2.5, 150.0])
+            rows = 30011
+            want = np.random.uniform(low=low, high=high, size=(rows, 3))
+            after = State.from_global()
+            np.random.set_state(saved)
+            st = State.from_global()
+            f32 = np.empty((rows // 7 + 7, 3), dtype=np.float32)
+            f64 = np.empty((100, 3))
+            # candidates 2..2 of every block of 7 rows
+            st.uniform_rows(rows, low, high, 7, 2, 3, f32, 100, f64)
+            sel = want[2::7].astype(np.float32)
+            ok = (np.array_equal(f64, want[:100]) and np.array_equal(f32[:len(sel)], sel) and _same(st, after))
+        elif kind == "normal":
+            np.random.normal()                                   # leave a cached Gaussian behind
+            start = np.random.get_state()
+            want = np.concatenate([np.random.normal(size=50001), np.random.normal(size=(3, 7)).ravel(),
+                                   np.random.normal(size=40000)])
+            after = State.from_global()
+            np.random.set_state(start)
+            st = State.from_global()
+            got = np.concatenate([st.standard_normal(50001), st.standard_normal(21), st.standard_normal(40000)])
+            ok = np.array_equal(want, got) and _same(st, after)
+    except Exception:
         ok = False
-        if lib is not None:
-            saved = np.random.get_state()
-            try:
-                want = np.random.random_sample(1500)            # crosses at least two 624-word blocks
-                after_want = np.random.get_state()
-                np.random.set_state(saved)
-                got = _fill(lib, 1500)
-                after_got = np.random.get_state()
-                ok = (got is not None and np.array_equal(want, got) and after_want[2] == after_got[2]
-                      and np.array_equal(after_want[1], after_got[1]))
-            finally:
-                np.random.set_state(saved)
-        _state["ok"] = bool(ok)
-    return _state["ok"]
+    finally:
+        np.random.set_state(saved)
+    return bool(ok)
+
+
+def _same(a, b):
+    return (a.pos.value == b.pos.value and a.has_gauss.value == b.has_gauss.value
+            and a.gauss.value == b.gauss.value and np.array_equal(a.key, b.key))
+
+
+def available(kind="double"):
+    """True when the helper is loaded and has reproduced NumPy's ``kind`` stream on this machine."""
+    ok = _state["ok"].get(kind)
+    if ok is None:
+        ok = _verify(kind)
+        _state["ok"][kind] = ok
+    return ok
 
 
 def random_sample(shape):
     """Drop-in for ``np.random.random_sample(shape)`` (legacy global generator)."""
     shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     n = int(np.prod(shape)) if shape else 1
-    if n >= 2048 and available():
-        out = _fill(_state["lib"], n)
-        if out is not None:
+    if n >= 2048 and available("double"):
+        st = State.from_global()
+        if st is not None:
+            out = st.random_sample(n)
+            st.to_global()
             return out.reshape(shape)
     return np.random.random_sample(shape)
+
+
+def standard_normal(shape):
+    """Drop-in for ``np.random.normal(size=shape)`` (loc 0, scale 1) of the legacy global generator."""
+    shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    n = int(np.prod(shape)) if shape else 1
+    if n >= 2048 and available("normal"):
+        st = State.from_global()
+        if st is not None:
+            out = st.standard_normal(n)
+            st.to_global()
+            return out.reshape(shape)
+    return np.random.normal(size=shape)
+
+
+def cem_samples(z, row_base, h, act_dim, mean, std, low, high, a_out, clip_out, seq_f32, n, sel_lo, sel_hi,
+                env_major, use_clipped):
+    """One CEM iteration's ``a = mean + z * std``, ``clip`` and the fp32 ``[h, m * nsel, act_dim]`` tensor the
+    rollout reads, in one threaded pass (``l2a_cem_samples``).  Returns False when the helper is unavailable."""
+    lib = _load()
+    if lib is None:
+        return False
+    rows = int(z.shape[0])
+    m = int(mean.shape[0])
+    assert z.flags.c_contiguous and a_out.flags.c_contiguous and mean.flags.c_contiguous and std.flags.c_contiguous
+    assert z.dtype == np.float64 and mean.dtype == np.float64 and std.dtype == np.float64
+    low = np.ascontiguousarray(low, dtype=np.float64)
+    high = np.ascontiguousarray(high, dtype=np.float64)
+    rc = lib.l2a_cem_samples(z.ctypes.data, rows, int(row_base), int(h), int(act_dim), mean.ctypes.data,
+                             std.ctypes.data, m, low.ctypes.data, high.ctypes.data, a_out.ctypes.data,
+                             clip_out.ctypes.data if clip_out is not None else None,
+                             seq_f32.ctypes.data if seq_f32 is not None else None, int(n), int(sel_lo), int(sel_hi),
+                             1 if env_major else 0, 1 if use_clipped else 0, threads())
+    if rc != 0:
+        raise RuntimeError("l2a_cem_samples failed (%d)" % rc)
+    return True

@@ -403,12 +403,8 @@ def test_device_cem_matches_host_loop_with_injected_normals(name, cem_mode):
     zs = [np.random.RandomState(100 + i).normal(size=(n, m, D)) for i in range(case["num_cem_iters"])]
     host = cases.product_controller(case, cem_mode=cem_mode, pipeline_chunks=1)   # whole-iteration draws are injected
     it = iter(zs)
-    orig = np.random.normal
-    try:
-        np.random.normal = lambda size=None: next(it)
-        a_host, _ = host.get_actions(obs0)
-    finally:
-        np.random.normal = orig
+    host._cem_draw = lambda n_, m_, D_: next(it).reshape(n_ * m_, D_)      # inject the iteration's normals
+    a_host, _ = host.get_actions(obs0)
     dev = cases.product_controller(case, rng="device", cem_mode=cem_mode)
     it2 = iter(zs)
     dev._cem_normal_device = lambda shape, device: torch.from_numpy(next(it2).astype(np.float32)).to(device)

@@ -145,12 +145,8 @@ def test_device_cem_matches_host_loop_with_injected_normals(cem_mode):
 
     host = oracle_backend.install(cases.product_controller(case, cem_mode=cem_mode), case)
     it = iter(zs)
-    orig = np.random.normal
-    try:
-        np.random.normal = lambda size=None: next(it)
-        a_host, _ = host.get_actions(obs0)
-    finally:
-        np.random.normal = orig
+    host._cem_draw = lambda n_, m_, D_: next(it).reshape(n_ * m_, D_)      # inject the iteration's normals
+    a_host, _ = host.get_actions(obs0)
 
     dev = oracle_backend.install(cases.product_controller(case, rng="device", cem_mode=cem_mode), case)
     it2 = iter(zs)

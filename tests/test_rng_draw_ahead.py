@@ -1,0 +1,197 @@
+"""Host RNG helper (``csrc/l2a_rng.c`` through ``utils/fast_rng``) and the draw-ahead chain against NumPy's legacy
+global generator - the stream the reference consumes (``policies/mpc_controller.py:67-69,85,114``).  Everything is
+bit-exact: values, order, and the generator state left behind (position and cached Gaussian)."""
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_backend
+from learning_to_adapt_amd.utils import fast_rng
+
+pytestmark = pytest.mark.skipif(not fast_rng.available("double"),
+                                reason="libl2a_rng.so not built (no gcc): the controller then uses NumPy's own calls")
+
+
+def _state_tuple():
+    st = np.random.get_state()
+    return (st[1].tobytes(), st[2], st[3], st[4])
+
+
+@pytest.fixture(params=[1, 2, 3, 8])
+def threads(request):
+    old = fast_rng.threads()
+    fast_rng.set_threads(request.param)
+    yield request.param
+    fast_rng.set_threads(old)
+
+
+def test_every_entry_point_is_verified_on_this_machine():
+    assert fast_rng.available("double") and fast_rng.available("uniform") and fast_rng.available("normal")
+
+
+def test_threaded_doubles_match_numpy(threads):
+    for seed, n in ((0, 70000), (1, 131073), (2, 624 * 150 + 311)):
+        np.random.seed(seed)
+        np.random.normal(size=5)                    # odd position inside a block + a cached Gaussian
+        want = np.random.random_sample(n)
+        after = _state_tuple()
+        np.random.seed(seed)
+        np.random.normal(size=5)
+        got = fast_rng.random_sample(n)
+        assert np.array_equal(want, got) and _state_tuple() == after
+
+
+def test_skip_is_the_same_as_drawing(threads):
+    np.random.seed(7)
+    st = fast_rng.State.from_global()
+    np.random.random_sample(123457)
+    st.skip_doubles(123457)
+    assert st.same_as_global()
+    st.skip_doubles(1)
+    assert not st.same_as_global()
+
+
+@pytest.mark.parametrize("shape", [dict(rows=30 * 2000, n=2000, lo=0, hi=2000, ad=6),       # config 2, one rank
+                                    dict(rows=30 * 2000, n=2000, lo=500, hi=750, ad=6),      # a shard
+                                    dict(rows=7 * 3 * 333, n=333, lo=100, hi=333, ad=8),     # m = 3 envs, ragged
+                                    dict(rows=5 * 64, n=64, lo=10, hi=10, ad=2)])            # empty shard
+def test_uniform_rows_is_the_reference_draw(threads, shape):
+    rows, n, lo, hi, ad = shape["rows"], shape["n"], shape["lo"], shape["hi"], shape["ad"]
+    low = -np.arange(1, ad + 1, dtype=np.float64)
+    high = np.arange(2, ad + 2, dtype=np.float64) * 0.75
+    np.random.seed(11)
+    want = np.random.uniform(low=low, high=high, size=(rows, ad))       # get_random_action, :67-69
+    after = _state_tuple()
+    np.random.seed(11)
+    st = fast_rng.State.from_global()
+    nsel = hi - lo
+    f32 = np.full((rows // n * nsel, ad), np.nan, dtype=np.float32) if nsel else None
+    f64 = np.empty((n, ad))
+    st.uniform_rows(rows, low, high, n, lo, hi, f32, n, f64)
+    st.to_global()
+    assert _state_tuple() == after
+    assert np.array_equal(f64, want[:n])
+    if nsel:
+        sel = want.reshape(-1, n, ad)[:, lo:hi, :].reshape(-1, ad).astype(np.float32)
+        assert np.array_equal(f32, sel)
+
+
+def test_legacy_gaussian_matches_numpy(threads):
+    for seed, sizes in ((0, [50001, 21, 40000]), (1, [720000]), (2, [1, 2, 3, 100000, 7])):
+        np.random.seed(seed)
+        if seed != 1:
+            np.random.normal()                      # start with a cached value
+        start = np.random.get_state()
+        want = [np.random.normal(size=s) for s in sizes]
+        after = _state_tuple()
+        tail = np.random.uniform()
+        np.random.set_state(start)
+        st = fast_rng.State.from_global()
+        got = [st.standard_normal(s) for s in sizes]
+        st.to_global()
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+        assert _state_tuple() == after and np.random.uniform() == tail
+
+
+def test_cem_samples_match_numpy(threads):
+    n, m, h, ad = 700, 3, 5, 4
+    D = h * ad
+    rs = np.random.RandomState(5)
+    z = rs.normal(size=(n, m, D))
+    mean, std = rs.normal(size=(m, D)) * 0.3, 0.5 + rs.uniform(size=(m, D))
+    low, high = -np.ones(ad) * 0.8, np.ones(ad) * 0.9
+    a_want = mean + z * std
+    clip_want = np.clip(a_want, np.concatenate([low] * h), np.concatenate([high] * h))
+    for env_major, use_clipped, lo, hi in ((False, False, 0, n), (True, True, 0, n), (False, False, 100, 350),
+                                            (True, True, 350, 700)):
+        nsel = hi - lo
+        a = np.empty((n * m, D))
+        c = np.empty((n * m, D))
+        seq = np.full((h, m * nsel, ad), np.nan, dtype=np.float32)
+        assert fast_rng.cem_samples(z.reshape(n * m, D), 0, h, ad, mean, std, low, high, a, c, seq, n, lo, hi,
+                                    env_major, use_clipped)
+        assert np.array_equal(a.reshape(n, m, D), a_want) and np.array_equal(c.reshape(n, m, D), clip_want)
+        src = clip_want if use_clipped else a_want
+        if env_major:       # mpc_controller cem_mode='fixed': row = i * n + j
+            full = np.transpose(src.transpose(1, 0, 2).reshape(m * n, h, ad), (1, 0, 2))
+        else:               # reference: the candidate-major rows read as if env-major (:92-96)
+            full = np.transpose(src.reshape(n * m, h, ad), (1, 0, 2))
+        want = full.reshape(h, m, n, ad)[:, :, lo:hi, :].reshape(h, m * nsel, ad).astype(np.float32)
+        assert np.array_equal(seq, want)
+
+
+# ---- the draw-ahead chain through the controller's host logic (launch replaced by the oracle) ----------------
+def _run_calls(cid_case, n_calls, draw_ahead, foreign_after=(), **kw):
+    case = dict(cid_case)
+    ctrl = oracle_backend.install(cases.product_controller(case, draw_ahead=draw_ahead, **kw), case)
+    rs = np.random.RandomState(3)
+    obs = [rs.randn(case["m"], ctrl.dynamics_model.obs_space_dims) for _ in range(n_calls)]
+    np.random.seed(case["seeds"][0])
+    out = []
+    for k in range(n_calls):
+        a, _ = ctrl.get_actions(obs[k])
+        out.append((a.copy(), ctrl.last_plan["best_index"].copy()))
+        if k in foreign_after:
+            np.random.normal(size=3)                # somebody else draws from the global generator
+    tail = (np.random.uniform(), np.random.normal())
+    return out, tail, ctrl
+
+
+@pytest.mark.parametrize("name", ["hc_rs_m2_n100_h7_e2", "c1_hc_rs_n500_h10_e1"])
+def test_draw_ahead_does_not_change_a_bit_rs(name):
+    case = cases.CASES[name]
+    base, tail0, _ = _run_calls(case, 4, draw_ahead=False)
+    ahead, tail1, ctrl = _run_calls(case, 4, draw_ahead=True)
+    assert tail0 == tail1
+    for (a0, i0), (a1, i1) in zip(base, ahead):
+        assert np.array_equal(a0, a1) and np.array_equal(i0, i1)
+    assert ctrl._ahead.hits == 3                    # calls 2..4 adopted the block prepared during the previous call
+    # a foreign consumer of np.random between two calls: the prepared block is dropped, the stream stays exact
+    base, tail0, _ = _run_calls(case, 4, draw_ahead=False, foreign_after=(1,))
+    ahead, tail1, ctrl = _run_calls(case, 4, draw_ahead=True, foreign_after=(1,))
+    assert tail0 == tail1
+    for (a0, i0), (a1, i1) in zip(base, ahead):
+        assert np.array_equal(a0, a1) and np.array_equal(i0, i1)
+    assert ctrl._ahead.hits == 2
+
+
+def test_draw_ahead_matches_the_reference_golden_first_call():
+    """Call 1 = the golden vector of the real reference planner; call 2 from the chain must equal a fresh
+    controller continuing from the same generator state without the chain."""
+    cid = "hc_rs_m2_n100_h7_e2_s0"
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    ctrl = oracle_backend.install(cases.product_controller(case, draw_ahead=True), case)
+    np.random.seed(seed)
+    a1, _ = ctrl.get_actions(gold["obs0"])
+    np.testing.assert_array_equal(a1, gold["chosen"])
+    state = np.random.get_state()
+    a2, _ = ctrl.get_actions(gold["obs0"] * 0.5)
+    assert ctrl._ahead.hits == 1
+    end = _state_tuple()
+    ref = oracle_backend.install(cases.product_controller(case, draw_ahead=False), case)
+    np.random.set_state(state)
+    b2, _ = ref.get_actions(gold["obs0"] * 0.5)
+    np.testing.assert_array_equal(a2, b2)
+    assert _state_tuple() == end
+
+
+def test_draw_ahead_does_not_change_a_bit_cem():
+    case = cases.CASES["hc_cem_m2_n100_h4"]
+    base, tail0, _ = _run_calls(case, 3, draw_ahead=False)
+    ahead, tail1, ctrl = _run_calls(case, 3, draw_ahead=True, foreign_after=(0,))
+    assert tail0 != tail1                           # different foreign draws: sanity check of the harness
+    base2, tail2, _ = _run_calls(case, 3, draw_ahead=False, foreign_after=(0,))
+    assert tail1 == tail2
+    for (a0, i0), (a1, i1) in zip(base2, ahead):
+        assert np.array_equal(a0, a1) and np.array_equal(i0, i1)
+    assert ctrl._ahead.hits >= case.get("num_cem_iters", 8)     # later iterations / calls came from the chain
+    # and the first call equals the reference's golden vector
+    gold = cases.load_golden("hc_cem_m2_n100_h4_s0")
+    c2 = oracle_backend.install(cases.product_controller(case, draw_ahead=True), case)
+    np.random.seed(0)
+    a, _ = c2.get_actions(gold["obs0"])
+    np.testing.assert_array_equal(a, gold["chosen"])
+    assert np.random.uniform() == float(gold["rng_next"])
