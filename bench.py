@@ -8,15 +8,22 @@
 Workload (BASELINE.json config 2, the configuration `metric` is quoted on): HalfCheetah-shaped
 synthetic inputs, n_candidates = 2000 per GPU, horizon 30, mean-ensemble of 5 MLPs
 26->512->512->20 (fp32), discount 1, random-init weights from the seeded recipe
-(learning_to_adapt_amd/utils/synthetic.py).  A "step" is one plan step: best-key memset +
-fused rollout kernel (+ one int64 MAX all-reduce when N > 1) over candidate actions that are
-already resident in HBM.  At N > 1 every rank owns its own 2000 candidates (weak scaling:
-config 4 = 16000 candidates over 8 GPUs) and `value` counts 2000-candidate controller steps:
-value = N * K / time.
+(learning_to_adapt_amd/utils/synthetic.py).  A "step" is one COMPLETED controller step: one call of the
+drop-in `MPCController.get_actions(obs)` in bit-exact parity mode - candidates drawn from NumPy's
+legacy global generator exactly as the reference draws them, cast, uploaded, rolled out by the fused
+kernel, arg-max (+ one int64 MAX all-reduce over RCCL when N > 1), 8 bytes read back, the chosen
+float64 action returned.  `value` = those calls per second.  At N > 1 the plan's candidates are
+sharded over the ranks, 2000 per GPU (weak scaling: N = 8 is BASELINE.json's config 4, one
+16000-candidate plan per step); `value` then counts 2000-candidate controller steps,
+value = N * plan_steps_per_s, and `config.plan_steps_per_s` states the plans themselves.
 
-One JSON line on stdout (rank 0).  Extra objects: `roofline` (fp32 MFMA roofline of the rollout
-kernel, measured live with HIP events on the launch stream) and `cpu_baseline` (the NumPy
-oracle = CPU restatement of the reference path, timed on this box's host cores, N = 1 only).
+Beside it, in `config`: the same loop with `rng="device"` (candidates drawn on the GPU) and the
+kernel-only loop over candidates resident in HBM (memset + kernel [+ all-reduce]) - the three modes of
+SURVEY.md H5.  Extra objects: `roofline` (fp32 MFMA roofline of the rollout kernel, HIP events around
+each launch on the launch stream) and `cpu_baseline` (the NumPy oracle = CPU restatement of the reference
+path, timed on this box's host cores, N = 1 only).
+
+`python bench.py --gpus N` without a torch.distributed.run environment launches the N ranks itself.
 """
 
 import argparse
@@ -84,6 +91,32 @@ def cpu_table():
         print(json.dumps(out), flush=True)
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one process per
+    GPU, rendezvous on 127.0.0.1) and hand their output through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _timed_calls(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,8 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true",
-                    help="skip the informational end-to-end get_actions modes (profiling runs: keeps the kernel "
-                         "statistics to the timed plan launches only)")
+                    help="profiling runs: only the kernel-only loop (candidates resident in HBM), so that the "
+                         "kernel statistics hold the timed plan launches and nothing else; `value` is then that loop")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps to time (0 = auto, ~10-30 s)")
     ap.add_argument("--cpu-table", action="store_true",
                     help="no GPU work: time the oracle (CPU restatement) on configs 1, 2 (E=1, E=5) and the "
@@ -101,12 +134,13 @@ def main():
     if args.cpu_table:
         return cpu_table()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the rollout path is HIP-only)"
     # Developer hook (tools/gpu_round.sh): L2A_BENCH_SHARE_GPU=1 runs every rank on GPU 0 over gloo so that
     # the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver; numbers are meaningless.
@@ -115,21 +149,31 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_ranks = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
+            backend = "gloo"
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            backend = "nccl"
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
+        ones = torch.ones((1,), dtype=torch.int64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(ones)                               # a real collective: how many ranks answered
+        rccl_ranks = int(ones.cpu()[0])
+        assert rccl_ranks == world
 
     from learning_to_adapt_amd import _lib
     from learning_to_adapt_amd.dynamics.native_model import NativeModel
+    from learning_to_adapt_amd.utils import fast_rng
     import cases
 
-    case = cases.CASES["c2_hc_rs_n2000_h30_e5"]
-    env, model = cases.product_model(case)       # host-side model (used by the end-to-end modes at N = 1)
+    n_glob = N_CAND * world
+    case = dict(cases.CASES["c2_hc_rs_n2000_h30_e5"], n=n_glob)
+    env, model = cases.product_model(case)       # the drop-in model (binds to this process' current GPU)
     native = NativeModel(OBS_DIM, ACT_DIM, HIDDEN, "relu", None, ENSEMBLE, "mean", device=local_rank)
     _, sets, norms = cases.recipe(case)
     for e in range(ENSEMBLE):
@@ -138,11 +182,29 @@ def main():
     dev = native.device
     spec = env.reward_spec
     gold = cases.load_golden("c2_hc_rs_n2000_h30_e5_s0")
-    obs0 = torch.from_numpy(gold["obs0"].astype(np.float32)).to(dev)
+    gold_glob = None                             # golden vector of the reference planner for THIS global plan
+    if world == 1:
+        gold_glob = gold
+    elif n_glob == 16000:
+        gold_glob = cases.load_golden("c4_hc_rs_n16000_h30_e5_s0")
+    obs_np = np.array(gold["obs0"])              # (c4 uses the same observation recipe)
+    obs0 = torch.from_numpy(obs_np.astype(np.float32)).to(dev)
 
-    # candidate actions resident in HBM: buffer 0 = the reference's seed-0 draw of THIS rank's
-    # shard (index check), buffers 1..3 = device-generated uniform candidates
-    n_glob = N_CAND * world
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.cpu()[0])
+
+    # ---- kernel-only loop: candidates resident in HBM ----------------------------------------------------------
+    # buffer 0 = the reference's seed-0 draw of THIS rank's shard (index check), 1..3 = device-generated
     np.random.seed(0)                        # the draw of mpc_controller.py:67-69,114 for n_glob candidates
     a0 = np.random.uniform(low=env.action_space.low, high=env.action_space.high,
                            size=(HORIZON * n_glob, ACT_DIM)).reshape((HORIZON, n_glob, ACT_DIM))
@@ -153,43 +215,27 @@ def main():
     for _ in range(3):
         bufs.append(torch.rand((HORIZON, N_CAND, ACT_DIM), generator=gen, device=dev) * 2.0 - 1.0)
     best = torch.zeros((1,), dtype=torch.int64, device=dev)
+    counter = [0]
 
-    def step(i):
+    def resident_step():
+        i = counter[0]
+        counter[0] += 1
         native.plan_rs(obs0, bufs[i % len(bufs)], 1, N_CAND, HORIZON, 1.0, spec, cand_offset=lo, best_key=best)
         if world > 1:
             dist.all_reduce(best, op=dist.ReduceOp.MAX)
 
-    # ---- correctness gate: the first plan must pick the reference planner's candidate ---------
-    step(0)
+    # correctness gate: the first plan must pick the reference planner's candidate
+    resident_step()
     torch.cuda.synchronize()
     ret0, idx0 = _lib.key_decode(int(best.cpu()[0]))
     index_match = None
-    if world == 1:
-        index_match = bool(idx0 == int(gold["best"][0]))
-        assert index_match, "plan picked candidate %d, reference picked %d" % (idx0, int(gold["best"][0]))
-
-    for i in range(args.warmup):
-        step(i)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    sync()
-    elapsed = time.perf_counter() - t0
+    if gold_glob is not None:
+        index_match = bool(idx0 == int(gold_glob["best"][0]))
+        assert index_match, "plan picked candidate %d, reference picked %d" % (idx0, int(gold_glob["best"][0]))
+    resident_s = max_over_ranks(_timed_calls(resident_step, args.steps, args.warmup, sync))
     native.ctx.launch_status()          # raises if any launch flagged a problem
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.cpu()[0])
 
-    # ---- kernel-only duration: HIP events around each launch on the launch stream -------------
+    # ---- kernel duration: HIP events around each launch on the launch stream -----------------------------------
     kern_ms = None
     if rank == 0:
         k2 = min(args.steps, 100)
@@ -204,29 +250,32 @@ def main():
     if world > 1:
         dist.barrier()
 
-    # ---- end-to-end modes through the drop-in MPCController (informational) --------------------
-    modes = {}
-    if rank == 0 and world == 1 and not args.no_e2e:
-        obs_np = np.array(gold["obs0"])              # NpzFile re-reads the archive member on every access
+    # ---- completed controller steps through the drop-in MPCController ------------------------------------------
+    e2e = {}
+    e2e_index_match = None
+    if not args.no_e2e:
         for mode in ("numpy", "device"):
             ctrl = cases.product_controller(case, model=model, env=env, rng=mode)
-            np.random.seed(0)
-            for _ in range(3):
-                ctrl.get_actions(obs_np)
-            torch.cuda.synchronize()
-            k3 = 50
-            t1 = time.perf_counter()
-            for _ in range(k3):
-                ctrl.get_actions(obs_np)
-            torch.cuda.synchronize()
-            modes["get_actions_rng_" + mode + "_steps_per_s"] = round(k3 / (time.perf_counter() - t1), 2)
+            np.random.seed(0)                   # every rank alike: the shards are slices of ONE candidate tensor
+            torch.manual_seed(0)
+            ctrl.get_actions(obs_np)
+            if mode == "numpy" and gold_glob is not None:
+                e2e_index_match = bool(int(ctrl.last_plan["best_index"][0]) == int(gold_glob["best"][0]))
+                assert e2e_index_match, "get_actions picked %d, reference picked %d" % (
+                    int(ctrl.last_plan["best_index"][0]), int(gold_glob["best"][0]))
+            e2e[mode] = max_over_ranks(_timed_calls(lambda: ctrl.get_actions(obs_np), args.steps, args.warmup, sync))
+            if mode == "numpy" and ctrl._ahead is not None:
+                e2e["draw_ahead_hits"] = int(ctrl._ahead.hits)
+            if ctrl._ahead is not None:
+                ctrl._ahead.stop()
 
     # ---- CPU baseline: the NumPy oracle on this box's host cores (N = 1, rank 0) ---------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import make_reward
         from oracle.planner import rollout_returns
-        dyn = cases.oracle_dynamics(case)
+        case1 = cases.CASES["c2_hc_rs_n2000_h30_e5"]
+        dyn = cases.oracle_dynamics(case1)
         reward = make_reward("half_cheetah", env.dt)
         a64 = a0.astype(np.float64)
         # NumPy/OpenBLAS with every hardware thread is slower than with a few (2000 x 512 GEMMs):
@@ -262,16 +311,17 @@ def main():
         cpu = {"value": round(1.0 / cpu_t, 4), "unit": "controller-steps/s", "cores": int(best_t),
                "kind": "port",
                "sample": "%d plan steps of the same workload (n=2000, h=30, ens=5) through oracle/ "
-                         "(NumPy/OpenBLAS fp32 MLP, float64 host state), %.2f s each; fastest of %s BLAS threads"
-                         % (k4, cpu_t, trials),
+                         "(NumPy/OpenBLAS fp32 MLP, float64 host state; candidates already drawn), %.2f s each; "
+                         "fastest of %s BLAS threads" % (k4, cpu_t, trials),
                "host_cpus": ncpu}
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
+        headline_s = e2e.get("numpy", resident_s)
+        ms_per_step = 1e3 * headline_s / args.steps
+        plan_steps = args.steps / headline_s
         out = {
             "metric": "controller-steps/sec (n_cand=2000, H=30, ens=5)",
-            "value": round(value, 3),
+            "value": round(world * plan_steps, 3),
             "unit": "controller-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -282,15 +332,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "HalfCheetah mb_mpc random shooting, n_candidates=2000 per GPU "
-                                   "(global %d), horizon=30, mean-ensemble=5 x MLP 26-512-512-20, m=1 env; "
-                                   "candidate actions resident in HBM" % n_glob,
-                       "global_candidates": n_glob, "plan_steps_per_s": round(args.steps / elapsed, 3),
-                       "mlp_steps_per_ms": round(world * N_CAND * HORIZON * ENSEMBLE / ms_per_step, 1),
-                       "collective": "int64 MAX all-reduce of 1 key per plan step" if world > 1 else "none",
-                       "action_index_match_vs_reference": index_match,
-                       "best_index": idx0, "best_return": round(ret0, 4)},
+            "config": {
+                "workload": "HalfCheetah mb_mpc random shooting, n_candidates=2000 per GPU (one plan of %d "
+                            "candidates per step), horizon=30, mean-ensemble=5 x MLP 26-512-512-20, m=1 env" % n_glob,
+                "step": ("completed MPCController.get_actions call, parity mode (host MT19937 draw identical to the "
+                         "reference, upload, fused rollout, arg-max%s, read-back)"
+                         % (", int64 MAX all-reduce" if world > 1 else "")) if "numpy" in e2e else
+                        "kernel-only: memset + fused rollout over candidates resident in HBM (--no-e2e)",
+                "value_definition": "n_gpus x plan_steps_per_s: 2000-candidate controller steps per second",
+                "candidates_per_plan": n_glob,
+                "plan_steps_per_s": round(plan_steps, 3),
+                "kernel_only_plan_steps_per_s": round(args.steps / resident_s, 3),
+                "kernel_only_ms_per_step": round(1e3 * resident_s / args.steps, 4),
+                "mlp_steps_per_ms": round(world * N_CAND * HORIZON * ENSEMBLE / ms_per_step, 1),
+                "collective": "int64 MAX all-reduce of 1 key per plan step" if world > 1 else "none",
+                "backend": backend, "rccl_ranks": rccl_ranks,
+                "action_index_match_vs_reference": index_match if e2e_index_match is None else
+                                                   bool(index_match and e2e_index_match),
+                "best_index": idx0, "best_return": round(ret0, 4),
+                "host_rng_threads": fast_rng.threads(),
+            },
         }
+        if "numpy" in e2e:
+            out["config"]["get_actions_parity_plan_steps_per_s"] = round(args.steps / e2e["numpy"], 3)
+            out["config"]["draw_ahead_hits"] = e2e.get("draw_ahead_hits")
+        if "device" in e2e:
+            out["config"]["get_actions_device_rng_plan_steps_per_s"] = round(args.steps / e2e["device"], 3)
         if kern_ms is not None:
             # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x 2 correction +
             # WRITE_SIZE, MI355X_MICROARCH.md section HBM); counters cannot be read live.
@@ -316,8 +383,6 @@ def main():
             }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        if modes:
-            out["config"].update(modes)
         print(json.dumps(out), flush=True)
 
     if world > 1:

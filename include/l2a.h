@@ -100,6 +100,8 @@ int l2a_launch_status(l2a_ctx* ctx, int* status_out);
 /* How many polls a split workgroup may spend waiting for its partner, per launch, before it gives up and sets
  * status bit 0 (0 = default 2^18, about half a second).  Tests use a tiny value to force the condition. */
 int l2a_set_spin_limit(l2a_ctx* ctx, unsigned int polls);
+/* Test hook (host only): OR `bits` into the status word, as if a launch had reported them. */
+int l2a_inject_status(l2a_ctx* ctx, int bits);
 /* Developer aid (tools/timeline.py): when `device_ptr` is non-NULL the MFMA kernel's first
  * candidate tile stamps the shader clock at its phase boundaries into it as u64
  * [group 2][step h][set 8][slot 8].  NULL (default) disables it.                               */

@@ -22,7 +22,7 @@ KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
 
 EXPORTED_SYMBOLS = (
     "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split",
-    "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit",
+    "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_get_weights",
     "l2a_plan_rs", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
@@ -69,6 +69,8 @@ def load():
     lib.l2a_set_debug_buffer.restype = i32
     lib.l2a_set_spin_limit.argtypes = [vp, c.c_uint]
     lib.l2a_set_spin_limit.restype = i32
+    lib.l2a_inject_status.argtypes = [vp, i32]
+    lib.l2a_inject_status.restype = i32
     lib.l2a_model_create.argtypes = [vp, i32, i32, i32, c.POINTER(i32), i32, i32, i32, i32, c.POINTER(vp)]
     lib.l2a_model_create.restype = i32
     lib.l2a_model_destroy.argtypes = [vp]

@@ -285,6 +285,12 @@ int l2a_set_split(l2a_ctx* ctx, int policy) {
     return L2A_OK;
 }
 
+int l2a_inject_status(l2a_ctx* ctx, int bits) {
+    if (!ctx) return L2A_EINVAL;
+    *ctx->status_host |= (unsigned int)bits;
+    return L2A_OK;
+}
+
 int l2a_set_spin_limit(l2a_ctx* ctx, unsigned int polls) {
     if (!ctx) return L2A_EINVAL;
     ctx->spin_limit = polls ? polls : (1u << 18);

@@ -192,7 +192,11 @@ class MetaMLPDynamicsModel(Serializable):
         o = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)).to(native.device)
         a = torch.from_numpy(np.ascontiguousarray(act, dtype=np.float32)).to(native.device)
         nxt = native.predict(o, a, n_blocks=n_blocks)
-        return nxt.cpu().numpy().astype(np.float64)
+        pred_obs = nxt.cpu().numpy().astype(np.float64)
+        if not native.ctx.check_or_degrade():      # a tile-split launch lost its partner: unsplit now, run again
+            pred_obs = native.predict(o, a, n_blocks=n_blocks).cpu().numpy().astype(np.float64)
+            native.ctx.launch_status()
+        return pred_obs
 
     # ------------------------------------------------------------------ adapt (reference :321-351)
     def adapt(self, obs, act, obs_next):

@@ -133,6 +133,9 @@ class MLPDynamicsModel(Serializable):
         a = torch.from_numpy(np.ascontiguousarray(act, dtype=np.float32)).to(native.device)
         nxt = native.predict(o, a)
         pred_obs = nxt.cpu().numpy().astype(np.float64)
+        if not native.ctx.check_or_degrade():      # a tile-split launch lost its partner: unsplit now, run again
+            pred_obs = native.predict(o, a).cpu().numpy().astype(np.float64)
+            native.ctx.launch_status()
         assert pred_obs.ndim == 2
         return pred_obs
 

@@ -29,6 +29,10 @@ Parity status
   (``dynamics/core/utils.py:111-142``, ``:264-296``) - dense = ``x @ W + b``,
   kernels ``[in, out]`` - and is cross-checked against float64 NumPy and
   torch CPU fp32 in ``tests/test_oracle.py``.
+* inner adaptation (``oracle/adapt.py``): restates ``meta_mlp_dynamics.py:321-345,96-120,409-421`` (zero-row
+  padding, pre/post split, mean-square loss, one SGD step).  ``tf.gradients`` is TensorFlow's: **unpinned at the
+  TensorFlow boundary**; the hand-written backward pass is pinned against float64 central finite differences
+  (``tools/gen_adapt_golden.py``, ``tests/test_adapt_oracle.py``) and by the fixture ``tests/golden/adapt_cases.npz``.
 * recurrent planner (``oracle/rnn_planner.py``): PINNED against the real
   ``RNNMPCController`` (``policies/rnn_mpc_controller.py``) the same way.
 * LSTM cell arithmetic (``oracle/rnn_dynamics.py``): unpinned at the

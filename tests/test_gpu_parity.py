@@ -83,7 +83,9 @@ def test_controller_matches_reference_golden(cid):
                                          (-gold["cem_returns"][it]).argsort(axis=-1) < k)
                           for it, tr in enumerate(trace))
         if not same_elites:
-            pytest.skip("declared rank tie inside the CEM elite mask (see teacher-forced test)")
+            # visible in the -q summary as `x` (never a silent skip): the end-to-end bit-equality does not apply,
+            # the per-iteration parity of this very case is asserted by test_cem_iterations_teacher_forced
+            pytest.xfail("declared rank tie inside the CEM elite mask (see teacher-forced test)")
     assert np.array_equal(ctrl.last_plan["best_index"], gold["best"])  # bit-exact index
     np.testing.assert_array_equal(actions, gold["chosen"])             # float64 action, bit for bit
     want_best = gold["returns"][np.arange(case["m"]), gold["best"]]
@@ -676,3 +678,91 @@ def test_invalid_plans_are_rejected():
 def test_device_info_reports_gfx950():
     info = _lib.Context.get(0).info()
     assert info["arch"].startswith("gfx950") and info["compute_units"] >= 200
+
+
+# ------------------------------------------------------------------------------------------
+# round 2: degrade instead of raising, draw-ahead on the device
+# ------------------------------------------------------------------------------------------
+@pytest.fixture
+def _fresh_split_state():
+    ctx = _lib.Context.get(0)
+    yield ctx
+    ctx.set_spin_limit(0)
+    ctx.set_split(1)
+    ctx.split_degraded = False
+    ctx.launch_status_value()
+
+
+@pytest.mark.parametrize("cid", ["c2_hc_rs_n2000_h30_e5_s0", "c5_hc_cem_n4000_h30_e5_s0", "c1_hc_rs_n500_h10_e1_s0"])
+def test_flagged_launch_is_relaunched_unsplit_not_raised(cid, _fresh_split_state):
+    """A status word set by a launch (injected on the host here, deterministically) must make the controller switch
+    the context to the unsplit geometry and relaunch - same action as the reference, no exception."""
+    ctx = _fresh_split_state
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    ctrl = cases.product_controller(case)
+    ctrl.dynamics_model.planner_model()            # create the context's model before injecting
+    np.random.seed(seed)
+    ctx.check(ctx.lib.l2a_inject_status(ctx.handle, 1), "l2a_inject_status")
+    actions, _ = ctrl.get_actions(gold["obs0"])
+    assert ctx.split_degraded is True
+    assert np.random.uniform() == float(gold["rng_next"])
+    if case["planner"] != "cem":
+        assert np.array_equal(ctrl.last_plan["best_index"], gold["best"])
+        np.testing.assert_array_equal(actions, gold["chosen"])
+    # a second flagged launch with the split already off is a real error
+    ctx.check(ctx.lib.l2a_inject_status(ctx.handle, 1), "l2a_inject_status")
+    with pytest.raises(_lib.L2AError):
+        ctrl.get_actions(gold["obs0"])
+
+
+def test_exchange_timeout_in_the_kernel_degrades(_fresh_split_state):
+    """The kernel's own time-out path: with one poll allowed per launch a split workgroup almost surely misses its
+    partner at some horizon step and flags the launch; whether or not it does, the controller must return the
+    reference's action (relaunching unsplit when flagged), and the launch must not take long."""
+    import time
+    ctx = _fresh_split_state
+    cid = "c2_hc_rs_n2000_h30_e5_s1"
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    ctrl = cases.product_controller(case, draw_ahead=False)
+    ctrl.dynamics_model.planner_model()
+    ctx.set_spin_limit(1)
+    np.random.seed(seed)
+    t = time.perf_counter()
+    actions, _ = ctrl.get_actions(gold["obs0"])
+    assert time.perf_counter() - t < 5.0
+    assert np.array_equal(ctrl.last_plan["best_index"], gold["best"])
+    np.testing.assert_array_equal(actions, gold["chosen"])
+    predicted = ctrl.dynamics_model.predict(np.repeat(gold["obs0"], 64, axis=0), np.zeros((64, 6)))
+    ctx.set_spin_limit(0)
+    ctx.set_split(0)
+    want = ctrl.dynamics_model.predict(np.repeat(gold["obs0"], 64, axis=0), np.zeros((64, 6)))
+    np.testing.assert_array_equal(predicted, want)
+
+
+@pytest.mark.parametrize("name", ["c2_hc_rs_n2000_h30_e5", "c3b_ant_rs_n500_h10_pb5_3x512", "hc_cem_m2_n100_h4"])
+def test_draw_ahead_on_the_device_changes_nothing(name):
+    """Consecutive controller steps with the draw-ahead chain (candidates of step k + 1 drawn and uploaded on a side
+    stream while step k runs) against the same steps without it: actions, indices, returns and the generator state
+    afterwards are identical; the chain really was used."""
+    case = cases.CASES[name]
+    env, model = cases.product_model(case)
+    rs = np.random.RandomState(5)
+    obs = [rs.randn(case["m"], env.observation_space.shape[0]) for _ in range(4)]
+    outs = []
+    for ahead in (False, True):
+        ctrl = cases.product_controller(case, model=model, env=env, draw_ahead=ahead)
+        np.random.seed(11)
+        seq = []
+        for k in range(4):
+            a, _ = ctrl.get_actions(obs[k])
+            seq.append((a.copy(), np.array(ctrl.last_plan["best_index"]), np.array(ctrl.last_plan["best_return"])))
+            if k == 1:
+                np.random.normal(size=3)           # a foreign draw: the prepared block must be dropped
+        outs.append((seq, np.random.uniform(), ctrl))
+    (s0, t0, _), (s1, t1, c1) = outs
+    assert t0 == t1
+    for (a0, i0, r0), (a1, i1, r1) in zip(s0, s1):
+        assert np.array_equal(a0, a1) and np.array_equal(i0, i1) and np.array_equal(r0, r1)
+    assert c1._ahead is not None and c1._ahead.hits >= 2

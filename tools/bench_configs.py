@@ -178,7 +178,7 @@ def main():
     np.random.seed(0)
     ctrl.get_actions(gold["obs0"])
     t0 = time.perf_counter()
-    k = 3
+    k = 10
     for _ in range(k):
         ctrl.get_actions(gold["obs0"])
     torch.cuda.synchronize()
