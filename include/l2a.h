@@ -31,6 +31,8 @@ typedef struct l2a_lstm l2a_lstm;
 #define L2A_EHIP (-2)        /* a HIP runtime call failed (message has hipGetErrorString)  */
 #define L2A_ENODEV (-3)      /* no usable gfx950 device                                    */
 #define L2A_ESTATE (-4)      /* call order violated (e.g. plan before weights were set)    */
+#define L2A_ESPLIT (-5)      /* l2a_plan_rs_sync only: a tile-split exchange timed out, the result is
+                                invalid; call l2a_set_split(ctx, 0) and repeat the call              */
 
 /* ---- enums ---------------------------------------------------------------------------- */
 /* hidden / output nonlinearity: dynamics/mlp_dynamics.py:16-23 (`_activations`).           */
@@ -155,6 +157,18 @@ int l2a_model_set_norm(l2a_model* model, int e, const double* mean_obs, const do
 int l2a_plan_rs(l2a_model* model, const float* obs0, const float* actions, int m, int n, int h,
                 double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
                 unsigned long long* best_key, void* stream);
+
+/* The blocking form of l2a_plan_rs - what `get_rs_action` (policies/mpc_controller.py:108-129) is to its caller:
+ * observations in (HOST fp32 [m, obs_dim], m <= 64), arg-max keys out (HOST u64 [m]), nothing else to do.  The
+ * library stages the observations in host-mapped memory that the kernel reads directly, keeps its own key slot
+ * (zeroed by the previous launch) and lets the last candidate tile of the launch publish the keys and a sequence
+ * number to a host-mapped mailbox which this call polls: no H2D copy, no memset, no D2H copy and no
+ * hipStreamSynchronize on the path.  `actions` (device) must already be ordered before `stream`.  Single GPU only
+ * (sharded plans need the keys on the device for the all-reduce: l2a_plan_rs).  Returns L2A_ESPLIT when the launch
+ * was flagged (see l2a_launch_status); the status word is consumed.                                          */
+int l2a_plan_rs_sync(l2a_model* model, const float* obs_host, const float* actions, int m, int n, int h,
+                     double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                     unsigned long long* keys_host_out, void* stream);
 
 /* A plan step cut along the horizon: launch k covers horizon steps t0 .. t0 + h_chunk - 1 of
  * get_rs_action's loop (policies/mpc_controller.py:116-127) and hands the per-candidate state and the

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libl2a_hip.so")
 
 # include/l2a.h
 L2A_OK = 0
+L2A_ESPLIT = -5
 ACT_CODES = {None: 0, "identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4}
 MODE_CODES = {"single": 0, "per_block": 1, "mean": 2}
 KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
@@ -25,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_get_weights",
-    "l2a_plan_rs", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
+    "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
     "l2a_packed_layer_floats", "l2a_pack_layer_host",
     "l2a_lstm_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_chunk",
     "l2a_lstm_predict", "l2a_lstm_mfma_eligible",
@@ -88,6 +89,8 @@ def load():
     lib.l2a_model_set_norm.restype = i32
     lib.l2a_plan_rs.argtypes = [vp, vp, vp, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32, vp, vp, vp]
     lib.l2a_plan_rs.restype = i32
+    lib.l2a_plan_rs_sync.argtypes = [vp, vp, vp, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32, vp, vp, vp]
+    lib.l2a_plan_rs_sync.restype = i32
     lib.l2a_plan_rs_chunk.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32, vp, vp, vp, vp, vp]
     lib.l2a_plan_rs_chunk.restype = i32
     lib.l2a_predict.argtypes = [vp, vp, vp, i32, i32, vp, vp]

@@ -10,12 +10,16 @@
 #include "l2a_adapt.h"
 #include "l2a_mfma_launch.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <immintrin.h>
+#include <unistd.h>
 
 namespace {
 
@@ -275,6 +279,9 @@ int l2a_init(int device, l2a_ctx** out) {
 void l2a_destroy(l2a_ctx* ctx) {
     if (!ctx) return;
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    if (ctx->mail_host) (void)hipHostFree(ctx->mail_host);
+    if (ctx->done_ctr) (void)hipFree(ctx->done_ctr);
+    if (ctx->key_ring) (void)hipFree(ctx->key_ring);
     delete ctx;
 }
 
@@ -648,6 +655,118 @@ int l2a_plan_rs(l2a_model* md, const float* obs0, const float* actions, int m, i
     p.ret_in = nullptr; p.disc0 = 1.0;
     p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
     return launch_rollout(md, p, stream_v);
+}
+
+// Allocates the context's result mailbox on first use.
+static int ensure_mail(l2a_ctx* ctx) {
+    if (ctx->mail_host) return L2A_OK;
+    l2a_mail* host = nullptr;
+    L2A_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&host), sizeof(l2a_mail), hipHostMallocMapped));
+    std::memset(host, 0, sizeof(l2a_mail));
+    l2a_mail* dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->done_ctr), sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(ctx->done_ctr, 0, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->key_ring), 2 * L2A_MAIL_KEYS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->key_ring, 0, 2 * L2A_MAIL_KEYS * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        (void)hipHostFree(host);
+        return fail(ctx, L2A_EHIP, std::string("allocating the result mailbox: ") + hipGetErrorString(e));
+    }
+    ctx->mail_host = host;
+    ctx->mail_dev = dev;
+    ctx->ring_clean[0] = ctx->ring_clean[1] = true;
+    return L2A_OK;
+}
+
+int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions, int m, int n, int h,
+                     double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                     unsigned long long* keys_host_out, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!obs_host || !actions || !reward || !keys_host_out)
+        return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: null obs / actions / reward / keys_host_out");
+    if (m < 1 || n < 1 || h < 1) return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: m, n and h must be >= 1");
+    if (m > L2A_MAIL_KEYS || (long long)m * md->obs_dim > L2A_MAIL_OBS)
+        return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: at most 64 envs / 4096 observation floats (use l2a_plan_rs)");
+    if ((long long)m * n > 0x3fffffffLL || cand_offset < 0 || (long long)cand_offset + n > 0x7fffffffLL)
+        return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: too many candidates");
+    if (reward->w_vel != 0.0f && (reward->vel_index < 0 || reward->vel_index >= md->obs_dim))
+        return fail(ctx, L2A_EINVAL, "reward.vel_index out of range");
+    if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
+        return fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
+    int rc = ensure_mail(ctx);
+    if (rc != L2A_OK) return rc;
+    int kind = ctx->kernel_kind;
+    if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
+    const bool publish = (kind == L2A_KERNEL_MFMA);        // the VALU kernel has no mailbox epilogue
+
+    const unsigned long long seq = ++ctx->mail_seq;
+    const int slot = (int)(seq & 1ull);
+    l2a_mail* mh = ctx->mail_host;
+    std::memcpy(mh->obs[slot], obs_host, sizeof(float) * (size_t)m * md->obs_dim);
+    unsigned long long* keys_dev = ctx->key_ring + (size_t)slot * L2A_MAIL_KEYS;
+    if (!ctx->ring_clean[slot])
+        L2A_HIP(ctx, hipMemsetAsync(keys_dev, 0, sizeof(unsigned long long) * L2A_MAIL_KEYS, stream));
+    ctx->ring_clean[slot] = false;
+
+    L2AKParams p;
+    fill_model_params(md, p);
+    p.obs0 = ctx->mail_dev->obs[slot]; p.actions = actions; p.returns_out = returns_out; p.best_key = keys_dev;
+    p.state_out = nullptr; p.obs_per_row = 0;
+    p.ret_in = nullptr; p.disc0 = 1.0;
+    p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
+    if (publish) {
+        p.done_ctr = ctx->done_ctr;
+        p.mail_keys = ctx->mail_dev->keys;
+        p.mail_seq_ptr = &ctx->mail_dev->seq;
+        p.mail_seq = seq;
+        p.next_keys = ctx->key_ring + (size_t)(slot ^ 1) * L2A_MAIL_KEYS;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = launch_rollout(md, p, stream_v);
+    if (rc != L2A_OK) { ctx->ring_clean[0] = ctx->ring_clean[1] = false; return rc; }
+    if (publish) {
+        ctx->ring_clean[slot ^ 1] = true;           // zeroed by this launch's last tile
+        // Sleep through most of the expected duration, then poll the mailbox word (host-mapped memory: no copy,
+        // no hipStreamSynchronize wake-up latency).
+        if (ctx->sync_ema_us > 400.0) usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
+        const volatile unsigned long long* seqp = &mh->seq;
+        unsigned long long spins = 0;
+        while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
+            _mm_pause();
+            if ((++spins & 0xffffull) == 0) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                    ctx->ring_clean[0] = ctx->ring_clean[1] = false;
+                    return fail(ctx, L2A_EHIP, std::string("l2a_plan_rs_sync: ") + hipGetErrorString(q));
+                }
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (q == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq && waited > 1.0) {
+                    ctx->ring_clean[0] = ctx->ring_clean[1] = false;
+                    return fail(ctx, L2A_EHIP, "l2a_plan_rs_sync: the stream drained but the mailbox was never written");
+                }
+                if (waited > 60.0) {
+                    ctx->ring_clean[0] = ctx->ring_clean[1] = false;
+                    return fail(ctx, L2A_EHIP, "l2a_plan_rs_sync: timed out waiting for the plan");
+                }
+            }
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        ctx->sync_ema_us = (ctx->sync_ema_us == 0.0) ? us : 0.75 * ctx->sync_ema_us + 0.25 * us;
+        for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
+    } else {
+        L2A_HIP(ctx, hipMemcpyAsync(mh->keys, keys_dev, sizeof(unsigned long long) * (size_t)m, hipMemcpyDeviceToHost, stream));
+        L2A_HIP(ctx, hipStreamSynchronize(stream));
+        for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
+    }
+    if (*ctx->status_host != 0) {       // a tile-split partner never arrived: the caller relaunches unsplit
+        *ctx->status_host = 0;
+        return fail(ctx, L2A_ESPLIT, "a tile-split exchange timed out (relaunch with l2a_set_split(ctx, 0))");
+    }
+    return L2A_OK;
 }
 
 int l2a_plan_rs_chunk(l2a_model* md, const float* state, int state_per_row, const float* actions, int m, int n,

@@ -8,6 +8,14 @@
 
 #include "../../include/l2a.h"
 
+#define L2A_MAIL_KEYS 64
+#define L2A_MAIL_OBS 4096
+struct l2a_mail {
+    unsigned long long seq;                     // last published launch
+    unsigned long long keys[L2A_MAIL_KEYS];     // its arg-max keys
+    float obs[2][L2A_MAIL_OBS];                 // observation staging, slot = launch parity (read by the kernel)
+};
+
 struct l2a_ctx {
     int device = 0;
     int kernel_kind = L2A_KERNEL_AUTO;
@@ -16,6 +24,14 @@ struct l2a_ctx {
     unsigned int* status_dev = nullptr;
     unsigned long long* dbg = nullptr;    // optional timeline buffer (l2a_set_debug_buffer)
     unsigned int spin_limit = 1u << 18;   // exchange polls per workgroup and launch before it gives up (~0.5 s)
+    // result mailbox of l2a_plan_rs_sync (allocated on first use)
+    struct l2a_mail* mail_host = nullptr; // host-mapped
+    struct l2a_mail* mail_dev = nullptr;  // device alias of mail_host
+    unsigned int* done_ctr = nullptr;     // device
+    unsigned long long* key_ring = nullptr;   // device [2][L2A_MAIL_KEYS]
+    bool ring_clean[2] = {false, false};
+    unsigned long long mail_seq = 0;
+    double sync_ema_us = 0.0;             // expected duration of the next blocking plan (sleep-then-spin)
     int num_cu = 0;
     int lds_per_block = 0;
     int clock_khz = 0;

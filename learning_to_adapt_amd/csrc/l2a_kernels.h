@@ -70,6 +70,13 @@ struct L2AKParams {
     unsigned int* status;       // host-visible word; bit 0 set = exchange timed out
     unsigned int spin_limit;    // polls one workgroup may spend waiting for its partner, per launch
     unsigned long long* dbg;    // optional phase timeline (tools/timeline.py); null in production
+    // ---- result mailbox (l2a_plan_rs_sync): the last candidate tile of the launch publishes the keys to
+    //      host-mapped memory, so the host learns the result without a copy or a stream synchronisation ----
+    unsigned int* done_ctr;             // device: tiles that have contributed their key (reset by the last one)
+    unsigned long long* mail_keys;      // host-mapped [m]
+    unsigned long long* mail_seq_ptr;   // host-mapped; null = no mailbox
+    unsigned long long mail_seq;        // value to publish
+    unsigned long long* next_keys;      // device key slot of the NEXT launch: zeroed here (saves its memset)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -146,4 +153,22 @@ __device__ __forceinline__ int l2a_logical_wg(int hw, int nwg) {
 }
 
 #define L2A_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Called by ONE thread per candidate tile after its atomicMax into best_key.  The tile that arrives last copies
+// the finished keys into the host-mapped mailbox, zeroes the next launch's key slot, rearms the counter and
+// finally publishes the launch's sequence number (system-scope release): the host polls that word.
+__device__ __forceinline__ void l2a_publish_result(const L2AKParams& p, int n_tiles) {
+    if (!p.mail_seq_ptr) return;
+    __threadfence();
+    const unsigned int prev = __hip_atomic_fetch_add(p.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u != (unsigned int)n_tiles) return;
+    for (int i = 0; i < p.m; ++i) {
+        const unsigned long long k = __hip_atomic_load(p.best_key + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.mail_keys + i, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.next_keys + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(p.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __hip_atomic_store(p.mail_seq_ptr, p.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 

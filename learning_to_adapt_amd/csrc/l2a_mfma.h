@@ -897,7 +897,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 const unsigned long long other = ((unsigned long long)hi << 32) | lo;
                 key = (other > key) ? other : key;
             }
-            if (lane == 0 && key != 0ull) atomicMax(p.best_key + env, key);
+            if (lane == 0) {
+                if (key != 0ull) atomicMax(p.best_key + env, key);
+                l2a_publish_result(p, n_tiles);
+            }
         }
     }
 }

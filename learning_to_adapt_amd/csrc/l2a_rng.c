@@ -521,4 +521,28 @@ int l2a_cem_samples(const double* z, long long rows, long long row_base, int h, 
     return 0;
 }
 
-int l2a_rng_version(void) { return 2; }
+/* ---- direct access to the global generator's words ------------------------------------------------------------
+ * `addr` = np.random.mtrand._rand._bit_generator.ctypes.state_address: NumPy's `mt19937_state`
+ * { uint32_t key[624]; int pos; } (numpy/random/src/mt19937/mt19937.h).  Comparing / storing 2.5 KB here replaces
+ * np.random.get_state() / set_state() (tens of microseconds each) on the controller's per-step path.  The Python
+ * side verifies the layout against get_state() before it trusts these. */
+typedef struct { uint32_t key[MT_N]; int pos; } np_mt19937_state;
+
+int l2a_mt19937_state_equal(const void* addr, const uint32_t* key, int pos) {
+    const np_mt19937_state* s = (const np_mt19937_state*)addr;
+    return (s->pos == pos && memcmp(s->key, key, sizeof(s->key)) == 0) ? 1 : 0;
+}
+
+void l2a_mt19937_state_store(void* addr, const uint32_t* key, int pos) {
+    np_mt19937_state* s = (np_mt19937_state*)addr;
+    memcpy(s->key, key, sizeof(s->key));
+    s->pos = pos;
+}
+
+void l2a_mt19937_state_load(const void* addr, uint32_t* key, int* pos) {
+    const np_mt19937_state* s = (const np_mt19937_state*)addr;
+    memcpy(key, s->key, sizeof(s->key));
+    *pos = s->pos;
+}
+
+int l2a_rng_version(void) { return 3; }

@@ -163,6 +163,30 @@ class NativeModel(object):
                                   _ptr(returns_out), _ptr(best_key), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_plan_rs")
 
+    def plan_rs_sync(self, obs_host, actions, m, n, h, discount, reward, cand_offset=0, returns_out=None):
+        """Blocking plan step (``l2a_plan_rs_sync``): ``obs_host`` is a HOST array ``[m, obs_dim]``; returns the
+        arg-max keys as a NumPy uint64 array ``[m]``, or ``None`` when the launch was flagged invalid (tile-split
+        partner missing) - the context has then been switched to the unsplit geometry and the caller repeats the
+        call.  ctypes releases the GIL for the duration, so other Python threads run while the GPU plans."""
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        assert actions.numel() == h * m * n * self.act_dim
+        obs = np.ascontiguousarray(obs_host, dtype=np.float32)
+        assert obs.size == m * self.obs_dim
+        keys = np.empty(m, dtype=np.uint64)
+        rc = self.lib.l2a_plan_rs_sync(self.handle, ctypes.c_void_p(obs.ctypes.data), _ptr(actions), int(m), int(n),
+                                       int(h), float(discount), ctypes.byref(reward), int(cand_offset),
+                                       _ptr(returns_out), ctypes.c_void_p(keys.ctypes.data), _stream_ptr(self.device))
+        if rc == _lib.L2A_ESPLIT:
+            if getattr(self.ctx, "split_degraded", False):
+                raise _lib.L2AError("rollout launch was flagged invalid with the tile split disabled")
+            self.ctx.set_split(0)
+            self.ctx.split_degraded = True
+            return None
+        self.ctx.check(rc, "l2a_plan_rs_sync")
+        return keys
+
+    sync_max_envs = 64
+
     def plan_rs_chunk(self, state, state_per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
                       returns_in=None, returns_out=None, state_out=None, best_key=None):
         """Horizon steps ``t0 .. t0 + h_chunk - 1`` of a plan (``l2a_plan_rs_chunk``); all tensors fp32 CUDA."""

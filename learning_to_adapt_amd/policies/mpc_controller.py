@@ -305,6 +305,27 @@ class MPCController(Policy, Serializable):
                        cand_offset=cand_offset, returns_out=rets, best_key=best)
         return best, rets
 
+    def _plan_keys(self, observations, a_dev, n_local, lo, world):
+        """Roll out ``a_dev`` and return the arg-max keys: as a NumPy uint64 array when the blocking single-GPU
+        launch is available (``l2a_plan_rs_sync``: observations staged in host-mapped memory, keys published to a
+        host-mapped mailbox by the last tile - no copies, no stream synchronisation; a launch flagged invalid is
+        repeated unsplit right here), else as the device tensor ``_rollout`` fills (sharded plans, recurrent
+        model, CPU test harness)."""
+        m = len(observations)
+        stock = getattr(self._rollout, "__func__", None) is MPCController._rollout      # not overridden / replaced
+        native = self.dynamics_model.planner_model() if (stock and world == 1 and n_local > 0) else None
+        if native is not None and getattr(native, "sync_max_envs", 0) >= m:
+            self._check_blocks(m)
+            for _ in range(2):
+                keys = native.plan_rs_sync(observations, a_dev, m, n_local, self.horizon, self.discount,
+                                           self._reward_spec, cand_offset=lo)
+                if keys is not None:
+                    return keys.view(np.int64)
+            raise _lib.L2AError("rollout launch failed twice")
+        if n_local > 0:
+            return self._rollout(observations, a_dev, n_local, lo, want_returns=False)[0]
+        return torch.zeros((m,), dtype=torch.int64, device=self._device())       # more ranks than candidates
+
     # ------------------------------------------------------------------ parity-mode draws
     def _draw_rows(self, rows, n, lo, hi, out_f32, rows64=0, out_f64=None):
         """``rows`` rows of the reference's draw (``get_random_action``, ``:67-69``) from the GLOBAL generator:
@@ -391,9 +412,7 @@ class MPCController(Policy, Serializable):
                 a_dev.mul_(high - low).add_(low)
 
             def relaunch():
-                if n_local > 0:
-                    return self._rollout(observations, a_dev, n_local, lo, want_returns=False)[0]
-                return torch.zeros((m,), dtype=torch.int64, device=dev)     # neutral key
+                return self._plan_keys(observations, a_dev, n_local, lo, world)
             best = relaunch()
 
         keys = self._combine_keys(best, relaunch, world)
@@ -422,6 +441,8 @@ class MPCController(Policy, Serializable):
         """Read the arg-max keys back (max all-reduce over the ranks first).  A launch flagged invalid (see
         ``_check_status``) is repeated with the unsplit geometry - before the collective, so that a rank never
         contributes a stale key."""
+        if isinstance(best, np.ndarray):        # blocking launch: keys already on the host, status already handled
+            return best
         if world > 1:
             self._sync()
             if self._check_status() is False:
@@ -450,10 +471,12 @@ class MPCController(Policy, Serializable):
         dev = self._device()
         ahead = self._use_draw_ahead("uniform")
         sig = ("rs", n, m, h, lo, hi)
-        blk = self._ahead_chain().take(sig) if ahead else None
+        chain = self._ahead_chain() if ahead else None
+        blk = chain.take(sig) if ahead else None
 
-        def neutral():
-            return torch.zeros((m,), dtype=torch.int64, device=dev)     # more ranks than candidates
+        def kick():     # the next controller step's candidates are drawn while this plan runs on the GPU
+            if ahead and not chain.active_for(sig):
+                chain.start(sig, self._rs_producer(n, m, h, lo, hi), depth=1, words_only=True)
 
         if blk is not None:
             cand_a, a_dev = blk["cand_a"], blk["a_dev"]
@@ -461,14 +484,15 @@ class MPCController(Policy, Serializable):
                 torch.cuda.current_stream(dev).wait_event(blk["event"])
 
             def relaunch():
-                return self._rollout(observations, a_dev, n_local, lo, want_returns=False)[0] if n_local > 0 \
-                    else neutral()
+                return self._plan_keys(observations, a_dev, n_local, lo, world)
+            kick()
             best = relaunch()
         elif n_local > 0 and self._can_pipeline(h, n_local):
             best, cand_a = self._plan_pipelined(observations, n, m, h, lo, hi, world)
 
             def relaunch():
                 return self._plan_pipelined(observations, n, m, h, lo, hi, world, redraw=False)[0]
+            kick()
         else:
             c64 = self._host64("rs_c64", (m * n, act_dim))
             if n_local > 0:
@@ -481,11 +505,9 @@ class MPCController(Policy, Serializable):
             cand_a = c64.reshape(m, n, act_dim)
 
             def relaunch():
-                return self._rollout(observations, a_dev, n_local, lo, want_returns=False)[0] if n_local > 0 \
-                    else neutral()
+                return self._plan_keys(observations, a_dev, n_local, lo, world)
+            kick()
             best = relaunch()
-        if ahead:       # the next controller step's candidates are drawn while this plan runs on the GPU
-            self._ahead_chain().start(sig, self._rs_producer(n, m, h, lo, hi), depth=1)
         return best, cand_a, relaunch
 
     # ------------------------------------------------------------------ parity mode, pipelined over the horizon

@@ -56,7 +56,7 @@ def _load():
             c = ctypes
             vp, ll, i32 = c.c_void_p, c.c_longlong, c.c_int
             ip = c.POINTER(i32)
-            if lib.l2a_rng_version() < 2:
+            if lib.l2a_rng_version() < 3:
                 return None
             lib.l2a_mt19937_fill_double_mt.argtypes = [vp, ip, vp, ll, i32]
             lib.l2a_mt19937_fill_double_mt.restype = i32
@@ -69,10 +69,27 @@ def _load():
             lib.l2a_cem_samples.argtypes = [vp, ll, ll, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, ll, ll, ll, i32, i32,
                                             i32]
             lib.l2a_cem_samples.restype = i32
+            lib.l2a_mt19937_state_equal.argtypes = [vp, vp, i32]
+            lib.l2a_mt19937_state_equal.restype = i32
+            lib.l2a_mt19937_state_store.argtypes = [vp, vp, i32]
+            lib.l2a_mt19937_state_store.restype = None
+            lib.l2a_mt19937_state_load.argtypes = [vp, vp, ip]
+            lib.l2a_mt19937_state_load.restype = None
             _state["lib"] = lib
         except (OSError, AttributeError):
             _state["lib"] = None
     return _state["lib"]
+
+
+def _global_addr():
+    """Address of the global legacy generator's `mt19937_state` (key[624], pos), or None."""
+    try:
+        bg = np.random.mtrand._rand._bit_generator
+        if type(bg).__name__ != "MT19937":
+            return None
+        return int(bg.ctypes.state_address)
+    except Exception:
+        return None
 
 
 class State(object):
@@ -104,6 +121,25 @@ class State(object):
         st = np.random.get_state()
         return (st[0] == "MT19937" and st[2] == self.pos.value and st[3] == self.has_gauss.value
                 and (not st[3] or st[4] == self.gauss.value) and np.array_equal(st[1], self.key))
+
+    # ---- word-level access (key + pos only; the cached Gaussian is neither compared nor written): enough for the
+    #      uniform stream, which never touches it - and ~1 us instead of get_state() / set_state() ----------------
+    def same_words_as_global(self):
+        if available("direct"):
+            addr = _global_addr()
+            if addr is not None:
+                return bool(_state["lib"].l2a_mt19937_state_equal(addr, self.key.ctypes.data, self.pos.value))
+        st = np.random.get_state()
+        return st[0] == "MT19937" and st[2] == self.pos.value and np.array_equal(st[1], self.key)
+
+    def words_to_global(self):
+        if available("direct"):
+            addr = _global_addr()
+            if addr is not None:
+                _state["lib"].l2a_mt19937_state_store(addr, self.key.ctypes.data, self.pos.value)
+                return
+        st = np.random.get_state()
+        np.random.set_state(("MT19937", self.key, self.pos.value, st[3], st[4]))
 
     # ---- draws on this state (advance it) ------------------------------------------------------------------
     def random_sample(self, n, out=None):
@@ -174,6 +210,28 @@ def _verify(kind):
             st.uniform_rows(rows, low, high, 7, 2, 3, f32, 100, f64)
             sel = want[2::7].astype(np.float32)
             ok = (np.array_equal(f64, want[:100]) and np.array_equal(f32[:len(sel)], sel) and _same(st, after))
+        elif kind == "direct":
+            addr = _global_addr()
+            if addr is not None:
+                np.random.random_sample(701)                     # somewhere inside a block
+                ref = np.random.get_state()
+                key = np.empty(624, dtype=np.uint32)
+                pos = ctypes.c_int(-1)
+                lib.l2a_mt19937_state_load(addr, key.ctypes.data, ctypes.byref(pos))
+                ok = np.array_equal(key, ref[1]) and pos.value == ref[2]
+                st = State(ref[1], ref[2], ref[3], ref[4])
+                ok = ok and bool(lib.l2a_mt19937_state_equal(addr, st.key.ctypes.data, st.pos.value))
+                want = np.random.random_sample(1300)             # advance the real generator ...
+                after = np.random.get_state()
+                np.random.set_state(ref)
+                got = st.random_sample(1300)                     # ... and the copy, then store the copy's words
+                lib.l2a_mt19937_state_store(addr, st.key.ctypes.data, st.pos.value)
+                now = np.random.get_state()
+                ok = (ok and np.array_equal(want, got) and np.array_equal(now[1], after[1]) and now[2] == after[2])
+                if ok:                                           # and the generator really continues from there
+                    nxt = np.random.random_sample(5)
+                    np.random.set_state(after)
+                    ok = np.array_equal(nxt, np.random.random_sample(5))
         elif kind == "normal":
             np.random.normal()                                   # leave a cached Gaussian behind
             start = np.random.get_state()

@@ -766,3 +766,38 @@ def test_draw_ahead_on_the_device_changes_nothing(name):
     for (a0, i0, r0), (a1, i1, r1) in zip(s0, s1):
         assert np.array_equal(a0, a1) and np.array_equal(i0, i1) and np.array_equal(r0, r1)
     assert c1._ahead is not None and c1._ahead.hits >= 2
+
+
+@pytest.mark.parametrize("kernel", ["auto", "valu"])
+@pytest.mark.parametrize("name,over", [("c2_hc_rs_n2000_h30_e5", dict(h=6)), ("hc_rs_m3_n64_h5", {}),
+                                        ("c3_ant_rs_n2000_h20_pb5", dict(n=333, h=4)), ("c1_hc_rs_n500_h10_e1", {})])
+def test_blocking_plan_publishes_the_same_keys(name, over, kernel):
+    """`l2a_plan_rs_sync` (observations read from host-mapped memory, keys published to the host-mapped mailbox by
+    the last candidate tile, key slot zeroed by the previous launch) against `l2a_plan_rs` + read-back: identical
+    keys over a run of back-to-back calls with changing inputs (both ring slots, counter re-arming), also when
+    classic launches are interleaved and for the VALU kernel (which takes the copy-back path inside)."""
+    case = dict(cases.CASES[name], **over)
+    if kernel == "valu" and case["n"] * case["m"] * case["h"] > 20000:
+        pytest.skip("VALU kernel: small cases only")
+    _set_kernel(kernel)
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    m, n, h = case["m"], case["n"], case["h"]
+    rs = np.random.RandomState(4)
+    od = env.observation_space.shape[0]
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    for it in range(7):
+        a = _rs_actions(case, 10 + it, env)
+        a_dev = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        obs0 = rs.randn(m, od)
+        native.plan_rs(torch.from_numpy(obs0.astype(np.float32)).to(dev), a_dev, m, n, h, case.get("discount", 1.0),
+                       env.reward_spec, cand_offset=3 * it, best_key=best)
+        want = best.cpu().numpy()
+        got = native.plan_rs_sync(obs0, a_dev, m, n, h, case.get("discount", 1.0), env.reward_spec, cand_offset=3 * it)
+        assert got is not None and np.array_equal(got.view(np.int64), want), (it, got, want)
+        if it % 3 == 2:     # two blocking launches in a row: the second one's key slot was zeroed by the first
+            got2 = native.plan_rs_sync(obs0, a_dev, m, n, h, case.get("discount", 1.0), env.reward_spec,
+                                       cand_offset=3 * it)
+            assert np.array_equal(got2, got)
+    _lib.Context.get(0).launch_status()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Where a parity-mode controller step spends its host time (config 2): wraps the controller's stages with timers."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+
+
+def main():
+    case = cases.CASES[sys.argv[1] if len(sys.argv) > 1 else "c2_hc_rs_n2000_h30_e5"]
+    env, model = cases.product_model(case)
+    obs = np.random.RandomState(1).randn(case["m"], env.observation_space.shape[0])
+    for mode, ahead in (("numpy", True), ("numpy", False), ("device", True)):
+        ctrl = cases.product_controller(case, model=model, env=env, rng=mode, draw_ahead=ahead)
+        acc = {}
+
+        def wrap(obj, name, label):
+            fn = getattr(obj, name)
+
+            def timed(*a, **k):
+                t = time.perf_counter()
+                r = fn(*a, **k)
+                acc[label] = acc.get(label, 0.0) + time.perf_counter() - t
+                return r
+            setattr(obj, name, timed)
+        np.random.seed(0)
+        for _ in range(5):
+            ctrl.get_actions(obs)
+        native = model.planner_model()
+        wrap(native, "plan_rs_sync", "plan_rs_sync (launch + wait)")
+        wrap(ctrl, "_plan_pipelined", "_plan_pipelined")
+        wrap(ctrl, "_draw_rows", "_draw_rows")
+        if ctrl._ahead is not None:
+            wrap(ctrl._ahead, "take", "ahead.take")
+            wrap(ctrl._ahead, "start", "ahead.start")
+            wrap(ctrl._ahead, "active_for", "ahead.active_for")
+        wrap(ctrl, "_rs_parity_plan", "_rs_parity_plan (total)")
+        torch.cuda.synchronize()
+        K = 200
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ctrl.get_actions(obs)
+        torch.cuda.synchronize()
+        tot = time.perf_counter() - t0
+        row = {"mode": mode, "draw_ahead": ahead, "ms_per_call": round(1e3 * tot / K, 4),
+               "stages_us": {k: round(1e6 * v / K, 1) for k, v in acc.items()},
+               "hits": None if ctrl._ahead is None else ctrl._ahead.hits}
+        print(json.dumps(row), flush=True)
+        if ctrl._ahead is not None:
+            ctrl._ahead.stop()
+
+
+if __name__ == "__main__":
+    main()
