@@ -675,7 +675,7 @@ static int ensure_mail(l2a_ctx* ctx) {
     }
     ctx->mail_host = host;
     ctx->mail_dev = dev;
-    ctx->ring_clean[0] = ctx->ring_clean[1] = true;
+    ctx->ring_dirty[0] = ctx->ring_dirty[1] = 0;
     return L2A_OK;
 }
 
@@ -708,9 +708,11 @@ int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions,
     l2a_mail* mh = ctx->mail_host;
     std::memcpy(mh->obs[slot], obs_host, sizeof(float) * (size_t)m * md->obs_dim);
     unsigned long long* keys_dev = ctx->key_ring + (size_t)slot * L2A_MAIL_KEYS;
-    if (!ctx->ring_clean[slot])
+    // Key-slot bookkeeping: ring_dirty[s] = how many leading entries of slot s may be non-zero.  A mailbox launch
+    // with m envs zeroes entries [0, m) of the OTHER slot in its epilogue; anything beyond needs a memset.
+    if (ctx->ring_dirty[slot] > 0)
         L2A_HIP(ctx, hipMemsetAsync(keys_dev, 0, sizeof(unsigned long long) * L2A_MAIL_KEYS, stream));
-    ctx->ring_clean[slot] = false;
+    ctx->ring_dirty[slot] = m;
 
     L2AKParams p;
     fill_model_params(md, p);
@@ -727,9 +729,9 @@ int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions,
     }
     const auto t0 = std::chrono::steady_clock::now();
     rc = launch_rollout(md, p, stream_v);
-    if (rc != L2A_OK) { ctx->ring_clean[0] = ctx->ring_clean[1] = false; return rc; }
+    if (rc != L2A_OK) { ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS; return rc; }
     if (publish) {
-        ctx->ring_clean[slot ^ 1] = true;           // zeroed by this launch's last tile
+        if (m >= ctx->ring_dirty[slot ^ 1]) ctx->ring_dirty[slot ^ 1] = 0;     // zeroed by this launch's last tile
         // Sleep through most of the expected duration, then poll the mailbox word (host-mapped memory: no copy,
         // no hipStreamSynchronize wake-up latency).
         if (ctx->sync_ema_us > 400.0) usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
@@ -740,16 +742,16 @@ int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions,
             if ((++spins & 0xffffull) == 0) {
                 const hipError_t q = hipStreamQuery(stream);
                 if (q != hipSuccess && q != hipErrorNotReady) {
-                    ctx->ring_clean[0] = ctx->ring_clean[1] = false;
+                    ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS;
                     return fail(ctx, L2A_EHIP, std::string("l2a_plan_rs_sync: ") + hipGetErrorString(q));
                 }
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (q == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq && waited > 1.0) {
-                    ctx->ring_clean[0] = ctx->ring_clean[1] = false;
+                    ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS;
                     return fail(ctx, L2A_EHIP, "l2a_plan_rs_sync: the stream drained but the mailbox was never written");
                 }
                 if (waited > 60.0) {
-                    ctx->ring_clean[0] = ctx->ring_clean[1] = false;
+                    ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS;
                     return fail(ctx, L2A_EHIP, "l2a_plan_rs_sync: timed out waiting for the plan");
                 }
             }

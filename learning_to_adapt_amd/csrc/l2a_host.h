@@ -29,7 +29,7 @@ struct l2a_ctx {
     struct l2a_mail* mail_dev = nullptr;  // device alias of mail_host
     unsigned int* done_ctr = nullptr;     // device
     unsigned long long* key_ring = nullptr;   // device [2][L2A_MAIL_KEYS]
-    bool ring_clean[2] = {false, false};
+    int ring_dirty[2] = {L2A_MAIL_KEYS, L2A_MAIL_KEYS};   // leading entries of each slot that may be non-zero
     unsigned long long mail_seq = 0;
     double sync_ema_us = 0.0;             // expected duration of the next blocking plan (sleep-then-spin)
     int num_cu = 0;

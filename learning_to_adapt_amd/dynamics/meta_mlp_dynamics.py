@@ -305,13 +305,25 @@ class MetaMLPDynamicsModel(Serializable):
 
     def fit(self, obs, act, obs_next, epochs=1000, compute_normalization=True,
             valid_split_ratio=None, rolling_average_persitency=None, verbose=False, log_tabular=False):
-        """First-order meta-training (stock PyTorch): sample ``meta_batch_size`` windows of
-        ``2 * batch_size`` consecutive transitions, adapt on the first half, minimise the
-        post-update loss on the second half (reference ``:165-275``, ``:353-390``)."""
+        """Meta-training (stock PyTorch), mirroring the reference's ``fit`` (``:167-268``):
+
+        * the paths of THIS call are normalised, split into train / validation by ``valid_split_ratio``
+          (``train_test_split``, ``:453-466``: a shuffle of the path indices from the global NumPy generator) and
+          APPENDED to ``_dataset_train`` / ``_dataset_test`` (``:193-203``) - the trainer hands over only the newest
+          iteration's rollouts and relies on the model to keep the older ones;
+        * a step samples ``meta_batch_size`` windows of ``2 * batch_size`` consecutive transitions from the
+          accumulated train set (``_get_batch``, ``:353-390``), adapts on the first half of each window and minimises
+          the mean post-update loss on the second half, differentiating through the inner step (``:96-141``);
+        * after every epoch the plain (un-adapted) loss ``self.loss`` (``:88``) is averaged over windows sampled from
+          the held-out set and drives the rolling-average early stop (``:236-262``)."""
         assert obs.ndim == 3 and obs.shape[2] == self.obs_space_dims
+        assert obs_next.ndim == 3 and obs_next.shape[2] == self.obs_space_dims
         assert act.ndim == 3 and act.shape[2] == self.action_space_dims
+        if valid_split_ratio is None:
+            valid_split_ratio = self.valid_split_ratio
         if rolling_average_persitency is None:
             rolling_average_persitency = self.rolling_average_persitency
+        assert 1 > valid_split_ratio >= 0
         if (self.normalization is None or compute_normalization) and self.normalize_input:
             self.compute_normalization(obs, act, obs_next)
         if self.normalize_input:
@@ -321,50 +333,89 @@ class MetaMLPDynamicsModel(Serializable):
             d_n = core.normalize(obs_next - obs, nm["delta"][0], nm["delta"][1])
         else:
             o_n, a_n, d_n = obs, act, obs_next - obs
+
+        # train_test_split (:453-466) over the paths, then accumulate (:193-203)
+        n_paths = o_n.shape[0]
+        indices = np.arange(n_paths)
+        np.random.shuffle(indices)
+        split_idx = int(n_paths * (1 - valid_split_ratio))
+        idx_train, idx_test = indices[:split_idx], indices[split_idx:]
+        new_train = dict(obs=o_n[idx_train], act=a_n[idx_train], delta=d_n[idx_train])
+        new_test = dict(obs=o_n[idx_test], act=a_n[idx_test], delta=d_n[idx_test])
+        if self._dataset_test is None:
+            self._dataset_test, self._dataset_train = new_test, new_train
+        else:
+            for key in ("obs", "act", "delta"):
+                self._dataset_test[key] = np.concatenate([self._dataset_test[key], new_test[key]])
+                self._dataset_train[key] = np.concatenate([self._dataset_train[key], new_train[key]])
+
         dev = core.training_device()
-        X = torch.as_tensor(np.concatenate([o_n, a_n], axis=2), dtype=torch.float32, device=dev)
-        Y = torch.as_tensor(d_n, dtype=torch.float32, device=dev)
-        num_paths, len_path = X.shape[:2]
-        bs = self.batch_size
-        assert len_path > 2 * bs, "paths must be longer than 2 * batch_size"
+
+        def to_dev(ds):
+            x = torch.as_tensor(np.concatenate([ds["obs"], ds["act"]], axis=2), dtype=torch.float32, device=dev)
+            return x, torch.as_tensor(ds["delta"], dtype=torch.float32, device=dev)
+        X, Y = to_dev(self._dataset_train)
+        # a held-out set can be empty (valid_split_ratio = 0, or a single path): validate on the train set then
+        # (the reference would fail in np.random.randint(0, 0))
+        XT, YT = to_dev(self._dataset_test) if self._dataset_test["obs"].shape[0] > 0 else (X, Y)
+        bs, mbs = self.batch_size, self.meta_batch_size
+        assert X.shape[1] > 2 * bs, "paths must be longer than 2 * batch_size"
         params = [p.to(dev).requires_grad_(True) for p in self._params]
         opt = torch.optim.Adam(params, lr=self.learning_rate)
-        steps_per_epoch = max(int(num_paths * len_path / (self.meta_batch_size * bs * 2)), 1)
+        steps_per_epoch = max(int(np.prod(X.shape[:2]) / (mbs * bs * 2)), 1)                   # :209-210
+        steps_test = max(int(np.prod(XT.shape[:2]) / (mbs * bs * 2)), 1)                       # :211-212
+        hid, out = self.hidden_nonlinearity, self.output_nonlinearity
+
+        def windows(x, y):          # _get_batch (:353-390): meta_batch_size windows of 2 * batch_size transitions
+            num_paths, len_path = x.shape[:2]
+            ip = np.random.randint(0, num_paths, size=mbs)
+            ib = np.random.randint(bs, len_path - bs, size=mbs)
+            return [(x[p_i, b_i - bs:b_i + bs], y[p_i, b_i - bs:b_i + bs]) for p_i, b_i in zip(ip, ib)]
+
         rolling, rolling_prev, last_epoch = None, None, 0
+        pre_losses, post_losses = [], []
         for epoch in range(epochs):
-            post_losses = []
+            pre_losses, post_losses = [], []
             for _ in range(steps_per_epoch):
-                ip = np.random.randint(0, num_paths, size=self.meta_batch_size)
-                ib = np.random.randint(bs, len_path - bs, size=self.meta_batch_size)
-                total = 0.0
-                for p_i, b_i in zip(ip, ib):
-                    xa, ya = X[p_i, b_i - bs:b_i], Y[p_i, b_i - bs:b_i]
-                    xb, yb = X[p_i, b_i:b_i + bs], Y[p_i, b_i:b_i + bs]
-                    pre = torch.mean((ya - core.mlp_forward(xa, params, self.hidden_nonlinearity,
-                                                            self.output_nonlinearity)) ** 2)
-                    grads = torch.autograd.grad(pre, params, create_graph=True)
+                pre_total, post_total = 0.0, 0.0
+                for xw, yw in windows(X, Y):
+                    xa, ya, xb, yb = xw[:bs], yw[:bs], xw[bs:], yw[bs:]                       # pre / post halves :99-100
+                    pre = torch.mean((ya - core.mlp_forward(xa, params, hid, out)) ** 2)       # :118
+                    grads = torch.autograd.grad(pre, params, create_graph=True)                # :409-421
                     fast = [p - self.inner_learning_rate * g for p, g in zip(params, grads)]
-                    total = total + torch.mean((yb - core.mlp_forward(xb, fast, self.hidden_nonlinearity,
-                                                                      self.output_nonlinearity)) ** 2)
-                loss = total / self.meta_batch_size
+                    post_total = post_total + torch.mean((yb - core.mlp_forward(xb, fast, hid, out)) ** 2)   # :133
+                    pre_total = pre_total + pre.detach()
+                loss = post_total / mbs                                                        # :139
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
                 opt.step()
                 post_losses.append(float(loss.detach()))
-            valid_loss = float(np.mean(post_losses))
-            if rolling is None:
+                pre_losses.append(float(pre_total / mbs))
+            with torch.no_grad():                                                              # :227-236
+                valid_losses = []
+                for _ in range(steps_test):
+                    ws = windows(XT, YT)
+                    xv = torch.cat([w[0] for w in ws], dim=0)
+                    yv = torch.cat([w[1] for w in ws], dim=0)
+                    valid_losses.append(float(torch.mean((yv - core.mlp_forward(xv, params, hid, out)) ** 2)))   # :88
+            valid_loss = float(np.mean(valid_losses))
+            if rolling is None:                                                                # :238-243
                 rolling, rolling_prev = 1.5 * valid_loss, 2 * valid_loss
+                if valid_loss < 0:
+                    rolling, rolling_prev = valid_loss / 1.5, valid_loss / 2
             rolling = rolling_average_persitency * rolling + (1.0 - rolling_average_persitency) * valid_loss
             last_epoch = epoch
             if verbose:
-                print("Training MetaDynamicsModel - epoch %i -- post loss: %.4f  mov_avg: %.4f"
-                      % (epoch, valid_loss, rolling))
-            if rolling_prev < rolling or epoch == epochs - 1:
+                print("Training MetaDynamicsModel - epoch %i -- train loss: %.4f  valid loss: %.4f  mov_avg: %.4f"
+                      % (epoch, float(np.mean(post_losses)), valid_loss, rolling))
+            if rolling_prev < rolling or epoch == epochs - 1:                                  # :258-261
                 break
             rolling_prev = rolling
         self._params = [p.detach().to("cpu").contiguous() for p in params]
         self._base_dirty = True
-        self.fit_stats = dict(Epochs=last_epoch)
+        self.fit_stats = {"Epochs": last_epoch, "Post-Loss": float(np.mean(post_losses)) if post_losses else None,
+                          "Pre-Loss": float(np.mean(pre_losses)) if pre_losses else None,
+                          "TrainPaths": int(X.shape[0]), "ValidPaths": int(self._dataset_test["obs"].shape[0])}
         return self.fit_stats
 
     # ------------------------------------------------------------------ pickling (reference :434-445)

@@ -141,3 +141,38 @@ def test_two_rank_recurrent_plan_equals_single_process_plan(cid, tmp_path):
             assert np.array_equal(o["best_%d" % k], gold["best_%d" % k])
             np.testing.assert_array_equal(o["actions_%d" % k], gold["chosen_%d" % k])
             np.testing.assert_array_equal(o["c_%d" % k], gold["hidden_c_%d" % k])
+
+
+def _worker_bad_seed(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        import oracle_backend
+        from learning_to_adapt_amd import _lib
+        case = cases.CASES["hc_rs_m3_n64_h5"]
+        gold = cases.load_golden("hc_rs_m3_n64_h5_s0")
+        ctrl = oracle_backend.install(cases.product_controller(case), case)
+        np.random.seed(100 + rank)                # the common `seed + rank` mistake
+        try:
+            ctrl.get_actions(gold["obs0"])
+            verdict = "planned"
+        except _lib.L2AError as exc:
+            verdict = "refused: %s" % exc
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write(verdict)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_seeded_differently_are_refused(tmp_path):
+    """Sharded parity mode combines keys that index ONE candidate tensor: ranks whose generators differ must not
+    plan silently."""
+    world = 2
+    mp.spawn(_worker_bad_seed, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        with open(os.path.join(str(tmp_path), "rank%d.txt" % r)) as f:
+            assert f.read().startswith("refused: candidate sharding needs identical")

@@ -787,7 +787,16 @@ def test_blocking_plan_publishes_the_same_keys(name, over, kernel):
     rs = np.random.RandomState(4)
     od = env.observation_space.shape[0]
     best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    # a second model with ONE env planning on the same context in between: its launches zero only one entry of
+    # the other key slot (the slots are per context, shared by every model on it)
+    one = cases.CASES["hc_rs_n1_h1"]
+    env1, model1 = cases.product_model(one)
+    native1 = model1.planner_model()
+    a1 = torch.from_numpy(np.ascontiguousarray(_rs_actions(one, 1, env1), dtype=np.float32)).to(dev)
+    obs1 = rs.randn(1, env1.observation_space.shape[0])
     for it in range(7):
+        for _ in range(it % 3):
+            assert native1.plan_rs_sync(obs1, a1, 1, one["n"], one["h"], 1.0, env1.reward_spec) is not None
         a = _rs_actions(case, 10 + it, env)
         a_dev = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         obs0 = rs.randn(m, od)

@@ -1,0 +1,11 @@
+#!/bin/bash
+TAG=${1:-r02c}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+echo "== pytest -m gpu"
+timeout 1200 python -m pytest tests -m gpu -q --timeout 300 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -30 $OUT/pytest_gpu.log
+echo "== probe"
+timeout 300 python tools/probe_e2e.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl; tail -5 $OUT/probe.err
+timeout 300 python tools/probe_e2e.py c5_hc_cem_n4000_h30_e5 > $OUT/probe_cem.jsonl 2> $OUT/probe_cem.err; cat $OUT/probe_cem.jsonl; tail -5 $OUT/probe_cem.err

@@ -25,10 +25,10 @@ def main():
         def wrap(obj, name, label):
             fn = getattr(obj, name)
 
-            def timed(*a, **k):
+            def timed(*a, _acc=acc, **k):
                 t = time.perf_counter()
                 r = fn(*a, **k)
-                acc[label] = acc.get(label, 0.0) + time.perf_counter() - t
+                _acc[label] = _acc.get(label, 0.0) + time.perf_counter() - t
                 return r
             setattr(obj, name, timed)
         np.random.seed(0)
@@ -43,8 +43,25 @@ def main():
             wrap(ctrl._ahead, "start", "ahead.start")
             wrap(ctrl._ahead, "active_for", "ahead.active_for")
         wrap(ctrl, "_rs_parity_plan", "_rs_parity_plan (total)")
+        wrap(ctrl, "_cem_draw", "_cem_draw")
+        wrap(ctrl, "_cem_rollout_pipelined", "_cem_rollout_pipelined")
+        wrap(ctrl, "_cem_refit", "_cem_refit")
+        wrap(ctrl, "_cem_iteration", "_cem_iteration (total)")
+        wrap(ctrl, "_upload_obs", "_upload_obs")
+        wrap(ctrl, "_to_device", "_to_device")
+        from learning_to_adapt_amd.utils import fast_rng
+        if not hasattr(fast_rng, "_orig_cem_samples"):
+            fast_rng._orig_cem_samples = fast_rng.cem_samples
+        _cs = fast_rng._orig_cem_samples
+
+        def timed_cs(*a, _acc=acc, **k):
+            t = time.perf_counter()
+            r = _cs(*a, **k)
+            _acc["cem_samples"] = _acc.get("cem_samples", 0.0) + time.perf_counter() - t
+            return r
+        fast_rng.cem_samples = timed_cs
         torch.cuda.synchronize()
-        K = 200
+        K = 200 if case["planner"] == "rs" else 20
         t0 = time.perf_counter()
         for _ in range(K):
             ctrl.get_actions(obs)
