@@ -1,0 +1,178 @@
+"""Load snapshots written by the reference trainer and plan with them.
+
+The reference saves ``dict(itr, policy, env, dynamics_model)`` with ``joblib.dump``
+(``trainers/mb_trainer.py:118-122``, ``logger/logger.py:376-396``: ``params.pkl`` / ``itr_N.pkl``).  The objects are
+pickled by class path plus constructor arguments (``utils/serializable.py:44-49``); the dynamics models add their
+weights in the layout
+
+    {'init_args': {'__args': (...), '__kwargs': {...}},
+     'normalization': OrderedDict(obs=(mean, std), delta=(mean, std), act=(mean, std)),
+     'networks': [{'network_params': OrderedDict(name -> ndarray)}]}
+
+(``dynamics/meta_mlp_dynamics.py:434-445``, ``dynamics/mlp_dynamics.py`` / ``rnn_dynamics.py:319-330``,
+``dynamics/core/layers.py:103-113``; names ``hidden_i/kernel``, ``hidden_i/bias``, ``output/kernel``,
+``output/bias`` or ``rnn/lstm_cell/kernel`` ... in ``get_params()`` order).
+
+The class paths in such a file start with ``learning_to_adapt.``; this package's drop-in classes live under
+``learning_to_adapt_amd.`` with the same module and class names and the same ``__setstate__`` contract.
+``load_snapshot`` resolves the former to the latter while unpickling (nothing is imported from the reference) and
+maps the reference's MuJoCo env classes - whose physics needs the proprietary simulator and is out of scope - to
+``SyntheticEnv`` stand-ins of the same shapes, spaces, ``dt`` and ``reward``: exactly what the planner consumes.
+"""
+
+import contextlib
+import importlib
+import pickle
+import sys
+import types
+
+import numpy as np
+
+from ..envs.synthetic_env import SyntheticEnv
+from ..spaces import Box
+from .serializable import Serializable
+
+_PREFIX_REF, _PREFIX_OWN = "learning_to_adapt", "learning_to_adapt_amd"
+
+# reference env module -> (class name, SyntheticEnv kind)
+_ENV_CLASSES = {
+    "envs.half_cheetah_env": ("HalfCheetahEnv", "half_cheetah"),
+    "envs.half_cheetah_blocks_env": ("HalfCheetahBlocksEnv", "half_cheetah"),
+    "envs.half_cheetah_hfield_env": ("HalfCheetahHFieldEnv", "half_cheetah"),
+    "envs.ant_env": ("AntEnv", "ant"),
+    "envs.arm_7dof_env": ("Arm7DofEnv", "arm_7dof"),
+}
+# modules whose classes exist here under the same names
+_SAME_NAME = ("dynamics.mlp_dynamics", "dynamics.meta_mlp_dynamics", "dynamics.rnn_dynamics",
+              "policies.mpc_controller", "policies.rnn_mpc_controller", "utils.serializable")
+
+
+def _env_stub(name, kind):
+    def __init__(self, *args, **kwargs):
+        SyntheticEnv.__init__(self, kind)
+        self.reference_init_args = (args, kwargs)        # task, reset_every_episode, ... (physics options)
+
+    def __setstate__(self, state):
+        __init__(self, *state.get("__args", ()), **state.get("__kwargs", {}))
+
+    def __getstate__(self):
+        return {"__args": self.reference_init_args[0], "__kwargs": self.reference_init_args[1]}
+    return type(name, (SyntheticEnv,), {"__init__": __init__, "__setstate__": __setstate__,
+                                         "__getstate__": __getstate__, "__module__": __name__,
+                                         "__doc__": "stand-in for the reference's %s" % name})
+
+
+# module-level, so that objects rebuilt from a snapshot can be pickled again (by THIS package's class path)
+HalfCheetahEnv = _env_stub("HalfCheetahEnv", "half_cheetah")
+HalfCheetahBlocksEnv = _env_stub("HalfCheetahBlocksEnv", "half_cheetah")
+HalfCheetahHFieldEnv = _env_stub("HalfCheetahHFieldEnv", "half_cheetah")
+AntEnv = _env_stub("AntEnv", "ant")
+Arm7DofEnv = _env_stub("Arm7DofEnv", "arm_7dof")
+
+
+class AdamOptimizer(object):
+    """Placeholder for ``tf.train.AdamOptimizer`` found among recorded constructor arguments (never instantiated:
+    the drop-in models train with ``torch.optim.Adam``)."""
+
+
+class NormalizedEnv(Serializable):
+    """``envs/normalized_env.py:24-122`` as far as the planner looks: the wrapped env behind ``_wrapped_env`` (NOT
+    ``wrapped_env`` - the reference's policies therefore do not unwrap it), attribute forwarding
+    (``:64-82``), and the action space rescaled to ``+-normalization_scale`` (``:57-62``)."""
+
+    def __init__(self, env, scale_reward=1., normalize_obs=False, normalize_reward=False, obs_alpha=0.001,
+                 reward_alpha=0.001, normalization_scale=1.):
+        Serializable.quick_init(self, locals())
+        self._wrapped_env = env
+        self._normalization_scale = normalization_scale
+        self._obs_mean = np.zeros(env.observation_space.shape)
+        self._obs_var = np.ones(env.observation_space.shape)
+
+    @property
+    def action_space(self):
+        ub = np.ones(self._wrapped_env.action_space.shape) * self._normalization_scale
+        return Box(-1 * ub, ub)
+
+    def __getattr__(self, attr):
+        if attr.startswith("__") or attr == "_wrapped_env":
+            raise AttributeError(attr)
+        return getattr(self._wrapped_env, attr)
+
+    def __getstate__(self):
+        d = Serializable.__getstate__(self)
+        d["_obs_mean"], d["_obs_var"] = self._obs_mean, self._obs_var
+        return d
+
+    def __setstate__(self, d):
+        Serializable.__setstate__(self, d)
+        self._obs_mean, self._obs_var = d.get("_obs_mean", self._obs_mean), d.get("_obs_var", self._obs_var)
+
+
+def _alias_modules():
+    """{reference module name: module object} for everything a snapshot may name."""
+    out = {}
+    for sub in _SAME_NAME:
+        out["%s.%s" % (_PREFIX_REF, sub)] = importlib.import_module("%s.%s" % (_PREFIX_OWN, sub))
+    box = types.ModuleType("%s.spaces.box" % _PREFIX_REF)        # spaces/box.py: Box lives in spaces.py here
+    box.Box = Box
+    out[box.__name__] = box
+    for sub, (cls_name, kind) in _ENV_CLASSES.items():
+        mod = types.ModuleType("%s.%s" % (_PREFIX_REF, sub))
+        setattr(mod, cls_name, globals()[cls_name])
+        out[mod.__name__] = mod
+    # constructor arguments recorded by quick_init include defaults such as `optimizer=tf.train.AdamOptimizer`
+    # (mlp_dynamics.py:34): a class reference into TensorFlow, which is neither installed nor needed to plan
+    try:
+        importlib.import_module("tensorflow")
+    except ImportError:
+        adam = types.ModuleType("tensorflow.python.training.adam")
+        adam.AdamOptimizer = AdamOptimizer
+        out[adam.__name__] = adam
+    norm = types.ModuleType("%s.envs.normalized_env" % _PREFIX_REF)
+    norm.NormalizedEnv = NormalizedEnv
+    norm.normalize = NormalizedEnv
+    out[norm.__name__] = norm
+    return out
+
+
+@contextlib.contextmanager
+def reference_class_paths():
+    """Within the block, ``learning_to_adapt.<module>`` resolves to this package's drop-in modules (and env
+    stand-ins) for ``pickle`` / ``joblib``.  Refuses to run when a real ``learning_to_adapt`` is importable -
+    then the snapshot should simply be loaded with it."""
+    if _PREFIX_REF in sys.modules and not getattr(sys.modules[_PREFIX_REF], "_l2a_alias", False):
+        raise RuntimeError("a real `learning_to_adapt` package is already imported; aliasing would shadow it")
+    aliases = _alias_modules()
+    parents = {}
+    for name in aliases:
+        parts = name.split(".")
+        for i in range(1, len(parts)):
+            pkg = ".".join(parts[:i])
+            if pkg not in aliases and pkg not in parents and pkg not in sys.modules:
+                m = types.ModuleType(pkg)
+                m.__path__ = []
+                m._l2a_alias = True
+                parents[pkg] = m
+    installed = dict(parents, **aliases)
+    saved = {k: sys.modules.get(k) for k in installed}
+    sys.modules.update(installed)
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def load_snapshot(path):
+    """``joblib.load`` (or plain ``pickle``) of a reference snapshot -> ``dict(itr, policy, env, dynamics_model)``
+    built from this package's classes; ``policy.get_actions`` then plans on the GPU with the trained weights."""
+    with reference_class_paths():
+        try:
+            import joblib
+            return joblib.load(path)
+        except ImportError:
+            with open(path, "rb") as f:
+                return pickle.load(f)
