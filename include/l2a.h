@@ -227,6 +227,23 @@ int l2a_model_adapt_sgd(l2a_model* model, const void* const* base_ptrs, const fl
  * the sizes l2a_model_set_weights takes) - e.g. to read back adapted sets (`_adapted_param_values`).    */
 int l2a_model_get_weights(l2a_model* model, int e, void* const* device_ptrs_out, void* stream);
 
+/* ---- sharded plans: the one collective ------------------------------------------------------
+ * Candidates are independent, so G GPUs (one process and one context each) plan disjoint shards of one candidate
+ * tensor (l2a_plan_rs with cand_offset = first global index of the shard) and combine the per-shard keys with ONE
+ * in-place MAX all-reduce of m u64 words over RCCL / xGMI - the reference has no collective (single process);
+ * the semantics preserved are np.argmax's "first maximum" over the whole candidate set
+ * (policies/mpc_controller.py:128-129), which the key packing encodes (see l2a_key_encode).
+ *   l2a_comm_unique_id : rank 0 fills a 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *                        (file, pipe, MPI, torch.distributed store)
+ *   l2a_comm_init      : every rank, same id; binds the communicator to the context's device (ncclCommInitRank)
+ *   l2a_allreduce_best : best_key device u64 [m], in place, enqueued on `stream` after the plan
+ * RCCL is loaded at run time on the first of these calls; without it they fail with L2A_ENODEV and single-GPU
+ * planning is unaffected.  (The Python drop-in uses torch.distributed - the same RCCL - for this step.)          */
+int l2a_comm_unique_id(char id_out[128]);
+int l2a_comm_init(l2a_ctx* ctx, int rank, int world, const char id[128]);
+int l2a_comm_destroy(l2a_ctx* ctx);
+int l2a_allreduce_best(l2a_ctx* ctx, unsigned long long* best_key, int m, void* stream);
+
 /* ---- recurrent planner (ReBAL) --------------------------------------------------------------
  * Single-layer LSTM dynamics model: `RNNDynamicsModel` (dynamics/rnn_dynamics.py:11-100) built by
  * `create_rnn` (dynamics/core/utils.py:192-236) with cell_type='lstm' - the configuration of

@@ -278,6 +278,7 @@ int l2a_init(int device, l2a_ctx** out) {
 
 void l2a_destroy(l2a_ctx* ctx) {
     if (!ctx) return;
+    (void)l2a_comm_destroy(ctx);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->mail_host) (void)hipHostFree(ctx->mail_host);
     if (ctx->done_ctr) (void)hipFree(ctx->done_ctr);

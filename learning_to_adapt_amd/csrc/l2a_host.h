@@ -32,6 +32,9 @@ struct l2a_ctx {
     int ring_dirty[2] = {L2A_MAIL_KEYS, L2A_MAIL_KEYS};   // leading entries of each slot that may be non-zero
     unsigned long long mail_seq = 0;
     double sync_ema_us = 0.0;             // expected duration of the next blocking plan (sleep-then-spin)
+    // RCCL communicator of sharded plans (l2a_comm.hip); null = single GPU
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
     int num_cu = 0;
     int lds_per_block = 0;
     int clock_khz = 0;

@@ -3,7 +3,11 @@
  * the reference's planner would write against include/l2a.h.  Test infrastructure (tests/test_c_abi.py
  * compiles it with gcc and runs it on the GPU box).
  *
- * usage: abi_demo <case.bin> ; the file is written by the test:
+ * usage: abi_demo <case.bin> [rank world idfile] ; without the three extra arguments one process plans the whole
+ * case.  With them, `world` processes (one per GPU: device = rank % visible devices) each plan the candidate
+ * shard [rank * n / world, (rank + 1) * n / world) with global indices (cand_offset) and combine their keys with
+ * l2a_allreduce_best (RCCL): rank 0 creates the communicator id and writes it to `idfile`, the others wait for it.
+ * Every rank prints the same lines.  The case file is written by the test:
  *   int32 header[8] = {obs_dim, act_dim, n_hidden, hidden0, m, n, h, vel_index}
  *   float  dt, ctrl_coef
  *   per layer: kernel [in, out] fp32, bias [out] fp32          (reference parameter order)
@@ -14,6 +18,8 @@
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 #include "l2a.h"
 
@@ -45,8 +51,12 @@ int main(int argc, char** argv) {
     const int obs_dim = hd[0], act_dim = hd[1], n_hidden = hd[2], width = hd[3], m = hd[4], n = hd[5], h = hd[6];
     float* rw_par = (float*)rd(f, 2 * sizeof(float));
 
+    const int sharded = (argc >= 5);
+    const int rank = sharded ? atoi(argv[2]) : 0, world = sharded ? atoi(argv[3]) : 1;
+    int n_dev = 1;
+    CHECK_HIP(hipGetDeviceCount(&n_dev));
     l2a_ctx* ctx = NULL;
-    if (l2a_init(0, &ctx) != L2A_OK) { fprintf(stderr, "l2a_init: %s\n", l2a_last_error(NULL)); return 3; }
+    if (l2a_init(rank % n_dev, &ctx) != L2A_OK) { fprintf(stderr, "l2a_init: %s\n", l2a_last_error(NULL)); return 3; }
     int hidden[8];
     for (int i = 0; i < n_hidden; ++i) hidden[i] = width;
     l2a_model* model = NULL;
@@ -73,12 +83,41 @@ int main(int argc, char** argv) {
     float* acts = (float*)rd(f, sizeof(float) * (size_t)h * m * n * act_dim);
     fclose(f);
     float* d_obs0 = (float*)to_device(obs0, sizeof(float) * (size_t)m * obs_dim);
-    float* d_acts = (float*)to_device(acts, sizeof(float) * (size_t)h * m * n * act_dim);
     unsigned long long* d_key = NULL;
     CHECK_HIP(hipMalloc((void**)&d_key, sizeof(unsigned long long) * (size_t)m));
 
+    /* this rank's shard of the candidate tensor [h, m * n, act_dim] -> [h, m * n_loc, act_dim] */
+    const int lo = (int)((long long)rank * n / world), hi = (int)((long long)(rank + 1) * n / world), n_loc = hi - lo;
+    float* shard = (float*)malloc(sizeof(float) * (size_t)h * m * (n_loc > 0 ? n_loc : 1) * act_dim);
+    for (int t = 0; t < h; ++t)
+        for (int i = 0; i < m; ++i)
+            memcpy(shard + ((size_t)(t * m + i) * n_loc) * act_dim, acts + ((size_t)(t * m + i) * n + lo) * act_dim,
+                   sizeof(float) * (size_t)n_loc * act_dim);
+    float* d_acts = (float*)to_device(shard, sizeof(float) * (size_t)h * m * (n_loc > 0 ? n_loc : 1) * act_dim);
+
+    if (sharded) {
+        char id[128];
+        if (rank == 0) {
+            CHECK_L2A(ctx, l2a_comm_unique_id(id));
+            char tmp[1024];
+            snprintf(tmp, sizeof(tmp), "%s.tmp", argv[4]);
+            FILE* g = fopen(tmp, "wb");
+            if (!g || fwrite(id, 1, 128, g) != 128) { perror("idfile"); return 7; }
+            fclose(g);
+            rename(tmp, argv[4]);
+        } else {
+            FILE* g = NULL;
+            for (int tries = 0; tries < 600 && !(g = fopen(argv[4], "rb")); ++tries) usleep(100000);
+            if (!g || fread(id, 1, 128, g) != 128) { fprintf(stderr, "no communicator id in %s\n", argv[4]); return 7; }
+            fclose(g);
+        }
+        CHECK_L2A(ctx, l2a_comm_init(ctx, rank, world, id));
+    }
+
     l2a_reward rw = {1.0f, 1.0f / rw_par[0], 0.0f, rw_par[1], 0.0f, hd[7], 0, 0};      /* half_cheetah_env.py:58-65 */
-    CHECK_L2A(ctx, l2a_plan_rs(model, d_obs0, d_acts, m, n, h, 1.0f, &rw, 0, NULL, d_key, NULL));
+    if (n_loc > 0) CHECK_L2A(ctx, l2a_plan_rs(model, d_obs0, d_acts, m, n_loc, h, 1.0, &rw, lo, NULL, d_key, NULL));
+    else CHECK_HIP(hipMemset(d_key, 0, sizeof(unsigned long long) * (size_t)m));            /* neutral key */
+    if (sharded) CHECK_L2A(ctx, l2a_allreduce_best(ctx, d_key, m, NULL));
     unsigned long long* key = (unsigned long long*)malloc(sizeof(unsigned long long) * (size_t)m);
     CHECK_HIP(hipMemcpy(key, d_key, sizeof(unsigned long long) * (size_t)m, hipMemcpyDeviceToHost));   /* = the sync */
     int status = 0;

@@ -58,9 +58,23 @@ def test_c_demo_picks_the_reference_candidates(tmp_path):
                 f.write(np.ascontiguousarray(nm[key][j], dtype=np.float64).tobytes())
         f.write(np.ascontiguousarray(gold["obs0"], dtype=np.float32).tobytes())
         f.write(np.ascontiguousarray(a, dtype=np.float32).tobytes())
-    out = subprocess.check_output([_build(tmp_path), path], timeout=120).decode().strip().splitlines()
-    assert len(out) == case["m"]
-    for i, line in enumerate(out):
-        tok = line.split()
-        assert int(tok[1]) == i and int(tok[3]) == int(gold["best"][i])
-        assert abs(float(tok[5]) - float(gold["returns"][i, gold["best"][i]])) <= 1e-4 * max(1.0, abs(float(tok[5])))
+    exe = _build(tmp_path)
+
+    def check(out):
+        out = out.decode().strip().splitlines()
+        assert len(out) == case["m"]
+        for i, line in enumerate(out):
+            tok = line.split()
+            assert int(tok[1]) == i and int(tok[3]) == int(gold["best"][i])
+            assert abs(float(tok[5]) - float(gold["returns"][i, gold["best"][i]])) <= 1e-4 * max(1.0, abs(float(tok[5])))
+    check(subprocess.check_output([exe, path], timeout=120))
+    # the sharded form: one rank per GPU, keys combined by l2a_allreduce_best over RCCL.  One rank here (RCCL
+    # refuses two ranks on one device); with more GPUs visible the same program runs as a real multi-rank job.
+    import torch
+    world = max(1, min(torch.cuda.device_count(), 4))
+    idfile = os.path.join(str(tmp_path), "comm.id")
+    procs = [subprocess.Popen([exe, path, str(r), str(world), idfile], stdout=subprocess.PIPE) for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0
+        check(out)
