@@ -15,6 +15,7 @@
  *   float  obs0[m * obs_dim], actions[h * m * n * act_dim]
  * prints: one line per env "env <i> index <idx> return <ret>"
  */
+#define _DEFAULT_SOURCE   /* usleep */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
