@@ -255,6 +255,26 @@ int l2a_lstm_create(l2a_ctx* ctx, int obs_dim, int act_dim, int units, int cell_
                     l2a_lstm** out);
 void l2a_lstm_destroy(l2a_lstm* model);
 
+/* The other recurrent models `create_rnn` (dynamics/core/utils.py:192-236) can build: `cell_type` 'lstm' / 'gru' /
+ * 'rnn' and several stacked layers (`len(hidden_sizes) > 1` -> tf.nn.rnn_cell.MultiRNNCell).  One LSTM layer is
+ * the model of l2a_lstm_create (MFMA kernel); everything else runs on the generic VALU kernel (the layers' units
+ * may sum to about 800).  Cell arithmetic: tensorflow==1.13.1 LSTMCell / GRUCell; 'rnn' = BasicRNNCell
+ * (h = act([x | h] K + b)) - the reference passes the abstract `tf.nn.rnn_cell.RNNCell` there (:209), which cannot
+ * be instantiated, so this is the evident intent, not a measured behaviour.
+ * Parameters (l2a_lstm_set_weights), in `get_params()` order, kernels row-major [in_l + U_l, .] with the layer's
+ * input first (in_0 = obs_dim + act_dim, in_l = U_(l-1)):
+ *   lstm layer: kernel [., 4 U] (gates i j f o), bias [4 U]
+ *   gru layer:  gates/kernel [., 2 U] (r | u), gates/bias [2 U], candidate/kernel [., U], candidate/bias [U]
+ *   rnn layer:  kernel [., U], bias [U]
+ * then output/kernel [U_top, obs_dim], output/bias [obs_dim].
+ * State: wherever the l2a_lstm_* entry points take c / h [rows, units], a stack takes the layers' states
+ * concatenated, [rows, sum(U_l)]; c is read and written for LSTM stacks only (pass any valid buffer otherwise). */
+#define L2A_CELL_LSTM 0
+#define L2A_CELL_GRU 1
+#define L2A_CELL_RNN 2
+int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const int* units, int cell_type,
+                   int cell_act, int output_act, l2a_lstm** out);
+
 /* Upload the four trainable variables in the reference's order (rnn.get_params(),
  * dynamics/core/layers.py:219-221): rnn/lstm_cell/kernel [obs_dim + act_dim + units, 4 * units]
  * (TF gate order i, j, f, o), rnn/lstm_cell/bias [4 * units], output/kernel [units, obs_dim],

@@ -20,6 +20,7 @@ L2A_ESPLIT = -5
 ACT_CODES = {None: 0, "identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4}
 MODE_CODES = {"single": 0, "per_block": 1, "mean": 2}
 KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
+CELL_CODES = {"lstm": 0, "gru": 1, "rnn": 2}
 
 EXPORTED_SYMBOLS = (
     "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split",
@@ -29,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
     "l2a_packed_layer_floats", "l2a_pack_layer_host",
     "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best",
-    "l2a_lstm_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_chunk",
+    "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_chunk",
     "l2a_lstm_predict", "l2a_lstm_mfma_eligible",
 )
 
@@ -116,6 +117,8 @@ def load():
     lib.l2a_allreduce_best.restype = i32
     lib.l2a_lstm_create.argtypes = [vp, i32, i32, i32, i32, i32, c.POINTER(vp)]
     lib.l2a_lstm_create.restype = i32
+    lib.l2a_rnn_create.argtypes = [vp, i32, i32, i32, c.POINTER(i32), i32, i32, i32, c.POINTER(vp)]
+    lib.l2a_rnn_create.restype = i32
     lib.l2a_lstm_destroy.argtypes = [vp]
     lib.l2a_lstm_destroy.restype = None
     lib.l2a_lstm_set_weights.argtypes = [vp, c.POINTER(vp), vp]

@@ -26,6 +26,8 @@
 #include "l2a_kernels.h"
 #include "l2a_mfma.h"
 
+#define L2A_RNN_MAX_LAYERS 4
+
 struct L2ALstmParams {
     // ---- model -------------------------------------------------------------------------
     const float* wblk;
@@ -38,6 +40,10 @@ struct L2ALstmParams {
     int obs_dim, act_dim, in_dim, units;
     int cell_act, output_act;
     int KG0, OT;
+    // generic stacks (l2a_rnn_create; l2a_rnn_valu.h): `units` is then the state width sum(layer_units)
+    int n_layers, cell_type;
+    int layer_units[L2A_RNN_MAX_LAYERS];
+    long long layer_w[L2A_RNN_MAX_LAYERS][2], layer_b[L2A_RNN_MAX_LAYERS][2];   // offsets of the layer's kernels / biases
     // ---- launch ------------------------------------------------------------------------
     const float* obs0;          // [m, obs_dim] (or [R, obs_dim] when obs_per_row)
     const float* c0;            // [m, U] (or [R, U] when hid_per_row)

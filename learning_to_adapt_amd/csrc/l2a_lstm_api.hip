@@ -7,6 +7,7 @@
 #include "l2a_lstm.h"
 #include "l2a_lstm_valu.h"
 #include "l2a_lstm_launch.h"
+#include "l2a_rnn_valu.h"
 
 #include <cstring>
 #include <string>
@@ -23,6 +24,11 @@ struct l2a_lstm {
     long long raw_wk = 0, raw_bk = 0, raw_wo = 0, raw_bo = 0, pk_wg = 0, pk_wout = 0, pk_bout = 0, nm_off = 0;
     bool weights_set = false, norm_set = false;
     std::vector<float> norm_stage;
+    // generic stacks (l2a_rnn_create): any cell type / several layers -> l2a_rnn_valu_k; `units` = sum(lunits)
+    bool generic = false;
+    int n_layers = 1, cell_type = L2A_CELL_LSTM;
+    int lunits[L2A_RNN_MAX_LAYERS] = {0};
+    long long lw[L2A_RNN_MAX_LAYERS][2] = {{0}}, lb[L2A_RNN_MAX_LAYERS][2] = {{0}};
 };
 
 namespace {
@@ -43,6 +49,11 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
     p.obs_dim = md->obs_dim; p.act_dim = md->act_dim; p.in_dim = md->in_dim; p.units = md->units;
     p.cell_act = md->cell_act; p.output_act = md->output_act;
     p.KG0 = md->KG0; p.OT = md->OT;
+    p.n_layers = md->n_layers; p.cell_type = md->cell_type;
+    for (int l = 0; l < L2A_RNN_MAX_LAYERS; ++l) {
+        p.layer_units[l] = md->lunits[l];
+        for (int q = 0; q < 2; ++q) { p.layer_w[l][q] = md->lw[l][q]; p.layer_b[l][q] = md->lb[l][q]; }
+    }
     p.disc0 = 1.0;
 }
 
@@ -56,8 +67,20 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v) {
     if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
     if (kind == L2A_KERNEL_MFMA && !md->mfma_ok)
         return l2a_fail(ctx, L2A_EINVAL, "LSTM shape is not eligible for the MFMA kernel "
-                                         "(needs units in {128, 256, 512}, obs_dim <= 64, act_dim <= 16)");
+                                         "(needs a single LSTM layer, units in {128, 256, 512}, obs_dim <= 64, act_dim <= 16)");
     p.dbg = ctx->dbg;
+    if (md->generic) {
+        p.tiles_per_env = l2a_ceil_div(p.n, L2A_LVT);
+        const int smem = (md->in_dim + 3 * md->units + 2 * md->obs_dim + 1) * L2A_LVT * 4;
+        if (smem > ctx->lds_per_block)
+            return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the generic recurrent kernel (" + std::to_string(smem) +
+                                             " B): the layers' units may sum to about 800 at most");
+        L2A_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l2a_rnn_valu_k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL(l2a_rnn_valu_k, dim3((unsigned)(p.m * p.tiles_per_env)), dim3(256), smem, stream, p);
+        L2A_HIP(ctx, hipGetLastError());
+        return L2A_OK;
+    }
     if (kind == L2A_KERNEL_MFMA) {
         const int nt = 1;
         const int UT = L2A_NW * md->UTW, U = md->units;
@@ -134,6 +157,65 @@ int l2a_lstm_create(l2a_ctx* ctx, int obs_dim, int act_dim, int units, int cell_
     return L2A_OK;
 }
 
+int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const int* units, int cell_type,
+                   int cell_act, int output_act, l2a_lstm** out) {
+    if (!ctx) return L2A_EINVAL;
+    if (!out || !units) return l2a_fail(ctx, L2A_EINVAL, "l2a_rnn_create: null argument");
+    *out = nullptr;
+    if (n_layers < 1 || n_layers > L2A_RNN_MAX_LAYERS)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_rnn_create: 1 to " + std::to_string(L2A_RNN_MAX_LAYERS) + " layers");
+    if (cell_type != L2A_CELL_LSTM && cell_type != L2A_CELL_GRU && cell_type != L2A_CELL_RNN)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_rnn_create: unknown cell type");
+    if (n_layers == 1 && cell_type == L2A_CELL_LSTM)        // the run_rebal.py configuration: MFMA-capable model
+        return l2a_lstm_create(ctx, obs_dim, act_dim, units[0], cell_act, output_act, out);
+    if (obs_dim < 1 || act_dim < 1) return l2a_fail(ctx, L2A_EINVAL, "obs_dim and act_dim must be >= 1");
+    if (cell_act < 0 || cell_act > L2A_ACT_SWISH || output_act < 0 || output_act > L2A_ACT_SWISH)
+        return l2a_fail(ctx, L2A_EINVAL, "unsupported nonlinearity");
+    int width = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (units[l] < 1 || units[l] > 1024) return l2a_fail(ctx, L2A_EINVAL, "units must be in [1, 1024]");
+        width += units[l];
+    }
+    l2a_lstm* md = new l2a_lstm();
+    md->ctx = ctx;
+    md->generic = true;
+    md->n_layers = n_layers; md->cell_type = cell_type;
+    md->obs_dim = obs_dim; md->act_dim = act_dim; md->in_dim = obs_dim + act_dim; md->units = width;
+    md->cell_act = cell_act; md->output_act = output_act;
+    md->KG0 = l2a_ceil_div(md->in_dim, 16);
+    md->OT = l2a_ceil_div(obs_dim, 16);
+    long long off = 0;
+    auto take = [&off](long long n) { long long o = off; off += (n + 15) / 16 * 16; return o; };
+    int kin = md->in_dim;
+    for (int l = 0; l < n_layers; ++l) {
+        const int U = units[l];
+        md->lunits[l] = U;
+        const int cols0 = (cell_type == L2A_CELL_LSTM) ? 4 * U : (cell_type == L2A_CELL_GRU ? 2 * U : U);
+        md->lw[l][0] = take((long long)(kin + U) * cols0);
+        md->lb[l][0] = take(cols0);
+        if (cell_type == L2A_CELL_GRU) {
+            md->lw[l][1] = take((long long)(kin + U) * U);
+            md->lb[l][1] = take(U);
+        }
+        kin = U;
+    }
+    md->raw_wo = take((long long)kin * obs_dim);
+    md->raw_bo = take(obs_dim);
+    md->pk_bout = take(16 * md->OT);
+    md->nm_off = take(32 * md->KG0 + 32 * md->OT);
+    md->total = off;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&md->wblk), (size_t)off * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(md->wblk, 0, (size_t)off * sizeof(float));
+    if (e != hipSuccess) {
+        std::string msg = std::string("allocating recurrent model storage: ") + hipGetErrorString(e);
+        delete md;
+        return l2a_fail(ctx, L2A_EHIP, msg);
+    }
+    *out = md;
+    return L2A_OK;
+}
+
 void l2a_lstm_destroy(l2a_lstm* md) {
     if (!md) return;
     if (md->wblk) {
@@ -147,10 +229,38 @@ int l2a_lstm_set_weights(l2a_lstm* md, const void* const* device_ptrs, void* str
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
     if (!device_ptrs) return l2a_fail(ctx, L2A_EINVAL, "device_ptrs is null");
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4 && !md->generic; ++i)
         if (!device_ptrs[i]) return l2a_fail(ctx, L2A_EINVAL, "null LSTM parameter pointer " + std::to_string(i));
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     l2a_device_guard guard(ctx->device);
+    if (md->generic) {
+        // per layer: lstm (kernel, bias) | gru (gates/kernel, gates/bias, candidate/kernel, candidate/bias) |
+        // rnn (kernel, bias); then output/kernel, output/bias
+        int pi = 0, kin = md->in_dim;
+        auto copy = [&](long long off, size_t count) -> int {
+            const void* src = device_ptrs[pi++];
+            if (!src) return l2a_fail(ctx, L2A_EINVAL, "null recurrent parameter pointer " + std::to_string(pi - 1));
+            L2A_HIP(ctx, hipMemcpyAsync(md->wblk + off, src, sizeof(float) * count, hipMemcpyDeviceToDevice, stream));
+            return L2A_OK;
+        };
+        for (int l = 0; l < md->n_layers; ++l) {
+            const int Ul = md->lunits[l];
+            const int cols0 = (md->cell_type == L2A_CELL_LSTM) ? 4 * Ul : (md->cell_type == L2A_CELL_GRU ? 2 * Ul : Ul);
+            int rc = copy(md->lw[l][0], (size_t)(kin + Ul) * cols0);
+            if (rc == L2A_OK) rc = copy(md->lb[l][0], (size_t)cols0);
+            if (rc == L2A_OK && md->cell_type == L2A_CELL_GRU) {
+                rc = copy(md->lw[l][1], (size_t)(kin + Ul) * Ul);
+                if (rc == L2A_OK) rc = copy(md->lb[l][1], (size_t)Ul);
+            }
+            if (rc != L2A_OK) return rc;
+            kin = Ul;
+        }
+        int rc = copy(md->raw_wo, (size_t)kin * md->obs_dim);
+        if (rc == L2A_OK) rc = copy(md->raw_bo, (size_t)md->obs_dim);
+        if (rc != L2A_OK) return rc;
+        md->weights_set = true;
+        return L2A_OK;
+    }
     const int U = md->units;
     const float* wk = static_cast<const float*>(device_ptrs[0]);
     const float* wo = static_cast<const float*>(device_ptrs[2]);

@@ -14,7 +14,9 @@ from .native_model import _dvec, _ptr, _stream_ptr
 
 
 class NativeLSTM(object):
-    def __init__(self, obs_dim, act_dim, units, cell_act="tanh", output_act=None, device=None):
+    def __init__(self, obs_dim, act_dim, units, cell_act="tanh", output_act=None, device=None, cell_type="lstm"):
+        """``units``: int (one layer) or a sequence (stacked cells, ``l2a_rnn_create``).  ``self.units`` is the
+        state width ``sum(units)`` - the row length of every c / h tensor handed to the launches."""
         if not torch.cuda.is_available():
             raise _lib.L2AError("no MI355X visible to PyTorch-ROCm: the rollout path is HIP-only "
                                 "(there is no CPU fallback)")
@@ -23,13 +25,19 @@ class NativeLSTM(object):
         self.ctx = _lib.Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device("cuda", device)
-        self.obs_dim, self.act_dim, self.units = int(obs_dim), int(act_dim), int(units)
+        self.layer_units = tuple(int(u) for u in (units if isinstance(units, (tuple, list)) else (units,)))
+        self.cell_type = cell_type
+        self.obs_dim, self.act_dim, self.units = int(obs_dim), int(act_dim), int(sum(self.layer_units))
         if cell_act not in _lib.ACT_CODES or output_act not in _lib.ACT_CODES:
             raise _lib.L2AError("nonlinearity %r / %r is not supported by the HIP kernels" % (cell_act, output_act))
+        if cell_type not in _lib.CELL_CODES:
+            raise _lib.L2AError("cell type %r is not supported by the HIP kernels" % (cell_type,))
         handle = ctypes.c_void_p()
-        rc = self.lib.l2a_lstm_create(self.ctx.handle, self.obs_dim, self.act_dim, self.units,
-                                      _lib.ACT_CODES[cell_act], _lib.ACT_CODES[output_act], ctypes.byref(handle))
-        self.ctx.check(rc, "l2a_lstm_create")
+        arr = (ctypes.c_int * len(self.layer_units))(*self.layer_units)
+        rc = self.lib.l2a_rnn_create(self.ctx.handle, self.obs_dim, self.act_dim, len(self.layer_units), arr,
+                                     _lib.CELL_CODES[cell_type], _lib.ACT_CODES[cell_act], _lib.ACT_CODES[output_act],
+                                     ctypes.byref(handle))
+        self.ctx.check(rc, "l2a_rnn_create")
         self.handle = handle
         self._keep = {}
 
@@ -45,17 +53,18 @@ class NativeLSTM(object):
             pass
 
     def set_weights(self, params):
-        """``params``: [kernel [in + U, 4U], bias [4U], output kernel [U, obs_dim], output bias]."""
-        U, k_in = self.units, self.obs_dim + self.act_dim + self.units
-        shapes = [(k_in, 4 * U), (4 * U,), (U, self.obs_dim), (self.obs_dim,)]
-        assert len(params) == 4, "expected 4 parameter arrays"
+        """``params``: the model's variables in ``get_params()`` order (``dynamics/rnn_cells.param_spec``); for one
+        LSTM layer [kernel [in + U, 4U], bias [4U], output kernel [U, obs_dim], output bias]."""
+        from . import rnn_cells
+        shapes = [shape for _, shape in rnn_cells.param_spec(self.obs_dim, self.act_dim, self.layer_units, self.cell_type)]
+        assert len(params) == len(shapes), "expected %d parameter arrays" % len(shapes)
         dev = []
         for p, shp in zip(params, shapes):
             t = torch.as_tensor(p) if not torch.is_tensor(p) else p
             t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
             assert tuple(t.shape) == shp, "LSTM parameter has shape %s, expected %s" % (tuple(t.shape), shp)
             dev.append(t)
-        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in dev])
+        ptrs = (ctypes.c_void_p * len(dev))(*[t.data_ptr() for t in dev])
         self.ctx.check(self.lib.l2a_lstm_set_weights(self.handle, ptrs, _stream_ptr(self.device)), "l2a_lstm_set_weights")
         self._keep["w"] = dev
 

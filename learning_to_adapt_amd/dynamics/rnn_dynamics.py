@@ -8,9 +8,12 @@ backprop_steps``; same ``predict(obs, act, hidden) -> (pred_obs, next_hidden)``,
 pickling surface.  Nonlinearities are given by name (``'tanh'`` = the reference default
 ``tf.nn.tanh``).
 
-Scope: the single-layer LSTM cell of the run script (``cell_type='lstm'``, one entry in
-``hidden_sizes``).  The hidden state is an ``LSTMStateTuple(c, h)`` of float32 arrays
-``[batch, units]``, as ``sess.run(cell.zero_state)`` yields in the reference (``:273-293``).
+Cells: everything ``create_rnn`` (``dynamics/core/utils.py:192-236``) builds - ``cell_type`` ``'lstm'``
+(the run script's), ``'gru'``, ``'rnn'`` and stacks (several entries in ``hidden_sizes`` = ``MultiRNNCell``);
+see ``dynamics/rnn_cells.py``.  The hidden state has the reference's structure (``:273-293``): an
+``LSTMStateTuple(c, h)`` of float32 arrays ``[batch, units]`` for one LSTM layer, a plain array for one GRU / RNN
+layer, a list / tuple of those for a stack.  One LSTM layer of 128 / 256 / 512 units runs on the fused MFMA kernel,
+every other configuration on the generic VALU kernel (``csrc/l2a_rnn_valu.h``).
 
 * ``predict`` runs on the MI355X through ``l2a_lstm_predict``.
 * ``RNNMPCController`` asks for the ``NativeLSTM`` handle (``planner_model()``) and launches the
@@ -27,12 +30,10 @@ import numpy as np
 import torch
 
 from ..utils.serializable import Serializable
-from . import core
+from . import core, rnn_cells
+from .rnn_cells import LSTMStateTuple, FORGET_BIAS  # noqa: F401  (re-exported)
 
-LSTMStateTuple = namedtuple("LSTMStateTuple", ("c", "h"))      # field order of tf.nn.rnn_cell.LSTMStateTuple
-
-PARAM_NAMES = ("rnn/lstm_cell/kernel", "rnn/lstm_cell/bias", "output/kernel", "output/bias")
-FORGET_BIAS = 1.0                                               # tf.nn.rnn_cell.LSTMCell default
+PARAM_NAMES = ("rnn/lstm_cell/kernel", "rnn/lstm_cell/bias", "output/kernel", "output/bias")   # one LSTM layer
 
 
 def glorot_lstm_params(obs_dim, act_dim, units, rng):
@@ -97,39 +98,40 @@ class RNNDynamicsModel(Serializable):
         self.obs_space_dims = int(env.observation_space.shape[0])
         self.action_space_dims = int(env.action_space.shape[0])
 
-        if cell_type != "lstm":
-            raise NotImplementedError("cell_type %r: only the 'lstm' cell of run_scripts/run_rebal.py is built"
-                                      % (cell_type,))
+        if cell_type not in rnn_cells.CELL_TYPES:
+            raise NotImplementedError("cell_type %r (reference dynamics/core/utils.py:199-213 knows %s)"
+                                      % (cell_type, rnn_cells.CELL_TYPES))
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
-        if len(self.hidden_sizes) != 1:
-            raise NotImplementedError("stacked recurrent cells are not built (hidden_sizes=%r)" % (hidden_sizes,))
+        if not 1 <= len(self.hidden_sizes) <= 4:
+            raise NotImplementedError("1 to 4 stacked cells are supported (hidden_sizes=%r)" % (hidden_sizes,))
         if hidden_nonlinearity not in self._activations or output_nonlinearity not in self._activations:
             raise ValueError("unsupported nonlinearity %r / %r (supported: %s)"
                              % (hidden_nonlinearity, output_nonlinearity, self._activations))
         self.cell_type = cell_type
         self.units = self.hidden_sizes[0]
+        self.state_width = int(sum(self.hidden_sizes))
         self.hidden_nonlinearity = hidden_nonlinearity
         self.output_nonlinearity = output_nonlinearity
+        self._spec = rnn_cells.param_spec(self.obs_space_dims, self.action_space_dims, self.hidden_sizes, cell_type)
 
-        self._params = glorot_lstm_params(self.obs_space_dims, self.action_space_dims, self.units,
-                                          np.random.RandomState(init_seed))
+        self._params = rnn_cells.init_params(self.obs_space_dims, self.action_space_dims, self.hidden_sizes,
+                                             cell_type, np.random.RandomState(init_seed))
         self._native = None
         self._native_dirty = True
 
     # ------------------------------------------------------------------ parameters
     def get_param_values(self):
-        return OrderedDict((k, p.numpy().copy()) for k, p in zip(PARAM_NAMES, self._params))
+        return OrderedDict((k, p.numpy().copy()) for (k, _), p in zip(self._spec, self._params))
 
     def set_params(self, params):
         if isinstance(params, (dict, OrderedDict)):
-            params = [params[k] for k in PARAM_NAMES]
+            params = [params[k] for k, _ in self._spec]
         out = []
         for p in params:
             t = p.detach().clone() if torch.is_tensor(p) else torch.from_numpy(np.array(p, dtype=np.float32))
             out.append(t.to(dtype=torch.float32, device="cpu").contiguous())
-        U, k_in = self.units, self.obs_space_dims + self.action_space_dims + self.units
-        assert [tuple(t.shape) for t in out] == [(k_in, 4 * U), (4 * U,), (U, self.obs_space_dims),
-                                                 (self.obs_space_dims,)]
+        assert [tuple(t.shape) for t in out] == [shape for _, shape in self._spec], \
+            "expected parameters %s" % (self._spec,)
         self._params = out
         self._native_dirty = True
 
@@ -140,8 +142,8 @@ class RNNDynamicsModel(Serializable):
     def planner_model(self):
         from .native_lstm import NativeLSTM
         if self._native is None:
-            self._native = NativeLSTM(self.obs_space_dims, self.action_space_dims, self.units,
-                                      self.hidden_nonlinearity, self.output_nonlinearity)
+            self._native = NativeLSTM(self.obs_space_dims, self.action_space_dims, self.hidden_sizes,
+                                      self.hidden_nonlinearity, self.output_nonlinearity, cell_type=self.cell_type)
             self._native_dirty = True
         if self._native_dirty:
             self._native.set_weights(self._params)
@@ -157,8 +159,14 @@ class RNNDynamicsModel(Serializable):
 
     # ------------------------------------------------------------------ hidden state (reference :273-293)
     def get_initial_hidden(self, batch_size):
-        z = np.zeros((batch_size, self.units), dtype=np.float32)
-        return LSTMStateTuple(z.copy(), z.copy())
+        return rnn_cells.initial_hidden(self.cell_type, self.hidden_sizes, batch_size)
+
+    def pack_hidden(self, hidden):
+        """Reference hidden-state structure -> flat ``(c, h)`` float32 arrays ``[rows, sum(units)]``."""
+        return rnn_cells.pack_hidden(self.cell_type, self.hidden_sizes, hidden)
+
+    def unpack_hidden(self, c, h, as_tuple=False):
+        return rnn_cells.unpack_hidden(self.cell_type, self.hidden_sizes, c, h, as_tuple=as_tuple)
 
     # ------------------------------------------------------------------ predict (reference :233-252)
     def predict(self, obs, act, hidden_state):
@@ -166,12 +174,12 @@ class RNNDynamicsModel(Serializable):
         assert obs.ndim == 2 and obs.shape[1] == self.obs_space_dims
         assert act.ndim == 2 and act.shape[1] == self.action_space_dims
         native = self.planner_model()
-        c, h = hidden_state
+        c, h = self.pack_hidden(hidden_state)
         dev = native.device
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
         nxt, c_out, h_out = native.predict(up(obs), up(act), up(c), up(h))
         pred_obs = nxt.cpu().numpy().astype(np.float64)
-        return pred_obs, LSTMStateTuple(c_out.cpu().numpy(), h_out.cpu().numpy())
+        return pred_obs, self.unpack_hidden(c_out.cpu().numpy(), h_out.cpu().numpy(), as_tuple=True)
 
     # ------------------------------------------------------------------ fit (reference :102-231)
     def compute_normalization(self, obs, act, obs_next):
@@ -231,7 +239,9 @@ class RNNDynamicsModel(Serializable):
         opt = torch.optim.Adam(params, lr=self.learning_rate)
         rolling, rolling_prev = None, None
         epoch_times, last_epoch = [], 0
-        zeros = lambda b: torch.zeros((b, self.units), dtype=torch.float32, device=dev)  # noqa: E731
+        zero_state = lambda b: rnn_cells.zero_state(self.cell_type, self.hidden_sizes, b, dev)  # noqa: E731
+        forward = lambda x, st: rnn_cells.stack_forward(x, st, params, self.hidden_sizes, self.cell_type,  # noqa: E731
+                                                        self.hidden_nonlinearity, self.output_nonlinearity)
         for epoch in range(epochs):
             t0 = time.time()
             # the reference batches first and shuffles the batches (:258-260)
@@ -240,14 +250,13 @@ class RNNDynamicsModel(Serializable):
             losses = []
             for s in starts:
                 xb, yb = x_tr[s:s + self.batch_size], y_tr[s:s + self.batch_size]
-                c, h = zeros(xb.shape[0]), zeros(xb.shape[0])
+                state = zero_state(xb.shape[0])
                 sums, n_chunks = None, 0
                 for i in range(0, xb.shape[1], self.backprop_steps):       # truncated BPTT (:165-180)
-                    pred, c, h = lstm_forward(xb[:, i:i + self.backprop_steps], c, h, params,
-                                              self.hidden_nonlinearity, self.output_nonlinearity)
+                    pred, state = forward(xb[:, i:i + self.backprop_steps], state)
                     loss = torch.mean((pred - yb[:, i:i + self.backprop_steps]) ** 2)
                     grads = torch.autograd.grad(loss, params)
-                    c, h = c.detach(), h.detach()
+                    state = rnn_cells.detach_state(state)
                     sums = list(grads) if sums is None else [a + g for a, g in zip(sums, grads)]
                     n_chunks += 1
                     losses.append(float(loss.detach()))
@@ -256,8 +265,7 @@ class RNNDynamicsModel(Serializable):
                 opt.step()
             with torch.no_grad():
                 if x_te.shape[0] > 0:
-                    vpred, _, _ = lstm_forward(x_te, zeros(x_te.shape[0]), zeros(x_te.shape[0]), params,
-                                               self.hidden_nonlinearity, self.output_nonlinearity)
+                    vpred, _ = forward(x_te, zero_state(x_te.shape[0]))
                     valid_loss = float(torch.mean((vpred - y_te) ** 2))
                 else:
                     valid_loss = float(np.mean(losses)) if losses else 0.0

@@ -64,7 +64,7 @@ class RNNMPCController(MPCController):
     def _hidden_state(self):
         if self._hid_stale == "host":
             c, h = self._hid_dev
-            self._hid_host = type(self.dynamics_model.get_initial_hidden(1))(c.cpu().numpy(), h.cpu().numpy())
+            self._hid_host = self._unpack(c.cpu().numpy(), h.cpu().numpy())
             self._hid_stale = None
         return self._hid_host
 
@@ -74,10 +74,23 @@ class RNNMPCController(MPCController):
         self._hid_dev = None
         self._hid_stale = None if value is None else "dev"
 
+    # The model converts between the reference's hidden-state structure (LSTMStateTuple / array / list of those,
+    # rnn_dynamics.py:273-293) and the flat (c, h) [rows, sum(units)] arrays the kernels take; a model without the
+    # helpers is a single-layer LSTM whose state is the (c, h) pair itself.
+    def _pack(self, hidden):
+        if hasattr(self.dynamics_model, "pack_hidden"):
+            return self.dynamics_model.pack_hidden(hidden)
+        return hidden[0], hidden[1]
+
+    def _unpack(self, c, h):
+        if hasattr(self.dynamics_model, "unpack_hidden"):
+            return self.dynamics_model.unpack_hidden(c, h)
+        return type(self.dynamics_model.get_initial_hidden(1))(c, h)
+
     def _device_hidden(self, device):
-        """(c, h) CUDA tensors [m, units] of the current hidden state."""
+        """(c, h) CUDA tensors [m, sum(units)] of the current hidden state."""
         if self._hid_dev is None or self._hid_stale == "dev":
-            c, h = self._hid_host
+            c, h = self._pack(self._hid_host)
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
             self._hid_dev = (up(c), up(h))
             self._hid_stale = None
@@ -121,11 +134,14 @@ class RNNMPCController(MPCController):
             self._hidden_state = self.dynamics_model.get_initial_hidden(batch_size=len(dones))
         if not dones.any():
             return                                              # nothing to zero: no host round trip
-        zero = self.dynamics_model.get_initial_hidden(batch_size=1)
-        state = self._hidden_state                              # refreshes the host arrays if needed
-        for part, z in zip(state, zero):                        # LSTM state: (c, h)
-            part[dones] = z
-        self._hidden_state = state                              # device copy is stale now
+        # rows of finished envs go back to the cell's zero state (:139-163) - in the flat view, for every layer and
+        # both parts at once (the reference's own loop only handles LSTM layers and stacks)
+        zc, zh = self._pack(self.dynamics_model.get_initial_hidden(batch_size=1))
+        c, h = self._pack(self._hidden_state)                   # refreshes the host arrays if needed
+        c, h = np.array(c), np.array(h)
+        c[dones] = zc
+        h[dones] = zh
+        self._hidden_state = self._unpack(c, h)                 # device copy is stale now
 
     def repeat_hidden(self, hidden, n):
         """``:165-187``: every row n times (env-major).  Only the unfused path materialises this."""
@@ -133,6 +149,14 @@ class RNNMPCController(MPCController):
             rep = [self.repeat_hidden(part, n) for part in hidden]
             return type(hidden)(*rep) if hasattr(hidden, "_fields") else rep
         return np.repeat(hidden, n, axis=0)
+
+    def __getstate__(self):
+        state = dict()
+        state["init_args"] = Serializable.__getstate__(self)                # reference :189-192
+        return state
+
+    def __setstate__(self, state):
+        Serializable.__setstate__(self, state["init_args"] if "init_args" in state else state)
 
     # ------------------------------------------------------------------ fused rollout with the env's LSTM state
     def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):

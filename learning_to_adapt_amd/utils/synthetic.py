@@ -94,6 +94,23 @@ def make_lstm_set(obs_dim, act_dim, units, seed, bias_std=0.05):
     return [kernel, bias, wout, bout]
 
 
+def make_rnn_stack_set(obs_dim, act_dim, hidden_sizes, cell_type, seed, bias_std=0.05):
+    """Variables of a stack of recurrent cells + output layer in ``get_params()`` order
+    (``dynamics/rnn_cells.param_spec``): glorot-uniform kernels, small random biases (the GRU gate bias around its
+    TensorFlow initial value 1.0) so that bias handling is exercised."""
+    from ..dynamics import rnn_cells
+    rs = np.random.RandomState(seed)
+    out = []
+    for name, shape in rnn_cells.param_spec(obs_dim, act_dim, hidden_sizes, cell_type):
+        if len(shape) == 2:
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            out.append(rs.uniform(-lim, lim, size=shape).astype(np.float32))
+        else:
+            base = 1.0 if name.endswith("gates/bias") else 0.0
+            out.append((base + bias_std * rs.randn(*shape)).astype(np.float32))
+    return out
+
+
 def named_lstm_params(params):
     out = OrderedDict()
     for name, p in zip(("rnn/lstm_cell/kernel", "rnn/lstm_cell/bias", "output/kernel", "output/bias"), params):

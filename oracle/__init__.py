@@ -46,3 +46,4 @@ from .rewards import make_reward  # noqa: F401
 from .planner import rs_plan, cem_plan  # noqa: F401
 from .rnn_dynamics import OracleLSTMDynamics, LSTMStateTuple, lstm_step_f32  # noqa: F401
 from .rnn_planner import rnn_rs_plan, rnn_cem_plan, repeat_hidden  # noqa: F401
+from .rnn_cells import OracleRNNStackDynamics, gru_step_f32, basic_rnn_step_f32  # noqa: F401

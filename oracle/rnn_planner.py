@@ -20,9 +20,13 @@ from .rnn_dynamics import LSTMStateTuple
 
 
 def repeat_hidden(hidden, n):
-    """``rnn_mpc_controller.py:165-187`` for an LSTM state: every row n times, env-major."""
-    c, h = hidden
-    return LSTMStateTuple(np.repeat(c, n, axis=0), np.repeat(h, n, axis=0))
+    """``rnn_mpc_controller.py:165-187``: every row n times, env-major - for an LSTM state, a plain array
+    (GRU / RNN layer) or a list / tuple of those (stacked cells)."""
+    if isinstance(hidden, LSTMStateTuple):
+        return LSTMStateTuple(np.repeat(hidden.c, n, axis=0), np.repeat(hidden.h, n, axis=0))
+    if isinstance(hidden, (list, tuple)):
+        return [repeat_hidden(h, n) for h in hidden]
+    return np.repeat(hidden, n, axis=0)
 
 
 def rnn_rollout_returns(dynamics_model, reward_fn, observations, hidden, actions, n, discount):

@@ -40,14 +40,21 @@ def rnn_recipe(case):
     """(env, params, norm) of a recurrent case (single-layer LSTM + output layer)."""
     env = SyntheticEnv(case["env"])
     od, ad = env.observation_space.shape[0], env.action_space.shape[0]
-    params = synthetic.make_lstm_set(od, ad, case["units"], 1000)
+    if "hidden_sizes" in case:
+        params = synthetic.make_rnn_stack_set(od, ad, case["hidden_sizes"], case["cell_type"], 1000)
+    else:
+        params = synthetic.make_lstm_set(od, ad, case["units"], 1000)
     norm = synthetic.make_norm(od, ad, env.action_space.low, env.action_space.high, 2000)
     return env, params, norm
 
 
 def oracle_rnn_dynamics(case):
-    from oracle import OracleLSTMDynamics
+    from oracle import OracleLSTMDynamics, OracleRNNStackDynamics
     env, params, norm = rnn_recipe(case)
+    if "hidden_sizes" in case:
+        return OracleRNNStackDynamics(env.observation_space.shape[0], env.action_space.shape[0], case["hidden_sizes"],
+                                      case["cell_type"], params, norm,
+                                      hidden_nonlinearity=case.get("activation", "tanh"))
     return OracleLSTMDynamics(env.observation_space.shape[0], env.action_space.shape[0], params, norm,
                               hidden_nonlinearity=case.get("activation", "tanh"))
 
@@ -111,7 +118,8 @@ def product_controller(case, model=None, env=None, **kw):
 def product_rnn_model(case):
     from learning_to_adapt_amd.dynamics import RNNDynamicsModel
     env, params, norm = rnn_recipe(case)
-    model = RNNDynamicsModel(name="dyn", env=env, hidden_sizes=(case["units"],), cell_type="lstm",
+    model = RNNDynamicsModel(name="dyn", env=env, hidden_sizes=tuple(case.get("hidden_sizes", (case["units"],))),
+                             cell_type=case.get("cell_type", "lstm"),
                              hidden_nonlinearity=case.get("activation", "tanh"), init_seed=0)
     model.set_params(params)
     model.set_normalization(norm)

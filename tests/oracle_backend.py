@@ -62,8 +62,7 @@ def install_rnn(controller, case):
     def _rollout(observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
         m = len(observations)
         acts = actions_local.numpy().astype(np.float64)
-        c, h = controller._hidden_state
-        rets = rnn_rollout_returns(dyn, reward, observations, LSTMStateTuple(c, h), acts, n_local,
+        rets = rnn_rollout_returns(dyn, reward, observations, controller._hidden_state, acts, n_local,
                                    controller.discount)
         rets = rets.reshape(m, n_local).astype(np.float32)
         keys = np.zeros(m, dtype=np.int64)
@@ -73,8 +72,7 @@ def install_rnn(controller, case):
         return torch.from_numpy(keys), (torch.from_numpy(rets) if want_returns else None)
 
     def predict(obs, act, hidden):
-        nxt, hid = dyn.predict(obs, act, hidden)
-        return nxt, type(controller._hidden_state)(hid.c, hid.h)
+        return dyn.predict(obs, act, hidden)
 
     controller._check_status = lambda: None
     controller._upload_obs = lambda observations: None

@@ -16,6 +16,21 @@ from oracle import LSTMStateTuple, lstm_step_f32, make_reward, rnn_cem_plan, rnn
 RNN_IDS = cases.rnn_case_ids()
 
 
+def _flat(hidden):
+    """Any hidden-state structure (LSTMStateTuple / array / list or tuple of those) -> flat (c, h) [rows, W]."""
+    layers = [hidden] if (isinstance(hidden, np.ndarray) or hasattr(hidden, "_fields")) else list(hidden)
+    cs = [np.asarray(st[0]) if hasattr(st, "_fields") else np.zeros_like(np.asarray(st)) for st in layers]
+    hs = [np.asarray(st[1]) if hasattr(st, "_fields") else np.asarray(st) for st in layers]
+    return np.concatenate(cs, axis=1), np.concatenate(hs, axis=1)
+
+
+def _zero_rows(hidden, dones):
+    layers = [hidden] if (isinstance(hidden, np.ndarray) or hasattr(hidden, "_fields")) else list(hidden)
+    for st in layers:
+        for part in (st if hasattr(st, "_fields") else [st]):
+            part[dones] = 0.0
+
+
 def _replay(case, gold, plan_step, reset_hook):
     """Drive ``plan_step(k, obs) -> (chosen, hidden_after)`` over the recorded controller steps."""
     resets = {int(k): v for k, v in case.get("reset_after", {}).items()}
@@ -49,12 +64,11 @@ def test_oracle_reproduces_reference_rnn_controller(cid):
         assert np.array_equal(returns, gold["returns_%d" % k])
         assert np.array_equal(best, gold["best_%d" % k])
         assert np.array_equal(chosen, gold["chosen_%d" % k])
-        assert np.array_equal(hid.c, gold["hidden_c_%d" % k]) and np.array_equal(hid.h, gold["hidden_h_%d" % k])
+        c, h = _flat(hid)
+        assert np.array_equal(c, gold["hidden_c_%d" % k]) and np.array_equal(h, gold["hidden_h_%d" % k])
 
     def reset(dones):
-        zero = dyn.get_initial_hidden(1)
-        state["hid"].c[dones] = zero.c
-        state["hid"].h[dones] = zero.h
+        _zero_rows(state["hid"], dones)
 
     _replay(case, gold, step, reset)
     assert np.random.uniform() == float(gold["rng_next"])        # RNG consumption
@@ -101,7 +115,8 @@ def test_rnn_controller_host_logic_matches_golden(cid):
         assert info == {}
         assert np.array_equal(ctrl.last_plan["best_index"], gold["best_%d" % k])
         assert np.array_equal(chosen, gold["chosen_%d" % k])
-        assert np.array_equal(ctrl._hidden_state.c, gold["hidden_c_%d" % k])
+        c, h = _flat(ctrl._hidden_state)
+        assert np.array_equal(c, gold["hidden_c_%d" % k]) and np.array_equal(h, gold["hidden_h_%d" % k])
 
     _replay(case, gold, step, lambda dones: ctrl.reset(dones=dones))
     assert np.random.uniform() == float(gold["rng_next"])
@@ -123,9 +138,29 @@ def test_rnn_model_surface_and_pickling():
     ctrl2 = pickle.loads(pickle.dumps(ctrl))
     assert ctrl2.n_candidates == case["n"] and ctrl2.percent_elites == 0.05 and ctrl2._hidden_state is None
     with pytest.raises(NotImplementedError):
-        type(model)(name="x", env=env, hidden_sizes=(64,), cell_type="gru")
-    with pytest.raises(NotImplementedError):
-        type(model)(name="x", env=env, hidden_sizes=(64, 64))
+        type(model)(name="x", env=env, hidden_sizes=(64,), cell_type="ugrnn")
+    # the other cells of create_rnn (core/utils.py:199-220): parameter names / shapes and hidden-state structures
+    gru = type(model)(name="x", env=env, hidden_sizes=(64,), cell_type="gru", init_seed=0)
+    assert list(gru.get_param_values()) == ["rnn/gru_cell/gates/kernel", "rnn/gru_cell/gates/bias",
+                                            "rnn/gru_cell/candidate/kernel", "rnn/gru_cell/candidate/bias",
+                                            "output/kernel", "output/bias"]
+    assert gru.get_param_values()["rnn/gru_cell/gates/kernel"].shape == (26 + 64, 128)
+    assert np.all(gru.get_param_values()["rnn/gru_cell/gates/bias"] == 1.0)        # GRUCell's bias initialiser
+    assert isinstance(gru.get_initial_hidden(2), np.ndarray) and gru.get_initial_hidden(2).shape == (2, 64)
+    stack = type(model)(name="x", env=env, hidden_sizes=(48, 32), init_seed=0)
+    assert list(stack.get_param_values())[:4] == ["rnn/multi_rnn_cell/cell_0/lstm_cell/kernel",
+                                                  "rnn/multi_rnn_cell/cell_0/lstm_cell/bias",
+                                                  "rnn/multi_rnn_cell/cell_1/lstm_cell/kernel",
+                                                  "rnn/multi_rnn_cell/cell_1/lstm_cell/bias"]
+    assert stack.get_param_values()["rnn/multi_rnn_cell/cell_1/lstm_cell/kernel"].shape == (48 + 32, 128)
+    hid = stack.get_initial_hidden(3)
+    assert isinstance(hid, list) and len(hid) == 2 and hid[1].h.shape == (3, 32)
+    c, h = stack.pack_hidden(hid)
+    assert c.shape == h.shape == (3, 80)
+    back = stack.unpack_hidden(c, h, as_tuple=True)
+    assert isinstance(back, tuple) and back[0].c.shape == (3, 48)
+    twin = pickle.loads(pickle.dumps(stack))
+    assert all(np.array_equal(a, b) for a, b in zip(stack.get_param_values().values(), twin.get_param_values().values()))
 
 
 def test_rnn_fit_reduces_loss_on_a_learnable_sequence():
@@ -201,8 +236,9 @@ def test_gpu_rnn_controller_matches_golden(cid, kernel):
                 want = gold["returns_%d" % k][np.arange(case["m"]), gold["best_%d" % k]]
                 np.testing.assert_allclose(ctrl.last_plan["best_return"][safe], want[safe], rtol=1e-4, atol=1e-4)
             if safe.all():
-                np.testing.assert_allclose(ctrl._hidden_state.c, gold["hidden_c_%d" % k], rtol=1e-4, atol=2e-5)
-                np.testing.assert_allclose(ctrl._hidden_state.h, gold["hidden_h_%d" % k], rtol=1e-4, atol=2e-5)
+                c, h = _flat(ctrl._hidden_state)
+                np.testing.assert_allclose(c, gold["hidden_c_%d" % k], rtol=1e-4, atol=2e-5)
+                np.testing.assert_allclose(h, gold["hidden_h_%d" % k], rtol=1e-4, atol=2e-5)
 
         _replay(case, gold, step, lambda dones: ctrl.reset(dones=dones))
         if case["planner"] == "rnn_rs":
@@ -214,7 +250,9 @@ def test_gpu_rnn_controller_matches_golden(cid, kernel):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["mfma", "valu"])
 @pytest.mark.parametrize("name", ["hc_rnn_rs_m2_n64_h4_reset", "hc_rnn_rs_u128_n40_h3", "ant_rnn_rs_n100_h5_m2",
-                                  "hc_rnn_rs_m2_n64_h4_reset:relu", "hc_rnn_rs_u128_n40_h3:swish"])
+                                  "hc_rnn_rs_m2_n64_h4_reset:relu", "hc_rnn_rs_u128_n40_h3:swish",
+                                  "hc_rnn_rs_lstm2_n48_h4", "hc_rnn_rs_gru2_n48_h4", "hc_rnn_rs_gru1_u96_n40_h3",
+                                  "arm_rnn_rs_rnn1_u80_n40_h3", "hc_rnn_rs_rnn3_n32_h3:sigmoid"])
 def test_gpu_rnn_returns_table_matches_oracle(name, kernel):
     """Every candidate's return of one recurrent plan step, from a NON-zero hidden state (also with
     other cell activations than the default tanh)."""
@@ -224,15 +262,21 @@ def test_gpu_rnn_returns_table_matches_oracle(name, kernel):
     case = dict(cases.CASES[name])
     if act:
         case["activation"] = act
+    if kernel == "mfma" and "hidden_sizes" in case:
+        pytest.skip("stacks / GRU / RNN cells run on the generic kernel")
     env, model = cases.product_rnn_model(case)
     dyn = cases.oracle_rnn_dynamics(case)
     reward = make_reward(case["env"], env.dt)
     rs = np.random.RandomState(5)
     m, n, h, U = case["m"], case["n"], case["h"], case["units"]
     obs0 = rs.randn(m, env.observation_space.shape[0])
-    hid = LSTMStateTuple(rs.randn(m, U).astype(np.float32), np.tanh(rs.randn(m, U)).astype(np.float32))
+    flat = LSTMStateTuple(rs.randn(m, U).astype(np.float32), np.tanh(rs.randn(m, U)).astype(np.float32))
+    hid = model.unpack_hidden(flat.c, flat.h)            # the model's own structure (a stack: list of layer states)
+    if case.get("cell_type", "lstm") != "lstm":
+        flat = LSTMStateTuple(np.zeros_like(flat.c), flat.h)
     acts = rs.uniform(env.action_space.low, env.action_space.high, (h, m * n, env.action_space.shape[0]))
     want = rnn_rollout_returns(dyn, reward, obs0, hid, acts, n, case.get("discount", 1.0)).reshape(m, n)
+    hid = flat
     ctx = _lib.Context.get(0)
     ctx.set_kernel(kernel)
     try:
@@ -447,3 +491,33 @@ def test_gpu_rnn_pipelined_controller_equals_single_launch(cid):
                 assert np.array_equal(x, y)
     if case["h"] >= 6:
         assert np.array_equal(runs[0][0][1], gold["best_0"])
+
+
+@pytest.mark.parametrize("name", ["hc_rnn_rs_lstm2_n48_h4", "hc_rnn_rs_gru2_n48_h4", "hc_rnn_rs_gru1_u96_n40_h3",
+                                  "arm_rnn_rs_rnn1_u80_n40_h3", "hc_rnn_rs_rnn3_n32_h3"])
+def test_cell_restatements_match_the_torch_forward(name):
+    """The NumPy restatement of GRUCell / BasicRNNCell / MultiRNNCell (oracle/rnn_cells.py) against the package's
+    independent stock-PyTorch forward pass used for training (dynamics/rnn_cells.stack_forward), two steps."""
+    from learning_to_adapt_amd.dynamics import core, rnn_cells
+    case = cases.CASES[name]
+    env, params, norm = cases.rnn_recipe(case)
+    dyn = cases.oracle_rnn_dynamics(case)
+    rs = np.random.RandomState(0)
+    rows = 7
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    hid = dyn.get_initial_hidden(rows)
+    obs = rs.randn(rows, od)
+    tparams = [torch.from_numpy(np.asarray(p)) for p in params]
+    tstate = rnn_cells.zero_state(case["cell_type"], case["hidden_sizes"], rows, "cpu")
+    for _ in range(2):
+        act = rs.uniform(env.action_space.low, env.action_space.high, (rows, ad))
+        want, hid = dyn.predict(obs, act, hid)
+        x = np.concatenate([core.normalize(obs, *norm["obs"]), core.normalize(act, *norm["act"])], axis=1)
+        pred, tstate = rnn_cells.stack_forward(torch.as_tensor(x[:, None, :], dtype=torch.float32), tstate, tparams,
+                                               case["hidden_sizes"], case["cell_type"], case.get("activation", "tanh"), None)
+        got = obs + core.denormalize(pred[:, 0].numpy().astype(np.float64), *norm["delta"])
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+        obs = want
+    c, h = _flat(hid)
+    th = torch.cat([s[1] if isinstance(s, tuple) else s for s in tstate], dim=1).numpy()
+    np.testing.assert_allclose(h, th, rtol=2e-5, atol=2e-6)

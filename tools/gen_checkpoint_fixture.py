@@ -122,7 +122,8 @@ def main():
     rnn = Rnn("dyn", env, (case["units"],), "lstm", "tanh", None, 10, 0.001, True, Adam, 0.2, 0.99, 50)
     rnn.normalization = OrderedDict((k, (np.asarray(v[0]), np.asarray(v[1]))) for k, v in norm.items())
     rnn.network_params = named(params, ["rnn/lstm_cell/kernel", "rnn/lstm_cell/bias", "output/kernel", "output/bias"])
-    RPol = ref_class("learning_to_adapt.policies.rnn_mpc_controller", "RNNMPCController")
+    RPol = ref_class("learning_to_adapt.policies.rnn_mpc_controller", "RNNMPCController",
+                     lambda self, base: {"init_args": base})            # rnn_mpc_controller.py:189-192
     # rnn_mpc_controller.py:8-21: name, env, dynamics_model, reward_model, discount, use_cem, n_candidates, horizon,
     # num_cem_iters, percent_elites, use_reward_model
     rpol = RPol("policy", env, rnn, None, 1, False, case["n"], case["h"], 8, 0.05, False)
