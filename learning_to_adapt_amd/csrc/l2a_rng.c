@@ -121,7 +121,7 @@ L2A_CLONES static void mt_fill_double(mt_t* s, double* out, long long n) {
  * child has no worker threads: the pid check rebuilds the pool there. */
 #define L2A_MAXT 32
 typedef void (*job_fn)(void* arg, int tid, int nthreads);
-static struct {
+typedef struct l2a_pool {
     pthread_mutex_t mu;
     pthread_cond_t cv_start, cv_done;
     pthread_t th[L2A_MAXT];
@@ -133,75 +133,104 @@ static struct {
     unsigned gen;       /* job generation */
     int pending;
     unsigned seen0[L2A_MAXT];   /* generation each worker starts from (set by its creator) */
-} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, {0}};
-static pthread_mutex_t g_call_mu = PTHREAD_MUTEX_INITIALIZER;      /* one parallel job at a time */
+    pthread_mutex_t call_mu;    /* one parallel job at a time per pool */
+} l2a_pool;
+/* Two pools: the thread that first calls in (the controller's main thread: synchronous draws, l2a_cem_samples)
+ * owns pool 0, every other thread (the draw-ahead worker) shares pool 1 - a long draw-ahead job must not make the
+ * main thread's short passes queue behind it (measured: +4.7 ms per config-5 plan step with a single pool). */
+static l2a_pool g_pools[2] = {
+    {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, {0}, PTHREAD_MUTEX_INITIALIZER},
+    {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, {0}, PTHREAD_MUTEX_INITIALIZER}};
+static pthread_t g_main_thread;
+static int g_have_main = 0;
+static pthread_mutex_t g_main_mu = PTHREAD_MUTEX_INITIALIZER;
 
-static void* pool_worker(void* idp) {
-    const int id = (int)(intptr_t)idp;      /* 1 .. n_workers */
-    pthread_mutex_lock(&g_pool.mu);
-    unsigned seen = g_pool.seen0[id];
+typedef struct { l2a_pool* pool; int id; } worker_arg;
+static worker_arg g_worker_args[2][L2A_MAXT];
+
+static void* pool_worker(void* argp) {
+    l2a_pool* pl = ((worker_arg*)argp)->pool;
+    const int id = ((worker_arg*)argp)->id;         /* 1 .. n_workers */
+    pthread_mutex_lock(&pl->mu);
+    unsigned seen = pl->seen0[id];
     for (;;) {
-        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.cv_start, &g_pool.mu);
-        seen = g_pool.gen;
-        if (id < g_pool.nthreads) {
-            job_fn fn = g_pool.fn;
-            void* arg = g_pool.arg;
-            const int nt = g_pool.nthreads;
-            pthread_mutex_unlock(&g_pool.mu);
+        while (pl->gen == seen) pthread_cond_wait(&pl->cv_start, &pl->mu);
+        seen = pl->gen;
+        if (id < pl->nthreads) {
+            job_fn fn = pl->fn;
+            void* arg = pl->arg;
+            const int nt = pl->nthreads;
+            pthread_mutex_unlock(&pl->mu);
             fn(arg, id, nt);
-            pthread_mutex_lock(&g_pool.mu);
-            if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+            pthread_mutex_lock(&pl->mu);
+            if (--pl->pending == 0) pthread_cond_signal(&pl->cv_done);
         }
     }
     return NULL;
 }
 
 static void pool_atfork_child(void) {        /* the child owns no worker threads and no held locks */
-    pthread_mutex_init(&g_call_mu, NULL);
-    g_pool.pid = 0;
+    for (int q = 0; q < 2; ++q) {
+        pthread_mutex_init(&g_pools[q].call_mu, NULL);
+        g_pools[q].pid = 0;
+    }
+    pthread_mutex_init(&g_main_mu, NULL);
+    g_have_main = 0;
 }
 
 static void pool_register_atfork(void) { pthread_atfork(NULL, NULL, pool_atfork_child); }
+
+static l2a_pool* pool_of_caller(void) {
+    pthread_mutex_lock(&g_main_mu);
+    if (!g_have_main) { g_main_thread = pthread_self(); g_have_main = 1; }
+    const int q = pthread_equal(g_main_thread, pthread_self()) ? 0 : 1;
+    pthread_mutex_unlock(&g_main_mu);
+    return &g_pools[q];
+}
 
 static void run_parallel(job_fn fn, void* arg, int nthreads) {
     static pthread_once_t once = PTHREAD_ONCE_INIT;
     if (nthreads > L2A_MAXT) nthreads = L2A_MAXT;
     if (nthreads <= 1) { fn(arg, 0, 1); return; }
     pthread_once(&once, pool_register_atfork);
-    pthread_mutex_lock(&g_call_mu);
-    if (g_pool.pid != getpid()) {           /* first use, or a forked child */
-        pthread_mutex_init(&g_pool.mu, NULL);
-        pthread_cond_init(&g_pool.cv_start, NULL);
-        pthread_cond_init(&g_pool.cv_done, NULL);
-        g_pool.n_workers = 0;
-        g_pool.gen = 0;
-        g_pool.pid = getpid();
+    l2a_pool* pl = pool_of_caller();
+    const int q = (int)(pl - g_pools);
+    pthread_mutex_lock(&pl->call_mu);
+    if (pl->pid != getpid()) {              /* first use, or a forked child */
+        pthread_mutex_init(&pl->mu, NULL);
+        pthread_cond_init(&pl->cv_start, NULL);
+        pthread_cond_init(&pl->cv_done, NULL);
+        pl->n_workers = 0;
+        pl->gen = 0;
+        pl->pid = getpid();
     }
-    while (g_pool.n_workers < nthreads - 1) {
+    while (pl->n_workers < nthreads - 1) {
         pthread_attr_t at;
         pthread_attr_init(&at);
         pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
-        const int id = g_pool.n_workers + 1;
-        g_pool.seen0[id] = g_pool.gen;      /* jobs are only posted below, under g_call_mu */
-        if (pthread_create(&g_pool.th[id], &at, pool_worker, (void*)(intptr_t)id) != 0) {
+        const int id = pl->n_workers + 1;
+        pl->seen0[id] = pl->gen;            /* jobs are only posted below, under call_mu */
+        g_worker_args[q][id].pool = pl;
+        g_worker_args[q][id].id = id;
+        if (pthread_create(&pl->th[id], &at, pool_worker, &g_worker_args[q][id]) != 0) {
             pthread_attr_destroy(&at);
-            nthreads = g_pool.n_workers + 1;            /* make do with what we have */
+            nthreads = pl->n_workers + 1;               /* make do with what we have */
             break;
         }
         pthread_attr_destroy(&at);
-        g_pool.n_workers = id;
+        pl->n_workers = id;
     }
-    if (nthreads <= 1) { pthread_mutex_unlock(&g_call_mu); fn(arg, 0, 1); return; }
-    pthread_mutex_lock(&g_pool.mu);
-    g_pool.fn = fn; g_pool.arg = arg; g_pool.nthreads = nthreads; g_pool.pending = nthreads - 1;
-    g_pool.gen += 1;
-    pthread_cond_broadcast(&g_pool.cv_start);
-    pthread_mutex_unlock(&g_pool.mu);
+    if (nthreads <= 1) { pthread_mutex_unlock(&pl->call_mu); fn(arg, 0, 1); return; }
+    pthread_mutex_lock(&pl->mu);
+    pl->fn = fn; pl->arg = arg; pl->nthreads = nthreads; pl->pending = nthreads - 1;
+    pl->gen += 1;
+    pthread_cond_broadcast(&pl->cv_start);
+    pthread_mutex_unlock(&pl->mu);
     fn(arg, 0, nthreads);
-    pthread_mutex_lock(&g_pool.mu);
-    while (g_pool.pending != 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
-    pthread_mutex_unlock(&g_pool.mu);
-    pthread_mutex_unlock(&g_call_mu);
+    pthread_mutex_lock(&pl->mu);
+    while (pl->pending != 0) pthread_cond_wait(&pl->cv_done, &pl->mu);
+    pthread_mutex_unlock(&pl->mu);
+    pthread_mutex_unlock(&pl->call_mu);
 }
 
 static inline long long slice_lo(long long n, int tid, int nt) { return n * tid / nt; }

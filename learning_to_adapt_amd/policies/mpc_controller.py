@@ -284,8 +284,13 @@ class MPCController(Policy, Serializable):
     def _upload_obs(self, observations):
         """``[m, obs_dim]`` host observations -> the fp32 device buffer the rollout reads."""
         native = self.dynamics_model.planner_model()
-        obs0 = self._buf("obs0", (len(observations), native.obs_dim), torch.float32, native.device)
-        obs0.copy_(torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32)), non_blocking=False)
+        shape = (len(observations), native.obs_dim)
+        obs0 = self._buf("obs0", shape, torch.float32, native.device)
+        # through page-locked staging: an asynchronous copy instead of a pageable one that synchronises the stream
+        # (every caller reads the plan's result back before it uploads the next observation)
+        pin = self._pinned("obs0_pin", shape, native.device)
+        np.copyto(pin.numpy(), np.asarray(observations).reshape(shape), casting="same_kind")
+        obs0.copy_(pin, non_blocking=True)
         return obs0
 
     def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
