@@ -73,8 +73,190 @@ static inline uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
+
+/* ---- polynomial jump-ahead ------------------------------------------------------------------------------------
+ * The state s_k = (top bit of z_k, z_{k+1}, ..., z_{k+623}) of the raw word sequence z evolves linearly over GF(2):
+ * s_{k+1} = F s_k, with minimal polynomial phi(t) of degree 19937.  With g(t) = t^n mod phi(t),
+ * s_n = g(F) s_0 = sum_i g_i s_i, i.e. word-wise z_{n+j} = XOR over the set bits i of g of z_{i+j}: an XOR of at most
+ * 19937 windows of the next 19937 + 624 raw words - O(1) in n, against O(n) for regenerating the blocks in between
+ * (Haramoto, Matsumoto, Nishimura, Panneton, L'Ecuyer, "Efficient jump ahead for F2-linear random number generators",
+ * 2008 - the sliding-window form).  phi is found once per process by Berlekamp-Massey on 2 * 19937 output bits (its
+ * degree is checked); g is cached per distance (the planner's slice offsets repeat every controller step).
+ * mt_skip uses the jump beyond L2A_JUMP_MIN_WORDS, where it beats block regeneration (~0.14 ns per word). */
+#define MT_DEG 19937
+#define PW ((MT_DEG + 64) / 64)                 /* 64-bit words of a polynomial of degree <= MT_DEG: 312 */
+#define L2A_JUMP_MIN_WORDS (3LL << 20)
+
+typedef struct { uint64_t w[PW]; } poly_t;
+static poly_t g_phi;                            /* minimal polynomial, bit i = coefficient of t^i */
+static int g_phi_ready = 0;
+static pthread_mutex_t g_jump_mu = PTHREAD_MUTEX_INITIALIZER;
+#define JUMP_CACHE 64
+static struct { long long n; poly_t g; } g_jump_cache[JUMP_CACHE];
+static int g_jump_cached = 0;
+
+static inline int pbit(const uint64_t* p, int i) { return (int)((p[i >> 6] >> (i & 63)) & 1u); }
+
+/* Berlekamp-Massey over GF(2): minimal polynomial of the bit sequence seq[0..n). */
+static int berlekamp_massey(const uint8_t* seq, int n, uint64_t* out, int words) {
+    uint64_t* C = (uint64_t*)calloc((size_t)words, 8);
+    uint64_t* B = (uint64_t*)calloc((size_t)words, 8);
+    uint64_t* T = (uint64_t*)calloc((size_t)words, 8);
+    uint64_t* S = (uint64_t*)calloc((size_t)words, 8);         /* reversed sliding window of the sequence */
+    if (!C || !B || !T || !S) { free(C); free(B); free(T); free(S); return -1; }
+    C[0] = B[0] = 1;
+    int L = 0, m = 1;
+    for (int N = 0; N < n; ++N) {
+        /* S = bits s_N, s_{N-1}, ... at positions 0, 1, ...: shift left by one, insert s_N */
+        uint64_t carry = seq[N];
+        for (int k = 0; k < words; ++k) { const uint64_t nc = S[k] >> 63; S[k] = (S[k] << 1) | carry; carry = nc; }
+        /* discrepancy d = sum_{i=0..L} C_i s_{N-i} */
+        uint64_t acc = 0;
+        const int lw = (L >> 6) + 1;
+        for (int k = 0; k < lw && k < words; ++k) acc ^= C[k] & S[k];
+        const int d = __builtin_parityll(acc);
+        if (!d) { ++m; continue; }
+        const int grow = (2 * L <= N);
+        if (grow) memcpy(T, C, (size_t)words * 8);
+        /* C ^= B << m */
+        const int ws = m >> 6, bs = m & 63;
+        for (int k = words - 1; k >= ws; --k) {
+            uint64_t v = B[k - ws] << bs;
+            if (bs && k - ws - 1 >= 0) v |= B[k - ws - 1] >> (64 - bs);
+            C[k] ^= v;
+        }
+        if (grow) { L = N + 1 - L; memcpy(B, T, (size_t)words * 8); m = 1; } else { ++m; }
+    }
+    /* connection polynomial C(x) = 1 + c_1 x + ... + c_L x^L  <->  minimal polynomial t^L + c_1 t^(L-1) + ... + c_L */
+    memset(out, 0, (size_t)words * 8);
+    for (int i = 0; i <= L; ++i)
+        if (pbit(C, i)) out[(L - i) >> 6] |= 1ull << ((L - i) & 63);
+    free(C); free(B); free(T); free(S);
+    return L;
+}
+
+static int phi_init(void) {
+    if (g_phi_ready) return 0;
+    mt_t s;
+    uint32_t x = 19650218u;                                     /* any non-degenerate state will do */
+    for (int k = 0; k < MT_N; ++k) { s.key[k] = x; x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(k + 1); }
+    s.pos = MT_N;
+    const int n = 2 * MT_DEG + 64;
+    uint8_t* bits = (uint8_t*)malloc((size_t)n);
+    if (!bits) return -1;
+    for (int k = 0; k < n; ++k) {                               /* bit 0 of every raw word: a linear output */
+        if (s.pos >= MT_N) { mt_regen(s.key); s.pos = 0; }
+        bits[k] = (uint8_t)(s.key[s.pos++] & 1u);
+    }
+    uint64_t tmp[2 * PW + 4];
+    const int L = berlekamp_massey(bits, n, tmp, 2 * PW + 4);
+    free(bits);
+    if (L != MT_DEG) return -2;
+    memcpy(g_phi.w, tmp, sizeof(g_phi.w));
+    g_phi_ready = 1;
+    return 0;
+}
+
+/* r = (a * b) mod phi, degrees < MT_DEG */
+static void poly_mulmod(const poly_t* a, const poly_t* b, poly_t* r) {
+    uint64_t prod[2 * PW + 1];
+    memset(prod, 0, sizeof(prod));
+    for (int i = 0; i < MT_DEG; ++i) {
+        if (!pbit(a->w, i)) continue;
+        const int ws = i >> 6, bs = i & 63;
+        for (int k = 0; k < PW; ++k) {
+            prod[k + ws] ^= b->w[k] << bs;
+            if (bs) prod[k + ws + 1] ^= b->w[k] >> (64 - bs);
+        }
+    }
+    for (int d = 2 * MT_DEG - 2; d >= MT_DEG; --d) {            /* reduce: t^d = t^(d - DEG) * (phi - t^DEG) */
+        if (!pbit(prod, d)) continue;
+        const int sh = d - MT_DEG, ws = sh >> 6, bs = sh & 63;
+        for (int k = 0; k < PW; ++k) {
+            prod[k + ws] ^= g_phi.w[k] << bs;
+            if (bs) prod[k + ws + 1] ^= g_phi.w[k] >> (64 - bs);
+        }
+    }
+    memcpy(r->w, prod, sizeof(r->w));
+    r->w[PW - 1] &= (1ull << (MT_DEG & 63)) - 1;                /* bits >= DEG are gone after the reduction */
+}
+
+/* g = t^n mod phi (cached) */
+static int jump_poly(long long n, poly_t* out) {
+    pthread_mutex_lock(&g_jump_mu);
+    int rc = phi_init();
+    if (rc == 0) {
+        int hit = -1;
+        for (int k = 0; k < g_jump_cached; ++k)
+            if (g_jump_cache[k].n == n) { hit = k; break; }
+        if (hit < 0) {
+            poly_t result, base, tmp;
+            memset(&result, 0, sizeof(result)); result.w[0] = 1;     /* 1 */
+            memset(&base, 0, sizeof(base)); base.w[0] = 2;           /* t */
+            for (long long e = n; e > 0; e >>= 1) {
+                if (e & 1) { poly_mulmod(&result, &base, &tmp); result = tmp; }
+                if (e > 1) { poly_mulmod(&base, &base, &tmp); base = tmp; }
+            }
+            hit = (g_jump_cached < JUMP_CACHE) ? g_jump_cached++ : (int)((unsigned long long)n % JUMP_CACHE);
+            g_jump_cache[hit].n = n;
+            g_jump_cache[hit].g = result;
+        }
+        *out = g_jump_cache[hit].g;
+    }
+    pthread_mutex_unlock(&g_jump_mu);
+    return rc;
+}
+
+/* Replace the block s->key by the block `blocks` regenerations later (blocks >= 1), in O(1). */
+L2A_CLONES static int mt_jump_blocks(mt_t* s, long long blocks) {
+    poly_t g;
+    const long long n = blocks * MT_N - 1;      /* s_{W-1}: (top bit of z_{W-1}, z_W .. z_{W+622}), W = 624 * blocks */
+    if (jump_poly(n, &g) != 0) return -1;
+    enum { RAW = MT_DEG + MT_N + MT_N };
+    uint32_t* z = (uint32_t*)malloc(sizeof(uint32_t) * RAW);
+    if (!z) return -1;
+    memcpy(z, s->key, sizeof(s->key));
+    for (int b = 1; (b + 1) * MT_N <= RAW; ++b) {               /* the next raw words, block by block */
+        memcpy(z + b * MT_N, z + (b - 1) * MT_N, sizeof(s->key));
+        mt_regen(z + b * MT_N);
+    }
+    uint32_t acc[MT_N];
+    memset(acc, 0, sizeof(acc));
+    for (int w = 0; w < PW; ++w) {
+        uint64_t bitsw = g.w[w];
+        while (bitsw) {
+            const int i = (w << 6) + __builtin_ctzll(bitsw);
+            bitsw &= bitsw - 1;
+            const uint32_t* win = z + i;
+            for (int j = 0; j < MT_N; ++j) acc[j] ^= win[j];
+        }
+    }
+    free(z);
+    /* acc[0] = z_{W-1} (only its top bit is meaningful), acc[1..623] = z_W .. z_{W+622}; one more recurrence step
+     * gives z_{W+623} = z_{W+396} ^ twist(top(z_{W-1}) | low(z_W)) */
+    const uint32_t y = (acc[0] & MT_UP) | (acc[1] & MT_LO);
+    const uint32_t last = acc[MT_M] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1U)) & MT_A);
+    memcpy(s->key, acc + 1, sizeof(uint32_t) * (MT_N - 1));
+    s->key[MT_N - 1] = last;
+    return 0;
+}
+
 /* Advance the state by `words` 32-bit outputs without producing them. */
 static void mt_skip(mt_t* s, long long words) {
+    if (words >= L2A_JUMP_MIN_WORDS && s->pos <= MT_N) {
+        /* whole blocks by the polynomial jump, the remainder (< 624 words) by position */
+        long long target = (long long)s->pos + words;       /* index in the z sequence of the current block */
+        if (s->pos == MT_N) { mt_regen(s->key); s->pos = 0; target -= MT_N; }
+        const long long blocks = target / MT_N;
+        if (blocks >= 1) {
+            mt_t saved = *s;
+            if (mt_jump_blocks(s, blocks) == 0) {
+                s->pos = (int)(target - blocks * MT_N);
+                return;
+            }
+            *s = saved;                                      /* (allocation failure: fall through to regeneration) */
+        }
+    }
     while (words > 0) {
         if (s->pos >= MT_N) { mt_regen(s->key); s->pos = 0; }
         long long take = MT_N - s->pos;
@@ -437,9 +619,20 @@ int l2a_mt19937_fill_gauss(uint32_t* key, int* pos, int* has_gauss, double* gaus
         gauss_job j;
         memset(&j, 0, sizeof(j));
         j.s0 = &s; j.attempts = attempts;
-        j.tmp = (double*)malloc(sizeof(double) * 2 * (size_t)attempts);
-        j.tmp_idx = (int*)malloc(sizeof(int) * (size_t)attempts);
-        if (!j.tmp || !j.tmp_idx) { free(j.tmp); free(j.tmp_idx); return -2; }
+        /* per-thread scratch kept between calls: a fresh 15 MB allocation per draw would be page-faulted in by
+         * every call (the planner draws 720 k normals five times per controller step) */
+        static __thread double* tl_tmp = NULL;
+        static __thread int* tl_idx = NULL;
+        static __thread long long tl_cap = 0;
+        if (attempts > tl_cap) {
+            free(tl_tmp); free(tl_idx);
+            tl_tmp = (double*)malloc(sizeof(double) * 2 * (size_t)attempts);
+            tl_idx = (int*)malloc(sizeof(int) * (size_t)attempts);
+            tl_cap = (tl_tmp && tl_idx) ? attempts : 0;
+            if (!tl_cap) { free(tl_tmp); free(tl_idx); tl_tmp = NULL; tl_idx = NULL; return -2; }
+        }
+        j.tmp = tl_tmp;
+        j.tmp_idx = tl_idx;
         /* run_parallel may fall back to fewer threads only when nt collapses to 1; slices are indexed by the
          * nt actually used, which the job functions receive */
         j.count[0] = -1;
@@ -472,7 +665,6 @@ int l2a_mt19937_fill_gauss(uint32_t* key, int* pos, int* has_gauss, double* gaus
         i += 2 * full + ((ends_here && odd) ? 1 : 0);
         pairs -= take;
         mt_skip(&s, 4 * used_attempts);
-        free(j.tmp); free(j.tmp_idx);
     }
     memcpy(key, s.key, sizeof(s.key));
     *pos = s.pos;
@@ -574,4 +766,35 @@ void l2a_mt19937_state_load(const void* addr, uint32_t* key, int* pos) {
     *pos = s->pos;
 }
 
-int l2a_rng_version(void) { return 3; }
+/* Test hook: the same skip with the jump forced on (use_jump = 1, any distance >= 624) or off (0). */
+int l2a_mt19937_skip_mode(uint32_t* key, int* pos, long long words, int use_jump) {
+    if (!key || !pos || words < 0 || *pos < 0 || *pos > MT_N) return -1;
+    mt_t s;
+    memcpy(s.key, key, sizeof(s.key));
+    s.pos = *pos;
+    if (use_jump) {
+        long long target = (long long)s.pos + words;
+        if (s.pos == MT_N) { mt_regen(s.key); s.pos = 0; target -= MT_N; }
+        const long long blocks = target / MT_N;
+        if (blocks >= 1) {
+            if (mt_jump_blocks(&s, blocks) != 0) return -2;
+            s.pos = (int)(target - blocks * MT_N);
+        } else {
+            s.pos = (int)target;
+        }
+    } else {
+        long long left = words;
+        while (left > 0) {
+            if (s.pos >= MT_N) { mt_regen(s.key); s.pos = 0; }
+            long long take = MT_N - s.pos;
+            if (take > left) take = left;
+            s.pos += (int)take;
+            left -= take;
+        }
+    }
+    memcpy(key, s.key, sizeof(s.key));
+    *pos = s.pos;
+    return 0;
+}
+
+int l2a_rng_version(void) { return 4; }

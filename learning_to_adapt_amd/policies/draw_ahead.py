@@ -20,6 +20,7 @@ Either way the numbers, their order and the generator state seen by everybody el
 import collections
 import os
 import threading
+import time
 
 from ..utils import fast_rng
 
@@ -47,6 +48,8 @@ class DrawAhead(object):
         self.hits = 0
         self.cooldown = 0
         self.words_only = False     # compare / store key + pos only (uniform stream; ~1 us instead of ~50)
+        self.produce_s = 0.0        # time the worker spent producing blocks (diagnostics)
+        self.produced = 0
 
     @property
     def n_slots(self):
@@ -138,10 +141,13 @@ class DrawAhead(object):
                 slot = self.slot
                 self.slot = (self.slot + 1) % self.n_slots
             payload, error = None, None
+            t0 = time.perf_counter()
             try:
                 payload = producer(state, slot)
             except BaseException as exc:        # surfaces as a miss on the consumer side
                 error = exc
+            self.produce_s += time.perf_counter() - t0
+            self.produced += 1
             with self.cv:
                 if gen == self.gen:
                     blk.payload, blk.error, blk.end = payload, error, state

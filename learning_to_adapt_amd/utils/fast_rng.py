@@ -56,12 +56,14 @@ def _load():
             c = ctypes
             vp, ll, i32 = c.c_void_p, c.c_longlong, c.c_int
             ip = c.POINTER(i32)
-            if lib.l2a_rng_version() < 3:
+            if lib.l2a_rng_version() < 4:
                 return None
             lib.l2a_mt19937_fill_double_mt.argtypes = [vp, ip, vp, ll, i32]
             lib.l2a_mt19937_fill_double_mt.restype = i32
             lib.l2a_mt19937_skip.argtypes = [vp, ip, ll]
             lib.l2a_mt19937_skip.restype = i32
+            lib.l2a_mt19937_skip_mode.argtypes = [vp, ip, ll, i32]
+            lib.l2a_mt19937_skip_mode.restype = i32
             lib.l2a_mt19937_uniform_rows.argtypes = [vp, ip, ll, i32, vp, vp, ll, ll, ll, vp, ll, vp, i32]
             lib.l2a_mt19937_uniform_rows.restype = i32
             lib.l2a_mt19937_fill_gauss.argtypes = [vp, ip, ip, _dp, vp, ll, i32]
@@ -152,8 +154,14 @@ class State(object):
             raise RuntimeError("l2a_mt19937_fill_double_mt failed (%d)" % rc)
         return out
 
-    def skip_doubles(self, n):
-        rc = _state["lib"].l2a_mt19937_skip(self.key.ctypes.data, ctypes.byref(self.pos), 2 * int(n))
+    def skip_doubles(self, n, jump=None):
+        """Advance by ``n`` doubles.  ``jump``: None = the library's choice (polynomial jump-ahead for long
+        distances, block regeneration otherwise), True / False = force one of them (tests)."""
+        lib = _state["lib"]
+        if jump is None:
+            rc = lib.l2a_mt19937_skip(self.key.ctypes.data, ctypes.byref(self.pos), 2 * int(n))
+        else:
+            rc = lib.l2a_mt19937_skip_mode(self.key.ctypes.data, ctypes.byref(self.pos), 2 * int(n), 1 if jump else 0)
         if rc != 0:
             raise RuntimeError("l2a_mt19937_skip failed (%d)" % rc)
 

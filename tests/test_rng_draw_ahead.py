@@ -195,3 +195,39 @@ def test_draw_ahead_does_not_change_a_bit_cem():
     a, _ = c2.get_actions(gold["obs0"])
     np.testing.assert_array_equal(a, gold["chosen"])
     assert np.random.uniform() == float(gold["rng_next"])
+
+
+def test_polynomial_jump_ahead_equals_block_regeneration():
+    """`mt_jump_blocks` (t^n mod the degree-19937 minimal polynomial, found by Berlekamp-Massey at run time, applied
+    as an XOR of state windows) against stepping the generator: same key words and position for short, odd and long
+    distances, from a mid-block position; then the stream continues identically."""
+    np.random.seed(123)
+    np.random.random_sample(77)                     # somewhere inside a block
+    for n_doubles in (1, 311, 312, 313, 1000, 624 * 50 + 17, 2_000_003):
+        a = fast_rng.State.from_global()
+        b = a.copy()
+        a.skip_doubles(n_doubles, jump=False)
+        b.skip_doubles(n_doubles, jump=True)
+        assert a.pos.value == b.pos.value and np.array_equal(a.key, b.key), n_doubles
+        assert np.array_equal(a.random_sample(1500), b.random_sample(1500))
+    # against NumPy itself
+    st = fast_rng.State.from_global()
+    want = np.random.random_sample(1_700_000)[-5:]
+    st.skip_doubles(1_700_000 - 5, jump=True)
+    assert np.array_equal(st.random_sample(5), want)
+
+
+def test_long_threaded_draw_uses_the_jump_and_matches_numpy():
+    """4 M doubles on 8 threads: the later slices start more than 3 M words into the stream, beyond which `mt_skip`
+    jumps instead of regenerating - the values must still be NumPy's."""
+    old = fast_rng.threads()
+    fast_rng.set_threads(8)
+    try:
+        np.random.seed(9)
+        want = np.random.random_sample(4_000_000)
+        after = _state_tuple()
+        np.random.seed(9)
+        got = fast_rng.random_sample(4_000_000)
+        assert np.array_equal(want, got) and _state_tuple() == after
+    finally:
+        fast_rng.set_threads(old)

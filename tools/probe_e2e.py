@@ -69,7 +69,9 @@ def main():
         tot = time.perf_counter() - t0
         row = {"mode": mode, "draw_ahead": ahead, "ms_per_call": round(1e3 * tot / K, 4),
                "stages_us": {k: round(1e6 * v / K, 1) for k, v in acc.items()},
-               "hits": None if ctrl._ahead is None else ctrl._ahead.hits}
+               "hits": None if ctrl._ahead is None else ctrl._ahead.hits,
+               "worker_ms_per_block": None if (ctrl._ahead is None or not ctrl._ahead.produced) else
+               round(1e3 * ctrl._ahead.produce_s / ctrl._ahead.produced, 3)}
         print(json.dumps(row), flush=True)
         if ctrl._ahead is not None:
             ctrl._ahead.stop()
