@@ -12,7 +12,8 @@ import os
 from .envs.reward_spec import RewardSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libl2a_hip.so")
+# L2A_LIB_PATH: developer override for kernel A/B runs (tools/build_variant.py); the product loads the in-tree build
+LIB_PATH = os.environ.get("L2A_LIB_PATH") or os.path.join(_HERE, "libl2a_hip.so")
 
 # include/l2a.h
 L2A_OK = 0

@@ -87,6 +87,9 @@ __host__ __device__ inline void l2a_lstm_pack_decode(long long idx, int KG0, int
 
 // Phase timeline for tools/timeline_lstm.py: the waves of workgroup 0 stamp the shader clock,
 // dbg[((t * 4 + wave) * 16 + slot].  One uniform branch per stamp, pinned by scheduling barriers.
+#ifndef L2A_TIMELINE
+#define L2A_LTS(slot)
+#else
 #define L2A_LTS(slot)                                                                       \
     if (p.dbg && bid == 0) {                                                                \
         unsigned long long ts_;                                                             \
@@ -95,6 +98,7 @@ __host__ __device__ inline void l2a_lstm_pack_decode(long long idx, int KG0, int
         __builtin_amdgcn_sched_barrier(0);                                                  \
         if (lane == 0) p.dbg[((long long)t * 4 + wave) * 16 + (slot)] = ts_;                \
     }
+#endif
 
 __device__ __forceinline__ float l2a_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 

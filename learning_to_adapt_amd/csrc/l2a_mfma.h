@@ -88,13 +88,20 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
 #define L2A_OPAQUE(v) asm volatile("" : "+v"(v))
 
 // Phase timeline for tools/timeline.py: every wave of candidate tile 0 stamps the shader clock at
-// phase boundaries, dbg[(((grp * h + t) * 8 + e) * 8 + wave) * 16 + slot].  One uniform branch per stamp.
+// phase boundaries, dbg[(((grp * h + t) * 8 + e) * 8 + wave) * 16 + slot].  One uniform branch per stamp - which
+// also ends a basic block, i.e. keeps the scheduler from moving instructions across phase boundaries (measured:
+// 0.6 % of a config-2 plan, 2.7 % of a config-1 plan).  Hence only in builds with -DL2A_TIMELINE
+// (tools/build_variant.py timeline -DL2A_TIMELINE); the product library carries no stamps.
+#ifndef L2A_TIMELINE
+#define L2A_TS(slot)
+#else
 #define L2A_TS(slot)                                                                        \
     if (p.dbg && pairid == 0 && e < 8) {                                                    \
         unsigned long long ts_;                                                             \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");       \
         if (lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + e) * 8 + wave) * 16 + (slot)] = ts_; \
     }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Hidden->hidden layer GEMM for this wave's TPW output tiles (accumulators only; the caller
@@ -794,7 +801,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                         for (int c = 0; c < OT; ++c) xlds[((k * NT + nt) * OT + c) * 64 + lane] = oth[k][nt][c];
                 { const int e = 7; L2A_TS(12) }
+#ifdef L2A_TIMELINE
                 if (p.dbg && pairid == 0 && lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + 7) * 8 + wave) * 16 + 14] = spins;
+#endif
             }
             { const int e = 7; L2A_TS(10) }
             __syncthreads();

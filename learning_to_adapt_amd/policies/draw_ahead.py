@@ -67,13 +67,17 @@ class DrawAhead(object):
             blk = self.blocks[0]
             while not blk.done:
                 self.cv.wait()
-            same = blk.base.same_words_as_global() if self.words_only else blk.base.same_as_global()
-            if blk.error is not None or not same:
+            # Word-level compare / store (~1 us instead of get_state / set_state) is exact whenever no cached Gaussian
+            # is involved: with has_gauss == 0 on both sides of the block the words ARE the state (nobody can set the
+            # flag without consuming words).  Uniform chains never touch the flag at all.
+            fast = self.words_only or (blk.error is None and not blk.base.has_gauss.value and not blk.end.has_gauss.value)
+            same = blk.error is None and (blk.base.same_words_as_global() if fast else blk.base.same_as_global())
+            if not same:
                 self._flush()
                 self.misses += 1
                 return None
             self.blocks.popleft()
-            if self.words_only:
+            if fast:
                 blk.end.words_to_global()
             else:
                 blk.end.to_global()

@@ -36,6 +36,12 @@ timeout 600 python tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.e
 timeout 300 python tools/parity_report.py > $OUT/parity_report.txt 2> $OUT/parity.err; echo "parity rc=$?"
 timeout 120 python tools/timeline.py > $OUT/timeline.txt 2>&1; echo "timeline rc=$?"
 timeout 120 python tools/timeline_lstm.py 256 4096 > $OUT/timeline_lstm.txt 2>&1; echo "timeline_lstm rc=$?"
+echo "== host RNG helper / end-to-end stage probes"
+timeout 300 python tools/bench_rng.py > $OUT/rng.jsonl 2>&1; echo "rng rc=$?"
+timeout 300 python tools/probe_e2e.py > $OUT/probe_c2.jsonl 2> $OUT/probe.err; echo "probe c2 rc=$?"
+timeout 300 python tools/probe_e2e.py c5_hc_cem_n4000_h30_e5 > $OUT/probe_c5.jsonl 2>> $OUT/probe.err; echo "probe c5 rc=$?"
+echo "== N = 2 code path: two gloo ranks sharing this GPU (self-launch; numbers meaningless)"
+L2A_BENCH_SHARE_GPU=1 L2A_SPLIT=0 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/bench_share2.json 2> $OUT/bench_share2.err; echo "share2 rc=$?"
 # keep the merged-back payload small
 find $OUT/prof -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $OUT

@@ -9,6 +9,14 @@ import ctypes
 import os
 import sys
 
+# the phase stamps exist only in a library built with -DL2A_TIMELINE (they cost the product kernel 0.6 %):
+#   python tools/build_variant.py timeline -DL2A_TIMELINE
+_TL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "learning_to_adapt_amd",
+                   "libl2a_hip_timeline.so")
+if not os.path.exists(_TL):
+    raise SystemExit("build the timeline library first: python tools/build_variant.py timeline -DL2A_TIMELINE")
+os.environ["L2A_LIB_PATH"] = _TL
+
 import numpy as np
 import torch
 
