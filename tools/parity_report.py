@@ -52,7 +52,7 @@ for cid in cases.rnn_case_ids():
     np.random.seed(seed)
     resets = {int(k): v for k, v in case.get("reset_after", {}).items()}
     for k in range(case["steps"]):
-        c_prev, h_prev = (np.array(x) for x in ctrl._hidden_state)
+        c_prev, h_prev = (np.array(x) for x in model.pack_hidden(ctrl._hidden_state))       # flat [m, sum(units)]
         state = np.random.get_state()
         a = sample_rs_actions(env.action_space.low, env.action_space.high, case["n"], case["m"], case["h"])
         np.random.set_state(state)
@@ -66,8 +66,9 @@ for cid in cases.rnn_case_ids():
         rel = np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want)))
         ok = np.array_equal(np.argmax(got, axis=1), gold["best_%d" % k])
         ctrl.get_actions(gold["obs"][k])
-        herr = max(float(np.max(np.abs(ctrl._hidden_state.c - gold["hidden_c_%d" % k]))),
-                   float(np.max(np.abs(ctrl._hidden_state.h - gold["hidden_h_%d" % k]))))
+        c_now, h_now = model.pack_hidden(ctrl._hidden_state)
+        herr = max(float(np.max(np.abs(c_now - gold["hidden_c_%d" % k]))),
+                   float(np.max(np.abs(h_now - gold["hidden_h_%d" % k]))))
         print("%-36s %10.2e %10.2e %8s %.2e" % ("%s (%d)" % (cid, k), rel, np.max(np.abs(got - want)),
                                                "equal" if ok else "DIFF", herr))
         if k in resets:
