@@ -21,6 +21,14 @@
 //                       gate arithmetic is register-local and the cell state c never leaves registers;
 //                       h travels through a double-buffered LDS region; ONE barrier per step.
 //  * l2a_lstm_valu_k  - generic fp32 VALU path (any U); baseline + fallback.
+//
+// Unit-tile split (template parameter SPLIT, plans of at most CUs / 2 candidate tiles): workgroup g of a tile owns
+// the lower / upper half of the unit tiles - every wave UTW / 2 of them, all four gates - i.e. half of the gate GEMM's
+// output columns over the FULL K range (x, then all of h: the same per-tile summation order as the unsplit kernel,
+// so both give the same bits).  Per step the two workgroups swap (a) their halves of the new h - each wave publishes
+// its own tiles right after the gate arithmetic, so they travel under the output layer - and (b) the output layer's
+// half sums S_g = ((c0+c1)+c2)+c3 over their own unit chunks; total = S_0 + S_1 is the unsplit kernel's canonical
+// reduce.  Same self-validating {tag, v, tag, v} granules, bounded spin and status word as l2a_mfma.h.
 #pragma once
 
 #include "l2a_kernels.h"
@@ -63,6 +71,12 @@ struct L2ALstmParams {
     double discount;
     l2a_reward rw;
     unsigned long long* dbg;
+    // ---- unit-tile split (SPLIT instances): two workgroups share a candidate tile, see l2a_lstm_mfma_k ----
+    int split;                  // 0 | 1
+    unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1
+    unsigned long long* xbuf;   // exchange granules [pair][group][slot][UT / 2 + OT][2][64] x 16 B
+    unsigned int* status;       // host-visible word; bit 0 set = exchange timed out
+    unsigned int spin_limit;    // polls one wave may spend waiting for its partner, per launch
 };
 
 // Gate-matrix tile order: tile T = w * (4 UTW) + q * UTW + uu  <->  gate q (i, j, f, o) of unit tile
@@ -154,14 +168,16 @@ __device__ __forceinline__ void l2a_lstm_gemm(__amdgpu_buffer_rsrc_t rs, const i
     }
 }
 
-template <int NT, int UTW, int OT, int KG0>
+template <int NT, int UTW, int OT, int KG0, bool SPLIT>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmParams p) {
     static_assert(UTW % 2 == 0, "a wave's 4 UTW gate tiles are processed in passes of 8");
+    static_assert(!SPLIT || NT == 1, "the unit-tile split shares single candidate tiles");
     constexpr int UT = L2A_NW * UTW;            // unit tiles = h k-groups
     constexpr int U = 16 * UT;
     constexpr int KG = KG0 + UT;                // k-groups of the gate matrix
-    constexpr int GTW = 4 * UTW;                // gate tiles per wave
-    constexpr int TW = 8;                       // gate tiles per pass
+    constexpr int UTWS = SPLIT ? UTW / 2 : UTW; // unit tiles this wave owns
+    constexpr int GTW = 4 * UTWS;               // gate tiles per wave
+    constexpr int TW = GTW < 8 ? GTW : 8;       // gate tiles per pass
     constexpr int NP = GTW / TW;                // passes
     constexpr int HT = UT;                      // (name used by the L2A_STAGE macros: LDS stride)
     // LDS: h fragments, double buffered; output-layer chunk partials, double buffered; constants
@@ -179,11 +195,13 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jc = lane & 15;
     const int qq = lane >> 4;
-    const int u0 = wave * UTW;                  // first unit tile of this wave
-
     const int bid = l2a_logical_wg(blockIdx.x, gridDim.x);
-    const int env = bid / p.tiles_per_env;
-    const int tb = bid - env * p.tiles_per_env;
+    const int n_tiles = p.m * p.tiles_per_env;
+    const int grp = SPLIT ? bid / n_tiles : 0;              // which of the two workgroups of a tile
+    const int pairid = SPLIT ? bid - grp * n_tiles : bid;   // the candidate tile
+    const int u0 = SPLIT ? grp * (UT / 2) + wave * UTWS : wave * UTW;   // first unit tile of this wave
+    const int env = pairid / p.tiles_per_env;
+    const int tb = pairid - env * p.tiles_per_env;
     const int R = p.m * p.n;
     const int obs_dim = p.obs_dim, act_dim = p.act_dim;
 
@@ -205,7 +223,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
     }
 
     // ---- state, cell state (registers) and h (LDS buffer 0) ----------------------------------
-    f32x4 st[NT][OT], creg[NT][UTW];
+    f32x4 st[NT][OT], creg[NT][UTWS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const float* orow = p.obs0 + (p.obs_per_row ? (long long)row[nt] : (long long)env) * obs_dim;
@@ -219,10 +237,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             }
         const long long hrow = (p.hid_per_row ? (long long)row[nt] : (long long)env) * U;
 #pragma unroll
-        for (int uu = 0; uu < UTW; ++uu) {
+        for (int uu = 0; uu < UTWS; ++uu)
             creg[nt][uu] = *reinterpret_cast<const f32x4*>(p.c0 + hrow + 16 * (u0 + uu) + 4 * qq);
-            hbuf[(nt * UT + u0 + uu) * 64 + lane] = *reinterpret_cast<const f32x4*>(p.h0 + hrow + 16 * (u0 + uu) + 4 * qq);
-        }
+#pragma unroll
+        for (int uu = 0; uu < UTW; ++uu)        // the whole h goes to LDS (split: both halves, no exchange needed yet)
+            hbuf[(nt * UT + wave * UTW + uu) * 64 + lane] =
+                *reinterpret_cast<const f32x4*>(p.h0 + hrow + 16 * (wave * UTW + uu) + 4 * qq);
     }
     __syncthreads();
 
@@ -259,7 +279,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
     for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
         for (int tt = 0; tt < TW; ++tt) {
-            voffx[ps][tt] = lane * 16 + (wave * GTW + ps * TW + tt) * KG * 1024;
+            // local gate tile lt = q * UTWS + uu <-> gate q of unit tile u = u0 + uu, stored as packed tile
+            // (u / UTW) * 4 UTW + q * UTW + u % UTW (l2a_lstm_pack_decode); unsplit: wave * GTW + lt
+            const int lt = ps * TW + tt, q = lt / UTWS, u = u0 + (lt - q * UTWS);
+            voffx[ps][tt] = lane * 16 + ((u / UTW) * (4 * UTW) + q * UTW + (u % UTW)) * KG * 1024;
             voffh[ps][tt] = voffx[ps][tt] + KG0 * 1024;
         }
     f32x4 pfX[KG0][TW];             // x k-groups of pass 0 of the upcoming step (fetched across the barrier)
@@ -268,8 +291,13 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
         for (int tt = 0; tt < TW; ++tt) pfX[g][tt] = l2a_ldw(rs, voffx[0][tt] + g * 1024, 0);
     f32x4 pfA[TW], pfB[TW];         // h k-groups 0 / 1 of the upcoming pass
-    f32x4 pfO[UTW][OT];             // output-layer A fragments of this wave's unit tiles
-    f32x4 hreg[NT][UTW];
+    f32x4 pfO[UTWS][OT];            // output-layer A fragments of this wave's unit tiles
+    f32x4 hreg[NT][UTWS];
+    // exchange (SPLIT): regions of 2 KiB = 2 granules x 64 lanes x 16 B; [0, UT / 2) = the group's h tiles, then OT
+    // tiles of the output-layer half sum
+    constexpr int XREG = (UT / 2 + OT) * 2048;
+    const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, SPLIT ? (long long)n_tiles * 4 * XREG : 16);
+    unsigned int spin_left = p.spin_limit;
 
     for (int t = 0; t < p.h; ++t) {
         const f32x4* hcur = hbuf + (t & 1) * HB;
@@ -361,7 +389,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 l2a_lstm_gemm<NT, TW, HT>(rs, voffh[ps], hcur, pfA, pfB, acc[ps], lane,
                     [&]() {
 #pragma unroll
-                        for (int uu = 0; uu < UTW; ++uu)
+                        for (int uu = 0; uu < UTWS; ++uu)
 #pragma unroll
                             for (int c = 0; c < OT; ++c)
                                 if (((uu * OT + c) & 1) == 0)
@@ -369,7 +397,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                     },
                     [&]() {
 #pragma unroll
-                        for (int uu = 0; uu < UTW; ++uu)
+                        for (int uu = 0; uu < UTWS; ++uu)
 #pragma unroll
                             for (int c = 0; c < OT; ++c)
                                 if (((uu * OT + c) & 1) == 1)
@@ -380,8 +408,19 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 
         L2A_LTS(2)
         // ---- gate arithmetic (register local) -> c, h ------------------------------------------
+        const unsigned int xtag = p.xtag + (unsigned int)(t + 1);
+        auto xbase = [&](int g) { return ((pairid * 2 + g) * 2 + (t & 1)) * XREG + lane * 16; };
+        auto xput = [&](int r, const f32x4& v) {       // region r of this group: one f32x4 per lane
 #pragma unroll
-        for (int uu = 0; uu < UTW; ++uu) {
+            for (int hh = 0; hh < 2; ++hh) {
+                u32x4 g;
+                g.x = xtag; g.y = __float_as_uint(v[2 * hh]);
+                g.z = xtag; g.w = __float_as_uint(v[2 * hh + 1]);
+                __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp) + (r * 2 + hh) * 1024, 0, 16);
+            }
+        };
+#pragma unroll
+        for (int uu = 0; uu < UTWS; ++uu) {
             f32x4 bias[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -391,7 +430,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 f32x4 z[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int lt = q * UTW + uu;
+                    const int lt = q * UTWS + uu;
                     z[q] = acc[lt / TW][nt][lt % TW] + bias[q];
                 }
                 f32x4 cn, hn;
@@ -419,16 +458,20 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 creg[nt][uu] = cn;
                 hreg[nt][uu] = hn;
                 hnext[(nt * UT + u0 + uu) * 64 + lane] = hn;
+                if (SPLIT) xput(wave * UTWS + uu, hn);      // this half of h travels under the output layer
             }
         }
 
         L2A_LTS(3)
         // ---- output layer: this wave's unit tiles are its k-groups; chunk partials -> LDS -------
         {
+            // chunks of CS unit tiles, each its own MFMA chain: a wave owns 2 of the 8 (unsplit) or 1 of its
+            // group's 4 (SPLIT: chunk index grp * 4 + wave in the canonical order)
             constexpr int CS = UTW / 2;
-            f32x4 oacc[2][NT][OT];
+            constexpr int NCH = SPLIT ? 1 : 2;
+            f32x4 oacc[NCH][NT][OT];
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -438,18 +481,18 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                    for (int ch = 0; ch < 2; ++ch)
+                    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                             for (int c = 0; c < OT; ++c)
                                 oacc[ch][nt][c] = L2A_MFMA(pfO[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], oacc[ch][nt][c]);
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int c = 0; c < OT; ++c) pb[(((2 * wave + ch) * NT + nt) * OT + c) * 64 + lane] = oacc[ch][nt][c];
+                    for (int c = 0; c < OT; ++c) pb[(((NCH * wave + ch) * NT + nt) * OT + c) * 64 + lane] = oacc[ch][nt][c];
         }
         L2A_LTS(4)
 #pragma unroll
@@ -458,6 +501,59 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             for (int tt = 0; tt < TW; ++tt) pfX[g][tt] = l2a_ldw(rs, voffx[0][tt] + g * 1024, 0);
         __syncthreads();
         L2A_LTS(5)
+
+        // ---- SPLIT: this group's half sum S_g, swap with the partner (its half of h rides along) ------
+        f32x4 xsum[OT];             // SPLIT: S_0 + S_1 per obs tile (NT == 1)
+        if (SPLIT) {
+            f32x4 sown[OT];
+#pragma unroll
+            for (int c = 0; c < OT; ++c) {
+                f32x4 part[L2A_NW];
+#pragma unroll
+                for (int ch = 0; ch < L2A_NW; ++ch) part[ch] = pb[(ch * OT + c) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 sv = part[0];
+#pragma unroll
+                for (int w = 1; w < L2A_NW; ++w) sv += part[w];
+                sown[c] = sv;
+                if (wave == 0) xput(UT / 2 + c, sv);
+            }
+            f32x4 ph[UTWS], ps_[OT];
+#pragma unroll
+            for (int uu = 0; uu < UTWS; ++uu) ph[uu] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < OT; ++c) ps_[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            auto xget = [&](int r, f32x4& v) {
+                bool ok = true;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1) + (r * 2 + hh) * 1024, 0, 16);
+                    v[2 * hh] = __uint_as_float(g.y);
+                    v[2 * hh + 1] = __uint_as_float(g.w);
+                    ok = ok && (g.x == xtag) && (g.z == xtag);
+                }
+                return ok;
+            };
+            while (true) {      // every wave fetches its share of the partner's h tiles, and the partner's half sum
+                bool ok = true;
+#pragma unroll
+                for (int uu = 0; uu < UTWS; ++uu) ok = xget(wave * UTWS + uu, ph[uu]) && ok;
+#pragma unroll
+                for (int c = 0; c < OT; ++c) ok = xget(UT / 2 + c, ps_[c]) && ok;
+                if (__all(ok)) break;
+                if (spin_left == 0) {       // partner never arrived: flag it, do not hang (budget is per launch)
+                    if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                --spin_left;
+                __builtin_amdgcn_s_sleep(4);
+            }
+#pragma unroll
+            for (int uu = 0; uu < UTWS; ++uu)
+                hnext[((grp ^ 1) * (UT / 2) + wave * UTWS + uu) * 64 + lane] = ph[uu];
+#pragma unroll
+            for (int c = 0; c < OT; ++c) xsum[c] = (grp == 0) ? sown[c] + ps_[c] : ps_[c] + sown[c];   // S_0 + S_1
+        }
 
         // ---- every wave sums the 8 chunk partials in the canonical order, then reward / state ----
         const float disc_t = (float)disc_pow;
@@ -469,20 +565,25 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
             for (int c = 0; c < OT; ++c) {
                 // all LDS reads of this obs tile first (left alone the scheduler serialises read-wait-add)
-                f32x4 part[2 * L2A_NW];
-#pragma unroll
-                for (int ch = 0; ch < 2 * L2A_NW; ++ch) part[ch] = pb[((ch * NT + nt) * OT + c) * 64 + lane];
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(nrm + CST_BOUT + 16 * c + 4 * qq);
                 const f32x4 omu = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * c + 4 * qq);
                 const f32x4 osd = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4 s = part[0];
+                f32x4 s;
+                if (SPLIT) {
+                    s = xsum[c];
+                } else {
+                    f32x4 part[2 * L2A_NW];
 #pragma unroll
-                for (int w = 1; w < L2A_NW; ++w) s += part[w];
-                f32x4 s2 = part[L2A_NW];
+                    for (int ch = 0; ch < 2 * L2A_NW; ++ch) part[ch] = pb[((ch * NT + nt) * OT + c) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    s = part[0];
 #pragma unroll
-                for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w];
-                s += s2;
+                    for (int w = 1; w < L2A_NW; ++w) s += part[w];
+                    f32x4 s2 = part[L2A_NW];
+#pragma unroll
+                    for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w];
+                    s += s2;
+                }
                 s = l2a_act4(s + bias, p.output_act);
                 const f32x4 d = s * osd + omu;
                 const f32x4 nx = st[nt][c] + d;
@@ -504,6 +605,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
             ret[nt] = fmaf(disc_t, r, ret[nt]);
         }
+        if (SPLIT) __syncthreads();     // the partner's half of h is in LDS before the next step's gate GEMM reads it
         L2A_LTS(6)
     }
 
@@ -514,13 +616,13 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             if (valid[nt]) {
                 const long long orow = ((long long)env * p.n + cand[nt]) * U;
 #pragma unroll
-                for (int uu = 0; uu < UTW; ++uu) {
+                for (int uu = 0; uu < UTWS; ++uu) {
                     if (p.c_out) *reinterpret_cast<f32x4*>(p.c_out + orow + 16 * (u0 + uu) + 4 * qq) = creg[nt][uu];
                     if (p.h_out) *reinterpret_cast<f32x4*>(p.h_out + orow + 16 * (u0 + uu) + 4 * qq) = hreg[nt][uu];
                 }
             }
     }
-    if (wave == 0) {
+    if (wave == 0 && grp == 0) {
         unsigned long long key = 0ull;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

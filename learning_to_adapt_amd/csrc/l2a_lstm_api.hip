@@ -24,6 +24,9 @@ struct l2a_lstm {
     long long raw_wk = 0, raw_bk = 0, raw_wo = 0, raw_bo = 0, pk_wg = 0, pk_wout = 0, pk_bout = 0, nm_off = 0;
     bool weights_set = false, norm_set = false;
     std::vector<float> norm_stage;
+    unsigned long long* xbuf = nullptr;           // unit-tile split exchange granules
+    long long xbuf_bytes = 0;
+    unsigned int launch_nonce = 0;
     // generic stacks (l2a_rnn_create): any cell type / several layers -> l2a_rnn_valu_k; `units` = sum(lunits)
     bool generic = false;
     int n_layers = 1, cell_type = L2A_CELL_LSTM;
@@ -89,7 +92,31 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v) {
                          (32 * md->KG0 + 48 * md->OT + 4 * U) * 4;
         if (smem > ctx->lds_per_block)
             return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
-        const unsigned grid = (unsigned)((long long)p.m * p.tiles_per_env);
+        const long long tiles = (long long)p.m * p.tiles_per_env;
+        const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+        // Unit-tile split: two workgroups per candidate tile when that still fits one workgroup per CU (both must
+        // be resident: they swap their halves of h once per step).  Same bits as the unsplit launch.
+        p.split = (ctx->split_policy != 0 && 2 * tiles <= cus && p.h < 4096) ? 1 : 0;
+        if (p.split) {
+            const long long need = tiles * 4 * (long long)(UT / 2 + md->OT) * 2048;
+            if (need > md->xbuf_bytes) {
+                if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
+                L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need));
+                L2A_HIP(ctx, hipMemsetAsync(md->xbuf, 0, (size_t)need, stream));
+                md->xbuf_bytes = need;
+                md->launch_nonce = 0;
+            }
+            md->launch_nonce += 1;
+            if (md->launch_nonce >= (1u << 20)) {     // tag space exhausted: wipe stale tags, restart
+                L2A_HIP(ctx, hipMemsetAsync(md->xbuf, 0, (size_t)md->xbuf_bytes, stream));
+                md->launch_nonce = 1;
+            }
+            p.xtag = md->launch_nonce << 12;
+            p.xbuf = md->xbuf;
+            p.status = ctx->status_dev;
+            p.spin_limit = ctx->spin_limit;
+        }
+        const unsigned grid = (unsigned)(tiles * (p.split ? 2 : 1));
         const int rc = l2a_launch_lstm(md->UTW, nt, md->OT, md->KG0, &p, grid, smem, stream);
         if (rc == -100) return l2a_fail(ctx, L2A_EINVAL, "no MFMA LSTM kernel instance for this (obs_dim, act_dim, units)");
         if (rc != 0) return l2a_fail(ctx, L2A_EHIP, std::string("MFMA LSTM kernel launch: ") + hipGetErrorString((hipError_t)rc));
@@ -222,6 +249,7 @@ void l2a_lstm_destroy(l2a_lstm* md) {
         (void)hipDeviceSynchronize();
         (void)hipFree(md->wblk);
     }
+    if (md->xbuf) (void)hipFree(md->xbuf);
     delete md;
 }
 

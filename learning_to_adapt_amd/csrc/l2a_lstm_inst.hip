@@ -8,14 +8,20 @@
 
 namespace {
 
-template <int NT, int OT, int KG0>
-int launch_one(const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream) {
-    auto kernel = l2a_lstm_mfma_k<NT, L2A_INST_UTW, OT, KG0>;
+template <int NT, int OT, int KG0, bool SPLIT>
+int launch_split(const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream) {
+    auto kernel = l2a_lstm_mfma_k<NT, L2A_INST_UTW, OT, KG0, SPLIT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * L2A_NW), smem, stream, *p);
     return 0;
+}
+
+template <int NT, int OT, int KG0>
+int launch_one(const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream) {
+    return p->split ? launch_split<NT, OT, KG0, true>(p, grid, smem, stream)
+                    : launch_split<NT, OT, KG0, false>(p, grid, smem, stream);
 }
 
 }  // namespace

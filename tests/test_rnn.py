@@ -521,3 +521,54 @@ def test_cell_restatements_match_the_torch_forward(name):
     c, h = _flat(hid)
     th = torch.cat([s[1] if isinstance(s, tuple) else s for s in tstate], dim=1).numpy()
     np.testing.assert_allclose(h, th, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("units,m,n,h", [(256, 1, 2000, 6), (256, 2, 500, 5), (128, 1, 333, 4), (512, 3, 100, 3),
+                                          (256, 5, 500, 4)])
+def test_gpu_rnn_unit_tile_split_is_bit_identical(units, m, n, h):
+    """The LSTM kernel's unit-tile split (two workgroups per candidate tile, halves of h and of the output layer's
+    sum exchanged once per step; plans of at most CUs / 2 tiles) against the unsplit launch: returns, keys, the
+    handed-over chunk state and `predict` bit for bit.  (5 x 32 tiles = the ReBAL default is too large to split:
+    both policies run the same launch there.)"""
+    from learning_to_adapt_amd import _lib
+    case = dict(cases.CASES["hc_rnn_rs_u128_n40_h3"], units=units, m=m, n=n, h=h)
+    env, model = cases.product_rnn_model(case)
+    native = model.planner_model()
+    dev = native.device
+    ctx = _lib.Context.get(0)
+    rs = np.random.RandomState(units + n)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    obs0, c0 = up(rs.randn(m, 20)), up(rs.randn(m, units))
+    h0 = up(np.tanh(rs.randn(m, units)))
+    acts = up(rs.uniform(-1, 1, (h, m * n, 6)))
+    out = {}
+    try:
+        for policy in (0, 1):
+            ctx.set_split(policy)
+            rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(obs0, c0, h0, acts, m, n, h, 0.98, env.reward_spec, cand_offset=7, returns_out=rets, best_key=best)
+            # the same plan in two chunks (per-candidate state handed over)
+            r1 = torch.empty((m, n), dtype=torch.float32, device=dev)
+            r2 = torch.empty((m, n), dtype=torch.float32, device=dev)
+            st = torch.empty((m * n, 20), dtype=torch.float32, device=dev)
+            cc = torch.empty((m * n, units), dtype=torch.float32, device=dev)
+            hh = torch.empty((m * n, units), dtype=torch.float32, device=dev)
+            k2 = torch.zeros((m,), dtype=torch.int64, device=dev)
+            h1 = h // 2
+            native.plan_rs_chunk(obs0, c0, h0, False, acts[:h1].contiguous(), m, n, h1, 0, 0.98, env.reward_spec, cand_offset=7,
+                                 returns_out=r1, state_out=st, c_out=cc, h_out=hh)
+            native.plan_rs_chunk(st, cc, hh, True, acts[h1:].contiguous(), m, n, h - h1, h1, 0.98, env.reward_spec,
+                                 cand_offset=7, returns_in=r1, returns_out=r2, best_key=k2)
+            rows = min(m * n, 48)
+            nxt, c1, hn = native.predict(up(rs.randn(rows, 20) * 0 + 0.3), up(np.zeros((rows, 6))), cc[:rows].contiguous(),
+                                         hh[:rows].contiguous())
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            out[policy] = [t.cpu().numpy() for t in (rets, best, r2, k2, st, cc, hh, nxt, c1, hn)]
+    finally:
+        ctx.set_split(1)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[0][0], out[0][2]) and np.array_equal(out[0][1], out[0][3])     # chunks == one launch
