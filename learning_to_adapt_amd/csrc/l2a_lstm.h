@@ -133,7 +133,7 @@ __device__ __forceinline__ float l2a_fast_tanh(float x) {
 // next phase's first operands instead of reloading the final k-group).
 // ------------------------------------------------------------------------------------------
 template <int NT, int TW, int HT, class F2, class F3>
-__device__ __forceinline__ void l2a_lstm_gemm(__amdgpu_buffer_rsrc_t rs, const int (&voff)[TW], const f32x4* hin,
+__device__ __forceinline__ void l2a_lstm_gemm(__amdgpu_buffer_rsrc_t rs, const int (&voff)[TW], int sbase, const f32x4* hin,
                                               f32x4 (&aA)[TW], f32x4 (&aB)[TW], f32x4 (&acc)[NT][TW], int lane,
                                               F2 tail2, F3 tail3) {
     static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
@@ -148,14 +148,14 @@ __device__ __forceinline__ void l2a_lstm_gemm(__amdgpu_buffer_rsrc_t rs, const i
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int g = 0; g < HT - 4; g += 4) {
-        const int soff = (g + 2) * 1024;
+        const int soff = sbase + (g + 2) * 1024;     // sbase: byte offset of this call's first k-group (wave-uniform)
         L2A_STAGE(aA, bA, aC, bC, soff, 0, g + 2)
         L2A_STAGE(aB, bB, aD, bD, soff, 1024, g + 3)
         L2A_STAGE(aC, bC, aA, bA, soff, 2048, g + 4)
         L2A_STAGE(aD, bD, aB, bB, soff, 3072, g + 5)
     }
-    L2A_STAGE(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2)
-    L2A_STAGE(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1)
+    L2A_STAGE(aA, bA, aC, bC, sbase + (HT - 2) * 1024, 0, HT - 2)
+    L2A_STAGE(aB, bB, aD, bD, sbase + (HT - 2) * 1024, 1024, HT - 1)
     {
         tail2();
         L2A_STAGE_MFMA(aC, bC)
@@ -273,8 +273,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
     const long long wg_bytes = (long long)4 * UT * KG * 1024, wo_bytes = (long long)OT * UT * 1024;
     const __amdgpu_buffer_rsrc_t rs = l2a_rsrc(p.wblk + p.pk_wg, wg_bytes);
     const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(p.wblk + p.pk_wout, wo_bytes);
-    // byte offset of this lane in gate tile (pass, tt): x k-groups start at +0, h k-groups at +KG0 KiB
-    int voffx[NP][TW], voffh[NP][TW];
+    // byte offset of this lane in gate tile (pass, tt): x k-groups start at +0, h k-group k at + (KG0 + k) KiB (added
+    // as a wave-uniform scalar offset: one offset array serves both parts)
+    int voffx[NP][TW];
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
@@ -283,14 +284,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             // (u / UTW) * 4 UTW + q * UTW + u % UTW (l2a_lstm_pack_decode); unsplit: wave * GTW + lt
             const int lt = ps * TW + tt, q = lt / UTWS, u = u0 + (lt - q * UTWS);
             voffx[ps][tt] = lane * 16 + ((u / UTW) * (4 * UTW) + q * UTW + (u % UTW)) * KG * 1024;
-            voffh[ps][tt] = voffx[ps][tt] + KG0 * 1024;
         }
-    f32x4 pfX[KG0][TW];             // x k-groups of pass 0 of the upcoming step (fetched across the barrier)
-#pragma unroll
-    for (int g = 0; g < KG0; ++g)
-#pragma unroll
-        for (int tt = 0; tt < TW; ++tt) pfX[g][tt] = l2a_ldw(rs, voffx[0][tt] + g * 1024, 0);
-    f32x4 pfA[TW], pfB[TW];         // h k-groups 0 / 1 of the upcoming pass
+    f32x4 pfA[TW], pfB[TW];         // first two k-groups of the upcoming half-GEMM
     f32x4 pfO[UTWS][OT];            // output-layer A fragments of this wave's unit tiles
     f32x4 hreg[NT][UTWS];
     // exchange (SPLIT): regions of 2 KiB = 2 granules x 64 lanes x 16 B; [0, UT / 2) = the group's h tiles, then OT
@@ -299,10 +294,139 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
     const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, SPLIT ? (long long)n_tiles * 4 * XREG : 16);
     unsigned int spin_left = p.spin_limit;
 
+    // K order of a gate tile (the same in both launch geometries, so both give the same bits): the h k-groups of
+    // the HALF that contains the tile's own units, then the other half's, then the x k-groups.  A wave's unit
+    // tiles lie in one half (UT / 2 = 2 UTW), so the order is wave-uniform: own half at k-group kb_own.
+    constexpr int HH = UT / 2;
+    const int kb_own = (u0 >= HH) ? HH : 0, kb_oth = HH - kb_own;
+    const int sb_own = (KG0 + kb_own) * 1024, sb_oth = (KG0 + kb_oth) * 1024;      // scalar byte offsets of the halves
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt) {       // first operands of (step 0, pass 0, own half)
+        pfA[tt] = l2a_ldw(rs, voffx[0][tt], sb_own);
+        pfB[tt] = l2a_ldw(rs, voffx[0][tt], sb_own + 1024);
+    }
+
+    // The reduce / reward / state update of step t is deferred into iteration t + 1, behind that step's h-part
+    // (which needs h, not the state): in the SPLIT geometry the partner's half sum then has a whole GEMM to arrive.
+    float asq_prev[NT], disc_prev = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) asq_prev[nt] = 0.0f;
+
+    unsigned int xtag = 0;
+    auto xbase = [&](int g, int slot) { return ((pairid * 2 + g) * 2 + slot) * XREG + lane * 16; };
+    auto xput = [&](int r, int slot, const f32x4& v) {     // region r of this group: one f32x4 per lane
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            u32x4 g;
+            g.x = xtag; g.y = __float_as_uint(v[2 * hh]);
+            g.z = xtag; g.w = __float_as_uint(v[2 * hh + 1]);
+            __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, slot) + (r * 2 + hh) * 1024, 0, 16);
+        }
+    };
+    auto xget = [&](int r, int slot, unsigned int tag, f32x4& v) {
+        bool ok = true;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, 16);
+            v[2 * hh] = __uint_as_float(g.y);
+            v[2 * hh + 1] = __uint_as_float(g.w);
+            ok = ok && (g.x == tag) && (g.z == tag);
+        }
+        return ok;
+    };
+    auto spin = [&](bool ok) {      // true: stop polling (all granules valid, or the launch's budget is spent)
+        if (__all(ok)) return true;
+        if (spin_left == 0) {       // partner never arrived: flag it, do not hang
+            if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return true;
+        }
+        --spin_left;
+        __builtin_amdgcn_s_sleep(4);
+        return false;
+    };
+
+    // Deferred tail of step `tp` (its chunk partials are in pbuf[tp & 1]): canonical reduce, output activation,
+    // denormalisation, reward, state update.  SPLIT: S_0 + S_1 with the partner's half sum from the exchange.
+    f32x4 ps_[OT];                  // SPLIT: the partner's half sum of the step being finished
+#pragma unroll
+    for (int c = 0; c < OT; ++c) ps_[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto finish_step = [&](int tp, bool have_partner_sum) {
+        const f32x4* pbp = pbuf + (tp & 1) * PB;
+        f32x4 xsum[OT];
+        if (SPLIT) {
+            const unsigned int tag = p.xtag + (unsigned int)(tp + 1);
+            while (!have_partner_sum) {
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < OT; ++c) ok = xget(HH + c, tp & 1, tag, ps_[c]) && ok;
+                if (spin(ok)) break;
+            }
+#pragma unroll
+            for (int c = 0; c < OT; ++c) {
+                f32x4 part[L2A_NW];
+#pragma unroll
+                for (int ch = 0; ch < L2A_NW; ++ch) part[ch] = pbp[(ch * OT + c) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 sv = part[0];
+#pragma unroll
+                for (int w = 1; w < L2A_NW; ++w) sv += part[w];
+                xsum[c] = (grp == 0) ? sv + ps_[c] : ps_[c] + sv;          // S_0 + S_1
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq_prev[nt];
+            float psq = 0.0f;
+#pragma unroll
+            for (int c = 0; c < OT; ++c) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(nrm + CST_BOUT + 16 * c + 4 * qq);
+                const f32x4 omu = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * c + 4 * qq);
+                const f32x4 osd = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
+                f32x4 s;
+                if (SPLIT) {
+                    s = xsum[c];
+                } else {
+                    // all LDS reads of this obs tile first (left alone the scheduler serialises read-wait-add)
+                    f32x4 part[2 * L2A_NW];
+#pragma unroll
+                    for (int ch = 0; ch < 2 * L2A_NW; ++ch) part[ch] = pbp[((ch * NT + nt) * OT + c) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    s = part[0];
+#pragma unroll
+                    for (int w = 1; w < L2A_NW; ++w) s += part[w];
+                    f32x4 s2 = part[L2A_NW];
+#pragma unroll
+                    for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w];
+                    s += s2;
+                }
+                s = l2a_act4(s + bias, p.output_act);
+                const f32x4 d = s * osd + omu;
+                const f32x4 nx = st[nt][c] + d;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int dim = 16 * c + 4 * qq + ii;
+                    if (dim == p.rw.vel_index) plin += p.rw.w_vel * d[ii] * p.rw.inv_dt;
+                    const bool in_dist = (p.rw.dist_coef != 0.0f) && (dim >= p.rw.dist_index) &&
+                                         (dim < p.rw.dist_index + 3) && (dim < obs_dim);
+                    psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
+                }
+                st[nt][c] = nx;
+            }
+            plin += __shfl_xor(plin, 16);
+            plin += __shfl_xor(plin, 32);
+            psq += __shfl_xor(psq, 16);
+            psq += __shfl_xor(psq, 32);
+            float r = plin;
+            if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
+            ret[nt] = fmaf(disc_prev, r, ret[nt]);
+        }
+    };
+
     for (int t = 0; t < p.h; ++t) {
-        const f32x4* hcur = hbuf + (t & 1) * HB;
+        f32x4* hcur = hbuf + (t & 1) * HB;
         f32x4* hnext = hbuf + ((t + 1) & 1) * HB;
         f32x4* pb = pbuf + (t & 1) * PB;
+        xtag = p.xtag + (unsigned int)(t + 1);
         f32x4 av[NT][2];
         float asq[NT];
 #pragma unroll
@@ -320,7 +444,87 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
         load_actions((t + 1 < p.h) ? t + 1 : t, av_next);
         L2A_LTS(0)
 
-        // ---- x part of the gate GEMM: B = normalised [obs | act] from registers ---------------
+        f32x4 acc[NP][NT][TW];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int tt = 0; tt < TW; ++tt) acc[ps][nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // ---- h part, own half of the k-groups (this workgroup's own units: already in LDS) ---------------------
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            // the tail fetches the first operands of the next half-GEMM: next pass / first pass of the other half
+            const int pn = (ps + 1 < NP) ? ps + 1 : 0;
+            const int sn = (ps + 1 < NP) ? sb_own : sb_oth;
+            l2a_lstm_gemm<NT, TW, HH>(rs, voffx[ps], sb_own, hcur + kb_own * 64, pfA, pfB, acc[ps], lane,
+                [&]() {
+#pragma unroll
+                    for (int tt = 0; tt < TW; ++tt) pfA[tt] = l2a_ldw(rs, voffx[pn][tt], sn);
+                },
+                [&]() {
+#pragma unroll
+                    for (int tt = 0; tt < TW; ++tt) pfB[tt] = l2a_ldw(rs, voffx[pn][tt], sn + 1024);
+                });
+        }
+        L2A_LTS(1)
+        if (SPLIT && t > 0) {
+            // the partner's half of h(t) - published right after ITS gate phase of step t - 1, a GEMM ago - and, in
+            // the same sweep (an sc1 load round trip costs ~2.3k cycles whatever it fetches), its half sum of
+            // step t - 1, which the deferred tail below needs
+            const unsigned int tag = p.xtag + (unsigned int)t;
+            f32x4 ph[UTWS];
+#pragma unroll
+            for (int uu = 0; uu < UTWS; ++uu) ph[uu] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int uu = 0; uu < UTWS; ++uu) ok = xget(wave * UTWS + uu, (t - 1) & 1, tag, ph[uu]) && ok;
+#pragma unroll
+                for (int c = 0; c < OT; ++c) ok = xget(HH + c, (t - 1) & 1, tag, ps_[c]) && ok;
+                if (spin(ok)) break;
+            }
+#pragma unroll
+            for (int uu = 0; uu < UTWS; ++uu) hcur[((grp ^ 1) * HH + wave * UTWS + uu) * 64 + lane] = ph[uu];
+            L2A_LTS(7)
+            __syncthreads();
+            L2A_LTS(8)
+        }
+        // ---- h part, the other half ------------------------------------------------------------------------------
+        f32x4 pfX[TW];              // x k-group 0 of pass 0
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            if (ps + 1 < NP) {
+                const int pn = (ps + 1 < NP) ? ps + 1 : ps;
+                l2a_lstm_gemm<NT, TW, HH>(rs, voffx[ps], sb_oth, hcur + kb_oth * 64, pfA, pfB, acc[ps], lane,
+                    [&]() {
+#pragma unroll
+                        for (int tt = 0; tt < TW; ++tt) pfA[tt] = l2a_ldw(rs, voffx[pn][tt], sb_oth);
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int tt = 0; tt < TW; ++tt) pfB[tt] = l2a_ldw(rs, voffx[pn][tt], sb_oth + 1024);
+                    });
+            } else {
+                // the last tail fetches x k-group 0 of pass 0: it lands under the deferred tail of step t - 1
+                l2a_lstm_gemm<NT, TW, HH>(rs, voffx[ps], sb_oth, hcur + kb_oth * 64, pfA, pfB, acc[ps], lane,
+                    [&]() {
+#pragma unroll
+                        for (int tt = 0; tt < TW; tt += 2) pfX[tt] = l2a_ldw(rs, voffx[0][tt], 0);
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int tt = 1; tt < TW; tt += 2) pfX[tt] = l2a_ldw(rs, voffx[0][tt], 0);
+                    });
+            }
+        }
+        L2A_LTS(2)
+
+        // ---- deferred tail of step t - 1 -> state(t); then the x part: B = normalised [obs | act] -----------------
+        if (t > 0) finish_step(t - 1, true);
+        const float disc_t = (float)disc_pow;
+        disc_pow *= p.discount;
         f32x4 x[KG0][NT];
 #pragma unroll
         for (int g = 0; g < KG0; ++g) {
@@ -341,84 +545,48 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 }
             }
         }
-        f32x4 acc[NP][NT][TW];
+        {
+            // pass by pass, pinned: every accumulator is live here, so the x operands must not be hoisted - k-group 0
+            // of the NEXT pass and k-groups >= 1 of this pass are fetched under this pass's first 4 TW MFMAs
+            f32x4 a0[TW];
 #pragma unroll
-        for (int tt = 0; tt < TW; ++tt) {       // first operands of pass 0's h part
-            pfA[tt] = l2a_ldw(rs, voffh[0][tt], 0);
-            pfB[tt] = l2a_ldw(rs, voffh[0][tt] + 1024, 0);
-        }
+            for (int tt = 0; tt < TW; ++tt) a0[tt] = pfX[tt];
 #pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            f32x4 a[KG0][TW];
+            for (int ps = 0; ps < NP; ++ps) {
+                f32x4 ar[KG0 > 1 ? KG0 - 1 : 1][TW], n0[TW];
 #pragma unroll
-            for (int g = 0; g < KG0; ++g)
+                for (int g = 1; g < KG0; ++g)
 #pragma unroll
-                for (int tt = 0; tt < TW; ++tt)
-                    a[g][tt] = (ps == 0) ? pfX[g][tt] : l2a_ldw(rs, voffx[ps][tt] + g * 1024, 0);
+                    for (int tt = 0; tt < TW; ++tt) ar[g - 1][tt] = l2a_ldw(rs, voffx[ps][tt] + g * 1024, 0);
+                if (ps + 1 < NP) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                    for (int tt = 0; tt < TW; ++tt) n0[tt] = l2a_ldw(rs, voffx[(ps + 1 < NP) ? ps + 1 : ps][tt], 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tt = 0; tt < TW; ++tt) acc[ps][nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < KG0; ++g)
 #pragma unroll
-            for (int g = 0; g < KG0; ++g)
+                    for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
+                        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                            for (int tt = 0; tt < TW; ++tt)
+                                acc[ps][nt][tt] = L2A_MFMA((g == 0 ? a0[tt] : ar[g > 0 ? g - 1 : 0][tt])[ii], x[g][nt][ii],
+                                                           acc[ps][nt][tt]);
+                if (ps + 1 < NP) {
 #pragma unroll
-                        for (int tt = 0; tt < TW; ++tt)
-                            acc[ps][nt][tt] = L2A_MFMA(a[g][tt][ii], x[g][nt][ii], acc[ps][nt][tt]);
-        }
-
-        L2A_LTS(1)
-        // ---- h part, pass by pass; each pass fetches the next one's first operands in its tail ----
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            if (ps + 1 < NP) {
-                const int pn = (ps + 1 < NP) ? ps + 1 : ps;
-                l2a_lstm_gemm<NT, TW, HT>(rs, voffh[ps], hcur, pfA, pfB, acc[ps], lane,
-                    [&]() {
-#pragma unroll
-                        for (int tt = 0; tt < TW; ++tt) pfA[tt] = l2a_ldw(rs, voffh[pn][tt], 0);
-                    },
-                    [&]() {
-#pragma unroll
-                        for (int tt = 0; tt < TW; ++tt) pfB[tt] = l2a_ldw(rs, voffh[pn][tt] + 1024, 0);
-                    });
-            } else {
-                l2a_lstm_gemm<NT, TW, HT>(rs, voffh[ps], hcur, pfA, pfB, acc[ps], lane,
-                    [&]() {
-#pragma unroll
-                        for (int uu = 0; uu < UTWS; ++uu)
-#pragma unroll
-                            for (int c = 0; c < OT; ++c)
-                                if (((uu * OT + c) & 1) == 0)
-                                    pfO[uu][c] = l2a_ldw(rs_out, lane * 16 + (u0 + uu) * 1024, c * UT * 1024);
-                    },
-                    [&]() {
-#pragma unroll
-                        for (int uu = 0; uu < UTWS; ++uu)
-#pragma unroll
-                            for (int c = 0; c < OT; ++c)
-                                if (((uu * OT + c) & 1) == 1)
-                                    pfO[uu][c] = l2a_ldw(rs_out, lane * 16 + (u0 + uu) * 1024, c * UT * 1024);
-                    });
+                    for (int tt = 0; tt < TW; ++tt) a0[tt] = n0[tt];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        L2A_LTS(3)
+#pragma unroll
+        for (int uu = 0; uu < UTWS; ++uu)       // output-layer fragments of this wave's unit tiles: land under the gates
+#pragma unroll
+            for (int c = 0; c < OT; ++c) pfO[uu][c] = l2a_ldw(rs_out, lane * 16 + (u0 + uu) * 1024, c * UT * 1024);
 
-        L2A_LTS(2)
         // ---- gate arithmetic (register local) -> c, h ------------------------------------------
-        const unsigned int xtag = p.xtag + (unsigned int)(t + 1);
-        auto xbase = [&](int g) { return ((pairid * 2 + g) * 2 + (t & 1)) * XREG + lane * 16; };
-        auto xput = [&](int r, const f32x4& v) {       // region r of this group: one f32x4 per lane
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                u32x4 g;
-                g.x = xtag; g.y = __float_as_uint(v[2 * hh]);
-                g.z = xtag; g.w = __float_as_uint(v[2 * hh + 1]);
-                __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp) + (r * 2 + hh) * 1024, 0, 16);
-            }
-        };
 #pragma unroll
         for (int uu = 0; uu < UTWS; ++uu) {
             f32x4 bias[4];
@@ -458,11 +626,11 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 creg[nt][uu] = cn;
                 hreg[nt][uu] = hn;
                 hnext[(nt * UT + u0 + uu) * 64 + lane] = hn;
-                if (SPLIT) xput(wave * UTWS + uu, hn);      // this half of h travels under the output layer
+                if (SPLIT) xput(wave * UTWS + uu, t & 1, hn);      // this half of h(t + 1) travels under the next GEMM
             }
         }
 
-        L2A_LTS(3)
+        L2A_LTS(4)
         // ---- output layer: this wave's unit tiles are its k-groups; chunk partials -> LDS -------
         {
             // chunks of CS unit tiles, each its own MFMA chain: a wave owns 2 of the 8 (unsplit) or 1 of its
@@ -494,18 +662,17 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
                     for (int c = 0; c < OT; ++c) pb[(((NCH * wave + ch) * NT + nt) * OT + c) * 64 + lane] = oacc[ch][nt][c];
         }
-        L2A_LTS(4)
-#pragma unroll
-        for (int g = 0; g < KG0; ++g)       // next step's first operands, in flight across the barrier and the reduce
-#pragma unroll
-            for (int tt = 0; tt < TW; ++tt) pfX[g][tt] = l2a_ldw(rs, voffx[0][tt] + g * 1024, 0);
-        __syncthreads();
         L2A_LTS(5)
-
-        // ---- SPLIT: this group's half sum S_g, swap with the partner (its half of h rides along) ------
-        f32x4 xsum[OT];             // SPLIT: S_0 + S_1 per obs tile (NT == 1)
-        if (SPLIT) {
-            f32x4 sown[OT];
+#pragma unroll
+        for (int tt = 0; tt < TW; ++tt) {       // next step's first operands (pass 0, own half), in flight across the barrier
+            pfA[tt] = l2a_ldw(rs, voffx[0][tt], sb_own);
+            pfB[tt] = l2a_ldw(rs, voffx[0][tt], sb_own + 1024);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asq_prev[nt] = asq[nt];
+        disc_prev = disc_t;
+        __syncthreads();
+        if (SPLIT && wave == 0) {       // this group's half sum S_g of step t: ((c0+c1)+c2)+c3 over its own chunks
 #pragma unroll
             for (int c = 0; c < OT; ++c) {
                 f32x4 part[L2A_NW];
@@ -515,99 +682,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 f32x4 sv = part[0];
 #pragma unroll
                 for (int w = 1; w < L2A_NW; ++w) sv += part[w];
-                sown[c] = sv;
-                if (wave == 0) xput(UT / 2 + c, sv);
+                xput(HH + c, t & 1, sv);
             }
-            f32x4 ph[UTWS], ps_[OT];
-#pragma unroll
-            for (int uu = 0; uu < UTWS; ++uu) ph[uu] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < OT; ++c) ps_[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            auto xget = [&](int r, f32x4& v) {
-                bool ok = true;
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1) + (r * 2 + hh) * 1024, 0, 16);
-                    v[2 * hh] = __uint_as_float(g.y);
-                    v[2 * hh + 1] = __uint_as_float(g.w);
-                    ok = ok && (g.x == xtag) && (g.z == xtag);
-                }
-                return ok;
-            };
-            while (true) {      // every wave fetches its share of the partner's h tiles, and the partner's half sum
-                bool ok = true;
-#pragma unroll
-                for (int uu = 0; uu < UTWS; ++uu) ok = xget(wave * UTWS + uu, ph[uu]) && ok;
-#pragma unroll
-                for (int c = 0; c < OT; ++c) ok = xget(UT / 2 + c, ps_[c]) && ok;
-                if (__all(ok)) break;
-                if (spin_left == 0) {       // partner never arrived: flag it, do not hang (budget is per launch)
-                    if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-                --spin_left;
-                __builtin_amdgcn_s_sleep(4);
-            }
-#pragma unroll
-            for (int uu = 0; uu < UTWS; ++uu)
-                hnext[((grp ^ 1) * (UT / 2) + wave * UTWS + uu) * 64 + lane] = ph[uu];
-#pragma unroll
-            for (int c = 0; c < OT; ++c) xsum[c] = (grp == 0) ? sown[c] + ps_[c] : ps_[c] + sown[c];   // S_0 + S_1
         }
-
-        // ---- every wave sums the 8 chunk partials in the canonical order, then reward / state ----
-        const float disc_t = (float)disc_pow;
-        disc_pow *= p.discount;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[nt];
-            float psq = 0.0f;
-#pragma unroll
-            for (int c = 0; c < OT; ++c) {
-                // all LDS reads of this obs tile first (left alone the scheduler serialises read-wait-add)
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(nrm + CST_BOUT + 16 * c + 4 * qq);
-                const f32x4 omu = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * c + 4 * qq);
-                const f32x4 osd = *reinterpret_cast<const f32x4*>(nrm + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
-                f32x4 s;
-                if (SPLIT) {
-                    s = xsum[c];
-                } else {
-                    f32x4 part[2 * L2A_NW];
-#pragma unroll
-                    for (int ch = 0; ch < 2 * L2A_NW; ++ch) part[ch] = pb[((ch * NT + nt) * OT + c) * 64 + lane];
-                    __builtin_amdgcn_sched_barrier(0);
-                    s = part[0];
-#pragma unroll
-                    for (int w = 1; w < L2A_NW; ++w) s += part[w];
-                    f32x4 s2 = part[L2A_NW];
-#pragma unroll
-                    for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w];
-                    s += s2;
-                }
-                s = l2a_act4(s + bias, p.output_act);
-                const f32x4 d = s * osd + omu;
-                const f32x4 nx = st[nt][c] + d;
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int dim = 16 * c + 4 * qq + ii;
-                    if (dim == p.rw.vel_index) plin += p.rw.w_vel * d[ii] * p.rw.inv_dt;
-                    const bool in_dist = (p.rw.dist_coef != 0.0f) && (dim >= p.rw.dist_index) &&
-                                         (dim < p.rw.dist_index + 3) && (dim < obs_dim);
-                    psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
-                }
-                st[nt][c] = nx;
-            }
-            plin += __shfl_xor(plin, 16);
-            plin += __shfl_xor(plin, 32);
-            psq += __shfl_xor(psq, 16);
-            psq += __shfl_xor(psq, 32);
-            float r = plin;
-            if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
-            ret[nt] = fmaf(disc_t, r, ret[nt]);
-        }
-        if (SPLIT) __syncthreads();     // the partner's half of h is in LDS before the next step's gate GEMM reads it
         L2A_LTS(6)
     }
+    finish_step(p.h - 1, false);
 
     // ---- results ----------------------------------------------------------------------------
     if (p.c_out || p.h_out) {       // every wave writes its own unit tiles (predict)

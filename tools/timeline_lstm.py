@@ -45,10 +45,14 @@ native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(0)), "dbg")
 d = dbg.cpu().numpy().astype(np.int64)
-names = ["x-part", "h-part", "gates", "out", "barrier", "reduce+reward"]
+names = ["h own half", "poll+h other half", "deferred tail + x part", "gates", "out", "barrier (+S publish)"]
 print("units %d, n %d: median clocks per phase over steps 2.. (s_memtime ticks; 100 MHz -> x24 for shader clocks at 2.4 GHz)" % (units, n))
 for w in range(4):
     seg = np.median(np.diff(d[2:, w, :7], axis=1), axis=0)
-    print("  wave %d: " % w + "  ".join("%s %6.0f" % (nm, v) for nm, v in zip(names, seg)))
+    line = "  wave %d: " % w + "  ".join("%s %6.0f" % (nm, v) for nm, v in zip(names, seg))
+    if d[2:, w, 7].any():       # unit-tile split: the wait for the partner's half of h and the barrier behind it
+        line += "  | partner-h poll %6.0f  barrier %6.0f" % (np.median(d[2:, w, 7] - d[2:, w, 1]),
+                                                             np.median(d[2:, w, 8] - d[2:, w, 7]))
+    print(line)
 step = np.diff(d[:, 0, 0])
 print("  step period: median %d ticks (min %d max %d)" % (np.median(step), step.min(), step.max()))
