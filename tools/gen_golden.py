@@ -70,13 +70,13 @@ CASES = [
     dict(name="c2_hc_rs_n2000_h30_e5", env="half_cheetah", planner="rs", n=2000, h=30, m=1,
          mode="mean", E=5, hidden=[512, 512], seeds=[0, 1, 2, 3, 4, 5]),
     dict(name="c3_ant_rs_n2000_h20_pb5", env="ant", planner="rs", n=2000, h=20, m=5,
-         mode="per_block", E=5, hidden=[512, 512], seeds=[0, 1]),
+         mode="per_block", E=5, hidden=[512, 512], seeds=[0, 1, 2]),
     dict(name="c3b_ant_rs_n500_h10_pb5_3x512", env="ant", planner="rs", n=500, h=10, m=5,
          mode="per_block", E=5, hidden=[512, 512, 512], seeds=[0]),
     dict(name="c4_hc_rs_n16000_h30_e5", env="half_cheetah", planner="rs", n=16000, h=30, m=1,
-         mode="mean", E=5, hidden=[512, 512], seeds=[0]),
+         mode="mean", E=5, hidden=[512, 512], seeds=[0, 1]),
     dict(name="c5_hc_cem_n4000_h30_e5", env="half_cheetah", planner="cem", n=4000, h=30, m=1,
-         mode="mean", E=5, hidden=[512, 512], seeds=[0], num_cem_iters=5),
+         mode="mean", E=5, hidden=[512, 512], seeds=[0, 1], num_cem_iters=5),
     # edge cases
     dict(name="hc_rs_m3_n64_h5", env="half_cheetah", planner="rs", n=64, h=5, m=3,
          mode="single", E=1, hidden=[512, 512], seeds=[0]),

@@ -77,5 +77,31 @@ def main():
             ctrl._ahead.stop()
 
 
+def ab(attr, values, case_name="c2_hc_rs_n2000_h30_e5", rounds=4, calls=200):
+    """Same-process A/B of a controller attribute: alternating blocks of un-instrumented get_actions calls."""
+    case = cases.CASES[case_name]
+    env, model = cases.product_model(case)
+    obs = np.random.RandomState(1).randn(case["m"], env.observation_space.shape[0])
+    ctrl = cases.product_controller(case, model=model, env=env, rng="numpy", draw_ahead=True)
+    np.random.seed(0)
+    for _ in range(20):
+        ctrl.get_actions(obs)
+    out = {str(v): [] for v in values}
+    for _ in range(rounds):
+        for v in values:
+            setattr(ctrl, attr, v)
+            for _ in range(5):
+                ctrl.get_actions(obs)
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                ctrl.get_actions(obs)
+            out[str(v)].append(round(1e3 * (time.perf_counter() - t0) / calls, 4))
+    print(json.dumps({"ab": attr, "case": case_name, "ms_per_call": out}), flush=True)
+    ctrl._ahead.stop()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--ab":
+        ab(sys.argv[2], [True, False])
+    else:
+        main()
