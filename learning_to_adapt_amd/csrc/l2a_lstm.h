@@ -453,6 +453,20 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 for (int tt = 0; tt < TW; ++tt) acc[ps][nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         // ---- h part, own half of the k-groups (this workgroup's own units: already in LDS) ---------------------
+        // SPLIT: the first sweep for the partner's granules is ISSUED in the second-to-last refill slot of this half
+        // (vmcnt retires in order: any earlier and the weight pipeline would wait for the ~2.3k-cycle sc1 round trip),
+        // so that it travels under the last two stages' MFMAs instead of in front of an idle matrix pipe (only the other half's
+        // k-group-1 operands queue behind it, and those are first used after the sweep has been checked).
+#ifdef L2A_LSTM_NO_EARLY_SWEEP
+        constexpr bool EARLY = false;       // A/B switch (tools/build_variant.py): first sweep after the GEMM, as before
+#else
+        constexpr bool EARLY = true;
+#endif
+        constexpr int NXG = SPLIT ? 2 * (UTWS + OT) : 1;
+        u32x4 xg[NXG];
+        auto xraw = [&](int r, int slot, int hh) {
+            return __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, 16);
+        };
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
             // the tail fetches the first operands of the next half-GEMM: next pass / first pass of the other half
@@ -462,8 +476,18 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 [&]() {
 #pragma unroll
                     for (int tt = 0; tt < TW; ++tt) pfA[tt] = l2a_ldw(rs, voffx[pn][tt], sn);
+                    if (SPLIT && EARLY && ps == NP - 1 && t > 0) {
+#pragma unroll
+                        for (int uu = 0; uu < UTWS; ++uu)
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) xg[uu * 2 + hh] = xraw(wave * UTWS + uu, (t - 1) & 1, hh);
+#pragma unroll
+                        for (int c = 0; c < OT; ++c)
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) xg[(UTWS + c) * 2 + hh] = xraw(HH + c, (t - 1) & 1, hh);
+                    }
                 },
-                [&]() {
+                [&]() {     // (these operands are first used after the sweep has been checked)
 #pragma unroll
                     for (int tt = 0; tt < TW; ++tt) pfB[tt] = l2a_ldw(rs, voffx[pn][tt], sn + 1024);
                 });
@@ -475,15 +499,25 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             // step t - 1, which the deferred tail below needs
             const unsigned int tag = p.xtag + (unsigned int)t;
             f32x4 ph[UTWS];
+            bool ok = EARLY;
 #pragma unroll
-            for (int uu = 0; uu < UTWS; ++uu) ph[uu] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            while (true) {
-                bool ok = true;
+            for (int q = 0; EARLY && q < UTWS + OT; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const u32x4 g = xg[q * 2 + hh];
+                    v[2 * hh] = __uint_as_float(g.y);
+                    v[2 * hh + 1] = __uint_as_float(g.w);
+                    ok = ok && (g.x == tag) && (g.z == tag);
+                }
+                if (q < UTWS) ph[q < UTWS ? q : 0] = v; else ps_[q >= UTWS ? q - UTWS : 0] = v;
+            }
+            while (!spin(ok)) {
+                ok = true;
 #pragma unroll
                 for (int uu = 0; uu < UTWS; ++uu) ok = xget(wave * UTWS + uu, (t - 1) & 1, tag, ph[uu]) && ok;
 #pragma unroll
                 for (int c = 0; c < OT; ++c) ok = xget(HH + c, (t - 1) & 1, tag, ps_[c]) && ok;
-                if (spin(ok)) break;
             }
 #pragma unroll
             for (int uu = 0; uu < UTWS; ++uu) hcur[((grp ^ 1) * HH + wave * UTWS + uu) * 64 + lane] = ph[uu];

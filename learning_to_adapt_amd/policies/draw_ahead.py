@@ -56,13 +56,8 @@ class DrawAhead(object):
         return self.depth + 2
 
     # ------------------------------------------------------------------ consumer side
-    def take(self, sig, defer_wake=False):
-        """Payload of the next block if it is valid for the current global generator state, else None.
-
-        ``defer_wake``: do not wake the worker yet - the caller promises to call ``wake()`` right before it blocks in
-        the launch.  The worker's Python preamble (state copy, buffer look-ups) otherwise takes the GIL at the
-        consumer's next ctypes call and sits on the consumer's critical path (measured: 60 of the ~90 us a
-        controller step spends outside the launch)."""
+    def take(self, sig):
+        """Payload of the next block if it is valid for the current global generator state, else None."""
         with self.cv:
             if self.sig != sig or (self.producer is None and not self.blocks):
                 self._flush()
@@ -88,14 +83,8 @@ class DrawAhead(object):
                 blk.end.to_global()
             self.misses = 0
             self.hits += 1
-            if not defer_wake:
-                self.cv.notify_all()
-            return blk.payload
-
-    def wake(self):
-        """Let the worker go on with the next block (after a ``take(..., defer_wake=True)``)."""
-        with self.cv:
             self.cv.notify_all()
+            return blk.payload
 
     def active_for(self, sig):
         """Is the chain already producing blocks for this request shape?"""

@@ -94,7 +94,6 @@ class MPCController(Policy, Serializable):
         self._reward_spec = None if use_reward_model else reward_spec_for_env(env)
         self._bufs = {}
         self._ahead = None          # DrawAhead chain (parity mode), created on first use
-        self._defer_wake = True     # wake the chain's worker right before the launch, not when its block is taken
         self._ranks_checked = False
         self.last_plan = None       # diagnostics of the latest fused plan (returns, keys, ...)
 
@@ -478,12 +477,10 @@ class MPCController(Policy, Serializable):
         ahead = self._use_draw_ahead("uniform")
         sig = ("rs", n, m, h, lo, hi)
         chain = self._ahead_chain() if ahead else None
-        blk = chain.take(sig, defer_wake=self._defer_wake) if ahead else None
+        blk = chain.take(sig) if ahead else None
 
         def kick():     # the next controller step's candidates are drawn while this plan runs on the GPU
-            if blk is not None and self._defer_wake:
-                chain.wake()        # deferred to here: the worker then starts while this thread is inside the launch
-            elif ahead and not chain.active_for(sig):
+            if ahead and not chain.active_for(sig):
                 chain.start(sig, self._rs_producer(n, m, h, lo, hi), depth=1, words_only=True)
 
         if blk is not None:

@@ -25,7 +25,7 @@ def main():
     objs += [obj if i == (1, 8) else os.path.join(b.OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in b.INSTANCES]
     for u in b.LSTM_INSTANCES:
         lobj = os.path.join(b.OBJ_DIR, "l2a_lstm_%d.o" % u)
-        if u == 4 and "-DL2A_TIMELINE" in defs:                 # units 256: the recurrent timeline tool's shape
+        if u == 4 and any(("L2A_TIMELINE" in d or "L2A_LSTM" in d) for d in defs):     # units 256: the recurrent timeline tool's shape
             lobj = os.path.join(b.OBJ_DIR, "l2a_lstm_%d_%s.o" % (u, name))
             subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DL2A_INST_UTW=%d" % u] + defs +
                                   ["-c", os.path.join(b.HERE, "l2a_lstm_inst.hip"), "-o", lobj], cwd=b.HERE)
