@@ -223,6 +223,14 @@ int l2a_model_set_weights_strided(l2a_model* model, int first_set, int count, co
 int l2a_model_adapt_sgd(l2a_model* model, const void* const* base_ptrs, const float* x, const float* y, int m,
                         int rows, float lr, void* stream);
 
+/* The same step with the adaptation batches handed over as HOST arrays - which is how the reference's caller holds
+ * them (samplers/sampler.py:81-90 passes lists of NumPy arrays to dynamics_model.adapt).  x_host / y_host are copied
+ * into host-mapped staging that the kernels read directly (no H2D copy on the stream; two slots, so the call only
+ * waits when the launch two steps back is still running).  The arrays may be reused as soon as the call returns.
+ * Results are bit-identical to l2a_model_adapt_sgd.                                                       */
+int l2a_model_adapt_sgd_host(l2a_model* model, const void* const* base_ptrs, const float* x_host, const float* y_host,
+                             int m, int rows, float lr, void* stream);
+
 /* Copy weight set `e` out of the model in the reference's parameter order and layout (device fp32 buffers of
  * the sizes l2a_model_set_weights takes) - e.g. to read back adapted sets (`_adapted_param_values`).    */
 int l2a_model_get_weights(l2a_model* model, int e, void* const* device_ptrs_out, void* stream);

@@ -3,18 +3,23 @@
 // Reference: `MetaMLPDynamicsModel.adapt` (dynamics/meta_mlp_dynamics.py:321-345) runs, for every task i,
 // one SGD step theta_i = theta - lr * grad MSE(f_theta(x_i), y_i) (`_adapt_sym`, :409-421; loss :118) on
 // `adapt_batch_size` (16, run_scripts/run_grbal.py) normalised transitions, pulls the m adapted parameter
-// sets to the host and feeds them back on every later `sess.run`.  Here the step is two kernels that read the
-// base parameters once and write the adapted sets straight into the per-block model the planner launches on -
-// raw layout AND MFMA fragment order - so nothing is re-uploaded or re-packed (2 L + 1 + L launches, L layers):
+// sets to the host and feeds them back on every later `sess.run`.  Here the step reads the base parameters once and
+// writes the adapted sets straight into the per-block model the planner launches on - raw layout AND MFMA fragment
+// order - so nothing is re-uploaded or re-packed.  2 L launches for L layers:
 //
-//   l2a_adapt_prep_k / fwd_k / bwd_k : the forward and backward pass, one small launch per layer, every launch
-//                        spread over (64-unit slice, task) workgroups - the first version ran one workgroup
-//                        per task through all layers and was latency bound at ~1 ms, no better than the 45 stock
-//                        PyTorch launches it replaced.  dZ_L = 2 (y_hat - y) / (rows * obs_dim),
-//                        dZ_l = (W_l dZ_{l+1}) * act'(A_l); layer inputs A_l and the dZ_l ([dim][16 rows]) live
-//                        in a scratch buffer
-//   l2a_adapt_update_k : per layer, one thread per weight: g = sum_r A_l[k][r] dZ_{l+1}[u][r],
-//                        theta' = theta - lr g -> raw kernel, packed kernel; biases alike
+//   l2a_adapt_fwd_k (L) / l2a_adapt_bwd_k (L - 1) : the forward and backward pass, one launch per layer, every
+//                        launch spread over (64-unit slice, task) workgroups of 8 waves that each take an eighth of the
+//                        reduction - the first version ran one workgroup per task through all layers and was latency
+//                        bound at ~1 ms, no better than the 45 stock PyTorch launches it replaced.  Layer 0 reads x
+//                        itself (no transpose pass).  dZ_L = 2 (y_hat - y) / (rows * obs_dim),
+//                        dZ_l = (W_l dZ_{l+1}) * act'(A_l); layer inputs A_l and the dZ_l ([dim][16 rows]) live in a
+//                        scratch buffer.  The reduction loops fetch 8 weights per lane before the first FMA: the
+//                        unbatched loops were one exposed L2 round trip per k (rocprofv3: 58 us for a 512 x 512 layer
+//                        on 40 workgroups; the batched ones ~8 us)
+//   l2a_adapt_update_k (1) : all layers at once, one workgroup per (layer, 256 output units, 16 input rows, task): each
+//                        thread keeps its unit's dZ row in registers and walks the input rows,
+//                        g = sum_r A_l[k][r] dZ_{l+1}[u][r], theta' = theta - lr g -> raw kernel, packed kernel;
+//                        biases alike
 //
 // Rows beyond `rows` (padding up to 16) carry dZ = 0 and therefore no gradient.
 #pragma once
@@ -49,49 +54,92 @@ __device__ __forceinline__ float l2a_act_grad_from_output(float o, int kind) {
     }
 }
 
-#define L2A_ACC16(acc, w, v0, v1, v2, v3)                                                   \
-    acc[0] = fmaf(w, v0.x, acc[0]);   acc[1] = fmaf(w, v0.y, acc[1]);                        \
-    acc[2] = fmaf(w, v0.z, acc[2]);   acc[3] = fmaf(w, v0.w, acc[3]);                        \
-    acc[4] = fmaf(w, v1.x, acc[4]);   acc[5] = fmaf(w, v1.y, acc[5]);                        \
-    acc[6] = fmaf(w, v1.z, acc[6]);   acc[7] = fmaf(w, v1.w, acc[7]);                        \
-    acc[8] = fmaf(w, v2.x, acc[8]);   acc[9] = fmaf(w, v2.y, acc[9]);                        \
-    acc[10] = fmaf(w, v2.z, acc[10]); acc[11] = fmaf(w, v2.w, acc[11]);                      \
-    acc[12] = fmaf(w, v3.x, acc[12]); acc[13] = fmaf(w, v3.y, acc[13]);                      \
-    acc[14] = fmaf(w, v3.z, acc[14]); acc[15] = fmaf(w, v3.w, acc[15]);
+#define L2A_ACC16(acc, wt_, v0, v1, v2, v3)                                                   \
+    acc[0] = fmaf(wt_, v0.x, acc[0]);   acc[1] = fmaf(wt_, v0.y, acc[1]);                        \
+    acc[2] = fmaf(wt_, v0.z, acc[2]);   acc[3] = fmaf(wt_, v0.w, acc[3]);                        \
+    acc[4] = fmaf(wt_, v1.x, acc[4]);   acc[5] = fmaf(wt_, v1.y, acc[5]);                        \
+    acc[6] = fmaf(wt_, v1.z, acc[6]);   acc[7] = fmaf(wt_, v1.w, acc[7]);                        \
+    acc[8] = fmaf(wt_, v2.x, acc[8]);   acc[9] = fmaf(wt_, v2.y, acc[9]);                        \
+    acc[10] = fmaf(wt_, v2.z, acc[10]); acc[11] = fmaf(wt_, v2.w, acc[11]);                      \
+    acc[12] = fmaf(wt_, v3.x, acc[12]); acc[13] = fmaf(wt_, v3.y, acc[13]);                      \
+    acc[14] = fmaf(wt_, v3.z, acc[14]); acc[15] = fmaf(wt_, v3.w, acc[15]);
 
-// A_0 = x^T, zero padded to 16 rows.  grid (ceil(in_dim * 16 / 256), m).
-__global__ void l2a_adapt_prep_k(const L2AAdaptParams p) {
-    const int task = blockIdx.y, in_dim = p.dims[0];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= in_dim * L2A_AR) return;
-    const int k = i / L2A_AR, r = i - k * L2A_AR;
-    p.scratch[(long long)task * p.scratch_stride + p.a_off[0] + i] =
-        (r < p.rows) ? p.x[((long long)task * p.rows + r) * in_dim + k] : 0.0f;
-}
+#define L2A_AW 8        // waves per forward / backward workgroup (each takes 1 / 8 of the reduction)
+#define L2A_AB 8        // weights fetched per lane before the first FMA of a batch
+#define L2A_XS_MAX 128  // widest input layer whose batch is staged through LDS in the first forward launch
 
-// Forward through layer l for 64 output units of one task: grid (ceil(n_out / 64), m), 4 waves, wave w sums
-// its quarter of the k range (weights coalesced over the units), partials meet in LDS.  The last layer
-// writes dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.
-__global__ void __launch_bounds__(256) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
-    __shared__ float red[3][64][L2A_AR + 1];
-    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+// Forward through layer l for 64 output units of one task: grid (ceil(n_out / 64), m), 8 waves, wave w sums its
+// eighth of the k range (weights coalesced over the units), partials meet in LDS in a fixed order.  The last layer
+// writes dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.  Layer 0 takes its input rows from x.
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
+    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
+    // the wave index as a scalar: the A_l rows below are then wave-uniform addresses -> scalar loads (a vector load of
+    // one 16-byte value for 64 lanes still moves 1 KiB through the L1: measured 44 us per 512 x 512 layer that way)
+    const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.y;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
     const int u = blockIdx.x * 64 + lane;
     const bool live = u < n_out;
     float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float* A = sc + p.a_off[l];
-    const float* W = p.w[l];
-    const int chunk = (k_in + 3) / 4;
+    const float* W = p.w[l] + (live ? u : 0);
+    const int chunk = (k_in + L2A_AW - 1) / L2A_AW;
     const int k0 = ks * chunk, k1 = (k0 + chunk < k_in) ? k0 + chunk : k_in;
     float acc[L2A_AR];
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) acc[r] = 0.0f;
-    for (int k = k0; k < k1; ++k) {
-        const float w = live ? W[(long long)k * n_out + u] : 0.0f;
-        const float4* a = reinterpret_cast<const float4*>(A + k * L2A_AR);
-        const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-        L2A_ACC16(acc, w, a0, a1, a2, a3)
+    if (l == 0) {
+        // A_0[k][r] = x[task][r][k] (zero beyond `rows`).  x may live in host-mapped memory (l2a_model_adapt_sgd_host):
+        // one coalesced pass brings it into LDS - a single bus round trip instead of one per element - and workgroup 0
+        // of the task publishes A_0 for the update pass.
+        __shared__ float xs[L2A_XS_MAX * L2A_AR];
+        const float* x = p.x + (long long)task * p.rows * k_in;
+        const bool staged = k_in <= L2A_XS_MAX;
+        if (staged) {
+            for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) {      // x in its own order: coalesced
+                const int r = i / k_in, kk = i - r * k_in;
+                xs[kk * L2A_AR + r] = (r < p.rows) ? x[i] : 0.0f;
+            }
+            __syncthreads();
+            if (blockIdx.x == 0)
+                for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) sc[p.a_off[0] + i] = xs[i];
+        }
+        for (int k = k0; k < k1; ++k) {
+            const float w = W[(long long)k * n_out];          // dead lanes read unit 0's column and never store
+#pragma unroll
+            for (int r = 0; r < L2A_AR; ++r) {
+                float a;
+                if (staged) {
+                    a = xs[k * L2A_AR + r];
+                } else {
+                    a = (r < p.rows) ? x[r * k_in + k] : 0.0f;
+                    if (blockIdx.x == 0 && lane == r) sc[p.a_off[0] + k * L2A_AR + r] = a;
+                }
+                acc[r] = fmaf(w, a, acc[r]);
+            }
+        }
+    } else {
+        int k = k0;
+        for (; k + L2A_AB <= k1; k += L2A_AB) {
+            float w[L2A_AB];
+            float4 a[L2A_AB][4];
+#pragma unroll
+            for (int j = 0; j < L2A_AB; ++j) w[j] = W[(long long)(k + j) * n_out];
+#pragma unroll
+            for (int j = 0; j < L2A_AB; ++j) {
+                const float4* ap = reinterpret_cast<const float4*>(A + (k + j) * L2A_AR);
+                a[j][0] = ap[0]; a[j][1] = ap[1]; a[j][2] = ap[2]; a[j][3] = ap[3];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // all 40 loads of the batch in flight before the first FMA
+#pragma unroll
+            for (int j = 0; j < L2A_AB; ++j) { L2A_ACC16(acc, w[j], a[j][0], a[j][1], a[j][2], a[j][3]) }
+        }
+        for (; k < k1; ++k) {
+            const float w = W[(long long)k * n_out];
+            const float4* ap = reinterpret_cast<const float4*>(A + k * L2A_AR);
+            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+            L2A_ACC16(acc, w, a0, a1, a2, a3)
+        }
     }
     if (ks > 0) {
 #pragma unroll
@@ -103,21 +151,30 @@ __global__ void __launch_bounds__(256) l2a_adapt_fwd_k(const L2AAdaptParams p, i
     const bool last = (l == p.n_layers - 1);
     const float scale = 2.0f / (float)(p.rows * n_out);
     float* dst = sc + (last ? p.z_off[l + 1] : p.a_off[l + 1]) + u * L2A_AR;
+    float yv[L2A_AR];
+    if (last) {     // all target reads in flight together (y may live in host-mapped memory: one bus round trip, not 16)
+#pragma unroll
+        for (int r = 0; r < L2A_AR; ++r) yv[r] = p.y[((long long)task * p.rows + (r < p.rows ? r : 0)) * n_out + u];
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) {
-        float v = ((acc[r] + red[0][lane][r]) + red[1][lane][r]) + red[2][lane][r] + bias;
-        if (last) v = (r < p.rows) ? scale * (v - p.y[((long long)task * p.rows + r) * n_out + u]) : 0.0f;
+        float v = acc[r];
+#pragma unroll
+        for (int w = 0; w < L2A_AW - 1; ++w) v += red[w][lane][r];
+        v += bias;
+        if (last) v = (r < p.rows) ? scale * (v - yv[r]) : 0.0f;
         else v = l2a_act1(v, p.hidden_act);
         dst[r] = v;
     }
 }
 
 // dZ_l = (W_l dZ_{l+1}) * act'(A_l) for 64 input units k of layer l (1 <= l < L): grid (ceil(k_in / 64), m),
-// wave w sums its quarter of the u range.  Each lane walks its own weight row (16 consecutive u share a
-// cache line, so the row is fetched once).
-__global__ void __launch_bounds__(256) l2a_adapt_bwd_k(const L2AAdaptParams p, int l) {
-    __shared__ float red[3][64][L2A_AR + 1];
-    const int lane = threadIdx.x & 63, us = threadIdx.x >> 6;
+// wave w sums its eighth of the u range.  Each lane walks its own weight row, 8 consecutive weights (two 16-byte
+// loads when the row stride allows) per batch.
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwd_k(const L2AAdaptParams p, int l) {
+    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
+    const int lane = threadIdx.x & 63, us = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.y;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
     const int k = blockIdx.x * 64 + lane;
@@ -125,15 +182,37 @@ __global__ void __launch_bounds__(256) l2a_adapt_bwd_k(const L2AAdaptParams p, i
     float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float* Z = sc + p.z_off[l + 1];
     const float* wrow = p.w[l] + (long long)(live ? k : 0) * n_out;
-    const int chunk = (n_out + 3) / 4;
-    const int u0 = us * chunk, u1 = (u0 + chunk < n_out) ? u0 + chunk : n_out;
+    int chunk = (n_out + L2A_AW - 1) / L2A_AW;
+    chunk = (chunk + L2A_AB - 1) / L2A_AB * L2A_AB;           // batches start on multiples of 8
+    const int u0 = us * chunk < n_out ? us * chunk : n_out, u1 = (u0 + chunk < n_out) ? u0 + chunk : n_out;
+    const bool vec = (n_out % 4) == 0;                          // rows are 16-byte aligned
     float acc[L2A_AR];
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) acc[r] = 0.0f;
-    for (int u = u0; u < u1; ++u) {
+    int u = u0;
+    for (; u + L2A_AB <= u1; u += L2A_AB) {
+        float w[L2A_AB];
+        float4 z[L2A_AB][4];
+        if (vec) {
+            const float4 wa = *reinterpret_cast<const float4*>(wrow + u), wb = *reinterpret_cast<const float4*>(wrow + u + 4);
+            w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w; w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < L2A_AB; ++j) w[j] = wrow[u + j];
+        }
+#pragma unroll
+        for (int j = 0; j < L2A_AB; ++j) {
+            const float4* zp = reinterpret_cast<const float4*>(Z + (u + j) * L2A_AR);
+            z[j][0] = zp[0]; z[j][1] = zp[1]; z[j][2] = zp[2]; z[j][3] = zp[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < L2A_AB; ++j) { L2A_ACC16(acc, w[j], z[j][0], z[j][1], z[j][2], z[j][3]) }
+    }
+    for (; u < u1; ++u) {
         const float w = wrow[u];
-        const float4* z = reinterpret_cast<const float4*>(Z + u * L2A_AR);
-        const float4 z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3];
+        const float4* zp = reinterpret_cast<const float4*>(Z + u * L2A_AR);
+        const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
         L2A_ACC16(acc, w, z0, z1, z2, z3)
     }
     if (us > 0) {
@@ -146,43 +225,71 @@ __global__ void __launch_bounds__(256) l2a_adapt_bwd_k(const L2AAdaptParams p, i
     float* dst = sc + p.z_off[l] + k * L2A_AR;
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) {
-        const float v = ((acc[r] + red[0][lane][r]) + red[1][lane][r]) + red[2][lane][r];
+        float v = acc[r];
+#pragma unroll
+        for (int w = 0; w < L2A_AW - 1; ++w) v += red[w][lane][r];
         dst[r] = v * l2a_act_grad_from_output(A[r], p.hidden_act);
     }
 }
 
-// Layer l of every task (blockIdx.y): theta' = theta - lr * A_l^T dZ_{l+1}; one thread per kernel element,
-// the first n_out threads of the grid also do the bias.  Writes the raw layout and (when pk != null) the
-// MFMA fragment order (inverse of l2a_pack_decode); `pk_bias` = padded output-bias copy (last layer only).
-__global__ void l2a_adapt_update_k(const L2AAdaptParams p, int l, float lr, float* __restrict__ blk,
-                                   long long set_stride, long long raw_w, long long raw_b, long long pk,
-                                   int has_pk, long long pk_bias, int has_pk_bias) {
+// Where the adapted sets go: the per-block model's weight block (raw reference layout + MFMA fragment order), and
+// how the update launch's blockIdx.x maps to (layer, 256-unit block, 16-row chunk).
+#define L2A_UK 16       // input rows per update workgroup
+struct L2AAdaptDst {
+    float* blk;
+    long long set_stride;
+    long long raw_w[L2A_MAX_LAYERS], raw_b[L2A_MAX_LAYERS], pk[L2A_MAX_LAYERS];
+    long long pk_bout;
+    int has_pk;
+    float lr;
+    int first_block[L2A_MAX_LAYERS + 1];    // prefix sums of the layers' workgroup counts
+};
+
+// theta' = theta - lr * A_l^T dZ_{l+1} for every layer: grid (sum of the layers' blocks, m).  A thread owns one output
+// unit u (its dZ row stays in registers) and walks 16 input rows k; the row-0 workgroups also do the biases.  Writes
+// the raw layout and (has_pk) the MFMA fragment order (inverse of l2a_pack_decode); the last layer's bias also goes
+// to the padded output-bias copy.
+__global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p, const L2AAdaptDst d) {
+    int l = 0;
+    while (l + 1 < p.n_layers && (int)blockIdx.x >= d.first_block[l + 1]) ++l;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)k_in * n_out) return;
+    const int ublocks = (n_out + 255) / 256;
+    const int b = blockIdx.x - d.first_block[l];
+    const int kc = b / ublocks, ub = b - kc * ublocks;
+    const int u = ub * 256 + threadIdx.x;
+    if (u >= n_out) return;
     const int task = blockIdx.y;
-    const int k = (int)(idx / n_out), u = (int)(idx - (long long)k * n_out);
     const float* sc = p.scratch + (long long)task * p.scratch_stride;
-    const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[l] + k * L2A_AR);
-    const float4* z = reinterpret_cast<const float4*>(sc + p.z_off[l + 1] + u * L2A_AR);
-    float g = 0.0f, gb = 0.0f;
-#pragma unroll
-    for (int q = 0; q < L2A_AR / 4; ++q) {
-        const float4 av = a[q], zv = z[q];
-        g = fmaf(av.x, zv.x, g); g = fmaf(av.y, zv.y, g); g = fmaf(av.z, zv.z, g); g = fmaf(av.w, zv.w, g);
-        gb += (zv.x + zv.y) + (zv.z + zv.w);
+    const float4* zp = reinterpret_cast<const float4*>(sc + p.z_off[l + 1] + u * L2A_AR);
+    const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
+    float* dst = d.blk + (long long)task * d.set_stride;
+    const int KG = (k_in + 15) / 16;
+    const int k0 = kc * L2A_UK, k1 = (k0 + L2A_UK < k_in) ? k0 + L2A_UK : k_in;
+    const float* wsrc = p.w[l] + u;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[l] + k * L2A_AR);
+        const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+        float g = 0.0f;
+        g = fmaf(a0.x, z0.x, g); g = fmaf(a0.y, z0.y, g); g = fmaf(a0.z, z0.z, g); g = fmaf(a0.w, z0.w, g);
+        g = fmaf(a1.x, z1.x, g); g = fmaf(a1.y, z1.y, g); g = fmaf(a1.z, z1.z, g); g = fmaf(a1.w, z1.w, g);
+        g = fmaf(a2.x, z2.x, g); g = fmaf(a2.y, z2.y, g); g = fmaf(a2.z, z2.z, g); g = fmaf(a2.w, z2.w, g);
+        g = fmaf(a3.x, z3.x, g); g = fmaf(a3.y, z3.y, g); g = fmaf(a3.z, z3.z, g); g = fmaf(a3.w, z3.w, g);
+        const float wn = wsrc[(long long)k * n_out] - d.lr * g;
+        dst[d.raw_w[l] + (long long)k * n_out + u] = wn;
+        if (d.has_pk) {
+            const long long pidx = ((((long long)(u >> 4) * KG + (k >> 4)) * 64 + ((u & 15) + 16 * ((k & 15) >> 2))) << 2) + (k & 3);
+            dst[d.pk[l] + pidx] = wn;
+        }
     }
-    float* dst = blk + (long long)task * set_stride;
-    const float wn = p.w[l][idx] - lr * g;
-    dst[raw_w + idx] = wn;
-    if (has_pk) {
-        const int KG = (k_in + 15) / 16;
-        const long long pidx = ((((long long)(u >> 4) * KG + (k >> 4)) * 64 + ((u & 15) + 16 * ((k & 15) >> 2))) << 2) + (k & 3);
-        dst[pk + pidx] = wn;
-    }
-    if (k == 0) {
-        const float bn = p.b[l][u] - lr * gb;
-        dst[raw_b + u] = bn;
-        if (has_pk_bias) dst[pk_bias + u] = bn;
+    if (kc == 0) {
+        float gb = 0.0f;
+        gb += (z0.x + z0.y) + (z0.z + z0.w);
+        gb += (z1.x + z1.y) + (z1.z + z1.w);
+        gb += (z2.x + z2.y) + (z2.z + z2.w);
+        gb += (z3.x + z3.y) + (z3.z + z3.w);
+        const float bn = p.b[l][u] - d.lr * gb;
+        dst[d.raw_b[l] + u] = bn;
+        if (d.has_pk && l == p.n_layers - 1) dst[d.pk_bout + u] = bn;
     }
 }

@@ -53,6 +53,15 @@ struct l2a_model {
     unsigned int launch_nonce = 0;
     float* adapt_scratch = nullptr;               // l2a_model_adapt_sgd: layer inputs and dZ of every task
     long long adapt_scratch_floats = 0;
+    // l2a_model_adapt_sgd_host: two staging slots (host-mapped, read by the kernels directly)
+    struct adapt_slot {
+        float* stage_host = nullptr;
+        float* stage_dev = nullptr;
+        long long stage_floats = 0;
+        hipEvent_t done = nullptr;
+        bool pending = false;                     // `done` was recorded and not waited for yet
+    } aslot[2];
+    int aslot_next = 0;
 };
 
 namespace {
@@ -446,6 +455,10 @@ void l2a_model_destroy(l2a_model* md) {
     }
     if (md->xbuf) (void)hipFree(md->xbuf);
     if (md->adapt_scratch) (void)hipFree(md->adapt_scratch);
+    for (auto& sl : md->aslot) {
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.stage_host) (void)hipHostFree(sl.stage_host);
+    }
     delete md;
 }
 
@@ -502,9 +515,11 @@ int l2a_model_set_weights(l2a_model* md, int e, const void* const* device_ptrs, 
     return l2a_model_set_weights_strided(md, e, 1, device_ptrs, nullptr, stream_v);
 }
 
-int l2a_model_adapt_sgd(l2a_model* md, const void* const* base_ptrs, const float* x, const float* y, int m,
-                        int rows, float lr, void* stream_v) {
-    if (!md) return L2A_EINVAL;
+namespace {
+
+// Argument checks + parameter block of one adaptation step; grows the scratch buffer (may synchronise `stream`).
+int adapt_prepare(l2a_model* md, const void* const* base_ptrs, const float* x, const float* y, int m, int rows,
+                  hipStream_t stream, L2AAdaptParams& ap) {
     l2a_ctx* ctx = md->ctx;
     if (!base_ptrs || !x || !y) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd: null pointer");
     if (md->mode != L2A_MODE_PER_BLOCK) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd needs a per-block model");
@@ -514,9 +529,6 @@ int l2a_model_adapt_sgd(l2a_model* md, const void* const* base_ptrs, const float
     if (md->output_act != L2A_ACT_IDENTITY || md->hidden_act == L2A_ACT_SWISH)
         return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd: needs an identity output layer and a relu / tanh / "
                                      "sigmoid / identity hidden nonlinearity");
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-    l2a_device_guard guard(ctx->device);
-    L2AAdaptParams ap;
     std::memset(&ap, 0, sizeof(ap));
     const int L = md->n_hidden + 1;
     ap.n_layers = L;
@@ -545,28 +557,92 @@ int l2a_model_adapt_sgd(l2a_model* md, const void* const* base_ptrs, const float
         md->adapt_scratch_floats = need;
     }
     ap.scratch = md->adapt_scratch;
-    hipLaunchKernelGGL(l2a_adapt_prep_k, dim3((unsigned)((ap.dims[0] * L2A_AR + 255) / 256), (unsigned)m), dim3(256), 0,
-                       stream, ap);
+    return L2A_OK;
+}
+
+// One adaptation step on `stream`: one launch per phase.
+int adapt_enqueue(l2a_model* md, const L2AAdaptParams& ap, int m, float lr, hipStream_t stream) {
+    l2a_ctx* ctx = md->ctx;
+    const int L = ap.n_layers;
+    L2AAdaptDst d;
+    std::memset(&d, 0, sizeof(d));
+    d.blk = md->wblk;
+    d.set_stride = md->set_stride;
+    d.has_pk = md->mfma_ok ? 1 : 0;
+    d.pk_bout = md->pk_bout;
+    d.lr = lr;
+    for (int l = 0; l < L; ++l) {
+        d.raw_w[l] = md->raw_w[l];
+        d.raw_b[l] = md->raw_b[l];
+        if (md->mfma_ok) {
+            if (l == 0) d.pk[l] = md->pk_w0;
+            else if (l < md->n_hidden) d.pk[l] = md->pk_wmid + (long long)(l - 1) * md->pk_wmid_stride;
+            else d.pk[l] = md->pk_wout;
+        }
+    }
     for (int l = 0; l < L; ++l)
-        hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3((unsigned)((ap.dims[l + 1] + 63) / 64), (unsigned)m), dim3(256), 0,
+        hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3((unsigned)((ap.dims[l + 1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
                            stream, ap, l);
     for (int l = L - 1; l >= 1; --l)
-        hipLaunchKernelGGL(l2a_adapt_bwd_k, dim3((unsigned)((ap.dims[l] + 63) / 64), (unsigned)m), dim3(256), 0,
+        hipLaunchKernelGGL(l2a_adapt_bwd_k, dim3((unsigned)((ap.dims[l] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
                            stream, ap, l);
     L2A_HIP(ctx, hipGetLastError());
-    for (int l = 0; l < L; ++l) {
-        const long long total = (long long)ap.dims[l] * ap.dims[l + 1];
-        long long pk = 0;
-        if (md->mfma_ok) {
-            if (l == 0) pk = md->pk_w0;
-            else if (l < md->n_hidden) pk = md->pk_wmid + (long long)(l - 1) * md->pk_wmid_stride;
-            else pk = md->pk_wout;
-        }
-        const dim3 grid((unsigned)((total + 255) / 256), (unsigned)m);
-        hipLaunchKernelGGL(l2a_adapt_update_k, grid, dim3(256), 0, stream, ap, l, lr, md->wblk, md->set_stride,
-                           md->raw_w[l], md->raw_b[l], pk, md->mfma_ok ? 1 : 0, md->pk_bout, (l == L - 1) ? 1 : 0);
-        L2A_HIP(ctx, hipGetLastError());
+    d.first_block[0] = 0;
+    for (int l = 0; l < L; ++l)
+        d.first_block[l + 1] = d.first_block[l] + ((ap.dims[l + 1] + 255) / 256) * ((ap.dims[l] + L2A_UK - 1) / L2A_UK);
+    hipLaunchKernelGGL(l2a_adapt_update_k, dim3((unsigned)d.first_block[L], (unsigned)m), dim3(256), 0, stream, ap, d);
+    L2A_HIP(ctx, hipGetLastError());
+    return L2A_OK;
+}
+
+}  // namespace
+
+int l2a_model_adapt_sgd(l2a_model* md, const void* const* base_ptrs, const float* x, const float* y, int m,
+                        int rows, float lr, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
+    L2AAdaptParams ap;
+    const int rc = adapt_prepare(md, base_ptrs, x, y, m, rows, stream, ap);
+    if (rc != L2A_OK) return rc;
+    const int rc2 = adapt_enqueue(md, ap, m, lr, stream);
+    if (rc2 != L2A_OK) return rc2;
+    for (int e = 0; e < m; ++e) md->weights_set[e] = 1;
+    return L2A_OK;
+}
+
+int l2a_model_adapt_sgd_host(l2a_model* md, const void* const* base_ptrs, const float* x_host, const float* y_host,
+                             int m, int rows, float lr, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
+    if (!x_host || !y_host) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd_host: null pointer");
+    if (m < 1 || m > md->n_sets || rows < 1 || rows > L2A_AR)
+        return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd_host: m must be in [1, n_sets], rows in [1, 16]");
+    auto& sl = md->aslot[md->aslot_next];
+    md->aslot_next ^= 1;
+    // the launch that last read this slot's staging must be through before the host overwrites it
+    if (sl.pending) { L2A_HIP(ctx, hipEventSynchronize(sl.done)); sl.pending = false; }
+    const long long xf = (long long)m * rows * md->in_dim, yf = (long long)m * rows * md->obs_dim;
+    if (xf + yf > sl.stage_floats) {
+        if (sl.stage_host) { L2A_HIP(ctx, hipHostFree(sl.stage_host)); sl.stage_host = nullptr; }
+        const long long cap = (long long)md->n_sets * L2A_AR * (md->in_dim + md->obs_dim);
+        L2A_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.stage_host), (size_t)cap * sizeof(float), hipHostMallocMapped));
+        L2A_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.stage_dev), sl.stage_host, 0));
+        sl.stage_floats = cap;
     }
+    if (!sl.done) L2A_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    std::memcpy(sl.stage_host, x_host, (size_t)xf * sizeof(float));
+    std::memcpy(sl.stage_host + xf, y_host, (size_t)yf * sizeof(float));
+    L2AAdaptParams ap;
+    const int rc = adapt_prepare(md, base_ptrs, sl.stage_dev, sl.stage_dev + xf, m, rows, stream, ap);
+    if (rc != L2A_OK) return rc;
+    const int rc2 = adapt_enqueue(md, ap, m, lr, stream);
+    if (rc2 != L2A_OK) return rc2;
+    L2A_HIP(ctx, hipEventRecord(sl.done, stream));
+    sl.pending = true;
     for (int e = 0; e < m; ++e) md->weights_set[e] = 1;
     return L2A_OK;
 }

@@ -205,14 +205,16 @@ class MetaMLPDynamicsModel(Serializable):
         self._num_adapted_models = len(obs)
         assert len(obs) == len(act) == len(obs_next)
         dev = core.training_device()
-        xs, ys = [], []
-        for ob, ac, ob_next in zip(obs, act, obs_next):
-            ob = np.asarray(ob, dtype=np.float64)
-            ac = np.asarray(ac, dtype=np.float64)
-            ob_next = np.asarray(ob_next, dtype=np.float64)
-            assert ob.ndim == 2 and ob.shape[1] == self.obs_space_dims
-            assert ac.ndim == 2 and ac.shape[1] == self.action_space_dims
-            assert ob_next.shape == ob.shape and ac.shape[0] == ob.shape[0]
+        xs = ys = None
+        if len({np.shape(o) for o in obs}) == 1:
+            # equal batches (the sampler's case): all tasks normalised in one pass - the same float64 arithmetic per
+            # element as the per-task loop below, a dozen NumPy calls instead of thirty (0.1 ms of a 2.7 ms step)
+            ob = np.asarray(obs, dtype=np.float64)
+            ac = np.asarray(act, dtype=np.float64)
+            ob_next = np.asarray(obs_next, dtype=np.float64)
+            assert ob.ndim == 3 and ob.shape[2] == self.obs_space_dims
+            assert ac.ndim == 3 and ac.shape[2] == self.action_space_dims
+            assert ob_next.shape == ob.shape and ac.shape[:2] == ob.shape[:2]
             if self.normalize_input:
                 nm = self._norm()
                 o_n = core.normalize(ob, nm["obs"][0], nm["obs"][1])
@@ -220,12 +222,30 @@ class MetaMLPDynamicsModel(Serializable):
                 d_n = core.normalize(ob_next - ob, nm["delta"][0], nm["delta"][1])
             else:
                 o_n, a_n, d_n = ob, ac, ob_next - ob
-            xs.append(np.concatenate([o_n, a_n], axis=1))
-            ys.append(d_n)
+            xs = np.concatenate([o_n, a_n], axis=2)         # [m, rows, in]: iterating yields the per-task arrays
+            ys = d_n
+        else:
+            xs, ys = [], []
+            for ob, ac, ob_next in zip(obs, act, obs_next):
+                ob = np.asarray(ob, dtype=np.float64)
+                ac = np.asarray(ac, dtype=np.float64)
+                ob_next = np.asarray(ob_next, dtype=np.float64)
+                assert ob.ndim == 2 and ob.shape[1] == self.obs_space_dims
+                assert ac.ndim == 2 and ac.shape[1] == self.action_space_dims
+                assert ob_next.shape == ob.shape and ac.shape[0] == ob.shape[0]
+                if self.normalize_input:
+                    nm = self._norm()
+                    o_n = core.normalize(ob, nm["obs"][0], nm["obs"][1])
+                    a_n = core.normalize(ac, nm["act"][0], nm["act"][1])
+                    d_n = core.normalize(ob_next - ob, nm["delta"][0], nm["delta"][1])
+                else:
+                    o_n, a_n, d_n = ob, ac, ob_next - ob
+                xs.append(np.concatenate([o_n, a_n], axis=1))
+                ys.append(d_n)
         # Only the real rows enter the pre-update loss: the reference pads each task with an equal
         # number of zero rows and then splits the task batch in two, pre = real half (:324-326, :99-103).
         if self._native_adapt_ok(xs):
-            # on the GPU: two kernels that write the adapted sets straight into the planner's per-block model
+            # on the GPU: kernels that write the adapted sets straight into the planner's per-block model
             from .native_model import NativeModel
             m = len(xs)
             if self._native_adapted is None or self._native_adapted.n_sets != m:
@@ -235,9 +255,10 @@ class MetaMLPDynamicsModel(Serializable):
                                                    self.hidden_sizes, self.hidden_nonlinearity,
                                                    self.output_nonlinearity, m, "per_block")
             native = self._native_adapted
-            x = torch.from_numpy(np.stack(xs).astype(np.float32)).to(native.device)
-            y = torch.from_numpy(np.stack(ys).astype(np.float32)).to(native.device)
-            native.adapt_sgd(self._device_params(native.device), x, y, self.inner_learning_rate)
+            # the batches stay on the host: the library stages them in host-mapped memory that the kernels read
+            # directly (l2a_model_adapt_sgd_host) - no H2D copies on the stream
+            native.adapt_sgd_host(self._device_params(native.device), np.asarray(xs, dtype=np.float32),
+                                  np.asarray(ys, dtype=np.float32), self.inner_learning_rate)
             self._adapted_stacked = None
             adapted = _ResidentSets(native, m)
         elif len({x.shape[0] for x in xs}) == 1:

@@ -115,6 +115,23 @@ class NativeModel(object):
         self.ctx.check(rc, "l2a_model_adapt_sgd")
         self._keep["adapt"] = (base, x, y)
 
+    def adapt_sgd_host(self, base_params, x, y, lr):
+        """``adapt_sgd`` with the batches as HOST float32 arrays ``[m, rows, in_dim]`` / ``[m, rows, obs_dim]``
+        (``l2a_model_adapt_sgd_host``: host-mapped staging, the launches replayed as one hipGraph)."""
+        m, rows = int(x.shape[0]), int(x.shape[1])
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        assert x.shape == (m, rows, self.obs_dim + self.act_dim) and y.shape == (m, rows, self.obs_dim)
+        base = self._keep.get("adapt_base")
+        if base is None or base[0] is not base_params:       # same list object = same tensors: keep the graph valid
+            dev = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in base_params]
+            base = (base_params, dev, (ctypes.c_void_p * len(dev))(*[t.data_ptr() for t in dev]))
+            self._keep["adapt_base"] = base
+        rc = self.lib.l2a_model_adapt_sgd_host(self.handle, base[2], ctypes.c_void_p(x.ctypes.data),
+                                               ctypes.c_void_p(y.ctypes.data), m, rows, float(lr),
+                                               _stream_ptr(self.device))
+        self.ctx.check(rc, "l2a_model_adapt_sgd_host")
+
     def get_weights(self, e):
         """Weight set ``e`` as fresh CUDA tensors in the reference's order and layout."""
         sizes = (self.obs_dim + self.act_dim,) + self.hidden_sizes + (self.obs_dim,)

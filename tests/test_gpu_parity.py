@@ -524,6 +524,36 @@ def test_device_adapt_matches_autograd(hidden, act, rows):
     np.testing.assert_allclose(picks[0][2], picks[1][2], rtol=1e-4, atol=1e-4)
 
 
+def test_host_staged_adapt_is_bit_identical_to_the_device_pointer_entry():
+    """`l2a_model_adapt_sgd_host` (batches copied into host-mapped staging that the kernels read directly, two slots)
+    against `l2a_model_adapt_sgd` on device tensors: every adapted parameter bit for bit - over repeated steps with
+    fresh data (both staging slots, arrays overwritten right after the call), a changed learning rate, fewer tasks /
+    rows."""
+    from learning_to_adapt_amd.dynamics.native_model import NativeModel
+    from learning_to_adapt_amd.utils import synthetic
+    od, ad, hidden, m = 41, 8, (512, 512, 512), 5
+    dev = torch.device("cuda:0")
+    base = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(dev)
+            for w in synthetic.make_weight_set(od, ad, list(hidden), 1000)]
+    plain = NativeModel(od, ad, hidden, "relu", None, m, "per_block")
+    staged = NativeModel(od, ad, hidden, "relu", None, m, "per_block")
+    rs = np.random.RandomState(0)
+    for step, (mm, rows, lr) in enumerate([(5, 16, 0.01), (5, 16, 0.01), (5, 16, 0.01), (5, 16, 0.02), (3, 9, 0.02),
+                                           (1, 1, 0.5), (5, 16, 0.01)]):
+        x = rs.randn(mm, rows, od + ad).astype(np.float32)
+        y = rs.randn(mm, rows, od).astype(np.float32)
+        plain.adapt_sgd(base, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), lr)
+        staged.adapt_sgd_host(base, x, y, lr)
+        x[:] = 0.0      # the arrays may be reused as soon as the call returns
+        y[:] = 0.0
+        for e in range(mm):
+            for a, b in zip(plain.get_weights(e), staged.get_weights(e)):
+                assert torch.equal(a, b), (step, e, tuple(a.shape))
+        assert not torch.equal(plain.get_weights(0)[0], base[0])
+    plain.close()
+    staged.close()
+
+
 @pytest.mark.parametrize("kernel", ["auto", "valu"])
 @pytest.mark.parametrize("name,over", [("c2_hc_rs_n2000_h30_e5", dict(h=9)), ("hc_rs_m3_n64_h5", dict(h=7)),
                                         ("c3_ant_rs_n2000_h20_pb5", dict(n=300, h=6)),

@@ -76,7 +76,7 @@ CASES = [
     dict(name="c4_hc_rs_n16000_h30_e5", env="half_cheetah", planner="rs", n=16000, h=30, m=1,
          mode="mean", E=5, hidden=[512, 512], seeds=[0, 1]),
     dict(name="c5_hc_cem_n4000_h30_e5", env="half_cheetah", planner="cem", n=4000, h=30, m=1,
-         mode="mean", E=5, hidden=[512, 512], seeds=[0, 1], num_cem_iters=5),
+         mode="mean", E=5, hidden=[512, 512], seeds=[0, 1, 2], num_cem_iters=5),
     # edge cases
     dict(name="hc_rs_m3_n64_h5", env="half_cheetah", planner="rs", n=64, h=5, m=3,
          mode="single", E=1, hidden=[512, 512], seeds=[0]),

@@ -36,6 +36,10 @@ timeout 600 python tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.e
 timeout 300 python tools/parity_report.py > $OUT/parity_report.txt 2> $OUT/parity.err; echo "parity rc=$?"
 timeout 120 python tools/timeline.py > $OUT/timeline.txt 2>&1; echo "timeline rc=$?"
 timeout 120 python tools/timeline_lstm.py 256 4096 > $OUT/timeline_lstm.txt 2>&1; echo "timeline_lstm rc=$?"
+timeout 120 python tools/timeline_lstm.py 256 2000 >> $OUT/timeline_lstm.txt 2>&1; echo "timeline_lstm (split) rc=$?"
+echo "== GrBAL adaptation step"
+timeout 120 python tools/probe_adapt.py 2> /dev/null > $OUT/probe_adapt.json; echo "probe_adapt rc=$?"
+bash tools/adapt_trace.sh > $OUT/adapt_trace.txt 2>&1; echo "adapt_trace rc=$?"; cd $GRAFT_REPO_ROOT
 echo "== host RNG helper / end-to-end stage probes"
 timeout 300 python tools/bench_rng.py > $OUT/rng.jsonl 2>&1; echo "rng rc=$?"
 timeout 300 python tools/probe_e2e.py > $OUT/probe_c2.jsonl 2> $OUT/probe.err; echo "probe c2 rc=$?"
