@@ -305,6 +305,18 @@ int l2a_lstm_plan_rs(l2a_lstm* model, const float* obs0, const float* c0, const 
                      const float* actions, int m, int n, int h, double discount, const l2a_reward* reward,
                      int cand_offset, float* returns_out, unsigned long long* best_key, void* stream);
 
+/* Blocking form of l2a_lstm_plan_rs for one GPU (see l2a_plan_rs_sync): `obs_host` [m, obs_dim] is a HOST array,
+ * the arg-max keys arrive in `keys_host_out` [m] through the host-mapped mailbox (MFMA kernel; the generic kernels copy
+ * and synchronise).  With c_next / h_next (device, [m, state width], not aliasing c0 / h0) the controller's own state
+ * is moved on as well: state' = cell(obs, first action of the winning candidate, state) - what
+ * `RNNMPCController.get_actions` does after planning (rnn_mpc_controller.py:57-65) - enqueued behind the plan without a
+ * host round trip (the action is gathered from `actions` on the device; its fp32 value is the one a host would pass).
+ * Returns L2A_ESPLIT like l2a_plan_rs_sync; c_next / h_next are then invalid too and the repeated call rewrites them. */
+int l2a_lstm_plan_rs_sync(l2a_lstm* model, const float* obs_host, const float* c0, const float* h0,
+                          const float* actions, int m, int n, int h, double discount, const l2a_reward* reward,
+                          int cand_offset, unsigned long long* keys_host_out, float* c_next, float* h_next,
+                          void* stream);
+
 /* l2a_lstm_plan_rs cut along the horizon (see l2a_plan_rs_chunk): launch k covers steps t0 .. t0 + h_chunk - 1
  * and hands per-candidate observation, LSTM state and accumulated returns to launch k + 1; the chain is
  * bit-identical to one launch.  t0 == 0: state [m, obs_dim], c / h [m, units] (per_row = 0); t0 > 0: the

@@ -756,6 +756,76 @@ static int ensure_mail(l2a_ctx* ctx) {
     return L2A_OK;
 }
 
+int l2a_mail_begin(l2a_ctx* ctx, int m, const float* obs_host, long long obs_floats, hipStream_t stream,
+                   l2a_mail_ticket* tk) {
+    if (m < 1 || m > L2A_MAIL_KEYS || obs_floats < 0 || obs_floats > L2A_MAIL_OBS)
+        return fail(ctx, L2A_EINVAL, "blocking plan: at most 64 envs / 4096 observation floats");
+    const int rc = ensure_mail(ctx);
+    if (rc != L2A_OK) return rc;
+    tk->seq = ++ctx->mail_seq;
+    tk->slot = (int)(tk->seq & 1ull);
+    std::memcpy(ctx->mail_host->obs[tk->slot], obs_host, sizeof(float) * (size_t)obs_floats);
+    tk->obs_dev = ctx->mail_dev->obs[tk->slot];
+    tk->keys_dev = ctx->key_ring + (size_t)tk->slot * L2A_MAIL_KEYS;
+    tk->next_keys = ctx->key_ring + (size_t)(tk->slot ^ 1) * L2A_MAIL_KEYS;
+    // Key-slot bookkeeping: ring_dirty[s] = how many leading entries of slot s may be non-zero.  A mailbox launch
+    // with m envs zeroes entries [0, m) of the OTHER slot in its epilogue; anything beyond needs a memset.
+    if (ctx->ring_dirty[tk->slot] > 0)
+        L2A_HIP(ctx, hipMemsetAsync(tk->keys_dev, 0, sizeof(unsigned long long) * L2A_MAIL_KEYS, stream));
+    ctx->ring_dirty[tk->slot] = m;
+    tk->t0_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    return L2A_OK;
+}
+
+int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tk, int m, bool published, int launch_rc, hipStream_t stream,
+                 unsigned long long* keys_host_out, const char* who) {
+    auto now_us = [] {
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    auto dirty = [&] { ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS; };
+    if (launch_rc != L2A_OK) { dirty(); return launch_rc; }
+    l2a_mail* mh = ctx->mail_host;
+    if (published) {
+        if (m >= ctx->ring_dirty[tk.slot ^ 1]) ctx->ring_dirty[tk.slot ^ 1] = 0;   // zeroed by this launch's last tile
+        // Sleep through most of the expected duration, then poll the mailbox word (host-mapped memory: no copy,
+        // no hipStreamSynchronize wake-up latency).
+        if (ctx->sync_ema_us > 400.0) usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
+        const volatile unsigned long long* seqp = &mh->seq;
+        unsigned long long spins = 0;
+        while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != tk.seq) {
+            _mm_pause();
+            if ((++spins & 0xffffull) == 0) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                    dirty();
+                    return fail(ctx, L2A_EHIP, std::string(who) + ": " + hipGetErrorString(q));
+                }
+                const double waited = (now_us() - tk.t0_us) * 1e-6;
+                if (q == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != tk.seq && waited > 1.0) {
+                    dirty();
+                    return fail(ctx, L2A_EHIP, std::string(who) + ": the stream drained but the mailbox was never written");
+                }
+                if (waited > 60.0) {
+                    dirty();
+                    return fail(ctx, L2A_EHIP, std::string(who) + ": timed out waiting for the plan");
+                }
+            }
+        }
+        const double us = now_us() - tk.t0_us;
+        ctx->sync_ema_us = (ctx->sync_ema_us == 0.0) ? us : 0.75 * ctx->sync_ema_us + 0.25 * us;
+        for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
+    } else {
+        L2A_HIP(ctx, hipMemcpyAsync(mh->keys, tk.keys_dev, sizeof(unsigned long long) * (size_t)m, hipMemcpyDeviceToHost, stream));
+        L2A_HIP(ctx, hipStreamSynchronize(stream));
+        for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
+    }
+    if (*ctx->status_host != 0) {       // a tile-split partner never arrived: the caller relaunches unsplit
+        *ctx->status_host = 0;
+        return fail(ctx, L2A_ESPLIT, "a tile-split exchange timed out (relaunch with l2a_set_split(ctx, 0))");
+    }
+    return L2A_OK;
+}
+
 int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions, int m, int n, int h,
                      double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
                      unsigned long long* keys_host_out, void* stream_v) {
@@ -774,26 +844,15 @@ int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions,
         return fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     l2a_device_guard guard(ctx->device);
-    int rc = ensure_mail(ctx);
-    if (rc != L2A_OK) return rc;
     int kind = ctx->kernel_kind;
     if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
     const bool publish = (kind == L2A_KERNEL_MFMA);        // the VALU kernel has no mailbox epilogue
-
-    const unsigned long long seq = ++ctx->mail_seq;
-    const int slot = (int)(seq & 1ull);
-    l2a_mail* mh = ctx->mail_host;
-    std::memcpy(mh->obs[slot], obs_host, sizeof(float) * (size_t)m * md->obs_dim);
-    unsigned long long* keys_dev = ctx->key_ring + (size_t)slot * L2A_MAIL_KEYS;
-    // Key-slot bookkeeping: ring_dirty[s] = how many leading entries of slot s may be non-zero.  A mailbox launch
-    // with m envs zeroes entries [0, m) of the OTHER slot in its epilogue; anything beyond needs a memset.
-    if (ctx->ring_dirty[slot] > 0)
-        L2A_HIP(ctx, hipMemsetAsync(keys_dev, 0, sizeof(unsigned long long) * L2A_MAIL_KEYS, stream));
-    ctx->ring_dirty[slot] = m;
-
+    l2a_mail_ticket tk;
+    int rc = l2a_mail_begin(ctx, m, obs_host, (long long)m * md->obs_dim, stream, &tk);
+    if (rc != L2A_OK) return rc;
     L2AKParams p;
     fill_model_params(md, p);
-    p.obs0 = ctx->mail_dev->obs[slot]; p.actions = actions; p.returns_out = returns_out; p.best_key = keys_dev;
+    p.obs0 = tk.obs_dev; p.actions = actions; p.returns_out = returns_out; p.best_key = tk.keys_dev;
     p.state_out = nullptr; p.obs_per_row = 0;
     p.ret_in = nullptr; p.disc0 = 1.0;
     p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
@@ -801,51 +860,11 @@ int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions,
         p.done_ctr = ctx->done_ctr;
         p.mail_keys = ctx->mail_dev->keys;
         p.mail_seq_ptr = &ctx->mail_dev->seq;
-        p.mail_seq = seq;
-        p.next_keys = ctx->key_ring + (size_t)(slot ^ 1) * L2A_MAIL_KEYS;
+        p.mail_seq = tk.seq;
+        p.next_keys = tk.next_keys;
     }
-    const auto t0 = std::chrono::steady_clock::now();
     rc = launch_rollout(md, p, stream_v);
-    if (rc != L2A_OK) { ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS; return rc; }
-    if (publish) {
-        if (m >= ctx->ring_dirty[slot ^ 1]) ctx->ring_dirty[slot ^ 1] = 0;     // zeroed by this launch's last tile
-        // Sleep through most of the expected duration, then poll the mailbox word (host-mapped memory: no copy,
-        // no hipStreamSynchronize wake-up latency).
-        if (ctx->sync_ema_us > 400.0) usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
-        const volatile unsigned long long* seqp = &mh->seq;
-        unsigned long long spins = 0;
-        while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
-            _mm_pause();
-            if ((++spins & 0xffffull) == 0) {
-                const hipError_t q = hipStreamQuery(stream);
-                if (q != hipSuccess && q != hipErrorNotReady) {
-                    ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS;
-                    return fail(ctx, L2A_EHIP, std::string("l2a_plan_rs_sync: ") + hipGetErrorString(q));
-                }
-                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                if (q == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq && waited > 1.0) {
-                    ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS;
-                    return fail(ctx, L2A_EHIP, "l2a_plan_rs_sync: the stream drained but the mailbox was never written");
-                }
-                if (waited > 60.0) {
-                    ctx->ring_dirty[0] = ctx->ring_dirty[1] = L2A_MAIL_KEYS;
-                    return fail(ctx, L2A_EHIP, "l2a_plan_rs_sync: timed out waiting for the plan");
-                }
-            }
-        }
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        ctx->sync_ema_us = (ctx->sync_ema_us == 0.0) ? us : 0.75 * ctx->sync_ema_us + 0.25 * us;
-        for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
-    } else {
-        L2A_HIP(ctx, hipMemcpyAsync(mh->keys, keys_dev, sizeof(unsigned long long) * (size_t)m, hipMemcpyDeviceToHost, stream));
-        L2A_HIP(ctx, hipStreamSynchronize(stream));
-        for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
-    }
-    if (*ctx->status_host != 0) {       // a tile-split partner never arrived: the caller relaunches unsplit
-        *ctx->status_host = 0;
-        return fail(ctx, L2A_ESPLIT, "a tile-split exchange timed out (relaunch with l2a_set_split(ctx, 0))");
-    }
-    return L2A_OK;
+    return l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_plan_rs_sync");
 }
 
 int l2a_plan_rs_chunk(l2a_model* md, const float* state, int state_per_row, const float* actions, int m, int n,

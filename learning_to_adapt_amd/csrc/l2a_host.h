@@ -55,6 +55,25 @@ int l2a_fail(const l2a_ctx* ctx, int code, const std::string& msg);
 
 inline int l2a_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- blocking launches through the result mailbox (l2a_plan_rs_sync, l2a_lstm_plan_rs_sync; defined in l2a_api.hip) ----
+struct l2a_mail_ticket {
+    unsigned long long seq = 0;                 // value the kernel publishes
+    int slot = 0;                               // observation staging / key slot of this launch
+    const float* obs_dev = nullptr;             // device alias of the staged observations
+    unsigned long long* keys_dev = nullptr;     // this launch's key slot (zeroed)
+    unsigned long long* next_keys = nullptr;    // the next launch's key slot (the last tile zeroes [0, m))
+    double t0_us = 0.0;                         // host clock when the ticket was drawn
+};
+// Stage `obs_floats` observation floats, pick and clear the key slot.  Kernel parameters of a publishing launch:
+// best_key = keys_dev, done_ctr = ctx->done_ctr, mail_keys = ctx->mail_dev->keys, mail_seq_ptr = &ctx->mail_dev->seq,
+// mail_seq = seq, next_keys.
+extern "C" int l2a_mail_begin(l2a_ctx* ctx, int m, const float* obs_host, long long obs_floats, hipStream_t stream,
+                              l2a_mail_ticket* ticket);
+// After the launch (`launch_rc` = its return code): wait for the keys - mailbox word when the kernel publishes, copy +
+// stream synchronisation otherwise - and check the status word (L2A_ESPLIT).
+extern "C" int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& ticket, int m, bool published, int launch_rc,
+                            hipStream_t stream, unsigned long long* keys_host_out, const char* who);
+
 // Makes the context's device current for the duration of an entry point and restores the caller's (a process
 // driving several GPUs, or a torch thread whose current device differs from the model's).
 struct l2a_device_guard {

@@ -157,7 +157,8 @@ __device__ __forceinline__ int l2a_logical_wg(int hw, int nwg) {
 // Called by ONE thread per candidate tile after its atomicMax into best_key.  The tile that arrives last copies
 // the finished keys into the host-mapped mailbox, zeroes the next launch's key slot, rearms the counter and
 // finally publishes the launch's sequence number (system-scope release): the host polls that word.
-__device__ __forceinline__ void l2a_publish_result(const L2AKParams& p, int n_tiles) {
+template <class Params>
+__device__ __forceinline__ void l2a_publish_result(const Params& p, int n_tiles) {
     if (!p.mail_seq_ptr) return;
     __threadfence();
     const unsigned int prev = __hip_atomic_fetch_add(p.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -77,6 +77,12 @@ struct L2ALstmParams {
     unsigned long long* xbuf;   // exchange granules [pair][group][slot][UT / 2 + OT][2][64] x 16 B
     unsigned int* status;       // host-visible word; bit 0 set = exchange timed out
     unsigned int spin_limit;    // polls one wave may spend waiting for its partner, per launch
+    // ---- result mailbox (l2a_lstm_plan_rs_sync; same protocol as L2AKParams, l2a_kernels.h) ----
+    unsigned int* done_ctr;
+    unsigned long long* mail_keys;
+    unsigned long long* mail_seq_ptr;   // null = no mailbox
+    unsigned long long mail_seq;
+    unsigned long long* next_keys;
 };
 
 // Gate-matrix tile order: tile T = w * (4 UTW) + q * UTW + uu  <->  gate q (i, j, f, o) of unit tile
@@ -764,7 +770,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 const unsigned long long other = ((unsigned long long)hi << 32) | lo;
                 key = (other > key) ? other : key;
             }
-            if (lane == 0 && key != 0ull) atomicMax(p.best_key + env, key);
+            if (lane == 0) {
+                if (key != 0ull) atomicMax(p.best_key + env, key);
+                l2a_publish_result(p, p.m * p.tiles_per_env);
+            }
         }
     }
 }

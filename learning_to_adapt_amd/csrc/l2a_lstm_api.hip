@@ -32,7 +32,20 @@ struct l2a_lstm {
     int n_layers = 1, cell_type = L2A_CELL_LSTM;
     int lunits[L2A_RNN_MAX_LAYERS] = {0};
     long long lw[L2A_RNN_MAX_LAYERS][2] = {{0}}, lb[L2A_RNN_MAX_LAYERS][2] = {{0}};
+    float* adv_buf = nullptr;                     // l2a_lstm_plan_rs_sync: [64, act_dim] chosen actions + [64, obs_dim] next obs
 };
+
+// First action of every env's winning candidate: out[i] = actions[step 0][i * n + (index(best_key[i]) - cand_offset)]
+// (key layout: l2a_key_pack; the index is clamped, a launch flagged invalid may have left anything in the key).
+__global__ void l2a_gather_best_k(const unsigned long long* best_key, const float* actions, int m, int n, int cand_offset,
+                                  int act_dim, float* out) {
+    const int i = blockIdx.x, d = threadIdx.x;
+    if (i >= m || d >= act_dim) return;
+    const unsigned int low = (unsigned int)(best_key[i] & 0x7fffffffull);
+    int idx = (int)(0x7fffffffu - low) - cand_offset;
+    idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
+    out[i * act_dim + d] = actions[((long long)i * n + idx) * act_dim + d];
+}
 
 namespace {
 
@@ -250,6 +263,7 @@ void l2a_lstm_destroy(l2a_lstm* md) {
         (void)hipFree(md->wblk);
     }
     if (md->xbuf) (void)hipFree(md->xbuf);
+    if (md->adv_buf) (void)hipFree(md->adv_buf);
     delete md;
 }
 
@@ -375,6 +389,64 @@ int l2a_lstm_plan_rs(l2a_lstm* md, const float* obs0, const float* c0, const flo
     p.returns_out = returns_out; p.best_key = best_key;
     p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
     return launch(md, p, stream_v);
+}
+
+int l2a_lstm_plan_rs_sync(l2a_lstm* md, const float* obs_host, const float* c0, const float* h0, const float* actions,
+                          int m, int n, int h, double discount, const l2a_reward* reward, int cand_offset,
+                          unsigned long long* keys_host_out, float* c_next, float* h_next, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!obs_host || !c0 || !h0 || !actions || !reward || !keys_host_out)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: null obs / c0 / h0 / actions / reward / keys_host_out");
+    if ((!c_next) != (!h_next)) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: pass c_next and h_next together");
+    if (c_next && (c_next == c0 || h_next == h0))
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: the next state must not alias the current one");
+    if (m < 1 || n < 1 || h < 1) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: m, n and h must be >= 1");
+    if ((long long)m * n > 0x3fffffffLL || cand_offset < 0 || (long long)cand_offset + n > 0x7fffffffLL)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: too many candidates");
+    if (reward->w_vel != 0.0f && (reward->vel_index < 0 || reward->vel_index >= md->obs_dim))
+        return l2a_fail(ctx, L2A_EINVAL, "reward.vel_index out of range");
+    if (reward->dist_coef != 0.0f && (reward->dist_index < 0 || reward->dist_index >= md->obs_dim))
+        return l2a_fail(ctx, L2A_EINVAL, "reward.dist_index out of range");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
+    int kind = ctx->kernel_kind;
+    if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
+    const bool publish = (kind == L2A_KERNEL_MFMA) && !md->generic;   // only the MFMA kernel has the mailbox epilogue
+    if (c_next && !md->adv_buf)
+        L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->adv_buf), sizeof(float) * L2A_MAIL_KEYS * (md->act_dim + md->obs_dim)));
+    l2a_mail_ticket tk;
+    int rc = l2a_mail_begin(ctx, m, obs_host, (long long)m * md->obs_dim, stream, &tk);
+    if (rc != L2A_OK) return rc;
+    L2ALstmParams p;
+    fill(md, p);
+    p.obs0 = tk.obs_dev; p.c0 = c0; p.h0 = h0; p.actions = actions;
+    p.best_key = tk.keys_dev;
+    p.m = m; p.n = n; p.h = h; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
+    if (publish) {
+        p.done_ctr = ctx->done_ctr;
+        p.mail_keys = ctx->mail_dev->keys;
+        p.mail_seq_ptr = &ctx->mail_dev->seq;
+        p.mail_seq = tk.seq;
+        p.next_keys = tk.next_keys;
+    }
+    rc = launch(md, p, stream_v);
+    if (rc == L2A_OK && c_next) {
+        // the controller's own state moves on with the chosen action (rnn_mpc_controller.py:63) - in stream order
+        // behind the plan, without waiting for the host to learn the arg-max
+        float* act_sel = md->adv_buf;
+        float* obs_next = md->adv_buf + (size_t)L2A_MAIL_KEYS * md->act_dim;
+        hipLaunchKernelGGL(l2a_gather_best_k, dim3((unsigned)m), dim3(64), 0, stream, tk.keys_dev, actions, m, n, cand_offset,
+                           md->act_dim, act_sel);
+        L2ALstmParams q;
+        fill(md, q);
+        q.obs0 = tk.obs_dev; q.c0 = c0; q.h0 = h0; q.actions = act_sel;
+        q.state_out = obs_next; q.c_out = c_next; q.h_out = h_next;
+        q.obs_per_row = 1; q.hid_per_row = 1;
+        q.m = 1; q.n = m; q.h = 1; q.discount = 1.0;
+        rc = launch(md, q, stream_v);
+    }
+    return l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_lstm_plan_rs_sync");
 }
 
 int l2a_lstm_plan_rs_chunk(l2a_lstm* md, const float* state, const float* c, const float* h, int per_row,

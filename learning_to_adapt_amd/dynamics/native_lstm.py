@@ -6,6 +6,7 @@ fused kernels run on torch's current HIP stream, ``L2AError`` on any failure, no
 
 import ctypes
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -99,6 +100,37 @@ class NativeLSTM(object):
                                        int(h), float(discount), ctypes.byref(reward), int(cand_offset),
                                        _ptr(returns_out), _ptr(best_key), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_lstm_plan_rs")
+
+    sync_max_envs = 64
+
+    def plan_rs_sync(self, obs_host, c0, h0, actions, m, n, h, discount, reward, cand_offset=0, c_next=None, h_next=None):
+        """Blocking plan step (``l2a_lstm_plan_rs_sync``): ``obs_host`` is a HOST array ``[m, obs_dim]``; returns the
+        arg-max keys as a NumPy uint64 array ``[m]``.  With ``c_next`` / ``h_next`` (CUDA ``[m, units]``, not aliasing
+        ``c0`` / ``h0``) the state is also advanced with every env's winning first action, in stream order behind
+        the plan.  ``None``: the launch was flagged invalid (unit-tile split partner missing) - the context has been
+        switched to the unsplit geometry and the caller repeats the call (which rewrites ``c_next`` / ``h_next``)."""
+        for t in (c0, h0, actions):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        assert actions.numel() == h * m * n * self.act_dim
+        assert c0.numel() == m * self.units and h0.numel() == m * self.units
+        if c_next is not None:
+            for t in (c_next, h_next):
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == m * self.units
+        obs = np.ascontiguousarray(obs_host, dtype=np.float32)
+        assert obs.size == m * self.obs_dim
+        keys = np.empty(m, dtype=np.uint64)
+        rc = self.lib.l2a_lstm_plan_rs_sync(self.handle, ctypes.c_void_p(obs.ctypes.data), _ptr(c0), _ptr(h0), _ptr(actions),
+                                            int(m), int(n), int(h), float(discount), ctypes.byref(reward),
+                                            int(cand_offset), ctypes.c_void_p(keys.ctypes.data), _ptr(c_next),
+                                            _ptr(h_next), _stream_ptr(self.device))
+        if rc == _lib.L2A_ESPLIT:
+            if getattr(self.ctx, "split_degraded", False):
+                raise _lib.L2AError("recurrent rollout launch was flagged invalid with the tile split disabled")
+            self.ctx.set_split(0)
+            self.ctx.split_degraded = True
+            return None
+        self.ctx.check(rc, "l2a_lstm_plan_rs_sync")
+        return keys
 
     def plan_rs_chunk(self, state, c, h, per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
                       returns_in=None, returns_out=None, state_out=None, c_out=None, h_out=None, best_key=None):

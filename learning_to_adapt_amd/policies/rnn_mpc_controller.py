@@ -25,6 +25,8 @@ class RNNMPCController(MPCController):
     _hid_host = None        # LSTMStateTuple of NumPy arrays (the reference's `_hidden_state`)
     _hid_dev = None         # (c, h) CUDA tensors
     _hid_stale = None       # which copy is out of date: None | "host" | "dev"
+    _hid_next = None        # (c, h) already advanced with the chosen actions by the blocking plan launch
+    _hid_flip = 0
 
     def __init__(
             self,
@@ -115,6 +117,10 @@ class RNNMPCController(MPCController):
         return actions, dict()
 
     def _advance_hidden(self, observations, actions):
+        if self._hid_next is not None:          # the blocking plan launch has done it in stream order (`_plan_keys`)
+            self._hid_dev, self._hid_next = self._hid_next, None
+            self._hid_stale = "host"
+            return
         if not self._fusable():
             _, self._hidden_state = self.dynamics_model.predict(np.array(observations), actions, self._hidden_state)
             return
@@ -159,6 +165,34 @@ class RNNMPCController(MPCController):
         Serializable.__setstate__(self, state["init_args"] if "init_args" in state else state)
 
     # ------------------------------------------------------------------ fused rollout with the env's LSTM state
+    def _plan_keys(self, observations, a_dev, n_local, lo, world):
+        """One GPU, random shooting: the blocking launch (``l2a_lstm_plan_rs_sync``) - observations staged in
+        host-mapped memory, keys through the mailbox - which also moves the controller's hidden state on with the
+        winning first actions, in stream order behind the plan (the value ``_advance_hidden`` would upload is the
+        fp32 candidate the kernel gathers).  Everything else goes through ``_rollout`` as before."""
+        m = len(observations)
+        self._hid_next = None
+        stock = getattr(self._rollout, "__func__", None) is RNNMPCController._rollout
+        native = self.dynamics_model.planner_model() if (stock and world == 1 and n_local > 0 and not self.use_cem) else None
+        if native is None or not hasattr(native, "plan_rs_sync") or getattr(native, "sync_max_envs", 0) < m:
+            return MPCController._plan_keys(self, observations, a_dev, n_local, lo, world)
+        dev = native.device
+        c0, h0 = self._device_hidden(dev)
+        assert tuple(c0.shape) == (m, native.units), "hidden state holds %d rows, %d observations were passed" % (
+            c0.shape[0], m)
+        self._hid_flip ^= 1
+        c1 = self._buf("adv_c%d" % self._hid_flip, (m, native.units), torch.float32, dev)
+        h1 = self._buf("adv_h%d" % self._hid_flip, (m, native.units), torch.float32, dev)
+        if c1.data_ptr() == c0.data_ptr() or h1.data_ptr() == h0.data_ptr():        # never write over the inputs
+            c1, h1 = torch.empty_like(c0), torch.empty_like(h0)
+        for _ in range(2):
+            keys = native.plan_rs_sync(observations, c0, h0, a_dev, m, n_local, self.horizon, self.discount,
+                                       self._reward_spec, cand_offset=lo, c_next=c1, h_next=h1)
+            if keys is not None:
+                self._hid_next = (c1, h1)
+                return keys.view(np.int64)
+        raise RuntimeError("recurrent rollout launch failed twice")
+
     def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
         native = self.dynamics_model.planner_model()
         m = len(observations)

@@ -572,3 +572,44 @@ def test_gpu_rnn_unit_tile_split_is_bit_identical(units, m, n, h):
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
     assert np.array_equal(out[0][0], out[0][2]) and np.array_equal(out[0][1], out[0][3])     # chunks == one launch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell,units,m,n,h", [("lstm", (256,), 5, 500, 10), ("lstm", (256,), 1, 2000, 6),
+                                              ("lstm", (128,), 3, 77, 4), ("gru", (64,), 2, 90, 3),
+                                              ("lstm", (64, 32), 2, 50, 3)])
+def test_gpu_blocking_recurrent_plan_matches_the_plain_launches(cell, units, m, n, h):
+    """`l2a_lstm_plan_rs_sync` (observations from host-mapped staging, keys through the mailbox, the controller's state
+    advanced in stream order with the winning first actions) against `l2a_lstm_plan_rs` + `l2a_lstm_predict` with the
+    action picked on the host: keys and next state bit for bit - MFMA kernel (mailbox, split and unsplit plans) and the
+    generic kernels (copy + synchronise), repeated calls, changing m."""
+    from learning_to_adapt_amd import _lib
+    case = dict(cases.CASES["hc_rnn_rs_u128_n40_h3"], units=units[0], m=m, n=n, h=h)
+    if cell != "lstm" or len(units) > 1:
+        case.update(cell_type=cell, hidden_sizes=list(units))
+    env, model = cases.product_rnn_model(case)
+    native = model.planner_model()
+    dev = native.device
+    U = native.units
+    rs = np.random.RandomState(U + n)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    c0, h0 = up(rs.randn(m, U)), up(np.tanh(rs.randn(m, U)))
+    for it in range(4):
+        obs = rs.randn(m, 20)
+        acts = up(rs.uniform(-1, 1, (h, m * n, 6)))
+        best = torch.zeros((m,), dtype=torch.int64, device=dev)
+        native.plan_rs(up(obs), c0, h0, acts, m, n, h, 0.97, env.reward_spec, cand_offset=11 * it, best_key=best)
+        want = best.cpu().numpy()
+        idx = np.array([_lib.key_decode(k)[1] for k in want]) - 11 * it
+        chosen = acts[0].reshape(m, n, 6)[torch.arange(m), torch.from_numpy(idx).to(dev)]
+        _, c_want, h_want = native.predict(up(obs), chosen.contiguous(), c0, h0)
+        c1 = torch.full((m, U), float("nan"), device=dev)
+        h1 = torch.full((m, U), float("nan"), device=dev)
+        got = native.plan_rs_sync(obs, c0, h0, acts, m, n, h, 0.97, env.reward_spec, cand_offset=11 * it, c_next=c1, h_next=h1)
+        assert got is not None and np.array_equal(got.view(np.int64), want), (it, got, want)
+        assert torch.equal(c1, c_want) and torch.equal(h1, h_want), it
+        keys_only = native.plan_rs_sync(obs, c0, h0, acts, m, n, h, 0.97, env.reward_spec, cand_offset=11 * it)
+        assert np.array_equal(keys_only, got)
+        c0, h0 = c1, h1
+    torch.cuda.synchronize()
+    _lib.Context.get(0).launch_status()

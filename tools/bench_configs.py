@@ -162,13 +162,15 @@ def main():
         ctrl = cases.product_rnn_controller(case, rng=mode)
         obs = np.random.RandomState(0).randn(5, 20)
         ctrl.reset(dones=[True] * 5)
-        ctrl.get_actions(obs)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(30):
+        np.random.seed(0)
+        for _ in range(10):         # steady state: the draw-ahead chain is running, buffers exist
             ctrl.get_actions(obs)
         torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / 30
+        t0 = time.perf_counter()
+        for _ in range(200):
+            ctrl.get_actions(obs)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 200
         print(json.dumps(dict(config="c6 ReBAL controller step end to end (plan + hidden-state advance), rng=" + mode,
                               ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1))), flush=True)
     # config 5: one CEM plan step (5 iterations x 4000 candidates) through the drop-in controller

@@ -16,10 +16,16 @@ import cases  # noqa: E402
 
 def main():
     case = cases.CASES[sys.argv[1] if len(sys.argv) > 1 else "c2_hc_rs_n2000_h30_e5"]
-    env, model = cases.product_model(case)
+    rnn = case["planner"].startswith("rnn")
+    env, model = cases.product_rnn_model(case) if rnn else cases.product_model(case)
     obs = np.random.RandomState(1).randn(case["m"], env.observation_space.shape[0])
     for mode, ahead in (("numpy", True), ("numpy", False), ("device", True)):
-        ctrl = cases.product_controller(case, model=model, env=env, rng=mode, draw_ahead=ahead)
+        if rnn:
+            ctrl = cases.product_rnn_controller(case, model=model, env=env, rng=mode)
+            ctrl.draw_ahead = ahead
+            ctrl.reset(dones=[True] * case["m"])
+        else:
+            ctrl = cases.product_controller(case, model=model, env=env, rng=mode, draw_ahead=ahead)
         acc = {}
 
         def wrap(obj, name, label):
@@ -35,7 +41,11 @@ def main():
         for _ in range(5):
             ctrl.get_actions(obs)
         native = model.planner_model()
-        wrap(native, "plan_rs_sync", "plan_rs_sync (launch + wait)")
+        if hasattr(native, "plan_rs_sync"):
+            wrap(native, "plan_rs_sync", "plan_rs_sync (launch + wait)")
+        if rnn:
+            wrap(ctrl, "_advance_hidden", "_advance_hidden")      # (wrapping `_rollout` would switch the blocking launch off)
+            wrap(ctrl, "_combine_keys", "_combine_keys (sync + read-back)")
         wrap(ctrl, "_plan_pipelined", "_plan_pipelined")
         wrap(ctrl, "_draw_rows", "_draw_rows")
         if ctrl._ahead is not None:
@@ -61,7 +71,7 @@ def main():
             return r
         fast_rng.cem_samples = timed_cs
         torch.cuda.synchronize()
-        K = 200 if case["planner"] == "rs" else 20
+        K = 200 if case["planner"].endswith("rs") else 20
         t0 = time.perf_counter()
         for _ in range(K):
             ctrl.get_actions(obs)
