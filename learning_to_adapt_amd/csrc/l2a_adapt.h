@@ -7,15 +7,18 @@
 // writes the adapted sets straight into the per-block model the planner launches on - raw layout AND MFMA fragment
 // order - so nothing is re-uploaded or re-packed.  2 L launches for L layers:
 //
-//   l2a_adapt_fwd_k (L) / l2a_adapt_bwd_k (L - 1) : the forward and backward pass, one launch per layer, every
-//                        launch spread over (64-unit slice, task) workgroups of 8 waves that each take an eighth of the
-//                        reduction - the first version ran one workgroup per task through all layers and was latency
-//                        bound at ~1 ms, no better than the 45 stock PyTorch launches it replaced.  Layer 0 reads x
-//                        itself (no transpose pass).  dZ_L = 2 (y_hat - y) / (rows * obs_dim),
-//                        dZ_l = (W_l dZ_{l+1}) * act'(A_l); layer inputs A_l and the dZ_l ([dim][16 rows]) live in a
-//                        scratch buffer.  The reduction loops fetch 8 weights per lane before the first FMA: the
-//                        unbatched loops were one exposed L2 round trip per k (rocprofv3: 58 us for a 512 x 512 layer
-//                        on 40 workgroups; the batched ones ~8 us)
+//   l2a_adapt_fwd0_k, l2a_adapt_fwd_k (L - 1), l2a_adapt_bwd_k (L - 1) : the forward and backward pass, one launch per
+//                        layer, every launch spread over (64-unit slice, task) workgroups of 8 waves that each take an
+//                        eighth of the reduction - the first version ran one workgroup per task through all layers and
+//                        was latency bound at ~1 ms, no better than the 45 stock PyTorch launches it replaced.  Layers
+//                        >= 1 run on the matrix core (16x16x4 fp32: units x rows x k), both operands coalesced vector
+//                        loads, 8 k-steps of operands in flight before the first MFMA; layer 0 (K = obs + act) is a
+//                        lane-per-unit FMA loop over the batch staged in LDS (it reads x itself: no transpose pass).
+//                        dZ_L = 2 (y_hat - y) / (rows * obs_dim), dZ_l = (W_l dZ_{l+1}) * act'(A_l); layer inputs A_l
+//                        and the dZ_l ([dim][16 rows]) live in a scratch buffer.  History (rocprofv3 dispatch trace,
+//                        tools/adapt_trace.sh): unbatched lane-per-unit loops, one exposed round trip per k: 58 us per
+//                        512 x 512 layer; batched loads + scalar loads for the activation rows: 19 us (the SGPR budget
+//                        keeps 5 of 8 row loads in flight); matrix core: see DESIGN.md 4.3
 //   l2a_adapt_update_k (1) : all layers at once, one workgroup per (layer, 256 output units, 16 input rows, task): each
 //                        thread keeps its unit's dZ row in registers and walks the input rows,
 //                        g = sum_r A_l[k][r] dZ_{l+1}[u][r], theta' = theta - lr g -> raw kernel, packed kernel;
@@ -54,91 +57,71 @@ __device__ __forceinline__ float l2a_act_grad_from_output(float o, int kind) {
     }
 }
 
-#define L2A_ACC16(acc, wt_, v0, v1, v2, v3)                                                   \
-    acc[0] = fmaf(wt_, v0.x, acc[0]);   acc[1] = fmaf(wt_, v0.y, acc[1]);                        \
-    acc[2] = fmaf(wt_, v0.z, acc[2]);   acc[3] = fmaf(wt_, v0.w, acc[3]);                        \
-    acc[4] = fmaf(wt_, v1.x, acc[4]);   acc[5] = fmaf(wt_, v1.y, acc[5]);                        \
-    acc[6] = fmaf(wt_, v1.z, acc[6]);   acc[7] = fmaf(wt_, v1.w, acc[7]);                        \
-    acc[8] = fmaf(wt_, v2.x, acc[8]);   acc[9] = fmaf(wt_, v2.y, acc[9]);                        \
-    acc[10] = fmaf(wt_, v2.z, acc[10]); acc[11] = fmaf(wt_, v2.w, acc[11]);                      \
-    acc[12] = fmaf(wt_, v3.x, acc[12]); acc[13] = fmaf(wt_, v3.y, acc[13]);                      \
-    acc[14] = fmaf(wt_, v3.z, acc[14]); acc[15] = fmaf(wt_, v3.w, acc[15]);
-
 #define L2A_AW 8        // waves per forward / backward workgroup (each takes 1 / 8 of the reduction)
-#define L2A_AB 8        // weights fetched per lane before the first FMA of a batch
+#define L2A_SB 8        // MFMA k-steps (of 4) whose operands are fetched before the first MFMA of a batch
 #define L2A_XS_MAX 128  // widest input layer whose batch is staged through LDS in the first forward launch
 
-// Forward through layer l for 64 output units of one task: grid (ceil(n_out / 64), m), 8 waves, wave w sums its
-// eighth of the k range (weights coalesced over the units), partials meet in LDS in a fixed order.  The last layer
-// writes dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.  Layer 0 takes its input rows from x.
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
+// Reduce the 8 waves' accumulators (4 unit tiles x f32x4 per lane) through LDS in a fixed order; wave 0 gets the sums.
+__device__ __forceinline__ void l2a_adapt_reduce(f32x4 (&acc)[4], float (&red)[L2A_AW - 1][64][L2A_AR + 1], int ks, int lane) {
+    if (ks > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[ks - 1][lane][4 * t + i] = acc[t][i];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int w = 0; w < L2A_AW - 1; ++w) acc[t][i] += red[w][lane][4 * t + i];
+    }
+}
+
+// First forward launch (layer 0, K = obs_dim + act_dim): 64 output units of one task per workgroup, lane = unit,
+// wave w sums its eighth of the k range.  A_0[k][r] = x[task][r][k] (zero beyond `rows`); x may live in host-mapped
+// memory (l2a_model_adapt_sgd_host): one coalesced pass brings it into LDS - a single bus round trip instead of one
+// per element - and workgroup 0 of the task publishes A_0 for the update pass.  grid (ceil(n_out / 64), m).
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptParams p) {
     __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
-    // the wave index as a scalar: the A_l rows below are then wave-uniform addresses -> scalar loads (a vector load of
-    // one 16-byte value for 64 lanes still moves 1 KiB through the L1: measured 44 us per 512 x 512 layer that way)
+    __shared__ float xs[L2A_XS_MAX * L2A_AR];
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.y;
-    const int k_in = p.dims[l], n_out = p.dims[l + 1];
+    const int k_in = p.dims[0], n_out = p.dims[1];
     const int u = blockIdx.x * 64 + lane;
     const bool live = u < n_out;
     float* sc = p.scratch + (long long)task * p.scratch_stride;
-    const float* A = sc + p.a_off[l];
-    const float* W = p.w[l] + (live ? u : 0);
+    const float* W = p.w[0] + (live ? u : 0);           // dead lanes read unit 0's column and never store
     const int chunk = (k_in + L2A_AW - 1) / L2A_AW;
     const int k0 = ks * chunk, k1 = (k0 + chunk < k_in) ? k0 + chunk : k_in;
+    const float* x = p.x + (long long)task * p.rows * k_in;
+    const bool staged = k_in <= L2A_XS_MAX;
+    if (staged) {
+        for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) {      // x in its own order: coalesced
+            const int r = i / k_in, kk = i - r * k_in;
+            xs[kk * L2A_AR + r] = (r < p.rows) ? x[i] : 0.0f;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) sc[p.a_off[0] + i] = xs[i];
+    }
     float acc[L2A_AR];
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) acc[r] = 0.0f;
-    if (l == 0) {
-        // A_0[k][r] = x[task][r][k] (zero beyond `rows`).  x may live in host-mapped memory (l2a_model_adapt_sgd_host):
-        // one coalesced pass brings it into LDS - a single bus round trip instead of one per element - and workgroup 0
-        // of the task publishes A_0 for the update pass.
-        __shared__ float xs[L2A_XS_MAX * L2A_AR];
-        const float* x = p.x + (long long)task * p.rows * k_in;
-        const bool staged = k_in <= L2A_XS_MAX;
-        if (staged) {
-            for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) {      // x in its own order: coalesced
-                const int r = i / k_in, kk = i - r * k_in;
-                xs[kk * L2A_AR + r] = (r < p.rows) ? x[i] : 0.0f;
+    for (int k = k0; k < k1; ++k) {
+        const float w = W[(long long)k * n_out];
+#pragma unroll
+        for (int r = 0; r < L2A_AR; ++r) {
+            float a;
+            if (staged) {
+                a = xs[k * L2A_AR + r];
+            } else {
+                a = (r < p.rows) ? x[r * k_in + k] : 0.0f;
+                if (blockIdx.x == 0 && lane == r) sc[p.a_off[0] + k * L2A_AR + r] = a;
             }
-            __syncthreads();
-            if (blockIdx.x == 0)
-                for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) sc[p.a_off[0] + i] = xs[i];
-        }
-        for (int k = k0; k < k1; ++k) {
-            const float w = W[(long long)k * n_out];          // dead lanes read unit 0's column and never store
-#pragma unroll
-            for (int r = 0; r < L2A_AR; ++r) {
-                float a;
-                if (staged) {
-                    a = xs[k * L2A_AR + r];
-                } else {
-                    a = (r < p.rows) ? x[r * k_in + k] : 0.0f;
-                    if (blockIdx.x == 0 && lane == r) sc[p.a_off[0] + k * L2A_AR + r] = a;
-                }
-                acc[r] = fmaf(w, a, acc[r]);
-            }
-        }
-    } else {
-        int k = k0;
-        for (; k + L2A_AB <= k1; k += L2A_AB) {
-            float w[L2A_AB];
-            float4 a[L2A_AB][4];
-#pragma unroll
-            for (int j = 0; j < L2A_AB; ++j) w[j] = W[(long long)(k + j) * n_out];
-#pragma unroll
-            for (int j = 0; j < L2A_AB; ++j) {
-                const float4* ap = reinterpret_cast<const float4*>(A + (k + j) * L2A_AR);
-                a[j][0] = ap[0]; a[j][1] = ap[1]; a[j][2] = ap[2]; a[j][3] = ap[3];
-            }
-            __builtin_amdgcn_sched_barrier(0);      // all 40 loads of the batch in flight before the first FMA
-#pragma unroll
-            for (int j = 0; j < L2A_AB; ++j) { L2A_ACC16(acc, w[j], a[j][0], a[j][1], a[j][2], a[j][3]) }
-        }
-        for (; k < k1; ++k) {
-            const float w = W[(long long)k * n_out];
-            const float4* ap = reinterpret_cast<const float4*>(A + k * L2A_AR);
-            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
-            L2A_ACC16(acc, w, a0, a1, a2, a3)
+            acc[r] = fmaf(w, a, acc[r]);
         }
     }
     if (ks > 0) {
@@ -147,89 +130,136 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptPar
     }
     __syncthreads();
     if (ks != 0 || !live) return;
-    const float bias = p.b[l][u];
-    const bool last = (l == p.n_layers - 1);
-    const float scale = 2.0f / (float)(p.rows * n_out);
-    float* dst = sc + (last ? p.z_off[l + 1] : p.a_off[l + 1]) + u * L2A_AR;
-    float yv[L2A_AR];
-    if (last) {     // all target reads in flight together (y may live in host-mapped memory: one bus round trip, not 16)
-#pragma unroll
-        for (int r = 0; r < L2A_AR; ++r) yv[r] = p.y[((long long)task * p.rows + (r < p.rows ? r : 0)) * n_out + u];
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    const float bias = p.b[0][u];
+    float* dst = sc + p.a_off[1] + u * L2A_AR;
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) {
         float v = acc[r];
 #pragma unroll
         for (int w = 0; w < L2A_AW - 1; ++w) v += red[w][lane][r];
-        v += bias;
-        if (last) v = (r < p.rows) ? scale * (v - yv[r]) : 0.0f;
-        else v = l2a_act1(v, p.hidden_act);
-        dst[r] = v;
+        dst[r] = l2a_act1(v + bias, p.hidden_act);
     }
 }
 
-// dZ_l = (W_l dZ_{l+1}) * act'(A_l) for 64 input units k of layer l (1 <= l < L): grid (ceil(k_in / 64), m),
-// wave w sums its eighth of the u range.  Each lane walks its own weight row, 8 consecutive weights (two 16-byte
-// loads when the row stride allows) per batch.
+// Forward through layer l >= 1 for 64 output units of one task on the matrix core: D[unit][row] += W^T[unit][k] A_l[k][row]
+// as v_mfma_f32_16x16x4_f32 (4 unit tiles per wave; lane (i, q) supplies W[k + q][u0 + 16 t + i] and A_l[k + q][i] - the
+// activation rows are one coalesced 256-byte load per k-step).  The 8 waves split the k-steps; operands of 8 k-steps are
+// fetched before the first MFMA; partial tiles meet in LDS in a fixed order.  The last layer writes
+// dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.  grid (ceil(n_out / 64), m).
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
+    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
+    const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.y;
+    const int k_in = p.dims[l], n_out = p.dims[l + 1];
+    const int u0 = blockIdx.x * 64;
+    float* sc = p.scratch + (long long)task * p.scratch_stride;
+    const float* A = sc + p.a_off[l];
+    const float* W = p.w[l];
+    int ucol[4];
+    bool uok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int u = u0 + 16 * t + i16;
+        uok[t] = u < n_out;
+        ucol[t] = uok[t] ? u : 0;
+    }
+    const int steps = (k_in + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
+    const int s0 = ks * per < steps ? ks * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; s += L2A_SB) {
+        float a[L2A_SB][4], b[L2A_SB];
+#pragma unroll
+        for (int j = 0; j < L2A_SB; ++j) {
+            const int k = 4 * (s + j) + q;
+            const bool ok = (s + j < s1) && (k < k_in);
+            const int kk = ok ? k : 0;
+            b[j] = A[kk * L2A_AR + i16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[j][t] = W[(long long)kk * n_out + ucol[t]];
+            if (!ok) b[j] = 0.0f;           // a zero row annihilates whatever the clamped weight loads returned
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all 40 loads of the batch in flight before the first MFMA
+#pragma unroll
+        for (int j = 0; j < L2A_SB; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(uok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
+    }
+    l2a_adapt_reduce(acc, red, ks, lane);
+    if (ks != 0) return;
+    const bool last = (l == p.n_layers - 1);
+    const float scale = 2.0f / (float)(p.rows * n_out);
+    float* dst = sc + (last ? p.z_off[l + 1] : p.a_off[l + 1]);
+    const int r = i16;                      // D fragment: lane (row r, q) holds units u0 + 16 t + 4 q + 0..3
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = u0 + 16 * t + 4 * q + i;
+            if (u >= n_out) continue;
+            float v = acc[t][i] + p.b[l][u];
+            if (last) v = (r < p.rows) ? scale * (v - p.y[((long long)task * p.rows + r) * n_out + u]) : 0.0f;
+            else v = l2a_act1(v, p.hidden_act);
+            dst[u * L2A_AR + r] = v;
+        }
+}
+
+// dZ_l = (W_l dZ_{l+1}) * act'(A_l) for 64 input units k of layer l (1 <= l < L), same scheme: D[k][row] += W[k][u] dZ[u][row],
+// lane (i, q) supplies W[k0 + 16 t + i][u + q] (16 weight rows x 16 bytes per load; a row's line is reused by the next 7
+// u-steps) and dZ_{l+1}[u + q][i]; the waves split the u-steps.  grid (ceil(k_in / 64), m).
 __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwd_k(const L2AAdaptParams p, int l) {
     __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
     const int lane = threadIdx.x & 63, us = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
     const int task = blockIdx.y;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
-    const int k = blockIdx.x * 64 + lane;
-    const bool live = k < k_in;
+    const int k0 = blockIdx.x * 64;
     float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float* Z = sc + p.z_off[l + 1];
-    const float* wrow = p.w[l] + (long long)(live ? k : 0) * n_out;
-    int chunk = (n_out + L2A_AW - 1) / L2A_AW;
-    chunk = (chunk + L2A_AB - 1) / L2A_AB * L2A_AB;           // batches start on multiples of 8
-    const int u0 = us * chunk < n_out ? us * chunk : n_out, u1 = (u0 + chunk < n_out) ? u0 + chunk : n_out;
-    const bool vec = (n_out % 4) == 0;                          // rows are 16-byte aligned
-    float acc[L2A_AR];
+    const float* wrow[4];
+    bool kok[4];
 #pragma unroll
-    for (int r = 0; r < L2A_AR; ++r) acc[r] = 0.0f;
-    int u = u0;
-    for (; u + L2A_AB <= u1; u += L2A_AB) {
-        float w[L2A_AB];
-        float4 z[L2A_AB][4];
-        if (vec) {
-            const float4 wa = *reinterpret_cast<const float4*>(wrow + u), wb = *reinterpret_cast<const float4*>(wrow + u + 4);
-            w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w; w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
-        } else {
+    for (int t = 0; t < 4; ++t) {
+        const int k = k0 + 16 * t + i16;
+        kok[t] = k < k_in;
+        wrow[t] = p.w[l] + (long long)(kok[t] ? k : 0) * n_out;
+    }
+    const int steps = (n_out + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
+    const int s0 = us * per < steps ? us * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
+    f32x4 acc[4];
 #pragma unroll
-            for (int j = 0; j < L2A_AB; ++j) w[j] = wrow[u + j];
-        }
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; s += L2A_SB) {
+        float a[L2A_SB][4], b[L2A_SB];
 #pragma unroll
-        for (int j = 0; j < L2A_AB; ++j) {
-            const float4* zp = reinterpret_cast<const float4*>(Z + (u + j) * L2A_AR);
-            z[j][0] = zp[0]; z[j][1] = zp[1]; z[j][2] = zp[2]; z[j][3] = zp[3];
+        for (int j = 0; j < L2A_SB; ++j) {
+            const int u = 4 * (s + j) + q;
+            const bool ok = (s + j < s1) && (u < n_out);
+            const int uu = ok ? u : 0;
+            b[j] = Z[uu * L2A_AR + i16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[j][t] = wrow[t][uu];
+            if (!ok) b[j] = 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < L2A_AB; ++j) { L2A_ACC16(acc, w[j], z[j][0], z[j][1], z[j][2], z[j][3]) }
-    }
-    for (; u < u1; ++u) {
-        const float w = wrow[u];
-        const float4* zp = reinterpret_cast<const float4*>(Z + u * L2A_AR);
-        const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
-        L2A_ACC16(acc, w, z0, z1, z2, z3)
-    }
-    if (us > 0) {
+        for (int j = 0; j < L2A_SB; ++j)
 #pragma unroll
-        for (int r = 0; r < L2A_AR; ++r) red[us - 1][lane][r] = acc[r];
+            for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
     }
-    __syncthreads();
-    if (us != 0 || !live) return;
-    const float* A = sc + p.a_off[l] + k * L2A_AR;
-    float* dst = sc + p.z_off[l] + k * L2A_AR;
+    l2a_adapt_reduce(acc, red, us, lane);
+    if (us != 0) return;
+    const int r = i16;
 #pragma unroll
-    for (int r = 0; r < L2A_AR; ++r) {
-        float v = acc[r];
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int w = 0; w < L2A_AW - 1; ++w) v += red[w][lane][r];
-        dst[r] = v * l2a_act_grad_from_output(A[r], p.hidden_act);
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 16 * t + 4 * q + i;
+            if (k >= k_in) continue;
+            sc[p.z_off[l] + k * L2A_AR + r] = acc[t][i] * l2a_act_grad_from_output(sc[p.a_off[l] + k * L2A_AR + r], p.hidden_act);
+        }
 }
 
 // Where the adapted sets go: the per-block model's weight block (raw reference layout + MFMA fragment order), and

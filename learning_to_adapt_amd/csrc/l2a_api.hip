@@ -580,7 +580,8 @@ int adapt_enqueue(l2a_model* md, const L2AAdaptParams& ap, int m, float lr, hipS
             else d.pk[l] = md->pk_wout;
         }
     }
-    for (int l = 0; l < L; ++l)
+    hipLaunchKernelGGL(l2a_adapt_fwd0_k, dim3((unsigned)((ap.dims[1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0, stream, ap);
+    for (int l = 1; l < L; ++l)
         hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3((unsigned)((ap.dims[l + 1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
                            stream, ap, l);
     for (int l = L - 1; l >= 1; --l)
