@@ -790,7 +790,8 @@ int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tk, int m, bool published,
         if (m >= ctx->ring_dirty[tk.slot ^ 1]) ctx->ring_dirty[tk.slot ^ 1] = 0;   // zeroed by this launch's last tile
         // Sleep through most of the expected duration, then poll the mailbox word (host-mapped memory: no copy,
         // no hipStreamSynchronize wake-up latency).
-        if (ctx->sync_ema_us > 400.0) usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
+        static const int sleep_mode = [] { const char* e = std::getenv("L2A_SYNC_SLEEP"); return e ? std::atoi(e) : 1; }();
+        if (sleep_mode && ctx->sync_ema_us > 400.0) usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
         const volatile unsigned long long* seqp = &mh->seq;
         unsigned long long spins = 0;
         while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != tk.seq) {

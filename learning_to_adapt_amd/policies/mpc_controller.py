@@ -643,17 +643,24 @@ class MPCController(Policy, Serializable):
                     seq = np.transpose(a_st.reshape(n, m, D).transpose(1, 0, 2).reshape((m * n, h, act_dim)), (1, 0, 2))
                 seq_loc = seq.reshape(h, m, n, act_dim)[:, :, lo:hi, :].astype(np.float32)
                 a_dev = self._upload(seq_loc.reshape(h, m * n_local, act_dim))
-            _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+            if n_local > 0:
+                _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+            else:               # more ranks than candidates: an empty shard still joins the collective
+                rets = torch.zeros((m, 0), dtype=torch.float32, device=self._device())
             if world > 1:
-                if any(self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] != n_local
-                       for r in range(world)):
-                    raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
-                self._sync()
-                if self._check_status() is False:
-                    _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
-                parts = [torch.empty_like(rets) for _ in range(world)]
-                torch.distributed.all_gather(parts, rets)
-                rets = torch.cat(parts, dim=1)
+                if n_local > 0:
+                    self._sync()
+                    if self._check_status() is False:
+                        _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+                # all-gather needs equal shapes: shards are padded to the widest one (they differ by at most one
+                # candidate) and cut back to their own width afterwards
+                widths = [self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] for r in range(world)]
+                wmax = max(widths)
+                mine = rets if n_local == wmax else torch.cat(
+                    [rets, torch.zeros((m, wmax - n_local), dtype=rets.dtype, device=rets.device)], dim=1)
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                torch.distributed.all_gather(parts, mine.contiguous())
+                rets = torch.cat([part[:, :w] for part, w in zip(parts, widths)], dim=1)
             returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
             if world == 1 and self._check_status() is False:
                 _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
@@ -764,8 +771,8 @@ class MPCController(Policy, Serializable):
         self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         n_local = hi - lo
-        if world > 1 and n % world != 0:
-            raise _lib.L2AError("CEM sharding needs n_candidates divisible by the world size")
+        widths = [self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] for r in range(world)]
+        wmax = max(widths)
         rets = None
         cand = None
         obs_dev = self._upload_obs(observations)             # once per plan step, not once per CEM iteration
@@ -780,11 +787,16 @@ class MPCController(Policy, Serializable):
             else:
                 cand = a_clip.permute(1, 0, 2).contiguous()                                       # [m, n, D]
             seq = cand[:, lo:hi, :].reshape(m * n_local, h, act_dim).permute(1, 0, 2).contiguous()
-            _, r_loc = self._rollout(observations, seq, n_local, lo, want_returns=True, obs_dev=obs_dev)
-            if world > 1:
-                parts = [torch.empty_like(r_loc) for _ in range(world)]
-                torch.distributed.all_gather(parts, r_loc)
-                rets = torch.cat(parts, dim=1)
+            if n_local > 0:
+                _, r_loc = self._rollout(observations, seq, n_local, lo, want_returns=True, obs_dev=obs_dev)
+            else:
+                r_loc = torch.zeros((m, 0), dtype=torch.float32, device=dev)
+            if world > 1:       # shards differ by at most one candidate: pad to the widest for the all-gather
+                mine = r_loc if n_local == wmax else torch.cat(
+                    [r_loc, torch.zeros((m, wmax - n_local), dtype=r_loc.dtype, device=dev)], dim=1)
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                torch.distributed.all_gather(parts, mine.contiguous())
+                rets = torch.cat([part[:, :w] for part, w in zip(parts, widths)], dim=1)
             else:
                 rets = r_loc
             if reference:

@@ -60,6 +60,24 @@ def test_two_rank_plan_equals_single_process_plan(cid, tmp_path):
         assert outs[0]["shard"][1] == outs[1]["shard"][0]          # contiguous, disjoint shards
 
 
+@pytest.mark.parametrize("cid,world", [("hc_rs_ragged_n37_h3_s0", 8), ("hc_rs_n1_h1_s0", 3), ("hc_cem_m2_n100_h4_s0", 8)])
+def test_many_rank_plan_equals_single_process_plan(cid, world, tmp_path):
+    """The driver's N = 8 shape on gloo: 8 ranks with uneven shards (37 = 5 + 5 + 5 + 5 + 5 + 4 + 4 + 4 candidates), more
+    ranks than candidates (some ranks hold an empty shard and still join the collective), CEM with its all-gather."""
+    mp.spawn(_worker, args=(world, _free_port(), cid, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import cases
+    gold = cases.load_golden(cid)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for o in outs:
+        assert np.array_equal(o["best"], gold["best"])
+        np.testing.assert_array_equal(o["actions"], gold["chosen"])
+    if outs[0]["shard"][0] >= 0:
+        edges = [int(outs[0]["shard"][0])] + [int(o["shard"][1]) for o in outs]
+        assert edges[0] == 0 and edges[-1] == cases.split_id(cid)[0]["n"]
+        assert all(int(o["shard"][0]) == e for o, e in zip(outs, edges[:-1]))      # contiguous, disjoint, complete
+
+
 def _worker_device_rng(rank, world, port, out_dir):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Copy the judged artefacts of one GPU round (gpurun_out/<tag>/, scratch) into profiles/ (tracked).
+#   bash tools/collect_profiles.sh r02
+TAG=${1:-r02}
+SRC=gpurun_out/$TAG
+DST=profiles
+cp $SRC/bench.json $DST/${TAG}_bench.json
+cp $SRC/bench_share2.json $DST/${TAG}_bench_share2_gloo.json
+cp $SRC/configs.jsonl $DST/${TAG}_configs.jsonl
+cp $SRC/host_cpu.txt $DST/${TAG}_host_cpu.txt
+cp $SRC/pmc_summary.txt $DST/${TAG}_pmc_summary.txt
+cp $SRC/probe_c2.jsonl $DST/${TAG}_probe_c2.jsonl
+cp $SRC/probe_c5.jsonl $DST/${TAG}_probe_c5.jsonl
+cp $SRC/rng.jsonl $DST/${TAG}_rng.jsonl
+cp $SRC/smoke.log $DST/${TAG}_smoke.log
+grep -v amdgpu.ids $SRC/timeline.txt > $DST/${TAG}_timeline.txt
+grep -v amdgpu.ids $SRC/timeline_lstm.txt > $DST/${TAG}_timeline_lstm.txt
+cp $SRC/parity_report.txt $DST/${TAG}_parity_report.txt
+cp $SRC/probe_adapt.json $DST/${TAG}_probe_adapt.json
+grep -v amdgpu.ids $SRC/adapt_trace.txt > $DST/${TAG}_adapt_trace.txt
+tail -12 $SRC/pytest_gpu.log | grep -v amdgpu.ids > $DST/${TAG}_pytest_gpu_tail.txt
+# rocprofv3 --stats: the rollout kernels only (torch's elementwise kernels have kilobyte-long names)
+f=$(find $SRC/prof -name "*kernel_stats.csv" | head -1)
+(head -1 "$f"; grep -E '^"(void )?l2a_' "$f") > $DST/${TAG}_kernel_stats.csv
+python tools/pmc_traffic.py $SRC > /dev/null 2>&1 || true
+ls -la $DST | grep ${TAG}_ | awk '{print $5, $9}'
