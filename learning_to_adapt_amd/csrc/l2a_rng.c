@@ -688,6 +688,7 @@ typedef struct {
     const double* z; long long rows, row_base; int h, act_dim; const double* mean; const double* std; int m;
     const double* low; const double* high; double* a_out; double* clip_out; float* seq;
     long long n, sel_lo, sel_hi; int env_major, use_clipped;
+    int t0, t1;         /* horizon steps [t0, t1) of every row (the rollout can be pipelined along the horizon) */
 } cem_job;
 
 L2A_CLONES static void cem_slice(void* argp, int tid, int nt) {
@@ -702,7 +703,8 @@ L2A_CLONES static void cem_slice(void* argp, int tid, int nt) {
         const double* zr = j->z + r * D;
         const double* mu = j->mean + (long long)env * D;
         const double* sd = j->std + (long long)env * D;
-        for (int t = 0; t < j->h; ++t)
+        const int d0 = j->t0 * ad, d1 = j->t1 * ad;
+        for (int t = j->t0; t < j->t1; ++t)
             for (int k = 0; k < ad; ++k) {
                 const int d = t * ad + k;
                 const double zs = zr[d] * sd[d];
@@ -712,15 +714,15 @@ L2A_CLONES static void cem_slice(void* argp, int tid, int nt) {
                 if (c > j->high[k]) c = j->high[k];
                 av[d] = v; cv[d] = c;
             }
-        memcpy(j->a_out + r * D, av, sizeof(double) * (size_t)D);
-        if (j->clip_out) memcpy(j->clip_out + r * D, cv, sizeof(double) * (size_t)D);
+        memcpy(j->a_out + r * D + d0, av + d0, sizeof(double) * (size_t)(d1 - d0));
+        if (j->clip_out) memcpy(j->clip_out + r * D + d0, cv + d0, sizeof(double) * (size_t)(d1 - d0));
         if (j->seq) {
             const long long prow = j->env_major ? (long long)env * j->n + g / j->m : g;
             const long long cand = prow % j->n, blk = prow / j->n;
             if (cand >= j->sel_lo && cand < j->sel_hi) {
                 const long long srow = blk * nsel + (cand - j->sel_lo);
                 const double* src = j->use_clipped ? cv : av;
-                for (int t = 0; t < j->h; ++t)
+                for (int t = j->t0; t < j->t1; ++t)
                     for (int k = 0; k < ad; ++k)
                         j->seq[((long long)t * seq_rows + srow) * ad + k] = (float)src[t * ad + k];
             }
@@ -728,18 +730,29 @@ L2A_CLONES static void cem_slice(void* argp, int tid, int nt) {
     }
 }
 
+/* Horizon steps [t0, t1) only: columns t0 * act_dim .. t1 * act_dim - 1 of a_out / clip_out and steps t0 .. t1 - 1 of
+ * seq_f32 (whose layout stays [h, m * nsel, act_dim]) - one slice of the rollout's horizon pipeline. */
+int l2a_cem_samples_steps(const double* z, long long rows, long long row_base, int h, int act_dim, const double* mean,
+                          const double* std, int m, const double* low, const double* high, double* a_out,
+                          double* clip_out, float* seq_f32, long long n, long long sel_lo, long long sel_hi,
+                          int env_major, int use_clipped, int t0, int t1, int nthreads) {
+    if (!z || !mean || !std || !low || !high || !a_out || rows < 0 || row_base < 0 || h < 1 || act_dim < 1 || m < 1)
+        return -1;
+    if (h * act_dim > 4096 || n < 1 || sel_lo < 0 || sel_hi < sel_lo || sel_hi > n || row_base + rows > n * m) return -1;
+    if (t0 < 0 || t1 < t0 || t1 > h) return -1;
+    cem_job j = {z, rows, row_base, h, act_dim, mean, std, m, low, high, a_out, clip_out,
+                 (sel_hi > sel_lo) ? seq_f32 : NULL, n, sel_lo, sel_hi, env_major, use_clipped, t0, t1};
+    if (rows * (long long)(t1 - t0) * act_dim < 65536) nthreads = 1;
+    if (rows > 0 && t1 > t0) run_parallel(cem_slice, &j, nthreads);
+    return 0;
+}
+
 int l2a_cem_samples(const double* z, long long rows, long long row_base, int h, int act_dim, const double* mean,
                     const double* std, int m, const double* low, const double* high, double* a_out,
                     double* clip_out, float* seq_f32, long long n, long long sel_lo, long long sel_hi,
                     int env_major, int use_clipped, int nthreads) {
-    if (!z || !mean || !std || !low || !high || !a_out || rows < 0 || row_base < 0 || h < 1 || act_dim < 1 || m < 1)
-        return -1;
-    if (h * act_dim > 4096 || n < 1 || sel_lo < 0 || sel_hi < sel_lo || sel_hi > n || row_base + rows > n * m) return -1;
-    cem_job j = {z, rows, row_base, h, act_dim, mean, std, m, low, high, a_out, clip_out,
-                 (sel_hi > sel_lo) ? seq_f32 : NULL, n, sel_lo, sel_hi, env_major, use_clipped};
-    if (rows * h * act_dim < 65536) nthreads = 1;
-    if (rows > 0) run_parallel(cem_slice, &j, nthreads);
-    return 0;
+    return l2a_cem_samples_steps(z, rows, row_base, h, act_dim, mean, std, m, low, high, a_out, clip_out, seq_f32, n,
+                                 sel_lo, sel_hi, env_major, use_clipped, 0, h, nthreads);
 }
 
 /* ---- direct access to the global generator's words ------------------------------------------------------------
@@ -797,4 +810,4 @@ int l2a_mt19937_skip_mode(uint32_t* key, int* pos, long long words, int use_jump
     return 0;
 }
 
-int l2a_rng_version(void) { return 4; }
+int l2a_rng_version(void) { return 5; }

@@ -94,6 +94,7 @@ class MPCController(Policy, Serializable):
         self._reward_spec = None if use_reward_model else reward_spec_for_env(env)
         self._bufs = {}
         self._ahead = None          # DrawAhead chain (parity mode), created on first use
+        self._cem_first_chunk = 4   # horizon steps of the first chunk of a pipelined CEM rollout (0: equal chunks)
         self._ranks_checked = False
         self.last_plan = None       # diagnostics of the latest fused plan (returns, keys, ...)
 
@@ -689,47 +690,60 @@ class MPCController(Policy, Serializable):
             std = np.std(elites, axis=1)
         return mean, std
 
-    def _cem_chunks(self, n):
-        """Candidate chunks of a pipelined CEM iteration: every chunk must still fill the chip on its own (about
-        2000 candidates = 125 tiles x 2 workgroups), otherwise the launches - which run back to back - each take as
-        long as a full one (measured: 5 chunks of 800 = 7.7 ms against 2.8 ms for the 4000 in one launch)."""
-        return max(1, min(self.pipeline_chunks, n // 2000))
+    def _cem_chunks(self, h):
+        """Horizon chunks of a pipelined CEM iteration: two or three (measured on config 5: 1 chunk 16.8 ms per plan
+        step, 2 or 3 chunks 16.35, 5 chunks 16.5; cutting the candidates instead: 18.1)."""
+        return max(1, min(self.pipeline_chunks, 3, h // 4))
 
     def _can_pipeline_cem(self, m, world, n):
-        """Single env, single rank: rows are candidates - the host prepares chunk k + 1 (``a = mean + z * std``,
-        clip, cast, transpose) while the GPU rolls out chunk k."""
-        return (m == 1 and world == 1 and self._cem_chunks(n) > 1
+        """Single env, single rank: the host prepares horizon chunk k + 1 (``a = mean + z * std``, clip, cast,
+        transpose of its steps) while the GPU rolls out chunk k."""
+        return (m == 1 and world == 1 and self._cem_chunks(self.horizon) > 1
                 and hasattr(self.dynamics_model.planner_model(), "plan_rs_chunk"))
 
     def _cem_rollout_pipelined(self, observations, z, a, a_st, mean2, std2, reference, relaunch=False):
-        """One CEM iteration's rollout for m == 1, pipelined over candidate chunks: ``a = mean + z * std``, the
-        clip, the fp32 cast and the ``[h, rows, act]`` transposition of chunk k + 1 run on the host
-        (``l2a_cem_samples``, threaded) while the GPU rolls out chunk k into its slice of the returns.
-        Fills ``a`` / ``a_st`` ``[n, D]``; returns ``returns [1, n]`` float64."""
+        """One CEM iteration's rollout for m == 1, pipelined ALONG THE HORIZON: ``a = mean + z * std``, the clip, the
+        fp32 cast and the ``[h, rows, act]`` transposition are elementwise in the horizon step, so the steps of chunk
+        k + 1 are prepared on the host (``l2a_cem_samples_steps``, threaded) and uploaded while the GPU rolls out chunk k
+        of ALL candidates (``l2a_plan_rs_chunk`` hands state and returns from launch to launch, bit-identical to one
+        launch).  Every launch keeps the full candidate count - the chip stays as full as with a single launch
+        (cutting the candidates instead made two half-empty launches of one full one: 2 x 1.52 ms against 2.77 ms for
+        config 5's 4000).  Fills ``a`` / ``a_st`` ``[n, D]``; returns ``returns [1, n]`` float64."""
         native = self.dynamics_model.planner_model()
         dev = native.device
         n, h = self.n_candidates, self.horizon
         act_dim = self.action_space.shape[0]
         self._check_blocks(1)
-        K = self._cem_chunks(n)
-        bounds = [(n * c) // K for c in range(K + 1)]
+        K = self._cem_chunks(h)
+        # a short first chunk - its samples are the only ones the GPU has to wait for - but long enough for the next
+        # chunk's samples to be ready when it ends (host: ~15-30 us per step of 4000 candidates, GPU: ~90 us)
+        h0 = max(2, min(self._cem_first_chunk, h // K)) if self._cem_first_chunk else h // K
+        bounds = [0] + [h0 + ((h - h0) * c) // (K - 1) for c in range(K)]
         obs0 = self._upload_obs(observations)
-        rets = self._buf("rets", (1, n), torch.float32, dev)
         low, high = self.action_space.low, self.action_space.high
+        pin = self._pinned("cem_pin_h", (h, n, act_dim))
+        a_dev = self._buf("cem_dev_h", (h, n, act_dim), torch.float32, dev)
+        rets = [self._buf("cem_ret%d" % i, (1, n), torch.float32, dev) for i in (0, 1)]
+        state = [self._buf("cem_state%d" % i, (n, native.obs_dim), torch.float32, dev) for i in (0, 1)]
         for c in range(K):
-            j0, j1 = bounds[c], bounds[c + 1]
-            nc = j1 - j0
-            shape = (h, nc, act_dim)
+            t0, t1 = bounds[c], bounds[c + 1]
             if not relaunch:
-                pin = self._pinned(("cem_pin", c), shape)
-                fast_rng.cem_samples(z[j0:j1], j0, h, act_dim, mean2, std2, low, high, a[j0:j1], a_st[j0:j1],
-                                     pin.numpy(), n, j0, j1, env_major=False, use_clipped=not reference)
-                a_dev = self._to_device(pin, ("cem_dev", c))
-            else:
-                a_dev = self._bufs[("cem_dev", c)]
-            native.plan_rs(obs0, a_dev, 1, nc, h, self.discount, self._reward_spec, cand_offset=j0,
-                           returns_out=rets[0, j0:j1])
-        returns = rets.cpu().numpy().astype(np.float64).reshape(1, n)
+                fast_rng.cem_samples(z, 0, h, act_dim, mean2, std2, low, high, a, a_st, pin.numpy(), n, 0, n,
+                                     env_major=False, use_clipped=not reference, steps=(t0, t1))
+                side = self._bufs.get("side_stream")
+                if side is None:
+                    side = self._bufs["side_stream"] = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(side):           # the upload of chunk k + 1 overlaps the rollout of chunk k
+                    a_dev[t0:t1].copy_(pin[t0:t1], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                torch.cuda.current_stream(dev).wait_event(ev)
+            last = (c == K - 1)
+            src, dst = (c + 1) % 2, c % 2
+            native.plan_rs_chunk(obs0 if c == 0 else state[src], c > 0, a_dev[t0:t1], 1, n, t1 - t0, t0, self.discount,
+                                 self._reward_spec, cand_offset=0, returns_in=rets[src] if c > 0 else None,
+                                 returns_out=rets[dst], state_out=None if last else state[dst])
+        returns = rets[(K - 1) % 2].cpu().numpy().astype(np.float64).reshape(1, n)
         if self._check_status() is False:
             if relaunch:
                 raise _lib.L2AError("rollout launch failed twice")

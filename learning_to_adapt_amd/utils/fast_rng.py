@@ -56,7 +56,7 @@ def _load():
             c = ctypes
             vp, ll, i32 = c.c_void_p, c.c_longlong, c.c_int
             ip = c.POINTER(i32)
-            if lib.l2a_rng_version() < 4:
+            if lib.l2a_rng_version() < 5:
                 return None
             lib.l2a_mt19937_fill_double_mt.argtypes = [vp, ip, vp, ll, i32]
             lib.l2a_mt19937_fill_double_mt.restype = i32
@@ -71,6 +71,9 @@ def _load():
             lib.l2a_cem_samples.argtypes = [vp, ll, ll, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, ll, ll, ll, i32, i32,
                                             i32]
             lib.l2a_cem_samples.restype = i32
+            lib.l2a_cem_samples_steps.argtypes = [vp, ll, ll, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, ll, ll, ll, i32,
+                                                  i32, i32, i32, i32]
+            lib.l2a_cem_samples_steps.restype = i32
             lib.l2a_mt19937_state_equal.argtypes = [vp, vp, i32]
             lib.l2a_mt19937_state_equal.restype = i32
             lib.l2a_mt19937_state_store.argtypes = [vp, vp, i32]
@@ -298,9 +301,10 @@ def standard_normal(shape):
 
 
 def cem_samples(z, row_base, h, act_dim, mean, std, low, high, a_out, clip_out, seq_f32, n, sel_lo, sel_hi,
-                env_major, use_clipped):
+                env_major, use_clipped, steps=None, nthreads=None):
     """One CEM iteration's ``a = mean + z * std``, ``clip`` and the fp32 ``[h, m * nsel, act_dim]`` tensor the
-    rollout reads, in one threaded pass (``l2a_cem_samples``).  Returns False when the helper is unavailable."""
+    rollout reads, in one threaded pass (``l2a_cem_samples``).  ``steps=(t0, t1)``: only those horizon steps (their
+    columns of ``a_out`` / ``clip_out``, their slices of ``seq_f32``).  Returns False when the helper is unavailable."""
     lib = _load()
     if lib is None:
         return False
@@ -310,11 +314,13 @@ def cem_samples(z, row_base, h, act_dim, mean, std, low, high, a_out, clip_out, 
     assert z.dtype == np.float64 and mean.dtype == np.float64 and std.dtype == np.float64
     low = np.ascontiguousarray(low, dtype=np.float64)
     high = np.ascontiguousarray(high, dtype=np.float64)
-    rc = lib.l2a_cem_samples(z.ctypes.data, rows, int(row_base), int(h), int(act_dim), mean.ctypes.data,
-                             std.ctypes.data, m, low.ctypes.data, high.ctypes.data, a_out.ctypes.data,
-                             clip_out.ctypes.data if clip_out is not None else None,
-                             seq_f32.ctypes.data if seq_f32 is not None else None, int(n), int(sel_lo), int(sel_hi),
-                             1 if env_major else 0, 1 if use_clipped else 0, threads())
+    t0, t1 = (0, int(h)) if steps is None else (int(steps[0]), int(steps[1]))
+    rc = lib.l2a_cem_samples_steps(z.ctypes.data, rows, int(row_base), int(h), int(act_dim), mean.ctypes.data,
+                                   std.ctypes.data, m, low.ctypes.data, high.ctypes.data, a_out.ctypes.data,
+                                   clip_out.ctypes.data if clip_out is not None else None,
+                                   seq_f32.ctypes.data if seq_f32 is not None else None, int(n), int(sel_lo), int(sel_hi),
+                                   1 if env_major else 0, 1 if use_clipped else 0, t0, t1,
+                                   threads() if nthreads is None else int(nthreads))
     if rc != 0:
-        raise RuntimeError("l2a_cem_samples failed (%d)" % rc)
+        raise RuntimeError("l2a_cem_samples_steps failed (%d)" % rc)
     return True

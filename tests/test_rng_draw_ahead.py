@@ -120,6 +120,14 @@ def test_cem_samples_match_numpy(threads):
             full = np.transpose(src.reshape(n * m, h, ad), (1, 0, 2))
         want = full.reshape(h, m, n, ad)[:, :, lo:hi, :].reshape(h, m * nsel, ad).astype(np.float32)
         assert np.array_equal(seq, want)
+        # the same pass cut along the horizon (the rollout's horizon pipeline): every slice fills only its steps
+        a2, c2 = np.full((n * m, D), np.nan), np.full((n * m, D), np.nan)
+        seq2 = np.full((h, m * nsel, ad), np.nan, dtype=np.float32)
+        for t0, t1 in ((0, 2), (2, 2), (2, 3), (3, h)):
+            assert fast_rng.cem_samples(z.reshape(n * m, D), 0, h, ad, mean, std, low, high, a2, c2, seq2, n, lo, hi,
+                                        env_major, use_clipped, steps=(t0, t1))
+            assert np.isnan(a2[:, t1 * ad:]).all() and not np.isnan(a2[:, :t1 * ad]).any()
+        assert np.array_equal(a2, a) and np.array_equal(c2, c) and np.array_equal(seq2, seq)
 
 
 # ---- the draw-ahead chain through the controller's host logic (launch replaced by the oracle) ----------------

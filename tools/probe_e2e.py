@@ -94,7 +94,7 @@ def ab(attr, values, case_name="c2_hc_rs_n2000_h30_e5", rounds=4, calls=200):
     obs = np.random.RandomState(1).randn(case["m"], env.observation_space.shape[0])
     ctrl = cases.product_controller(case, model=model, env=env, rng="numpy", draw_ahead=True)
     np.random.seed(0)
-    for _ in range(20):
+    for _ in range(5):
         ctrl.get_actions(obs)
     out = {str(v): [] for v in values}
     for _ in range(rounds):
@@ -112,6 +112,9 @@ def ab(attr, values, case_name="c2_hc_rs_n2000_h30_e5", rounds=4, calls=200):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--ab":
-        ab(sys.argv[2], [True, False])
+        if len(sys.argv) > 3:       # --ab <attr> <case> <value> <value> ...
+            ab(sys.argv[2], [int(v) for v in sys.argv[4:]], case_name=sys.argv[3], rounds=5, calls=20)
+        else:
+            ab(sys.argv[2], [True, False])
     else:
         main()
