@@ -235,6 +235,27 @@ int l2a_model_adapt_sgd_host(l2a_model* model, const void* const* base_ptrs, con
  * the sizes l2a_model_set_weights takes) - e.g. to read back adapted sets (`_adapted_param_values`).    */
 int l2a_model_get_weights(l2a_model* model, int e, void* const* device_ptrs_out, void* stream);
 
+/* ---- cross-entropy-method planner: the per-iteration work around the rollout, on the device -----------------------
+ * `MPCController.get_cem_action` (policies/mpc_controller.py:71-106).  reference = 1 keeps the reference's semantics
+ * (rollouts on the UNCLIPPED samples with its candidate-major rows read as env-major, :92-96; "elites" = the boolean
+ * rank mask of :101 pooled over the envs), 0 = clipped rollouts, env-major rows, true top-k per env.
+ *
+ * l2a_cem_sample: a = mean + z * std (:86), clip (:87) for all n * m sample rows of one iteration.  z [n, m, D]
+ * (device fp32, D = h * act_dim) or NULL: standard normals from Philox4x32-10 + Box-Muller, element e of the iteration
+ * drawing counter (offset + e) under `seed` - every rank of a sharded plan generates the same numbers.  mean / std
+ * [m, D], low / high [act_dim] (device).  Outputs: a_clip [n, m, D], a_raw [n, m, D] (optional, the unclipped samples)
+ * and seq [h, m * (hi - lo), act_dim], the candidate tensor l2a_plan_rs reads for candidates lo <= j < hi (this
+ * rank's shard; optional).
+ *
+ * l2a_cem_refit: elites of `returns` [m, n] and the update mean = alpha * mean + (1 - alpha) * mean(elites),
+ * std = std(elites) (:101-104; biased) on mean / std [m, D] in place; elite_rows [m * num_elites] is scratch.  No sort:
+ * the mask of :101 only needs the ranks of the first num_elites candidates.                                     */
+int l2a_cem_sample(l2a_ctx* ctx, const float* z, unsigned long long seed, unsigned long long offset,
+                   const float* mean, const float* std, const float* low, const float* high, int n, int m, int h,
+                   int act_dim, int reference, int lo, int hi, float* a_clip, float* a_raw, float* seq, void* stream);
+int l2a_cem_refit(l2a_ctx* ctx, const float* returns, const float* a_clip, int n, int m, int D, int num_elites,
+                  int reference, float alpha, int* elite_rows, float* mean, float* std, void* stream);
+
 /* ---- sharded plans: the one collective ------------------------------------------------------
  * Candidates are independent, so G GPUs (one process and one context each) plan disjoint shards of one candidate
  * tensor (l2a_plan_rs with cand_offset = first global index of the shard) and combine the per-shard keys with ONE

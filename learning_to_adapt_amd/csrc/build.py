@@ -19,7 +19,7 @@ RNG_OUT = os.path.join(PKG, "libl2a_rng.so")        # host-only helper (gcc), se
 OBJ_DIR = os.path.join(HERE, "_obj")
 HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_adapt.h", "l2a_mfma.h", "l2a_mfma_launch.h", "l2a_lstm.h",
            "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_lstm_launch.h", os.path.join("..", "..", "include", "l2a.h")]
-SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_comm.hip", "l2a_rng.c"]
+SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_rng.c"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -70,7 +70,8 @@ def build(force=False, verbose=True, only=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     jobs = [("l2a_api.hip", os.path.join(OBJ_DIR, "l2a_api.o"), []),
             ("l2a_lstm_api.hip", os.path.join(OBJ_DIR, "l2a_lstm_api.o"), []),
-            ("l2a_comm.hip", os.path.join(OBJ_DIR, "l2a_comm.o"), [])]
+            ("l2a_comm.hip", os.path.join(OBJ_DIR, "l2a_comm.o"), []),
+            ("l2a_cem.hip", os.path.join(OBJ_DIR, "l2a_cem.o"), [])]
     for utw in LSTM_INSTANCES:
         jobs.append(("l2a_lstm_inst.hip", os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % utw), ["-DL2A_INST_UTW=%d" % utw]))
     for nt, tpw in INSTANCES:
@@ -83,7 +84,8 @@ def build(force=False, verbose=True, only=None):
               % (" ".join(FLAGS), len(jobs), min(len(jobs), os.cpu_count() or 1)))
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
         list(pool.map(_compile, jobs))
-    objs = [os.path.join(OBJ_DIR, "l2a_api.o"), os.path.join(OBJ_DIR, "l2a_lstm_api.o"), os.path.join(OBJ_DIR, "l2a_comm.o")]
+    objs = [os.path.join(OBJ_DIR, "l2a_api.o"), os.path.join(OBJ_DIR, "l2a_lstm_api.o"), os.path.join(OBJ_DIR, "l2a_comm.o"),
+            os.path.join(OBJ_DIR, "l2a_cem.o")]
     objs += [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
     objs += [os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % u) for u in LSTM_INSTANCES]
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"], cwd=HERE)

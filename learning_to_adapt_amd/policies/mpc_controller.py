@@ -752,55 +752,65 @@ class MPCController(Policy, Serializable):
 
     # ------------------------------------------------------------------ CEM (reference :71-106)
     def _cem_normal_device(self, shape, device):
-        """Standard normals for on-device CEM.  Every rank must draw the SAME numbers (each one
-        keeps all samples and rolls out only its shard), hence a private generator with a fixed
-        seed sequence instead of torch's global one."""
-        gen = self._bufs.get("cem_gen")
-        if gen is None or gen.device != device:
-            gen = torch.Generator(device=device)
-            gen.manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
-            self._bufs["cem_gen"] = gen
-        return torch.randn(shape, generator=gen, device=device, dtype=torch.float32)
+        """Hook for tests: return the iteration's standard normals ``[n, m, D]`` as a CUDA fp32 tensor to inject them;
+        ``None`` (the default) lets ``l2a_cem_sample`` draw them on the device (Philox4x32-10 + Box-Muller - every
+        rank generates the same numbers: each one keeps all samples and rolls out only its shard)."""
+        return None
 
     def get_cem_action_device(self, observations, retry=False):
-        """CEM with sampling, clipping, elite selection and refit on the GPU (SURVEY.md section 8(f)
-        rank 2): the five host synchronisations and 5 x n*m*h*act_dim host normals per plan step
-        of the reference loop (``:84-104``) disappear; only the chosen action comes back.
-        ``cem_mode='reference'`` keeps the reference's semantics on the device - rollouts on the
-        UNCLIPPED samples, candidate-major rows (row = j*m + i read as env row // n), the rank-mask
-        "elites" of ``:101`` pooled over the envs; ``cem_mode='fixed'`` uses clipped rollouts,
-        env-major rows and true top-k elites per env.  Numbers come from torch's Philox generator, so
-        both are validated against the host loops with injected normals, not bit-for-bit against NumPy."""
+        """CEM with sampling, clipping, elite selection and refit on the GPU: the five
+        host synchronisations and 5 x n*m*h*act_dim host normals per plan step of the reference loop (``:84-104``)
+        disappear; only the chosen action comes back.  Per iteration three hand-written launches around the fused
+        rollout (``csrc/l2a_cem.hip``: ``l2a_cem_sample`` - draw, ``a = mean + z * std``, clip, the rollout's
+        candidate tensor in one pass; ``l2a_cem_refit`` - elite rows by rank counting instead of a sort, then their
+        mean / std).  ``cem_mode='reference'`` keeps the reference's semantics on the device - rollouts on the
+        UNCLIPPED samples, candidate-major rows (row = j*m + i read as env row // n), the rank-mask "elites" of
+        ``:101`` pooled over the envs; ``cem_mode='fixed'`` uses clipped rollouts, env-major rows and true top-k
+        elites per env.  The numbers are the library's own Philox stream, so both modes are validated against the
+        host loops with injected normals, not bit-for-bit against NumPy."""
+        import ctypes
+        from ..dynamics.native_model import _ptr, _stream_ptr
         reference = (self.cem_mode == "reference")
         n, m, h = self.n_candidates, len(observations), self.horizon
         act_dim = self.action_space.shape[0]
         D = h * act_dim
         dev = self._device()
+        native = self.dynamics_model.planner_model()
+        ctx, lib = native.ctx, native.lib
         num_elites = max(int(n * self.percent_elites), 1)
-        low = torch.as_tensor(np.concatenate([self.action_space.low] * h), dtype=torch.float32, device=dev)
-        high = torch.as_tensor(np.concatenate([self.action_space.high] * h), dtype=torch.float32, device=dev)
-        mean = torch.zeros((m, D), dtype=torch.float32, device=dev)
-        std = torch.ones((m, D), dtype=torch.float32, device=dev)
+        low = self._bufs.get("cem_low")
+        if low is None or low.device != dev:
+            low = self._bufs["cem_low"] = torch.as_tensor(np.asarray(self.action_space.low), dtype=torch.float32, device=dev)
+            self._bufs["cem_high"] = torch.as_tensor(np.asarray(self.action_space.high), dtype=torch.float32, device=dev)
+        high = self._bufs["cem_high"]
+        mean = self._buf("cem_mean", (m, D), torch.float32, dev).zero_()
+        std = self._buf("cem_std", (m, D), torch.float32, dev).fill_(1.0)
         rank, world = self._dist()
         self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         n_local = hi - lo
         widths = [self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] for r in range(world)]
         wmax = max(widths)
+        a_clip = self._buf("cem_a_clip", (n, m, D), torch.float32, dev)
+        a_raw = self._buf("cem_a_raw", (n, m, D), torch.float32, dev) if reference else None
+        seq = self._buf("cem_seq", (h, m * max(n_local, 1), act_dim), torch.float32, dev)
+        elite_rows = self._buf("cem_rows", (m * num_elites,), torch.int32, dev)
         rets = None
-        cand = None
         obs_dev = self._upload_obs(observations)             # once per plan step, not once per CEM iteration
-        gen0 = self._bufs.get("cem_gen")
-        gen_state = gen0.get_state() if gen0 is not None else None
-        for _ in range(self.num_cem_iters):
+        # counter-based stream: (seed, calls so far) - identical on every rank, reproducible under torch.manual_seed
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        if self._bufs.get("cem_seed") != seed:
+            self._bufs["cem_seed"], self._bufs["cem_calls"] = seed, 0
+        call0 = self._bufs["cem_calls"]
+        for it in range(self.num_cem_iters):
             z = self._cem_normal_device((n, m, D), dev)
-            a = mean + z * std                                                                # [n, m, D]
-            a_clip = torch.clamp(a, low, high)
-            if reference:
-                cand = a.reshape(m, n, D)                  # the reference's reading of the same memory (:92-96)
-            else:
-                cand = a_clip.permute(1, 0, 2).contiguous()                                       # [m, n, D]
-            seq = cand[:, lo:hi, :].reshape(m * n_local, h, act_dim).permute(1, 0, 2).contiguous()
+            if z is not None:
+                z = z.to(device=dev, dtype=torch.float32).contiguous()
+            offset = (call0 + it) * n * m * D
+            ctx.check(lib.l2a_cem_sample(ctx.handle, _ptr(z), ctypes.c_ulonglong(seed), ctypes.c_ulonglong(offset),
+                                         _ptr(mean), _ptr(std), _ptr(low), _ptr(high), n, m, h, act_dim,
+                                         1 if reference else 0, lo, hi, _ptr(a_clip), _ptr(a_raw),
+                                         _ptr(seq) if n_local > 0 else None, _stream_ptr(dev)), "l2a_cem_sample")
             if n_local > 0:
                 _, r_loc = self._rollout(observations, seq, n_local, lo, want_returns=True, obs_dev=obs_dev)
             else:
@@ -810,27 +820,16 @@ class MPCController(Policy, Serializable):
                     [r_loc, torch.zeros((m, wmax - n_local), dtype=r_loc.dtype, device=dev)], dim=1)
                 parts = [torch.empty_like(mine) for _ in range(world)]
                 torch.distributed.all_gather(parts, mine.contiguous())
-                rets = torch.cat([part[:, :w] for part, w in zip(parts, widths)], dim=1)
+                rets = torch.cat([part[:, :w] for part, w in zip(parts, widths)], dim=1).contiguous()
             else:
                 rets = r_loc
-            if reference:
-                # :101-104: positions of the descending argsort whose VALUE is < num_elites, used as a
-                # mask over candidates, pooled over envs; mean / std broadcast back to every env
-                mask = (torch.argsort(rets, dim=1, descending=True, stable=True) < num_elites).t()   # [n, m]
-                # masked moments instead of `a_clip[mask]`: boolean indexing needs the element count on the
-                # host (a sync per iteration); the mask always selects exactly m * num_elites samples
-                w = mask.to(torch.float32).unsqueeze(-1)                                      # [n, m, 1]
-                cnt = float(m * num_elites)
-                e_mean = (a_clip * w).sum(dim=(0, 1)) / cnt                                   # [D]
-                e_var = (((a_clip - e_mean) ** 2) * w).sum(dim=(0, 1)) / cnt
-                mean = mean * self.alpha + (1 - self.alpha) * e_mean
-                std = torch.sqrt(e_var).expand(m, D)
-            else:
-                top = torch.topk(rets, num_elites, dim=1).indices                             # [m, k]
-                elites = torch.gather(cand, 1, top.unsqueeze(-1).expand(m, num_elites, D))    # [m, k, D]
-                mean = mean * self.alpha + (1 - self.alpha) * elites.mean(dim=1)
-                std = elites.std(dim=1, unbiased=False)
+            ctx.check(lib.l2a_cem_refit(ctx.handle, _ptr(rets), _ptr(a_clip), n, m, D, num_elites,
+                                        1 if reference else 0, float(self.alpha), _ptr(elite_rows), _ptr(mean),
+                                        _ptr(std), _stream_ptr(dev)), "l2a_cem_refit")
         idx = torch.argmax(rets, dim=1)                                                       # [m]
+        # candidates as the rollout saw them: the reference reads the sample memory as [m, n, D] (:92-96) and returns
+        # the UNCLIPPED first action (:106); the fixed mode's candidate (i, j) is clipped sample row j * m + i
+        cand = a_raw.reshape(m, n, D) if reference else a_clip.permute(1, 0, 2)
         first = cand[torch.arange(m, device=dev), idx, :act_dim]
         out = first.cpu().numpy().astype(np.float64)
         bad = self._check_status() is False     # a launch lost its tile-split partner: the context is unsplit now
@@ -841,10 +840,8 @@ class MPCController(Policy, Serializable):
         if bad:
             if retry:
                 raise _lib.L2AError("rollout launch failed twice")
-            gen = self._bufs.get("cem_gen")
-            if gen is not None and gen_state is not None:
-                gen.set_state(gen_state)        # replay the same normals
-            return self.get_cem_action_device(observations, retry=True)
+            return self.get_cem_action_device(observations, retry=True)      # same counters: the same normals again
+        self._bufs["cem_calls"] = call0 + self.num_cem_iters
         self.last_plan = dict(best_index=idx.cpu().numpy(), best_return=rets.max(dim=1).values.cpu().numpy(),
                               cem_mean=mean.cpu().numpy(), cem_std=std.cpu().numpy())
         return out

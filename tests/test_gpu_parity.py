@@ -840,3 +840,102 @@ def test_blocking_plan_publishes_the_same_keys(name, over, kernel):
                                        cand_offset=3 * it)
             assert np.array_equal(got2, got)
     _lib.Context.get(0).launch_status()
+
+
+def _philox_normal_ref(seed, index):
+    """Python restatement of csrc/l2a_cem.hip's generator: Philox4x32-10 (Salmon et al. 2011) on counter
+    (index_lo, index_hi, 0x4c32614d, 0) under key (seed_lo, seed_hi), Box-Muller on the first two words."""
+    M = 0xFFFFFFFF
+    c = [index & M, (index >> 32) & M, 0x4C32614D, 0]
+    k0, k1 = seed & M, (seed >> 32) & M
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k0, p1 & M, (p0 >> 32) ^ c[3] ^ k1, p0 & M]
+        k0, k1 = (k0 + 0x9E3779B9) & M, (k1 + 0xBB67AE85) & M
+    u1 = np.float32(np.float32((c[0] >> 8) + 1.0) * np.float32(1.0 / 16777216.0))
+    u2 = np.float32(np.float32(c[1] >> 8) * np.float32(1.0 / 16777216.0))
+    return float(np.sqrt(-2.0 * np.log(float(u1))) * np.cos(6.28318530717958647692 * float(u2)))
+
+
+@pytest.mark.parametrize("reference", [True, False])
+def test_cem_kernels_match_numpy(reference):
+    """`l2a_cem_sample` / `l2a_cem_refit` on their own against NumPy: samples, clip and the rollout's candidate tensor (both
+    row readings, a candidate shard), the library's Philox normals (values of single counters, moments, determinism),
+    elite rows and refit - including exact ties in the returns, where the stable descending order decides."""
+    from learning_to_adapt_amd.dynamics.native_model import _ptr, _stream_ptr
+    ctx = _lib.Context.get(0)
+    lib = ctx.lib
+    dev = torch.device("cuda:0")
+    n, m, h, ad, k, alpha = 333, 3, 5, 4, 33, 0.1
+    D = h * ad
+    rs = np.random.RandomState(7)
+    z = rs.randn(n, m, D).astype(np.float32)
+    mean = (0.3 * rs.randn(m, D)).astype(np.float32)
+    std = (0.5 + rs.rand(m, D)).astype(np.float32)
+    low, high = (-0.8 * np.ones(ad)).astype(np.float32), (0.9 * np.ones(ad)).astype(np.float32)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    lo, hi = 100, 250
+    a_clip = torch.empty((n, m, D), device=dev)
+    a_raw = torch.empty((n, m, D), device=dev)
+    seq = torch.full((h, m * (hi - lo), ad), float("nan"), device=dev)
+    mean_d, std_d, z_d, low_d, high_d = up(mean), up(std), up(z), up(low), up(high)     # (kept alive: launches are async)
+    ctx.check(lib.l2a_cem_sample(ctx.handle, _ptr(z_d), 0, 0, _ptr(mean_d), _ptr(std_d), _ptr(low_d), _ptr(high_d),
+                                 n, m, h, ad, 1 if reference else 0, lo, hi, _ptr(a_clip), _ptr(a_raw), _ptr(seq),
+                                 _stream_ptr(dev)), "l2a_cem_sample")
+    a_want = mean[None] + z * std[None]
+    c_want = np.clip(a_want, np.tile(low, h), np.tile(high, h))
+    np.testing.assert_allclose(a_raw.cpu().numpy(), a_want, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(a_clip.cpu().numpy(), c_want, rtol=1e-6, atol=1e-6)
+    if reference:       # the reference reads its candidate-major rows as [m, n, D] (:92-96), unclipped
+        full = np.transpose(a_want.reshape(n * m, h, ad), (1, 0, 2)).reshape(h, m, n, ad)
+    else:
+        full = np.transpose(c_want.transpose(1, 0, 2).reshape(m * n, h, ad), (1, 0, 2)).reshape(h, m, n, ad)
+    np.testing.assert_allclose(seq.cpu().numpy(), full[:, :, lo:hi, :].reshape(h, m * (hi - lo), ad), rtol=1e-6, atol=1e-6)
+
+    # the library's own normals: counter -> value, moments, determinism, disjoint offsets
+    seed = 0x1234567887654321
+    g1 = torch.empty((n, m, D), device=dev)
+    g2 = torch.empty((n, m, D), device=dev)
+    zero, one = torch.zeros((m, D), device=dev), torch.ones((m, D), device=dev)
+    wide_lo, wide_hi = up(np.full(ad, -1e9, dtype=np.float32)), up(np.full(ad, 1e9, dtype=np.float32))
+    for buf, off in ((g1, 1000), (g2, 1000 + n * m * D)):
+        ctx.check(lib.l2a_cem_sample(ctx.handle, None, ctypes.c_ulonglong(seed), ctypes.c_ulonglong(off), _ptr(zero), _ptr(one),
+                                     _ptr(wide_lo), _ptr(wide_hi), n, m, h, ad, 1, 0, 0, _ptr(buf), None, None,
+                                     _stream_ptr(dev)), "l2a_cem_sample")
+    v1, v2 = g1.cpu().numpy().reshape(-1), g2.cpu().numpy().reshape(-1)
+    for e in (0, 1, 2, 63, 64, 4999, len(v1) - 1):
+        assert abs(v1[e] - _philox_normal_ref(seed, 1000 + e)) < 2e-5, e
+    assert np.isfinite(v1).all() and abs(v1.mean()) < 0.03 and abs(v1.std() - 1.0) < 0.03
+    assert abs(np.corrcoef(v1[:-1], v1[1:])[0, 1]) < 0.03 and abs(np.corrcoef(v1, v2)[0, 1]) < 0.03
+    g3 = torch.empty((n, m, D), device=dev)
+    ctx.check(lib.l2a_cem_sample(ctx.handle, None, ctypes.c_ulonglong(seed), ctypes.c_ulonglong(1000), _ptr(zero), _ptr(one),
+                                 _ptr(wide_lo), _ptr(wide_hi), n, m, h, ad, 1, 0, 0, _ptr(g3), None, None,
+                                 _stream_ptr(dev)), "l2a_cem_sample")
+    assert torch.equal(g1, g3)
+
+    # refit: returns with exact ties
+    rets = rs.randn(m, n).astype(np.float32)
+    rets[:, 5] = rets[:, 17]
+    rets[0, 40:44] = rets[0, 2]
+    rows = torch.empty((m * k,), dtype=torch.int32, device=dev)
+    rets_d = up(rets)
+    ctx.check(lib.l2a_cem_refit(ctx.handle, _ptr(rets_d), _ptr(a_clip), n, m, D, k, 1 if reference else 0, alpha,
+                                _ptr(rows), _ptr(mean_d), _ptr(std_d), _stream_ptr(dev)), "l2a_cem_refit")
+    a_st = a_clip.cpu().numpy().astype(np.float64)
+    order = np.argsort(-rets.astype(np.float64), axis=1, kind="stable")
+    if reference:
+        mask = (order < k).T                                            # mpc_controller.py:101
+        elites = a_st[mask]
+        want_mean = mean * alpha + (1 - alpha) * elites.mean(axis=0)
+        want_std = np.broadcast_to(elites.std(axis=0), (m, D))
+        got_rows = np.sort(rows.cpu().numpy().reshape(m, k), axis=1)
+        want_rows = np.stack([np.sort(np.nonzero(mask[:, i])[0] * m + i) for i in range(m)])
+    else:
+        elites = np.stack([a_st[order[i, :k], i] for i in range(m)])    # [m, k, D]
+        want_mean = mean * alpha + (1 - alpha) * elites.mean(axis=1)
+        want_std = elites.std(axis=1)
+        got_rows = rows.cpu().numpy().reshape(m, k)
+        want_rows = order[:, :k] * m + np.arange(m)[:, None]
+    assert np.array_equal(got_rows, want_rows)
+    np.testing.assert_allclose(mean_d.cpu().numpy(), want_mean, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(std_d.cpu().numpy(), want_std, rtol=2e-5, atol=2e-6)

@@ -21,7 +21,7 @@ def main():
     subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DL2A_INST_NT=1", "-DL2A_INST_TPW=8"] + defs +
                           ["-c", os.path.join(b.HERE, "l2a_mfma_inst.hip"), "-o", obj], cwd=b.HERE)
     objs = [os.path.join(b.OBJ_DIR, "l2a_api.o"), os.path.join(b.OBJ_DIR, "l2a_lstm_api.o"),
-            os.path.join(b.OBJ_DIR, "l2a_comm.o")]
+            os.path.join(b.OBJ_DIR, "l2a_comm.o"), os.path.join(b.OBJ_DIR, "l2a_cem.o")]
     objs += [obj if i == (1, 8) else os.path.join(b.OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in b.INSTANCES]
     for u in b.LSTM_INSTANCES:
         lobj = os.path.join(b.OBJ_DIR, "l2a_lstm_%d.o" % u)
