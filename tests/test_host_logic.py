@@ -131,34 +131,6 @@ def test_fit_reduces_loss_on_a_linear_system():
     assert np.mean((pred - target) ** 2) < 0.3      # an untrained net sits at ~1.0 (unit-variance targets)
 
 
-@pytest.mark.parametrize("cem_mode", ["fixed", "reference"])
-def test_device_cem_matches_host_loop_with_injected_normals(cem_mode):
-    """On-device CEM (torch ops around the fused rollout) against the host loop of the same mode fed
-    with the same normals ('reference' = the loop pinned bit for bit against the reference's own
-    get_cem_action by the golden vectors).  Runs on CPU tensors here (launch replaced by the
-    oracle); the gpu suite repeats it on the device."""
-    import torch
-    case = dict(cases.CASES["hc_cem_m2_n100_h4"])
-    obs0 = cases.load_golden("hc_cem_m2_n100_h4_s0")["obs0"]
-    n, m, D = case["n"], case["m"], case["h"] * 6
-    zs = [np.random.RandomState(100 + i).normal(size=(n, m, D)) for i in range(case["num_cem_iters"])]
-
-    host = oracle_backend.install(cases.product_controller(case, cem_mode=cem_mode), case)
-    it = iter(zs)
-    host._cem_draw = lambda n_, m_, D_: next(it).reshape(n_ * m_, D_)      # inject the iteration's normals
-    a_host, _ = host.get_actions(obs0)
-
-    dev = oracle_backend.install(cases.product_controller(case, rng="device", cem_mode=cem_mode), case)
-    it2 = iter(zs)
-    dev._cem_normal_device = lambda shape, device: torch.from_numpy(next(it2).astype(np.float32))
-    a_dev, _ = dev.get_actions(obs0)
-    tr = host.last_plan["cem_trace"][-1]
-    np.testing.assert_allclose(dev.last_plan["cem_mean"], np.broadcast_to(tr["mean"], (m, D)), rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(dev.last_plan["cem_std"], np.broadcast_to(tr["std"], (m, D)), rtol=1e-3, atol=1e-4)
-    assert np.array_equal(dev.last_plan["best_index"], host.last_plan["best_index"])
-    np.testing.assert_allclose(a_dev, a_host, rtol=1e-5, atol=1e-6)
-
-
 def test_fast_rng_reproduces_numpy_global_stream():
     """`utils/fast_rng.random_sample` (vectorised MT19937 helper, csrc/l2a_rng.c) against
     `np.random.random_sample`: same doubles, same generator state afterwards (cached Gaussian included),
