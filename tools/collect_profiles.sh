@@ -18,6 +18,8 @@ grep -v amdgpu.ids $SRC/timeline_lstm.txt > $DST/${TAG}_timeline_lstm.txt
 cp $SRC/parity_report.txt $DST/${TAG}_parity_report.txt
 cp $SRC/probe_adapt.json $DST/${TAG}_probe_adapt.json
 grep -v amdgpu.ids $SRC/adapt_trace.txt > $DST/${TAG}_adapt_trace.txt
+grep -v amdgpu.ids $SRC/cem_trace.txt | cut -c1-140 > $DST/${TAG}_cem_trace.txt
+cp $SRC/probe_jitter.json $DST/${TAG}_probe_jitter.json
 tail -12 $SRC/pytest_gpu.log | grep -v amdgpu.ids > $DST/${TAG}_pytest_gpu_tail.txt
 # rocprofv3 --stats: the rollout kernels only (torch's elementwise kernels have kilobyte-long names)
 f=$(find $SRC/prof -name "*kernel_stats.csv" | head -1)

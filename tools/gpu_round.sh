@@ -40,6 +40,8 @@ timeout 120 python tools/timeline_lstm.py 256 2000 >> $OUT/timeline_lstm.txt 2>&
 echo "== GrBAL adaptation step"
 timeout 120 python tools/probe_adapt.py 2> /dev/null > $OUT/probe_adapt.json; echo "probe_adapt rc=$?"
 bash tools/adapt_trace.sh > $OUT/adapt_trace.txt 2>&1; echo "adapt_trace rc=$?"; cd $GRAFT_REPO_ROOT
+bash tools/cem_trace.sh > $OUT/cem_trace.txt 2>&1; echo "cem_trace rc=$?"; cd $GRAFT_REPO_ROOT
+timeout 120 python tools/probe_jitter.py > $OUT/probe_jitter.json 2> /dev/null; echo "probe_jitter rc=$?"
 echo "== host RNG helper / end-to-end stage probes"
 timeout 300 python tools/bench_rng.py > $OUT/rng.jsonl 2>&1; echo "rng rc=$?"
 timeout 300 python tools/probe_e2e.py > $OUT/probe_c2.jsonl 2> $OUT/probe.err; echo "probe c2 rc=$?"

@@ -65,6 +65,10 @@ for _ in range(30):
 sync_t.clear()
 for v in stages.values():
     v.clear()
+if os.environ.get("NOGC"):
+    import gc
+    gc.collect()
+    gc.disable()
 tot = []
 for _ in range(1000):
     t = time.perf_counter()
@@ -73,7 +77,8 @@ for _ in range(1000):
 tot, sy = 1e6 * np.array(tot), 1e6 * np.array(sync_t)
 rest = tot - sy
 pc = lambda a: [round(float(np.percentile(a, q)), 1) for q in (5, 25, 50, 75, 95, 99)]  # noqa: E731
-print(json.dumps({"percentiles": [5, 25, 50, 75, 95, 99], "total_us": pc(tot), "plan_rs_sync_us": pc(sy), "python_rest_us": pc(rest),
+print(json.dumps({"gc_disabled": bool(os.environ.get("NOGC")), "calls_over_2000us": int((tot > 2000).sum()),
+                  "percentiles": [5, 25, 50, 75, 95, 99], "total_us": pc(tot), "plan_rs_sync_us": pc(sy), "python_rest_us": pc(rest),
                   "mean_total_us": round(float(tot.mean()), 1),
                   "by_block_of_100_mean_sync_us": [round(float(sy[i:i + 100].mean()), 1) for i in range(0, 1000, 100)],
                   "by_block_of_100_mean_rest_us": [round(float(rest[i:i + 100].mean()), 1) for i in range(0, 1000, 100)]}))
