@@ -43,7 +43,8 @@
 //
 // Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave (hidden
 // width = 16 * L2A_NW * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16), GACT =
-// generic activation functions (false: relu / identity only, branch-free).
+// generic activation functions (false: relu / identity only, branch-free), K0L = layer-0 MFMAs of the last input
+// k-group that can see non-zero operands (4 unless in_dim mod 16 is 1..3).
 #pragma once
 
 #include <type_traits>
@@ -283,7 +284,7 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
             for (int c = 0; c < OT; ++c) pbuf[(((chunk0 + ch) * NT + nt) * OT + c) * 64 + lane] = acc[ch][nt][c];
 }
 
-template <int NT, int TPW, int OT, int KG0, bool GACT>
+template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
     constexpr int HT = L2A_NW * TPW;
     constexpr int TH = TPW / 2;         // tiles per wave of a half member
@@ -594,15 +595,20 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                             norm_in(g, mu, iv, xg);
                         }
 #pragma unroll
-                        for (int ii = 0; ii < 4; ++ii)
+                        for (int ii = 0; ii < 4; ++ii) {
+                            // K0L: MFMA ii of the LAST k-group multiplies input features 16 (KG0 - 1) + 4 qq + ii; when the
+                            // input layer ends within the group's first K0L features (Ant: 49 = 3 * 16 + 1) the other
+                            // MFMAs see zero weights and zero inputs - skipping them leaves every bit as it was
+                            if (g == KG0 - 1 && ii >= K0L) continue;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                                 for (int tt = 0; tt < TPW; ++tt)
                                     acc[nt][tt] = L2A_MFMA(a[g][tt][ii], xg[nt][ii], acc[nt][tt]);
+                        }
                     }
                     // hint: the a[g >= 1] loads first, then one prefetch load per few MFMAs
-                    constexpr int NM = KG0 * 4 * NT * TPW;
+                    constexpr int NM = ((KG0 - 1) * 4 + K0L) * NT * TPW;
                     constexpr int PER = NM / (NPF > 0 ? NPF : 1) > 0 ? NM / (NPF > 0 ? NPF : 1) : 1;
                     __builtin_amdgcn_sched_group_barrier(0x020, (KG0 - 1) * TPW, 0);
 #pragma unroll

@@ -8,9 +8,9 @@
 
 namespace {
 
-template <int OT, int KG0, bool GACT>
+template <int OT, int KG0, bool GACT, int K0L = 4>
 int launch_one(const L2AKParams* p, unsigned grid, int smem, hipStream_t stream) {
-    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT>;
+    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -27,7 +27,11 @@ int launch_shape(int ot, int kg0, const L2AKParams* p, unsigned grid, int smem, 
         case 2 * 8 + 2: return launch_one<2, 2, GACT>(p, grid, smem, stream);
         case 2 * 8 + 3: return launch_one<2, 3, GACT>(p, grid, smem, stream);
         case 3 * 8 + 3: return launch_one<3, 3, GACT>(p, grid, smem, stream);
-        case 3 * 8 + 4: return launch_one<3, 4, GACT>(p, grid, smem, stream);
+        case 3 * 8 + 4:     // Ant: 41 + 8 = 49 inputs end one feature into the last k-group (its own instance; relu / identity)
+#ifndef L2A_NO_K0L
+            if (!GACT && p->in_dim == 49) return launch_one<3, 4, GACT, 1>(p, grid, smem, stream);
+#endif
+            return launch_one<3, 4, GACT>(p, grid, smem, stream);
         case 4 * 8 + 4: return launch_one<4, 4, GACT>(p, grid, smem, stream);
         case 4 * 8 + 5: return launch_one<4, 5, GACT>(p, grid, smem, stream);
         default: return -100;
