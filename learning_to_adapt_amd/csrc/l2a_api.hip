@@ -791,8 +791,16 @@ int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tk, int m, bool published,
         // Sleep through most of the expected duration, then poll the mailbox word (host-mapped memory: no copy,
         // no hipStreamSynchronize wake-up latency).
         static const int sleep_mode = [] { const char* e = std::getenv("L2A_SYNC_SLEEP"); return e ? std::atoi(e) : 1; }();
-        if (sleep_mode && ctx->sync_ema_us > 400.0) usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
+        // The estimate belongs to a plan SHAPE: it is reset whenever the previous blocking launch of the context had
+        // another one (a 1.5 ms plan's estimate made the first ~25 launches of a 0.2 ms plan oversleep, the estimate
+        // decaying by 5 % per launch: +40 us per step averaged over 200), and whenever a launch was overslept.
+        if (ctx->sync_shape != tk.shape) { ctx->sync_shape = tk.shape; ctx->sync_ema_us = 0.0; }
         const volatile unsigned long long* seqp = &mh->seq;
+        bool overslept = false;
+        if (sleep_mode && ctx->sync_ema_us > 400.0) {
+            usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
+            overslept = (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == tk.seq);
+        }
         unsigned long long spins = 0;
         while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != tk.seq) {
             _mm_pause();
@@ -814,7 +822,7 @@ int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tk, int m, bool published,
             }
         }
         const double us = now_us() - tk.t0_us;
-        ctx->sync_ema_us = (ctx->sync_ema_us == 0.0) ? us : 0.75 * ctx->sync_ema_us + 0.25 * us;
+        ctx->sync_ema_us = overslept ? 0.0 : (ctx->sync_ema_us == 0.0) ? us : 0.75 * ctx->sync_ema_us + 0.25 * us;
         for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
     } else {
         L2A_HIP(ctx, hipMemcpyAsync(mh->keys, tk.keys_dev, sizeof(unsigned long long) * (size_t)m, hipMemcpyDeviceToHost, stream));
@@ -852,6 +860,7 @@ int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions,
     l2a_mail_ticket tk;
     int rc = l2a_mail_begin(ctx, m, obs_host, (long long)m * md->obs_dim, stream, &tk);
     if (rc != L2A_OK) return rc;
+    tk.shape = (unsigned long long)(size_t)md ^ ((unsigned long long)m << 48) ^ ((unsigned long long)n << 24) ^ (unsigned long long)h;
     L2AKParams p;
     fill_model_params(md, p);
     p.obs0 = tk.obs_dev; p.actions = actions; p.returns_out = returns_out; p.best_key = tk.keys_dev;

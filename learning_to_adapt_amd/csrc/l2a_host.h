@@ -32,6 +32,7 @@ struct l2a_ctx {
     int ring_dirty[2] = {L2A_MAIL_KEYS, L2A_MAIL_KEYS};   // leading entries of each slot that may be non-zero
     unsigned long long mail_seq = 0;
     double sync_ema_us = 0.0;             // expected duration of the next blocking plan (sleep-then-spin)
+    unsigned long long sync_shape = 0;    // plan shape the estimate belongs to (l2a_mail_ticket::shape)
     // RCCL communicator of sharded plans (l2a_comm.hip); null = single GPU
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -63,6 +64,7 @@ struct l2a_mail_ticket {
     unsigned long long* keys_dev = nullptr;     // this launch's key slot (zeroed)
     unsigned long long* next_keys = nullptr;    // the next launch's key slot (the last tile zeroes [0, m))
     double t0_us = 0.0;                         // host clock when the ticket was drawn
+    unsigned long long shape = 0;               // caller's digest of (model, m, n, h): keys the wait-time estimate
 };
 // Stage `obs_floats` observation floats, pick and clear the key slot.  Kernel parameters of a publishing launch:
 // best_key = keys_dev, done_ctr = ctx->done_ctr, mail_keys = ctx->mail_dev->keys, mail_seq_ptr = &ctx->mail_dev->seq,

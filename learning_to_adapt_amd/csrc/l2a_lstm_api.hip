@@ -418,6 +418,7 @@ int l2a_lstm_plan_rs_sync(l2a_lstm* md, const float* obs_host, const float* c0, 
     l2a_mail_ticket tk;
     int rc = l2a_mail_begin(ctx, m, obs_host, (long long)m * md->obs_dim, stream, &tk);
     if (rc != L2A_OK) return rc;
+    tk.shape = (unsigned long long)(size_t)md ^ ((unsigned long long)m << 48) ^ ((unsigned long long)n << 24) ^ (unsigned long long)h;
     L2ALstmParams p;
     fill(md, p);
     p.obs0 = tk.obs_dev; p.c0 = c0; p.h0 = h0; p.actions = actions;
