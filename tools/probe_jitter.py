@@ -65,6 +65,9 @@ for _ in range(30):
 sync_t.clear()
 for v in stages.values():
     v.clear()
+if os.environ.get("PIN"):       # keep the calling thread on the core it is on (threads created earlier are unaffected)
+    import ctypes
+    os.sched_setaffinity(0, {ctypes.CDLL(None).sched_getcpu()})
 if os.environ.get("NOGC"):
     import gc
     gc.collect()
@@ -77,7 +80,7 @@ for _ in range(1000):
 tot, sy = 1e6 * np.array(tot), 1e6 * np.array(sync_t)
 rest = tot - sy
 pc = lambda a: [round(float(np.percentile(a, q)), 1) for q in (5, 25, 50, 75, 95, 99)]  # noqa: E731
-print(json.dumps({"gc_disabled": bool(os.environ.get("NOGC")), "calls_over_2000us": int((tot > 2000).sum()),
+print(json.dumps({"pinned": bool(os.environ.get("PIN")), "gc_disabled": bool(os.environ.get("NOGC")), "calls_over_2000us": int((tot > 2000).sum()),
                   "percentiles": [5, 25, 50, 75, 95, 99], "total_us": pc(tot), "plan_rs_sync_us": pc(sy), "python_rest_us": pc(rest),
                   "mean_total_us": round(float(tot.mean()), 1),
                   "by_block_of_100_mean_sync_us": [round(float(sy[i:i + 100].mean()), 1) for i in range(0, 1000, 100)],
@@ -89,4 +92,9 @@ if stages:
         v = 1e6 * np.array(v[:1000])
         out[k] = {"fast": round(float(v[~slow].mean()), 1), "slow": round(float(v[slow].mean()), 1) if slow.any() else None}
     print(json.dumps({"n_slow": int(slow.sum()), "stages_us": out}))
+    big = tot > 2000
+    if big.any():
+        print(json.dumps({"outliers": int(big.sum()), "mean_us_in_outliers": {k: round(float((1e6 * np.array(v[:1000]))[big].mean()), 1)
+                                                                               for k, v in stages.items() if len(v) >= 1000},
+                          "worker_ms_per_block": round(1e3 * ctrl._ahead.produce_s / max(ctrl._ahead.produced, 1), 3)}))
 ctrl._ahead.stop()
