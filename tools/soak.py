@@ -1,43 +1,90 @@
 #!/usr/bin/env python
-"""Soak run (needs a GPU): ~25 s of back-to-back plan launches in random order over six plan shapes (full
-tile split, tail split, unsplit, single model, h = 1 stale-tag case), checking the launch status word and that
-every shape keeps returning the same bits.  Last run: 50 800 launches, clean."""
-import sys, time, numpy as np, torch
+"""Soak: a minute of randomly mixed launches (split / unsplit / tail-split MLP plans, blocking launches, recurrent plans
+with and without the unit-tile split, adaptation steps) - the status word must stay clean and every plan must return the
+bits of its first run.  Developer aid, needs a GPU:  python tools/soak.py [seconds]"""
 import os
+import sys
+import time
+
+import numpy as np
+import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import cases
-from learning_to_adapt_amd import _lib
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+from learning_to_adapt_amd import _lib  # noqa: E402
+
 C = cases.CASES
-specs = [("c2_hc_rs_n2000_h30_e5", {}), ("c3_ant_rs_n2000_h20_pb5", dict(h=5)), ("c1_hc_rs_n500_h10_e1", {}),
-         ("c2_hc_rs_n2000_h30_e5", dict(n=4800, h=4)), ("hc_rs_m2_n100_h7_e2", {}), ("c2_hc_rs_n2000_h30_e5", dict(h=1))]
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 plans = []
-for name, over in specs:
+for name, over in [("c2_hc_rs_n2000_h30_e5", {}), ("c3_ant_rs_n2000_h20_pb5", dict(h=5)), ("c1_hc_rs_n500_h10_e1", {}),
+                   ("c2_hc_rs_n2000_h30_e5", dict(n=4800, h=4)), ("hc_rs_m2_n100_h7_e2", {}),
+                   ("c2_hc_rs_n2000_h30_e5", dict(h=1))]:
     case = dict(C[name], **over)
     env, model = cases.product_model(case)
     nat = model.planner_model()
     dev = nat.device
     m, n, h = case["m"], case["n"], case["h"]
     od, ad = env.observation_space.shape[0], env.action_space.shape[0]
-    obs0 = torch.randn((m, od), device=dev)
+    obs = np.random.RandomState(len(plans)).randn(m, od).astype(np.float32)
     a = (torch.rand((h, m * n, ad), device=dev) * 2 - 1) * float(env.action_space.high[0])
     best = torch.zeros((m,), dtype=torch.int64, device=dev)
     rets = torch.empty((m, n), dtype=torch.float32, device=dev)
-    nat.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, returns_out=rets, best_key=best)
+    obs_d = torch.from_numpy(obs).to(dev)
+
+    def run(nat=nat, obs_d=obs_d, a=a, m=m, n=n, h=h, env=env, best=best, rets=rets):
+        nat.plan_rs(obs_d, a, m, n, h, 1.0, env.reward_spec, returns_out=rets, best_key=best)
+        return best, rets
+
+    def run_sync(nat=nat, obs=obs, a=a, m=m, n=n, h=h, env=env):
+        return nat.plan_rs_sync(obs, a, m, n, h, 1.0, env.reward_spec)
+    k, r = run()
     torch.cuda.synchronize()
-    plans.append((nat, obs0, a, m, n, h, env, best, rets, best.clone(), rets.clone(), model))
+    plans.append(dict(run=run, run_sync=run_sync, key=k.clone(), rets=r.clone(), keep=(model, env)))
+for over in (dict(n=2000, h=30, m=1), dict(), dict(n=4096, h=6, m=1)):
+    case = dict(C["c6_hc_rnn_rs_n500_h10_m5"], **over)
+    env, model = cases.product_rnn_model(case)
+    nat = model.planner_model()
+    dev = nat.device
+    m, n, h, U = case["m"], case["n"], case["h"], case["units"]
+    obs = np.random.RandomState(7).randn(m, 20).astype(np.float32)
+    c0 = torch.randn((m, U), device=dev)
+    h0 = torch.tanh(torch.randn((m, U), device=dev))
+    a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+    obs_d = torch.from_numpy(obs).to(dev)
+    c1, h1 = torch.empty_like(c0), torch.empty_like(h0)
+
+    def run(nat=nat, obs_d=obs_d, c0=c0, h0=h0, a=a, m=m, n=n, h=h, env=env, best=best, rets=rets):
+        nat.plan_rs(obs_d, c0, h0, a, m, n, h, 1.0, env.reward_spec, returns_out=rets, best_key=best)
+        return best, rets
+
+    def run_sync(nat=nat, obs=obs, c0=c0, h0=h0, a=a, m=m, n=n, h=h, env=env, c1=c1, h1=h1):
+        return nat.plan_rs_sync(obs, c0, h0, a, m, n, h, 1.0, env.reward_spec, c_next=c1, h_next=h1)
+    k, r = run()
+    torch.cuda.synchronize()
+    plans.append(dict(run=run, run_sync=run_sync, key=k.clone(), rets=r.clone(), keep=(model, env)))
 ctx = _lib.Context.get(0)
 rs = np.random.RandomState(0)
-t0 = time.time(); count = 0
-while time.time() - t0 < 25:
+t0 = time.time()
+count = sync_count = 0
+while time.time() - t0 < seconds:
     for _ in range(200):
-        nat, obs0, a, m, n, h, env, best, rets, kref, rref, _ = plans[rs.randint(len(plans))]
-        nat.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, returns_out=rets, best_key=best)
+        p = plans[rs.randint(len(plans))]
+        if rs.rand() < 0.3:
+            keys = p["run_sync"]()
+            assert keys is not None and np.array_equal(keys.view(np.int64), p["key"].cpu().numpy())
+            sync_count += 1
+        else:
+            p["run"]()
         count += 1
     torch.cuda.synchronize()
     ctx.launch_status()
-    for nat, obs0, a, m, n, h, env, best, rets, kref, rref, _ in plans:
-        nat.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, returns_out=rets, best_key=best)
+    for p in plans:
+        k, r = p["run"]()
         torch.cuda.synchronize()
-        assert torch.equal(best, kref) and torch.equal(rets, rref)
-print("soak ok:", count, "mixed launches in %.1f s, status clean, results bit-stable" % (time.time() - t0))
+        assert torch.equal(k, p["key"]) and torch.equal(r, p["rets"])
+print("soak ok: %d mixed launches (%d of them blocking) over %d plan shapes in %.1f s, status word clean, every plan "
+      "bit-stable" % (count, sync_count, len(plans), time.time() - t0))
