@@ -12,6 +12,8 @@ CASES = {
     "ant_2x512_tanh_m3_b7": ("ant", (512, 512), "tanh", 3, 5, 7),            # ragged rows, fewer tasks than the meta batch
     "hc_2x128_sigmoid_m2_b16": ("half_cheetah", (128, 128), "sigmoid", 2, 2, 16),
     "hc_1x64_relu_m1_b3": ("half_cheetah", (64,), "relu", 1, 4, 3),          # non-MFMA shape, one task
+    "arm_200x72_relu_m2_b5": ("arm_7dof", (200, 72), "relu", 2, 3, 5),       # widths off every tile size (16 / 64 / k-step 4)
+    "hc_3x96_tanh_m4_b16": ("half_cheetah", (96, 96, 96), "tanh", 4, 4, 16),
 }
 
 
