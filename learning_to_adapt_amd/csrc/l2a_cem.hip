@@ -111,7 +111,10 @@ __global__ void __launch_bounds__(256) l2a_cem_rank_k(const float* returns, int 
                                                       int* elite_rows) {
     extern __shared__ float rs[];
     const int i = blockIdx.y;
-    for (int c = threadIdx.x; c < n; c += 256) rs[c] = returns[(long long)i * n + c];
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float x = returns[(long long)i * n + c];
+        rs[c] = (x != x) ? -__builtin_inff() : x;      // NaN returns sort last (np.argsort of -returns puts them there too);
+    }                                                  // with ties broken by index the ranks stay a permutation
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;

@@ -917,12 +917,14 @@ def test_cem_kernels_match_numpy(reference):
     rets = rs.randn(m, n).astype(np.float32)
     rets[:, 5] = rets[:, 17]
     rets[0, 40:44] = rets[0, 2]
+    rets[1, [7, 90, 200]] = np.nan                 # diverged rollouts: they sort last, like np.argsort(-returns) has them
+    rets[2, 11] = -np.inf
     rows = torch.empty((m * k,), dtype=torch.int32, device=dev)
     rets_d = up(rets)
     ctx.check(lib.l2a_cem_refit(ctx.handle, _ptr(rets_d), _ptr(a_clip), n, m, D, k, 1 if reference else 0, alpha,
                                 _ptr(rows), _ptr(mean_d), _ptr(std_d), _stream_ptr(dev)), "l2a_cem_refit")
     a_st = a_clip.cpu().numpy().astype(np.float64)
-    order = np.argsort(-rets.astype(np.float64), axis=1, kind="stable")
+    order = np.argsort(-np.where(np.isnan(rets), -np.inf, rets).astype(np.float64), axis=1, kind="stable")
     if reference:
         mask = (order < k).T                                            # mpc_controller.py:101
         elites = a_st[mask]
