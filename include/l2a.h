@@ -231,6 +231,16 @@ int l2a_model_adapt_sgd(l2a_model* model, const void* const* base_ptrs, const fl
 int l2a_model_adapt_sgd_host(l2a_model* model, const void* const* base_ptrs, const float* x_host, const float* y_host,
                              int m, int rows, float lr, void* stream);
 
+/* The same step from the UN-normalised transitions, as `dynamics_model.adapt(obs, act, next_obs)` receives them
+ * (meta_mlp_dynamics.py:321-326): float64 host arrays obs / next_obs [m, rows, obs_dim], act [m, rows, act_dim] and the six
+ * float64 normalisation vectors (`self.normalization`).  The first forward launch normalises inputs and target deltas
+ * itself - (v - mean) / (std + 1e-10) in float64, then the cast to fp32, i.e. the host's arithmetic bit for bit
+ * (mlp_dynamics.py:265-266) - so the host keeps nothing but the copy into staging.  Input layers of at most 128 features. */
+int l2a_model_adapt_sgd_raw(l2a_model* model, const void* const* base_ptrs, const double* obs_host,
+                            const double* act_host, const double* next_obs_host, const double* mean_obs,
+                            const double* std_obs, const double* mean_act, const double* std_act,
+                            const double* mean_delta, const double* std_delta, int m, int rows, float lr, void* stream);
+
 /* Copy weight set `e` out of the model in the reference's parameter order and layout (device fp32 buffers of
  * the sizes l2a_model_set_weights takes) - e.g. to read back adapted sets (`_adapted_param_values`).    */
 int l2a_model_get_weights(l2a_model* model, int e, void* const* device_ptrs_out, void* stream);

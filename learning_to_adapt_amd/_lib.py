@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split",
     "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
-    "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_get_weights",
+    "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_adapt_sgd_raw", "l2a_model_get_weights",
     "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
     "l2a_packed_layer_floats", "l2a_pack_layer_host",
     "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best",
@@ -88,6 +88,8 @@ def load():
     lib.l2a_model_adapt_sgd.restype = i32
     lib.l2a_model_adapt_sgd_host.argtypes = [vp, c.POINTER(vp), vp, vp, i32, i32, f32, vp]
     lib.l2a_model_adapt_sgd_host.restype = i32
+    lib.l2a_model_adapt_sgd_raw.argtypes = [vp, c.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]
+    lib.l2a_model_adapt_sgd_raw.restype = i32
     lib.l2a_model_get_weights.argtypes = [vp, i32, c.POINTER(vp), vp]
     lib.l2a_model_get_weights.restype = i32
     dp = c.POINTER(c.c_double)

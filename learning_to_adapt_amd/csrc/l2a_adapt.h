@@ -46,6 +46,14 @@ struct L2AAdaptParams {
     long long a_off[L2A_MAX_LAYERS];    // offset of A_l in a task's scratch
     long long z_off[L2A_MAX_LAYERS + 1];// offset of dZ_l (l = 1 .. L)
     int hmax;
+    // raw mode (l2a_model_adapt_sgd_raw): the batches arrive un-normalised as float64 and are normalised here exactly as
+    // the reference does on the host - (v - mean) / (std + 1e-10) in float64, then the cast to fp32 (mlp_dynamics.py:265-266,
+    // meta_mlp_dynamics.py:321-345) - x / y are then null
+    const double* raw_obs;              // [m, rows, obs_dim]
+    const double* raw_act;              // [m, rows, act_dim]
+    const double* raw_next;             // [m, rows, obs_dim]
+    const double* raw_norm;             // mean_obs[od] std_obs[od] mean_act[ad] std_act[ad] mean_delta[od] std_delta[od]
+    int obs_dim, act_dim;
 };
 
 __device__ __forceinline__ float l2a_act_grad_from_output(float o, int kind) {
@@ -97,11 +105,25 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
     const int chunk = (k_in + L2A_AW - 1) / L2A_AW;
     const int k0 = ks * chunk, k1 = (k0 + chunk < k_in) ? k0 + chunk : k_in;
     const float* x = p.x + (long long)task * p.rows * k_in;
-    const bool staged = k_in <= L2A_XS_MAX;
+    const bool staged = k_in <= L2A_XS_MAX;             // (raw mode is only launched for staged widths)
     if (staged) {
+        const int od = p.obs_dim, ad = p.act_dim;
         for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) {      // x in its own order: coalesced
             const int r = i / k_in, kk = i - r * k_in;
-            xs[kk * L2A_AR + r] = (r < p.rows) ? x[i] : 0.0f;
+            float v = 0.0f;
+            if (r < p.rows) {
+                if (p.raw_obs) {
+                    const bool is_obs = kk < od;
+                    const double raw = is_obs ? p.raw_obs[((long long)task * p.rows + r) * od + kk]
+                                              : p.raw_act[((long long)task * p.rows + r) * ad + (kk - od)];
+                    const double mu = is_obs ? p.raw_norm[kk] : p.raw_norm[2 * od + (kk - od)];
+                    const double sd = is_obs ? p.raw_norm[od + kk] : p.raw_norm[2 * od + ad + (kk - od)];
+                    v = (float)((raw - mu) / (sd + 1e-10));
+                } else {
+                    v = x[i];
+                }
+            }
+            xs[kk * L2A_AR + r] = v;
         }
         __syncthreads();
         if (blockIdx.x == 0)
@@ -200,8 +222,22 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptPar
             const int u = u0 + 16 * t + 4 * q + i;
             if (u >= n_out) continue;
             float v = acc[t][i] + p.b[l][u];
-            if (last) v = (r < p.rows) ? scale * (v - p.y[((long long)task * p.rows + r) * n_out + u]) : 0.0f;
-            else v = l2a_act1(v, p.hidden_act);
+            if (last) {
+                float y = 0.0f;
+                if (r < p.rows) {
+                    const long long e = ((long long)task * p.rows + r) * n_out + u;
+                    if (p.raw_obs) {        // normalised target delta, float64 like the host would compute it
+                        const int od = p.obs_dim, ad = p.act_dim;
+                        const double delta = p.raw_next[e] - p.raw_obs[e];
+                        y = (float)((delta - p.raw_norm[2 * od + 2 * ad + u]) / (p.raw_norm[3 * od + 2 * ad + u] + 1e-10));
+                    } else {
+                        y = p.y[e];
+                    }
+                }
+                v = (r < p.rows) ? scale * (v - y) : 0.0f;
+            } else {
+                v = l2a_act1(v, p.hidden_act);
+            }
             dst[u * L2A_AR + r] = v;
         }
 }

@@ -613,39 +613,99 @@ int l2a_model_adapt_sgd(l2a_model* md, const void* const* base_ptrs, const float
     return L2A_OK;
 }
 
-int l2a_model_adapt_sgd_host(l2a_model* md, const void* const* base_ptrs, const float* x_host, const float* y_host,
-                             int m, int rows, float lr, void* stream_v) {
-    if (!md) return L2A_EINVAL;
+extern "C++" {
+namespace {
+
+// Shared by the two host-array entry points: stage `bytes` (gathered by `fill` into the slot's host-mapped buffer),
+// run the step with the parameters `bind` derives from the staging's device alias.
+template <class Fill, class Bind>
+int adapt_staged(l2a_model* md, const void* const* base_ptrs, int m, int rows, float lr, hipStream_t stream,
+                 size_t bytes, Fill fill, Bind bind, const char* who) {
     l2a_ctx* ctx = md->ctx;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-    l2a_device_guard guard(ctx->device);
-    if (!x_host || !y_host) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd_host: null pointer");
     if (m < 1 || m > md->n_sets || rows < 1 || rows > L2A_AR)
-        return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd_host: m must be in [1, n_sets], rows in [1, 16]");
+        return fail(ctx, L2A_EINVAL, std::string(who) + ": m must be in [1, n_sets], rows in [1, 16]");
     auto& sl = md->aslot[md->aslot_next];
     md->aslot_next ^= 1;
     // the launch that last read this slot's staging must be through before the host overwrites it
     if (sl.pending) { L2A_HIP(ctx, hipEventSynchronize(sl.done)); sl.pending = false; }
-    const long long xf = (long long)m * rows * md->in_dim, yf = (long long)m * rows * md->obs_dim;
-    if (xf + yf > sl.stage_floats) {
+    if ((long long)bytes > sl.stage_floats * (long long)sizeof(float)) {
         if (sl.stage_host) { L2A_HIP(ctx, hipHostFree(sl.stage_host)); sl.stage_host = nullptr; }
-        const long long cap = (long long)md->n_sets * L2A_AR * (md->in_dim + md->obs_dim);
+        // room for either layout: fp32 [x | y] or float64 [obs | act | next | six normalisation vectors]
+        const long long cap = 2LL * md->n_sets * L2A_AR * (md->in_dim + md->obs_dim) + 4LL * (md->in_dim + md->obs_dim) + 16;
         L2A_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.stage_host), (size_t)cap * sizeof(float), hipHostMallocMapped));
         L2A_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.stage_dev), sl.stage_host, 0));
         sl.stage_floats = cap;
     }
     if (!sl.done) L2A_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    std::memcpy(sl.stage_host, x_host, (size_t)xf * sizeof(float));
-    std::memcpy(sl.stage_host + xf, y_host, (size_t)yf * sizeof(float));
+    fill(sl.stage_host);
     L2AAdaptParams ap;
-    const int rc = adapt_prepare(md, base_ptrs, sl.stage_dev, sl.stage_dev + xf, m, rows, stream, ap);
+    const float* dummy = sl.stage_dev;
+    const int rc = adapt_prepare(md, base_ptrs, dummy, dummy, m, rows, stream, ap);
     if (rc != L2A_OK) return rc;
+    bind(ap, sl.stage_dev);
     const int rc2 = adapt_enqueue(md, ap, m, lr, stream);
     if (rc2 != L2A_OK) return rc2;
     L2A_HIP(ctx, hipEventRecord(sl.done, stream));
     sl.pending = true;
     for (int e = 0; e < m; ++e) md->weights_set[e] = 1;
     return L2A_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int l2a_model_adapt_sgd_host(l2a_model* md, const void* const* base_ptrs, const float* x_host, const float* y_host,
+                             int m, int rows, float lr, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    l2a_device_guard guard(ctx->device);
+    if (!x_host || !y_host) return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd_host: null pointer");
+    const long long mm = m > 0 ? m : 0, rr = rows > 0 ? rows : 0;
+    const long long xf = mm * rr * md->in_dim, yf = mm * rr * md->obs_dim;
+    return adapt_staged(md, base_ptrs, m, rows, lr, reinterpret_cast<hipStream_t>(stream_v), (size_t)(xf + yf) * sizeof(float),
+        [&](float* host) {
+            std::memcpy(host, x_host, (size_t)xf * sizeof(float));
+            std::memcpy(host + xf, y_host, (size_t)yf * sizeof(float));
+        },
+        [&](L2AAdaptParams& ap, const float* dev) { ap.x = dev; ap.y = dev + xf; },
+        "l2a_model_adapt_sgd_host");
+}
+
+int l2a_model_adapt_sgd_raw(l2a_model* md, const void* const* base_ptrs, const double* obs_host, const double* act_host,
+                            const double* next_obs_host, const double* mean_obs, const double* std_obs,
+                            const double* mean_act, const double* std_act, const double* mean_delta,
+                            const double* std_delta, int m, int rows, float lr, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    l2a_device_guard guard(ctx->device);
+    if (!obs_host || !act_host || !next_obs_host || !mean_obs || !std_obs || !mean_act || !std_act || !mean_delta || !std_delta)
+        return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd_raw: null pointer");
+    if (md->in_dim > L2A_XS_MAX)
+        return fail(ctx, L2A_EINVAL, "l2a_model_adapt_sgd_raw: input layers of at most " + std::to_string(L2A_XS_MAX) +
+                                     " features (normalise on the host and use l2a_model_adapt_sgd_host)");
+    const int od = md->obs_dim, ad = md->act_dim;
+    const long long mm = m > 0 ? m : 0, rr = rows > 0 ? rows : 0;
+    const long long no = mm * rr * od, na = mm * rr * ad;
+    const long long doubles = 2 * no + na + 4 * od + 2 * ad;
+    return adapt_staged(md, base_ptrs, m, rows, lr, reinterpret_cast<hipStream_t>(stream_v), (size_t)doubles * sizeof(double),
+        [&](float* host_f) {
+            double* host = reinterpret_cast<double*>(host_f);
+            std::memcpy(host, obs_host, (size_t)no * sizeof(double));
+            std::memcpy(host + no, act_host, (size_t)na * sizeof(double));
+            std::memcpy(host + no + na, next_obs_host, (size_t)no * sizeof(double));
+            double* nv = host + 2 * no + na;
+            std::memcpy(nv, mean_obs, sizeof(double) * od);            std::memcpy(nv + od, std_obs, sizeof(double) * od);
+            std::memcpy(nv + 2 * od, mean_act, sizeof(double) * ad);   std::memcpy(nv + 2 * od + ad, std_act, sizeof(double) * ad);
+            std::memcpy(nv + 2 * od + 2 * ad, mean_delta, sizeof(double) * od);
+            std::memcpy(nv + 3 * od + 2 * ad, std_delta, sizeof(double) * od);
+        },
+        [&](L2AAdaptParams& ap, const float* dev_f) {
+            const double* dev = reinterpret_cast<const double*>(dev_f);
+            ap.x = nullptr; ap.y = nullptr;
+            ap.raw_obs = dev; ap.raw_act = dev + no; ap.raw_next = dev + no + na; ap.raw_norm = dev + 2 * no + na;
+            ap.obs_dim = od; ap.act_dim = ad;
+        },
+        "l2a_model_adapt_sgd_raw");
 }
 
 int l2a_model_get_weights(l2a_model* md, int e, void* const* device_ptrs_out, void* stream_v) {

@@ -132,6 +132,35 @@ class NativeModel(object):
                                                _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_model_adapt_sgd_host")
 
+    raw_adapt_max_inputs = 128
+
+    def adapt_sgd_raw(self, base_params, obs, act, obs_next, normalization, lr):
+        """``adapt_sgd`` from the un-normalised float64 transitions ``[m, rows, dim]`` and ``normalization`` (the
+        model's dict of (mean, std) pairs): the device normalises exactly as the host would
+        (``l2a_model_adapt_sgd_raw``)."""
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        act = np.ascontiguousarray(act, dtype=np.float64)
+        obs_next = np.ascontiguousarray(obs_next, dtype=np.float64)
+        m, rows = int(obs.shape[0]), int(obs.shape[1])
+        assert obs.shape == (m, rows, self.obs_dim) and act.shape == (m, rows, self.act_dim) and obs_next.shape == obs.shape
+        base = self._keep.get("adapt_base")
+        if base is None or base[0] is not base_params:
+            dev = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in base_params]
+            base = (base_params, dev, (ctypes.c_void_p * len(dev))(*[t.data_ptr() for t in dev]))
+            self._keep["adapt_base"] = base
+        nv = self._keep.get("adapt_norm")
+        if nv is None or nv[0] is not normalization:
+            vecs = [np.ascontiguousarray(normalization[k][j], dtype=np.float64) for k in ("obs", "act", "delta") for j in (0, 1)]
+            assert vecs[0].shape == (self.obs_dim,) and vecs[2].shape == (self.act_dim,) and vecs[4].shape == (self.obs_dim,)
+            nv = (normalization, vecs)
+            self._keep["adapt_norm"] = nv
+        p = [ctypes.c_void_p(v.ctypes.data) for v in nv[1]]
+        rc = self.lib.l2a_model_adapt_sgd_raw(self.handle, base[2], ctypes.c_void_p(obs.ctypes.data),
+                                              ctypes.c_void_p(act.ctypes.data), ctypes.c_void_p(obs_next.ctypes.data),
+                                              p[0], p[1], p[2], p[3], p[4], p[5], m, rows, float(lr),
+                                              _stream_ptr(self.device))
+        self.ctx.check(rc, "l2a_model_adapt_sgd_raw")
+
     def get_weights(self, e):
         """Weight set ``e`` as fresh CUDA tensors in the reference's order and layout."""
         sizes = (self.obs_dim + self.act_dim,) + self.hidden_sizes + (self.obs_dim,)

@@ -524,7 +524,7 @@ def test_device_adapt_matches_autograd(hidden, act, rows):
     np.testing.assert_allclose(picks[0][2], picks[1][2], rtol=1e-4, atol=1e-4)
 
 
-def test_host_staged_adapt_is_bit_identical_to_the_device_pointer_entry():
+def test_host_staged_and_raw_adapt_are_bit_identical_to_the_device_pointer_entry():
     """`l2a_model_adapt_sgd_host` (batches copied into host-mapped staging that the kernels read directly, two slots)
     against `l2a_model_adapt_sgd` on device tensors: every adapted parameter bit for bit - over repeated steps with
     fresh data (both staging slots, arrays overwritten right after the call), a changed learning rate, fewer tasks /
@@ -537,21 +537,32 @@ def test_host_staged_adapt_is_bit_identical_to_the_device_pointer_entry():
             for w in synthetic.make_weight_set(od, ad, list(hidden), 1000)]
     plain = NativeModel(od, ad, hidden, "relu", None, m, "per_block")
     staged = NativeModel(od, ad, hidden, "relu", None, m, "per_block")
+    raw = NativeModel(od, ad, hidden, "relu", None, m, "per_block")
     rs = np.random.RandomState(0)
+    norm = {"obs": (10.0 * rs.randn(od), 0.01 + rs.rand(od)), "act": (rs.randn(ad), 50.0 + 100.0 * rs.rand(ad)),
+            "delta": (0.1 * rs.randn(od), 1e-3 + 0.1 * rs.rand(od))}
     for step, (mm, rows, lr) in enumerate([(5, 16, 0.01), (5, 16, 0.01), (5, 16, 0.01), (5, 16, 0.02), (3, 9, 0.02),
                                            (1, 1, 0.5), (5, 16, 0.01)]):
-        x = rs.randn(mm, rows, od + ad).astype(np.float32)
-        y = rs.randn(mm, rows, od).astype(np.float32)
+        # un-normalised transitions; the host normalisation of MetaMLPDynamicsModel.adapt (float64, then the cast)
+        ob = norm["obs"][0] + norm["obs"][1] * rs.randn(mm, rows, od)
+        ac = rs.uniform(-150, 150, (mm, rows, ad))
+        nx = ob + norm["delta"][0] + norm["delta"][1] * rs.randn(mm, rows, od)
+        nz = lambda v, k: (v - norm[k][0]) / (norm[k][1] + 1e-10)  # noqa: E731
+        x = np.concatenate([nz(ob, "obs"), nz(ac, "act")], axis=2).astype(np.float32)
+        y = nz(nx - ob, "delta").astype(np.float32)
         plain.adapt_sgd(base, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), lr)
         staged.adapt_sgd_host(base, x, y, lr)
+        raw.adapt_sgd_raw(base, ob, ac, nx, norm, lr)       # normalised on the device, same arithmetic
         x[:] = 0.0      # the arrays may be reused as soon as the call returns
         y[:] = 0.0
+        ob[:] = 0.0
         for e in range(mm):
-            for a, b in zip(plain.get_weights(e), staged.get_weights(e)):
-                assert torch.equal(a, b), (step, e, tuple(a.shape))
+            for a, b, c in zip(plain.get_weights(e), staged.get_weights(e), raw.get_weights(e)):
+                assert torch.equal(a, b) and torch.equal(a, c), (step, e, tuple(a.shape))
         assert not torch.equal(plain.get_weights(0)[0], base[0])
     plain.close()
     staged.close()
+    raw.close()
 
 
 @pytest.mark.parametrize("kernel", ["auto", "valu"])
