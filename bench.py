@@ -23,6 +23,10 @@ SURVEY.md H5.  Extra objects: `roofline` (fp32 MFMA roofline of the rollout kern
 each launch on the launch stream) and `cpu_baseline` (the NumPy oracle = CPU restatement of the reference
 path, timed on this box's host cores, N = 1 only).
 
+`config.get_actions_parity_foreign_draw_plan_steps_per_s` is the parity loop with one foreign `np.random.uniform()`
+between calls (what an in-process env reset does): the draw-ahead block is stale every step and the draw is pipelined
+under the rollout instead.  At N > 1 `config.strong_scaling` compares the sharded plan with the SAME plan on one GPU.
+
 `python bench.py --gpus N` without a torch.distributed.run environment launches the N ranks itself.
 """
 
@@ -266,8 +270,46 @@ def main():
             e2e[mode] = max_over_ranks(_timed_calls(lambda: ctrl.get_actions(obs_np), args.steps, args.warmup, sync))
             if mode == "numpy" and ctrl._ahead is not None:
                 e2e["draw_ahead_hits"] = int(ctrl._ahead.hits)
+            if mode == "numpy":
+                # the mode an in-process env sees (n_parallel = 1: samplers/vectorized_env_executor.py:45 ->
+                # envs/mujoco_env.py:85-87 reset noise; samplers/utils.py rollout()): somebody else consumes the global
+                # generator between two plans, so the block drawn ahead is stale and the step draws synchronously
+                # (pipelined over the horizon under the rollout).  Every rank consumes alike: the shards stay slices of
+                # one candidate tensor.
+                def foreign_step():
+                    np.random.uniform()
+                    ctrl.get_actions(obs_np)
+                hits0 = int(ctrl._ahead.hits) if ctrl._ahead is not None else 0
+                e2e["foreign"] = max_over_ranks(_timed_calls(foreign_step, args.steps, min(args.warmup, 5), sync))
+                e2e["foreign_hits"] = (int(ctrl._ahead.hits) if ctrl._ahead is not None else 0) - hits0
             if ctrl._ahead is not None:
                 ctrl._ahead.stop()
+
+    # ---- strong scaling of THIS plan (n_glob candidates): rank 0 alone runs the whole plan on its one GPU ------------
+    strong = None
+    if world > 1:
+        full_ms = None
+        if rank == 0:
+            a_full = torch.rand((HORIZON, n_glob, ACT_DIM), generator=gen, device=dev) * 2.0 - 1.0
+            k3 = max(3, min(10, args.steps))
+            for _ in range(2):
+                native.plan_rs(obs0, a_full, 1, n_glob, HORIZON, 1.0, spec, best_key=best)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k3):
+                native.plan_rs(obs0, a_full, 1, n_glob, HORIZON, 1.0, spec, best_key=best)
+            torch.cuda.synchronize()
+            full_ms = 1e3 * (time.perf_counter() - t0) / k3
+            native.ctx.launch_status()
+            del a_full
+        dist.barrier()
+        if rank == 0:
+            n_ms = 1e3 * resident_s / args.steps
+            strong = {"plan_candidates": n_glob, "one_gpu_kernel_only_ms": round(full_ms, 4),
+                      "n_gpu_kernel_only_ms": round(n_ms, 4), "speedup": round(full_ms / n_ms, 3),
+                      "efficiency": round(full_ms / n_ms / world, 4),
+                      "note": "the SAME %d-candidate plan on one GPU (rank 0 alone) vs sharded over %d GPUs incl. the "
+                              "all-reduce; kernel-only loops" % (n_glob, world)}
 
     # ---- CPU baseline: the NumPy oracle on this box's host cores (N = 1, rank 0) ---------------
     cpu = None
@@ -356,6 +398,12 @@ def main():
         if "numpy" in e2e:
             out["config"]["get_actions_parity_plan_steps_per_s"] = round(args.steps / e2e["numpy"], 3)
             out["config"]["draw_ahead_hits"] = e2e.get("draw_ahead_hits")
+        if "foreign" in e2e:
+            out["config"]["get_actions_parity_foreign_draw_plan_steps_per_s"] = round(args.steps / e2e["foreign"], 3)
+            out["config"]["foreign_draw_note"] = ("one np.random.uniform() consumed between calls (an in-process env reset): "
+                                                  "draw-ahead hits in that loop: %d of %d" % (e2e["foreign_hits"], args.steps))
+        if strong is not None:
+            out["config"]["strong_scaling"] = strong
         if "device" in e2e:
             out["config"]["get_actions_device_rng_plan_steps_per_s"] = round(args.steps / e2e["device"], 3)
         if kern_ms is not None:

@@ -95,6 +95,12 @@ int l2a_set_kernel(l2a_ctx* ctx, int kind);
  * bit-identical under all three policies: the summation order is fixed (sets: group A + group B;
  * output layer: eight chunks of hidden units, ((c0+c1)+c2)+c3 + ((c4+c5)+c6)+c7).            */
 int l2a_set_split(l2a_ctx* ctx, int policy);
+/* Set batching of the MFMA kernel (models with two hidden layers).  A workgroup that runs several weight sets per
+ * horizon step (an ensemble member group) can run layer 0 of `sets` sets back to back, then their hidden GEMMs and
+ * output layers, then their reduces - two workgroup barriers per batch instead of two per set, the activations of a
+ * batch held in LDS side by side.  0 (default) = as many as fit the CU's LDS (at most 4), 1 = one set at a time.
+ * Arithmetic and summation order do not depend on it: results are bit-identical for every value.       */
+int l2a_set_batch(l2a_ctx* ctx, int sets);
 /* Status word of the launches issued since the last call (caller must have synchronised the
  * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch
  * with l2a_set_split(ctx, 0)).  Reading clears it.                                            */
@@ -282,6 +288,19 @@ int l2a_comm_unique_id(char id_out[128]);
 int l2a_comm_init(l2a_ctx* ctx, int rank, int world, const char id[128]);
 int l2a_comm_destroy(l2a_ctx* ctx);
 int l2a_allreduce_best(l2a_ctx* ctx, unsigned long long* best_key, int m, void* stream);
+/* What the ranks of a sharded plan all-reduce, packed on the device behind the plan launch (no host synchronisation
+ * between the launch and the collective): payload [m + 3] u64 =
+ *   [0, m)   the shard's arg-max keys (copied from best_key)
+ *   [m]      1 when this context's launch status word is set (a tile-split exchange timed out: the keys are invalid)
+ *   [m + 1]  digest & L2A_DIGEST_MASK, [m + 2]  L2A_DIGEST_MASK - (digest & L2A_DIGEST_MASK)
+ * After an in-place MAX all-reduce of the m + 3 words (l2a_allreduce_best with m + 3, or torch.distributed) every rank
+ * holds the global keys, knows whether ANY rank has to repeat its launch unsplit ([m] != 0: all ranks do, together),
+ * and whether every rank planned on the same candidate tensor ([m + 1] + [m + 2] == L2A_DIGEST_MASK iff all digests
+ * were equal; the digest is the caller's fingerprint of its RNG position).  One device-to-host copy of m + 3 words
+ * ends the step.  Every word is below 2^63, so signed 64-bit MAX (torch.int64) reduces them correctly.            */
+#define L2A_DIGEST_MASK 0x7fffffffffffull
+int l2a_plan_payload(l2a_ctx* ctx, const unsigned long long* best_key, int m, unsigned long long digest,
+                     unsigned long long* payload, void* stream);
 
 /* ---- recurrent planner (ReBAL) --------------------------------------------------------------
  * Single-layer LSTM dynamics model: `RNNDynamicsModel` (dynamics/rnn_dynamics.py:11-100) built by

@@ -24,13 +24,13 @@ KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
 CELL_CODES = {"lstm": 0, "gru": 1, "rnn": 2}
 
 EXPORTED_SYMBOLS = (
-    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split",
+    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split", "l2a_set_batch",
     "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_adapt_sgd_raw", "l2a_model_get_weights",
     "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
     "l2a_packed_layer_floats", "l2a_pack_layer_host",
-    "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best",
+    "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best", "l2a_plan_payload",
     "l2a_cem_sample", "l2a_cem_refit",
     "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_sync", "l2a_lstm_plan_rs_chunk",
     "l2a_lstm_predict", "l2a_lstm_mfma_eligible",
@@ -68,6 +68,11 @@ def load():
     lib.l2a_set_kernel.restype = i32
     lib.l2a_set_split.argtypes = [vp, i32]
     lib.l2a_set_split.restype = i32
+    if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_set_batch"):
+        lib.l2a_set_batch = lambda handle, sets: 0         # developer A/B against a library of an earlier round
+    else:
+        lib.l2a_set_batch.argtypes = [vp, i32]
+        lib.l2a_set_batch.restype = i32
     lib.l2a_launch_status.argtypes = [vp, c.POINTER(i32)]
     lib.l2a_launch_status.restype = i32
     lib.l2a_set_debug_buffer.argtypes = [vp, vp]
@@ -145,6 +150,11 @@ def load():
     lib.l2a_lstm_plan_rs_chunk.restype = i32
     lib.l2a_lstm_predict.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.l2a_lstm_predict.restype = i32
+    if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_plan_payload"):
+        pass                                               # developer A/B against a library of an earlier round
+    else:
+        lib.l2a_plan_payload.argtypes = [vp, vp, i32, c.c_ulonglong, vp, vp]
+        lib.l2a_plan_payload.restype = i32
     lib.l2a_lstm_mfma_eligible.argtypes = [i32, i32, i32]
     lib.l2a_lstm_mfma_eligible.restype = i32
     _lib = lib
@@ -204,6 +214,10 @@ class Context(object):
         """0 = never, 1 = auto (default; shares the middle set of odd ensembles), 2 = whole sets only."""
         self.check(self.lib.l2a_set_split(self.handle, int(policy)), "l2a_set_split")
 
+    def set_batch(self, sets):
+        """Sets per batch of the MFMA rollout: 0 = as many as fit the LDS (default), 1 = one at a time (bit-identical)."""
+        self.check(self.lib.l2a_set_batch(self.handle, int(sets)), "l2a_set_batch")
+
     def launch_status_value(self):
         """Status word of the launches since the last call (stream must be synchronised); reading clears it."""
         st = ctypes.c_int()
@@ -233,6 +247,16 @@ class Context(object):
         self.set_split(0)
         self.split_degraded = True
         return False
+
+    def force_unsplit(self):
+        """A rank of a sharded plan was told by the collective that SOME rank's launch lost its tile-split partner: all
+        ranks clear their status word, switch to the unsplit geometry (bit-identical results) and repeat the launch
+        together.  Raises when the split was already off - a second failure is not a placement problem."""
+        self.launch_status_value()
+        if getattr(self, "split_degraded", False):
+            raise L2AError("a rollout launch of the sharded plan was flagged invalid with the tile split disabled")
+        self.set_split(0)
+        self.split_degraded = True
 
     def set_spin_limit(self, polls):
         """Developer / test knob: polls a split workgroup waits for its partner per launch (0 = default)."""

@@ -151,9 +151,6 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         p.tiles_per_env = ceil_div(p.n, 16 * nt);
         const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
         p.cst_set = 32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H;
-        const int smem = 2 * p.sa_elems * 16 + e_loop * p.cst_set * 4 + 2 * nt * md->OT * 64 * 16;
-        if (smem > ctx->lds_per_block)
-            return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
         // Member split: two workgroups per candidate tile (group A | group B of the ensemble) when
         // that still fits one workgroup per CU - e.g. config 2: 125 tiles -> 250 workgroups.
         const long long pairs = (long long)p.m * p.tiles_per_env;
@@ -197,6 +194,37 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             p.spin_limit = ctx->spin_limit;
         }
         p.dbg = ctx->dbg;
+        // LDS layout (l2a_mfma.h): activation regions | chunk partials of a batch (lb > 1) | constants | exchange staging.
+        // lb = sets per batch: with two hidden layers, layer 0 of up to lb sets runs back to back, then their hidden
+        // GEMMs + output layers, then their reduces - two barriers per batch instead of two per set.  The largest lb
+        // (<= 4, <= the longest set sequence of a workgroup) that fits the CU's LDS; 1 = one set at a time.
+        const bool uniform_split = p.split && p.split_from < 0;
+        const int e_half = (e_loop + 1) / 2;
+        const int nseq = uniform_split ? e_half : e_loop;            // sets the busiest workgroup runs in sequence
+        const int ps_bytes = 2 * L2A_NW * nt * md->OT * 64 * 16;     // chunk partials of one set
+        const int x_bytes = 2 * nt * md->OT * 64 * 16;
+        const int cst_bytes_all = nseq * p.cst_set * 4;
+        p.n_cst = nseq;
+        p.lb = 1;
+        int part_bytes = 0;
+        if (md->n_hidden == 2 && ctx->batch_sets != 1) {
+            const int cap = ctx->batch_sets > 0 ? ctx->batch_sets : 4;
+            for (int lb = (nseq < cap ? nseq : cap); lb >= 2; --lb) {
+                // a shared (half) set writes only the lower half of its partial slot; its reduce still reads the upper
+                // half (branch-free), which then overlays the constants - keep that overlay inside the allocation
+                const bool trim = uniform_split && p.split == 2 && lb == nseq && cst_bytes_all + x_bytes >= ps_bytes / 2;
+                const int pbytes = lb * ps_bytes - (trim ? ps_bytes / 2 : 0);
+                if (lb * p.sa_elems * 16 + pbytes + cst_bytes_all + x_bytes <= ctx->lds_per_block) {
+                    p.lb = lb;
+                    part_bytes = pbytes;
+                    break;
+                }
+            }
+        }
+        p.cst_off = ((p.lb > 1 ? p.lb : 2) * p.sa_elems * 16 + part_bytes) / 16;
+        const int smem = p.cst_off * 16 + cst_bytes_all + x_bytes;
+        if (smem > ctx->lds_per_block)
+            return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
         const dim3 grid((unsigned)(pairs + (p.split ? split_pairs : 0))), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
         int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, &p, grid.x, smem, stream);
@@ -281,6 +309,8 @@ int l2a_init(int device, l2a_ctx** out) {
     }
     const char* sp = std::getenv("L2A_SPLIT");
     if (sp && sp[0] >= '0' && sp[0] <= '2') ctx->split_policy = sp[0] - '0';
+    const char* bs = std::getenv("L2A_BATCH");
+    if (bs && bs[0] >= '0' && bs[0] <= '4') ctx->batch_sets = bs[0] - '0';
     *out = ctx;
     return L2A_OK;
 }
@@ -299,6 +329,13 @@ int l2a_set_split(l2a_ctx* ctx, int policy) {
     if (!ctx) return L2A_EINVAL;
     if (policy < 0 || policy > 2) return fail(ctx, L2A_EINVAL, "split policy must be 0, 1 or 2");
     ctx->split_policy = policy;
+    return L2A_OK;
+}
+
+int l2a_set_batch(l2a_ctx* ctx, int sets) {
+    if (!ctx) return L2A_EINVAL;
+    if (sets < 0 || sets > 4) return fail(ctx, L2A_EINVAL, "sets per batch must be 0 (automatic) .. 4");
+    ctx->batch_sets = sets;
     return L2A_OK;
 }
 

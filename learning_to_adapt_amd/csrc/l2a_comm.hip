@@ -11,6 +11,21 @@
 #include <cstring>
 #include <string>
 
+// ---- payload of a sharded plan's collective (device side: one wave) -----------------------------------------------
+__global__ void l2a_plan_payload_k(const unsigned long long* best_key, int m, const unsigned int* status,
+                                   unsigned long long digest, unsigned long long* payload) {
+    for (int i = threadIdx.x; i < m; i += blockDim.x) payload[i] = best_key[i];
+    if (threadIdx.x == 0) {
+        // the status word lives in host-mapped memory; the rollout kernel ORed into it with system scope and has
+        // completed (stream order)
+        const unsigned int st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long d = digest & L2A_DIGEST_MASK;
+        payload[m] = st ? 1ull : 0ull;
+        payload[m + 1] = d;
+        payload[m + 2] = L2A_DIGEST_MASK - d;
+    }
+}
+
 namespace {
 
 // the subset of rccl.h used here (ABI-stable: NCCL 2.x)
@@ -112,3 +127,14 @@ int l2a_allreduce_best(l2a_ctx* ctx, unsigned long long* best_key, int m, void* 
 }
 
 }  // extern "C"
+
+extern "C" int l2a_plan_payload(l2a_ctx* ctx, const unsigned long long* best_key, int m, unsigned long long digest,
+                                unsigned long long* payload, void* stream) {
+    if (!ctx) return L2A_EINVAL;
+    if (!best_key || !payload || m < 1) return l2a_fail(ctx, L2A_EINVAL, "l2a_plan_payload: null pointer or m < 1");
+    l2a_device_guard guard(ctx->device);
+    hipLaunchKernelGGL(l2a_plan_payload_k, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), best_key, m,
+                       ctx->status_dev, digest, payload);
+    L2A_HIP(ctx, hipGetLastError());
+    return L2A_OK;
+}

@@ -45,6 +45,9 @@ struct L2AKParams {
     int KG0, OT;                // ceil(in_dim/16), ceil(obs_dim/16)
     int sa_elems;               // MFMA: f32x4 elements per LDS activation region
     int cst_set;                // MFMA: floats of per-set constants cached in LDS (norm + biases)
+    int lb;                     // MFMA: sets per batch (layer 0 of lb sets, one barrier, their GEMMs, one barrier, reduces)
+    int cst_off;                // MFMA: start of the constants in LDS, in f32x4 elements from the base
+    int n_cst;                  // MFMA: constant slots laid out (>= the sets any workgroup of the launch runs)
     float hid_floor, out_floor; // MFMA fast activations: relu = max(x, 0), identity = max(x, -inf)
     int hmax;                   // VALU: widest hidden layer
     // ---- launch ------------------------------------------------------------------------

@@ -39,12 +39,13 @@ struct l2a_lstm {
 // (key layout: l2a_key_pack; the index is clamped, a launch flagged invalid may have left anything in the key).
 __global__ void l2a_gather_best_k(const unsigned long long* best_key, const float* actions, int m, int n, int cand_offset,
                                   int act_dim, float* out) {
-    const int i = blockIdx.x, d = threadIdx.x;
-    if (i >= m || d >= act_dim) return;
+    const int i = blockIdx.x;
+    if (i >= m) return;
     const unsigned int low = (unsigned int)(best_key[i] & 0x7fffffffull);
     int idx = (int)(0x7fffffffu - low) - cand_offset;
     idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
-    out[i * act_dim + d] = actions[((long long)i * n + idx) * act_dim + d];
+    for (int d = threadIdx.x; d < act_dim; d += blockDim.x)      // any action width (the generic cells take act_dim > 64)
+        out[i * act_dim + d] = actions[((long long)i * n + idx) * act_dim + d];
 }
 
 namespace {
@@ -73,7 +74,7 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
     p.disc0 = 1.0;
 }
 
-int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v) {
+int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = true) {
     l2a_ctx* ctx = md->ctx;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     l2a_device_guard guard(ctx->device);
@@ -109,7 +110,7 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v) {
         const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
         // Unit-tile split: two workgroups per candidate tile when that still fits one workgroup per CU (both must
         // be resident: they swap their halves of h once per step).  Same bits as the unsplit launch.
-        p.split = (ctx->split_policy != 0 && 2 * tiles <= cus && p.h < 4096) ? 1 : 0;
+        p.split = (allow_split && ctx->split_policy != 0 && 2 * tiles <= cus && p.h < 4096) ? 1 : 0;
         if (p.split) {
             const long long need = tiles * 4 * (long long)(UT / 2 + md->OT) * 2048;
             if (need > md->xbuf_bytes) {
@@ -445,7 +446,9 @@ int l2a_lstm_plan_rs_sync(l2a_lstm* md, const float* obs_host, const float* c0, 
         q.state_out = obs_next; q.c_out = c_next; q.h_out = h_next;
         q.obs_per_row = 1; q.hid_per_row = 1;
         q.m = 1; q.n = m; q.h = 1; q.discount = 1.0;
-        rc = launch(md, q, stream_v);
+        // NEVER tile-split: l2a_mail_end reads the status word as soon as the PLAN has published, while this launch may
+        // still run - an exchange timeout in it would be noticed one call late and the state it wrote adopted
+        rc = launch(md, q, stream_v, false);
     }
     return l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_lstm_plan_rs_sync");
 }

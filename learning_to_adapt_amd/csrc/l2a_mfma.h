@@ -222,13 +222,13 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
 // (hidden tile == k-group of the output layer, D fragment == B fragment: no LDS round trip).
 // The K reduction is cut into chunks of TPW / 2 k-groups, each its own MFMA chain, written to
 // pbuf[(chunk * NT + nt) * OT + c]; a full member's wave owns chunks 2w and 2w + 1, a half
-// member's wave owns chunk w of its workgroup's half.  Also launches the next (step, set)'s
-// layer-0 operand loads so that they are in flight across the barrier that follows.
-template <int NT, int TW, int TPW, int OT>
+// member's wave owns chunk w of its workgroup's half.  `prefetch` issues the NPF operand loads of
+// the phase that follows (the next set's hidden GEMM inside a batch, else the next layer 0), so
+// that they are in flight across the barrier / under the MFMAs here.
+template <int NT, int TW, int TPW, int OT, int NPF, class PF>
 __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x4 (&pfO)[TPW][OT],
-                                              __amdgpu_buffer_rsrc_t rs_out, int tile0,
-                                              __amdgpu_buffer_rsrc_t r0n, const int (&voff0)[TPW],
-                                              f32x4 (&pfL0)[TPW], f32x4* pbuf, int chunk0, int lane) {
+                                              __amdgpu_buffer_rsrc_t rs_out, int tile0, PF prefetch,
+                                              f32x4* pbuf, int chunk0, int lane) {
     constexpr int HT = L2A_NW * TPW;
     constexpr int CS = TPW / 2;         // tiles per chunk
     constexpr int NCH = TW / CS;        // chunks this wave owns (2 = full member, 1 = half member)
@@ -239,8 +239,7 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
         for (int c = 0; c < OT; ++c)
             a[tt][c] = (tt < L2A_PFT(TW, OT)) ? pfO[tt][c]
                                               : l2a_ldw(rs_out, lane * 16 + (tile0 + tt) * 1024, c * HT * 1024);
-#pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0n, voff0[tt], 0);     // k-group 0 only
+    prefetch();
     f32x4 acc[NCH][NT][OT];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
@@ -259,8 +258,8 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
 #pragma unroll
                     for (int c = 0; c < OT; ++c)
                         acc[ch][nt][c] = L2A_MFMA(a[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], acc[ch][nt][c]);
-    // issue order hint: the late output fragments first (one per 4 MFMAs), then the next layer-0
-    // operands spread over the remaining MFMAs - 8 VMEM issues in a row would idle the matrix pipe
+    // issue order hint: the late output fragments first (one per 2 MFMAs), then the prefetch loads
+    // spread over the remaining MFMAs - 8 VMEM issues in a row would idle the matrix pipe
     {
         constexpr int NLATE = (TW - L2A_PFT(TW, OT)) * OT;
         constexpr int NMFMA = TW * 4 * NT * OT;
@@ -269,9 +268,9 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
-        constexpr int PER = (NMFMA - 2 * NLATE) / TPW > 0 ? (NMFMA - 2 * NLATE) / TPW : 1;
+        constexpr int PER = (NMFMA - 2 * NLATE) / NPF > 0 ? (NMFMA - 2 * NLATE) / NPF : 1;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
+        for (int i = 0; i < NPF; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
@@ -284,20 +283,30 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
             for (int c = 0; c < OT; ++c) pbuf[(((chunk0 + ch) * NT + nt) * OT + c) * 64 + lane] = acc[ch][nt][c];
 }
 
-template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4>
+template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
     constexpr int HT = L2A_NW * TPW;
     constexpr int TH = TPW / 2;         // tiles per wave of a half member
     static_assert(TPW % 2 == 0, "half members split a wave's tiles in two");
     // Per-set constants cached in LDS: [in_mu 16 KG0][in_inv 16 KG0][out_mu 16 OT][out_sd 16 OT]
-    // [out_bias 16 OT][hidden biases n_hidden x H] - p.cst_set floats per weight set.
+    // [out_bias 16 OT][hidden biases n_hidden x H] - p.cst_set floats per weight set, one slot per set of this
+    // workgroup's sequence (slot i = the i-th set it runs).
     constexpr int CST_BOUT = 32 * KG0 + 32 * OT;
     constexpr int CST_BHID = CST_BOUT + 16 * OT;
+    constexpr int PS = 2 * L2A_NW * NT * OT * 64;       // f32x4 of output-layer chunk partials per set
     const int NRM_SET = p.cst_set;
+    // LDS: activation regions [max(2, LB)][sa_elems] | (LB > 1: chunk partials of a batch) | constants | exchange staging.
+    // LB = sets per batch (p.lb).  LB == 1: one set at a time, two regions used in turn (layer in / layer out, the
+    // output partials in whichever is free).  LB > 1 (two hidden layers only): layer 0 of LB sets -> region j each,
+    // ONE barrier, then every set's hidden GEMM + output layer back to back (partials -> their own area), ONE
+    // barrier, all reduces - two barriers per batch instead of two per set, and the MFMA-light phases of
+    // consecutive sets overlap each other's latencies.  Same arithmetic in the same order: bit-identical.
+    const int LB = p.lb;
     extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
     f32x4* buf0 = reinterpret_cast<f32x4*>(l2a_smem);
     f32x4* buf1 = buf0 + p.sa_elems;
-    float* nrm = reinterpret_cast<float*>(buf1 + p.sa_elems);
+    f32x4* pbase = buf0 + (LB > 1 ? LB : 2) * p.sa_elems;
+    float* nrm = reinterpret_cast<float*>(buf0 + p.cst_off);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -333,7 +342,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const int tb = pairid - env * p.tiles_per_env;
     const int R = p.m * p.n;
     const int obs_dim = p.obs_dim, act_dim = p.act_dim;
-    const int n_hidden = p.n_hidden;
+    // N1: the model has ONE hidden layer (its own instances: no hidden->hidden GEMM, layer 0 feeds the output layer from
+    // registers) - a compile-time fact, so that neither path keeps the other's operand registers alive
+    const int n_hidden = N1 ? 1 : p.n_hidden;
 
     int cand[NT], row[NT];
     bool valid[NT];
@@ -344,15 +355,27 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         row[nt] = env * p.n + (valid[nt] ? cand[nt] : p.n - 1);
     }
 
-    // ---- constants of every set this workgroup uses -> LDS ---------------------------------
+    // Which sets this workgroup runs (split: 0 = all; 1 = group A | group B; 2 = as 1, but the
+    // last set of group A is SHARED: both workgroups run it as a "half member" - layer 0 and the
+    // inner hidden layers in full, the last hidden layer and the output layer for one half of the
+    // hidden tiles each - which balances odd ensembles and lets a single model use two CUs).
+    // Both workgroups run their full sets first and the shared one last.
     const bool per_block = (p.mode == L2A_MODE_PER_BLOCK);
     const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
     const int e_half = (e_loop + 1) >> 1;                   // group A = [0, e_half), B = [e_half, e_loop)
-    f32x4* xlds = reinterpret_cast<f32x4*>(nrm + e_loop * NRM_SET);   // [2][NT * OT][64], split only
-    for (int i = tid; i < e_loop * NRM_SET; i += 64 * L2A_NW) {
+    const int e_shared = (split == 2) ? e_half - 1 : -1;
+    const int n_full = !split ? e_loop : (grp == 0 ? e_half - (split == 2 ? 1 : 0) : e_loop - e_half);
+    const int n_seq = n_full + (split == 2 ? 1 : 0);
+    const int full0 = (split && grp == 1) ? e_half : 0;       // first full set of this workgroup
+    auto seq = [&](int i) { return (i < n_full) ? full0 + i : e_shared; };
+    auto set_base = [&](int e) { return p.wblk + (long long)(per_block ? env : e) * p.set_stride; };
+
+    // ---- constants of every set this workgroup uses -> LDS (slot i = set seq(i)) ---------------
+    f32x4* xlds = reinterpret_cast<f32x4*>(nrm + p.n_cst * NRM_SET);   // [2][NT * OT][64], split only
+    for (int i = tid; i < n_seq * NRM_SET; i += 64 * L2A_NW) {
         const int s = i / NRM_SET;
         const int o = i - s * NRM_SET;
-        const float* src = p.wblk + (long long)(per_block ? env : s) * p.set_stride;
+        const float* src = set_base(seq(s));
         float v;
         if (o < CST_BOUT) v = src[p.nm_off + o];
         else if (o < CST_BHID) v = src[p.pk_bout + (o - CST_BOUT)];
@@ -380,26 +403,64 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     __syncthreads();
 
     // ---- actions occupy input k-groups ga0 and ga0 + 1 (act_dim <= 16) ----------------------
+    // Fetched with raw buffer loads from a per-step descriptor (base = the step's [R, act_dim] slab, SALU only):
+    // the lane's eight 32-bit byte offsets are loop invariants, and the slots of an input k-group that hold no
+    // action (state features, padding) point past the slab - the bounds check returns 0.0 for them, so there
+    // is neither a lane mask nor a select per element.
     const int ga0 = obs_dim >> 4;
     f32x4 av_next[NT][2];
-    auto load_actions = [&](int t, f32x4 (&dst)[NT][2]) {
+    int aoff[NT][2][4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float* arow = p.actions + ((long long)t * R + row[nt]) * act_dim;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+                const bool in = (ka >= 0) && (ka < act_dim);
+                aoff[nt][s][ii] = in ? (row[nt] * act_dim + ka) * 4 : 0x7ffffff0;
+            }
+    const long long a_step = (long long)R * act_dim;            // floats per horizon step
+    auto load_actions = [&](int t, f32x4 (&dst)[NT][2]) {
+        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
-                    const bool in = (ka >= 0) && (ka < act_dim);
-                    const float v = arow[in ? ka : 0];
-                    dst[nt][s][ii] = in ? v : 0.0f;
-                }
+                for (int ii = 0; ii < 4; ++ii)
+                    dst[nt][s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[nt][s][ii], 0, 0));
+    };
+    // The actions of step t + 1 are taken over (and those of step t + 2 requested) while step t's exchange
+    // travels: nothing after the last layer 0 of a step reads `av`.
+    f32x4 av[NT][2];
+    float asq[NT];
+    auto take_actions = [&](int t_fetch) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            av[nt][0] = av_next[nt][0];
+            av[nt][1] = av_next[nt][1];
+            float s = 0.0f;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                s = fmaf(av[nt][0][ii], av[nt][0][ii], s);
+                s = fmaf(av[nt][1][ii], av[nt][1][ii], s);
+            }
+            asq[nt] = s;
         }
+        load_actions((t_fetch < p.h) ? t_fetch : p.h - 1, av_next);
     };
     load_actions(0, av_next);
+    take_actions(1);
 
+    // -DL2A_RET64 (experiment, tools/build_variant.py): the per-candidate return accumulated in float64 like the
+    // reference's `returns` (:98,126) and rounded to fp32 once at the end - profiles/r03_parity_report.txt records
+    // what that does to the CEM rank ties (nothing measurable: the error is the fp32 state's, not the sum's)
+#ifdef L2A_RET64
+    double ret[NT];
+#else
     float ret[NT];
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ret[nt] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[nt] ? cand[nt] : p.n - 1)] : 0.0f;
 
@@ -408,19 +469,6 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const float e_count = (float)e_loop;
     double disc_pow = p.disc0;  // discount ** t, carried in float64 like the reference (:126)
     unsigned int spin_left = p.spin_limit;      // exchange polls this workgroup may still spend (whole launch)
-
-    // Which sets this workgroup runs (split: 0 = all; 1 = group A | group B; 2 = as 1, but the
-    // last set of group A is SHARED: both workgroups run it as a "half member" - layer 0 and the
-    // inner hidden layers in full, the last hidden layer and the output layer for one half of the
-    // hidden tiles each - which balances odd ensembles and lets a single model use two CUs).
-    // Both workgroups run their full sets first and the shared one last, so the group sums of
-    // the full sets can be published (and travel) while the half set is still being computed.
-    const int e_shared = (split == 2) ? e_half - 1 : -1;
-    const int n_full = !split ? e_loop : (grp == 0 ? e_half - (split == 2 ? 1 : 0) : e_loop - e_half);
-    const int n_seq = n_full + (split == 2 ? 1 : 0);
-    const int full0 = (split && grp == 1) ? e_half : 0;       // first full set of this workgroup
-    auto seq = [&](int i) { return (i < n_full) ? full0 + i : e_shared; };
-    auto set_base = [&](int e) { return p.wblk + (long long)(per_block ? env : e) * p.set_stride; };
     const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
@@ -446,22 +494,6 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     }
 
     for (int t = 0; t < p.h; ++t) {
-        f32x4 av[NT][2];
-        float asq[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            av[nt][0] = av_next[nt][0];
-            av[nt][1] = av_next[nt][1];
-            float s = 0.0f;
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                s = fmaf(av[nt][0][ii], av[nt][0][ii], s);
-                s = fmaf(av[nt][1][ii], av[nt][1][ii], s);
-            }
-            asq[nt] = s;
-        }
-        load_actions((t + 1 < p.h) ? t + 1 : t, av_next);   // prefetch the next step's actions
-
         // dsum: finished group; dgrp: group being summed; qsh: this workgroup's half of the shared
         // set's raw output sum (split == 2)
         f32x4 dsum[NT][OT], dgrp[NT][OT], qsh[NT][OT];
@@ -511,29 +543,23 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             return ok;
         };
 
-        for (int i = 0; i < n_seq; ++i) {
-            const int e = seq(i);
-            if (e == e_half && !split) {      // group A complete: park it, start group B
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int c = 0; c < OT; ++c) {
-                        dsum[nt][c] = dgrp[nt][c];
-                        dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-            }
-            const bool is_half = (e == e_shared);
-            const float* wb = set_base(e);
-            const float* wb_next = set_base(seq((i + 1 < n_seq) ? i + 1 : 0));      // next (step, set)
-            const float* nr = nrm + e * NRM_SET;    // per_block / single: e == 0
-            const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
-            const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(wb_next + p.pk_w0, w0_bytes);
-
+        for (int b0 = 0; b0 < n_seq; b0 += LB) {
+            const int nb = (n_seq - b0 < LB) ? n_seq - b0 : LB;
             f32x4 hreg[NT][TPW];    // activations of the LAST hidden layer (stay in registers)
-            L2A_TS(0)
 
-            // ---- layer 0: B = normalised [obs | act] built from the state fragment ---------
-            {
+            // ======== phase A: layer 0 of every set of the batch ==================================
+            // B = normalised [obs | act] built from the state fragment; result -> LDS region j (hcur when LB == 1)
+            // (a generic lambda instantiated twice - "another layer 0 follows" / "the batch's first GEMM follows" - and the
+            // last iteration peeled: on every path into the GEMM its first operands have just been requested, so no
+            // register of one phase's prefetch is carried through the other's code)
+            auto layer0 = [&](int j, auto last_tag) {
+                constexpr bool last_l0 = decltype(last_tag)::value;
+                const int i = b0 + j;
+                const int e = seq(i);
+                const float* wb = set_base(e);
+                const float* nr = nrm + i * NRM_SET;
+                const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
+                L2A_TS(0)
                 // k-group 0 arrived with the previous phase; the others land under its MFMAs
                 const __amdgpu_buffer_rsrc_t r0 = l2a_rsrc(wb + p.pk_w0, w0_bytes);
                 f32x4 a[KG0][TPW];
@@ -575,7 +601,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     for (int g = 0; g < KG0; ++g) norm_in(g, mu[g], iv[g], xin[XPRE ? g : 0]);
                 }
                 f32x4 acc[NT][TPW];
-                // layer-0 MFMAs; called from both branches below so that each branch's operand
+                // layer-0 MFMAs; called from every branch below so that each branch's operand
                 // prefetch shares a basic block with them and can be interleaved (NPF loads)
                 auto l0_mfma = [&](auto npf_tag) {
                     constexpr int NPF = decltype(npf_tag)::value;
@@ -612,22 +638,30 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     constexpr int PER = NM / (NPF > 0 ? NPF : 1) > 0 ? NM / (NPF > 0 ? NPF : 1) : 1;
                     __builtin_amdgcn_sched_group_barrier(0x020, (KG0 - 1) * TPW, 0);
 #pragma unroll
-                    for (int i = 0; i < NPF; ++i) {
+                    for (int k = 0; k < NPF; ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 };
                 // operands of the phase after this one
-                if (n_hidden == 1) {
+                if (N1) {
 #pragma unroll
                     for (int tt = 0; tt < L2A_PFT(TPW, OT); ++tt)
 #pragma unroll
                         for (int c = 0; c < OT; ++c)
                             pfO[tt][c] = l2a_ldw(rs_out, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
                     l0_mfma(std::integral_constant<int, L2A_PFT(TPW, OT) * OT>{});
+                } else if (!last_l0) {
+                    // the next set's layer 0 follows: its k-group 0
+                    const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(set_base(seq(i + 1)) + p.pk_w0, w0_bytes);
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0n, voff0[tt], 0);
+                    l0_mfma(std::integral_constant<int, TPW>{});
                 } else {
-                    const __amdgpu_buffer_rsrc_t rs1 = l2a_rsrc(wb + p.pk_wmid, wm_bytes);
-                    const bool next_half = is_half && n_hidden == 2;
+                    // the first hidden GEMM of the batch follows (set seq(b0))
+                    const int e0 = seq(b0);
+                    const __amdgpu_buffer_rsrc_t rs1 = l2a_rsrc(set_base(e0) + p.pk_wmid, wm_bytes);
+                    const bool next_half = (e0 == e_shared) && n_hidden == 2;
                     if (next_half) {
 #pragma unroll
                         for (int tt = 0; tt < TH; ++tt) {
@@ -653,74 +687,134 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
                 }
                 L2A_TS(10)
-                if (n_hidden > 1) {
+                if (!N1) {
+                    f32x4* hdst = (LB > 1) ? buf0 + j * p.sa_elems : hcur;
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) hcur[(nt * HT + c0 + tt) * 64 + lane] = hreg[nt][tt];
+                        for (int nt = 0; nt < NT; ++nt) hdst[(nt * HT + c0 + tt) * 64 + lane] = hreg[nt][tt];
                 }
-            }
+                L2A_TS(1)
+            };
+            for (int j = 0; j + 1 < nb; ++j) layer0(j, std::false_type{});
+            layer0(nb - 1, std::true_type{});
 
-            // ---- hidden -> hidden layers; the last one keeps its output in registers and feeds
-            //      the output layer directly --------------------------------------------------
-            L2A_TS(1)
-            if (n_hidden > 1) {
-                __syncthreads();
+            // ======== phase B: hidden -> hidden layers and the fused output layer, set by set ======
+            // the last hidden layer keeps its output in registers and feeds the output layer directly
+            if (!N1) __syncthreads();
+            // (again a generic lambda, the batch's last set peeled: a set that is not the last of its batch is a full
+            // member and hands over to the next set's GEMM, the last one hands over to a layer 0)
+            auto member = [&](int j, auto last_tag) {
+                constexpr bool last_set = decltype(last_tag)::value;
+                const int i = b0 + j;
+                const int e = seq(i);
+                const bool is_half = last_set && (e == e_shared);
+                const float* wb = set_base(e);
+                const float* nr = nrm + i * NRM_SET;
+                const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
+                f32x4* pb = (LB > 1) ? pbase + j * PS : hoth;      // LB == 1: re-read below, after the inner layers' swaps
                 L2A_TS(2)
-                f32x4 acc[NT][TPW];
-                for (int l = 1; l < n_hidden - 1; ++l) {
-                    const float* wl = wb + p.pk_wmid + (long long)(l - 1) * p.pk_wmid_stride;
-                    const bool next_half = is_half && (l == n_hidden - 2);
-                    l2a_hidden_gemm<NT, TPW, TPW, OT, false>(l2a_rsrc(wl, wm_bytes), l2a_rsrc(wl + p.pk_wmid_stride, wm_bytes),
-                                                             voff, next_half ? voffh : voff, next_half ? TH : TPW, 0,
-                                                             hcur, pfA, pfB, pfO, acc, lane);
-                    const float* bl = nr + CST_BHID + l * (16 * HT);
+                if (!N1) {
+                    f32x4 acc[NT][TPW];
+                    for (int l = 1; last_set && l < n_hidden - 1; ++l) {        // inner layers: LB == 1 only (the set is its batch)
+                        const float* wl = wb + p.pk_wmid + (long long)(l - 1) * p.pk_wmid_stride;
+                        const bool next_half = is_half && (l == n_hidden - 2);
+                        l2a_hidden_gemm<NT, TPW, TPW, OT, false>(l2a_rsrc(wl, wm_bytes), l2a_rsrc(wl + p.pk_wmid_stride, wm_bytes),
+                                                                 voff, next_half ? voffh : voff, next_half ? TH : TPW, 0,
+                                                                 hcur, pfA, pfB, pfO, acc, lane);
+                        const float* bl = nr + CST_BHID + l * (16 * HT);
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
+                        for (int tt = 0; tt < TPW; ++tt) {
+                            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            hoth[(nt * HT + c0 + tt) * 64 + lane] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                            for (int nt = 0; nt < NT; ++nt)
+                                hoth[(nt * HT + c0 + tt) * 64 + lane] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                        }
+                        __syncthreads();
+                        f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
                     }
-                    __syncthreads();
-                    f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
+                    if (LB == 1) pb = hoth;
+                    const f32x4* hin = (LB > 1) ? buf0 + j * p.sa_elems : hcur;
+                    const __amdgpu_buffer_rsrc_t rs_last =
+                        l2a_rsrc(wb + p.pk_wmid + (long long)(n_hidden - 2) * p.pk_wmid_stride, wm_bytes);
+                    const float* bl = nr + CST_BHID + (n_hidden - 1) * (16 * HT);
+                    if (!is_half) {
+                        l2a_hidden_gemm<NT, TPW, TPW, OT, true>(rs_last, rs_out, voff, voff, TPW, c0, hin, pfA, pfB, pfO,
+                                                                acc, lane);
+#pragma unroll
+                        for (int tt = 0; tt < TPW; ++tt) {
+                            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                        }
+                    } else {
+                        l2a_hidden_gemm<NT, TH, TPW, OT, true>(rs_last, rs_out, voffh, voffh, TH, tile0h, hin, pfA, pfB,
+                                                               pfO, acc, lane);
+#pragma unroll
+                        for (int tt = 0; tt < TH; ++tt) {
+                            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (tile0h + tt) + 4 * qq);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                        }
+                    }
                 }
-                const __amdgpu_buffer_rsrc_t rs_last =
-                    l2a_rsrc(wb + p.pk_wmid + (long long)(n_hidden - 2) * p.pk_wmid_stride, wm_bytes);
-                const float* bl = nr + CST_BHID + (n_hidden - 1) * (16 * HT);
-                if (!is_half) {
-                    l2a_hidden_gemm<NT, TPW, TPW, OT, true>(rs_last, rs_out, voff, voff, TPW, c0, hcur, pfA, pfB, pfO,
-                                                            acc, lane);
-#pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
-                    }
-                    L2A_TS(3)
-                    l2a_out_phase<NT, TPW, TPW, OT>(hreg, pfO, rs_out, c0, r0n, voff0, pfL0, hoth, 2 * wave, lane);
-                } else {
-                    l2a_hidden_gemm<NT, TH, TPW, OT, true>(rs_last, rs_out, voffh, voffh, TH, tile0h, hcur, pfA, pfB,
-                                                           pfO, acc, lane);
-#pragma unroll
-                    for (int tt = 0; tt < TH; ++tt) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (tile0h + tt) + 4 * qq);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
-                    }
-                    L2A_TS(3)
-                    l2a_out_phase<NT, TH, TPW, OT>(hreg, pfO, rs_out, tile0h, r0n, voff0, pfL0, hoth, wave, lane);
-                }
-            } else {
                 L2A_TS(3)
-                l2a_out_phase<NT, TPW, TPW, OT>(hreg, pfO, rs_out, c0, r0n, voff0, pfL0, hoth, 2 * wave, lane);
-            }
-            L2A_TS(4)
+                // output layer; its MFMAs cover the first operand loads of the phase that follows: the next set's hidden
+                // GEMM inside a batch, else layer 0 of the next batch / step
+                if (last_set) {
+                    const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(set_base(seq((i + 1 < n_seq) ? i + 1 : 0)) + p.pk_w0, w0_bytes);
+                    auto pf_l0 = [&]() {
+#pragma unroll
+                        for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0n, voff0[tt], 0);     // k-group 0 only
+                    };
+                    if (is_half) l2a_out_phase<NT, TH, TPW, OT, TPW>(hreg, pfO, rs_out, tile0h, pf_l0, pb, wave, lane);
+                    else l2a_out_phase<NT, TPW, TPW, OT, TPW>(hreg, pfO, rs_out, c0, pf_l0, pb, 2 * wave, lane);
+                } else {
+                    const int en = seq(i + 1);
+                    const __amdgpu_buffer_rsrc_t rsn = l2a_rsrc(set_base(en) + p.pk_wmid, wm_bytes);   // nb > 1: two hidden layers
+                    if (en == e_shared) {
+                        l2a_out_phase<NT, TPW, TPW, OT, 2 * TH>(hreg, pfO, rs_out, c0, [&]() {
+#pragma unroll
+                            for (int tt = 0; tt < TH; ++tt) {
+                                pfA[tt] = l2a_ldw(rsn, voffh[tt], 0);
+                                pfB[tt] = l2a_ldw(rsn, voffh[tt] + 1024, 0);
+                            }
+                        }, pb, 2 * wave, lane);
+                    } else {
+                        l2a_out_phase<NT, TPW, TPW, OT, 2 * TPW>(hreg, pfO, rs_out, c0, [&]() {
+#pragma unroll
+                            for (int tt = 0; tt < TPW; ++tt) {
+                                pfA[tt] = l2a_ldw(rsn, voff[tt], 0);
+                                pfB[tt] = l2a_ldw(rsn, voff[tt] + 1024, 0);
+                            }
+                        }, pb, 2 * wave, lane);
+                    }
+                }
+                L2A_TS(4)
+            };
+            for (int j = 0; j + 1 < nb; ++j) member(j, std::false_type{});
+            member(nb - 1, std::true_type{});
+
+            // ======== phase C: canonical reduce of every set of the batch ===========================
             __syncthreads();
-            L2A_TS(5)
-            {
+            for (int j = 0; j < nb; ++j) {
+                const int i = b0 + j;
+                const int e = seq(i);
+                const bool is_half = (e == e_shared);
+                const float* nr = nrm + i * NRM_SET;
+                const f32x4* pb = (LB > 1) ? pbase + j * PS : hoth;
+                L2A_TS(5)
+                if (e == e_half && !split) {      // group A complete: park it, start group B
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c) {
+                            dsum[nt][c] = dgrp[nt][c];
+                            dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                }
                 // Sum the chunk partials in the canonical order ((c0+c1)+c2)+c3 [+ ((c4+c5)+c6)+c7].
                 // A half member holds only its own four chunks; the other four arrive at the end of
                 // the step from the partner workgroup.
@@ -734,7 +828,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                     for (int ch = 0; ch < 2 * L2A_NW; ++ch)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) part[ch][nt] = hoth[((ch * NT + nt) * OT + c) * 64 + lane];
+                        for (int nt = 0; nt < NT; ++nt) part[ch][nt] = pb[((ch * NT + nt) * OT + c) * 64 + lane];
                     const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BOUT + 16 * c + 4 * qq);
                     const f32x4 omu = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * c + 4 * qq);
                     const f32x4 osd = *reinterpret_cast<const f32x4*>(nr + 32 * KG0 + 16 * OT + 16 * c + 4 * qq);
@@ -756,24 +850,35 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         }
                     }
                 }
+                // the group sum of the full sets leaves as soon as it exists (LB == 1: it travels under the half set)
+                if (split == 2 && i == n_full - 1 && wave == 0) xput(0, dgrp);
+                L2A_TS(6)
             }
-            // LDS hazards.  The partial sums live in `hoth`; `hcur` was last read by the final
+            // LDS hazards.  LB == 1: the partial sums live in `hoth`; `hcur` was last read by the final
             // hidden layer, before the barrier above.  n_hidden >= 2: the next writes are layer 0
             // -> `hcur` (free) and, only after the layer-0 barrier, `hoth` again (every wave has
             // finished these reads by then).  n_hidden == 1: there is no layer-0 barrier, the next
             // partial sums would land in `hoth` while slow waves still read it -> alternate regions.
-            if (n_hidden == 1) { f32x4* tmp = hcur; hcur = hoth; hoth = tmp; }
-            if (split == 2 && i == n_full - 1 && wave == 0) xput(0, dgrp);   // travels under the half set
-            L2A_TS(6)
+            // LB > 1: regions and partial areas are rewritten only after the next batch's / step's
+            // barriers, which every wave reaches after these reads.
+            if (N1) { f32x4* tmp = hcur; hcur = hoth; hoth = tmp; }
         }
 
         // ---- combine the two workgroups of a tile ---------------------------------------------
         { const int e = 7; L2A_TS(9) }
+        float asq_t[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asq_t[nt] = asq[nt];
         if (split) {
             if (wave == 0) {
                 if (split == 2) xput(1, qsh);
                 else xput(0, dgrp);
-                { const int e = 7; L2A_TS(11) }
+            }
+            { const int e = 7; L2A_TS(11) }
+            // while the records travel (a write-through store + an sc1 load across two XCDs' L2s: ~4k clocks),
+            // take over the next step's actions and request the ones after them
+            take_actions(t + 2);
+            if (wave == 0) {
                 f32x4 oth[2][NT][OT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -814,7 +919,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             { const int e = 7; L2A_TS(10) }
             __syncthreads();
             { const int e = 7; L2A_TS(13) }
-            const float* nrs = nrm + (e_shared < 0 ? 0 : e_shared) * NRM_SET;
+            const float* nrs = nrm + (n_seq - 1) * NRM_SET;     // the shared set is the last of the sequence
             {   // every LDS read of the combine first, then the arithmetic (one exposed round trip, not four)
                 f32x4 cb[OT], cm[OT], cs[OT], og[NT][OT], oq[NT][OT];
 #pragma unroll
@@ -844,6 +949,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         dgrp[nt][c] = gb;
                     }
             }
+        } else {
+            take_actions(t + 2);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -852,10 +959,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
         // ---- ensemble mean, reward, state update -------------------------------------------
         const float disc_t = (float)disc_pow;
+        const double disc_pow_t = disc_pow;     // (used by the L2A_RET64 experiment build)
+        (void)disc_pow_t;
         disc_pow *= p.discount;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[nt];
+            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq_t[nt];
             float psq = 0.0f;
 #pragma unroll
             for (int c = 0; c < OT; ++c) {
@@ -878,7 +987,11 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             psq += __shfl_xor(psq, 32);
             float r = plin;
             if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
+#ifdef L2A_RET64
+            ret[nt] += disc_pow_t * (double)r;
+#else
             ret[nt] = fmaf(disc_t, r, ret[nt]);
+#endif
         }
         { const int e = 7; L2A_TS(7) }     // end of the step (after exchange, reward, state update)
     }
@@ -889,8 +1002,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (valid[nt] && qq == 0) {
-                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[nt]] = ret[nt];
-                const unsigned long long k = l2a_key_pack(ret[nt], p.cand_offset + cand[nt]);
+                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[nt]] = (float)ret[nt];
+                const unsigned long long k = l2a_key_pack((float)ret[nt], p.cand_offset + cand[nt]);
                 key = (k > key) ? k : key;
             }
             if (p.state_out && valid[nt]) {

@@ -8,9 +8,11 @@
 
 namespace {
 
-template <int OT, int KG0, bool GACT, int K0L = 4>
+template <int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false>
 int launch_one(const L2AKParams* p, unsigned grid, int smem, hipStream_t stream) {
-    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L>;
+    // one hidden layer: its own instances (no hidden->hidden GEMM in them), generic activation code only
+    if (!N1 && p->n_hidden == 1) return launch_one<OT, KG0, true, 4, true>(p, grid, smem, stream);
+    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L, N1>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;

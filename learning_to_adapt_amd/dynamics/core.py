@@ -34,6 +34,18 @@ def xavier_params(sizes, rng):
     return params
 
 
+def nonlinearity_name(fn):
+    """The reference's models accept TensorFlow functions (``hidden_nonlinearity=tf.nn.tanh`` is the recorded default of
+    ``RNNDynamicsModel``, ``rnn_dynamics.py:21``; ``run_rebal.py`` never overrides it) as well as strings.  A callable is
+    resolved by its ``__name__`` - that is all a snapshot keeps of it (a pickled global) and all the drop-in needs."""
+    if fn is None or isinstance(fn, str):
+        return fn
+    name = getattr(fn, "__name__", None)
+    if callable(fn) and name in ("relu", "tanh", "sigmoid", "swish", "identity"):
+        return name
+    return fn       # left as it is: the constructors refuse it with their usual message
+
+
 def torch_act(name):
     if name in (None, "identity"):
         return lambda x: x

@@ -87,6 +87,8 @@ class MetaMLPDynamicsModel(Serializable):
 
         self.obs_space_dims = int(env.observation_space.shape[0])
         self.action_space_dims = int(env.action_space.shape[0])
+        hidden_nonlinearity = core.nonlinearity_name(hidden_nonlinearity)      # tf.nn.tanh & co. by name
+        output_nonlinearity = core.nonlinearity_name(output_nonlinearity)
         if hidden_nonlinearity not in self._activations or output_nonlinearity not in self._activations:
             raise ValueError("unsupported nonlinearity %r / %r" % (hidden_nonlinearity, output_nonlinearity))
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)

@@ -59,6 +59,8 @@ class MLPDynamicsModel(Serializable):
         self.obs_space_dims = int(env.observation_space.shape[0])
         self.action_space_dims = int(env.action_space.shape[0])
 
+        hidden_nonlinearity = core.nonlinearity_name(hidden_nonlinearity)      # tf.nn.tanh & co. by name
+        output_nonlinearity = core.nonlinearity_name(output_nonlinearity)
         if hidden_nonlinearity not in self._activations or output_nonlinearity not in self._activations:
             raise ValueError("unsupported nonlinearity %r / %r (supported: %s)"
                              % (hidden_nonlinearity, output_nonlinearity, self._activations))

@@ -104,6 +104,8 @@ class RNNDynamicsModel(Serializable):
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
         if not 1 <= len(self.hidden_sizes) <= 4:
             raise NotImplementedError("1 to 4 stacked cells are supported (hidden_sizes=%r)" % (hidden_sizes,))
+        hidden_nonlinearity = core.nonlinearity_name(hidden_nonlinearity)      # tf.nn.tanh & co. by name
+        output_nonlinearity = core.nonlinearity_name(output_nonlinearity)
         if hidden_nonlinearity not in self._activations or output_nonlinearity not in self._activations:
             raise ValueError("unsupported nonlinearity %r / %r (supported: %s)"
                              % (hidden_nonlinearity, output_nonlinearity, self._activations))

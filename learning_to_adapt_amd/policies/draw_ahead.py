@@ -56,17 +56,33 @@ class DrawAhead(object):
         return self.depth + 2
 
     # ------------------------------------------------------------------ consumer side
+    def _worker_alive(self):
+        return self.pid == os.getpid() and self.thread is not None and self.thread.is_alive()
+
     def take(self, sig):
         """Payload of the next block if it is valid for the current global generator state, else None."""
+        if self.pid is not None and self.pid != os.getpid():
+            # forked child: the worker thread did not come along and the condition variable may have been held at fork
+            # time - start from scratch (the caller draws synchronously and restarts the chain)
+            self.cv = threading.Condition()
+            self.blocks = collections.deque()
+            self.sig = self.producer = self.tail = self.thread = None
+            self.pid = None
+            self.gen += 1
+            return None
         with self.cv:
             if self.sig != sig or (self.producer is None and not self.blocks):
                 self._flush()
                 return None
-            while not self.blocks:          # the worker has been told to produce and is about to post the block
-                self.cv.wait()
+            # the worker has been told to produce and is about to post the block; should it have died, fall back to the
+            # synchronous draw instead of waiting for ever
+            while not self.blocks or not self.blocks[0].done:
+                if not self._worker_alive():
+                    self._flush()
+                    self.misses += 1
+                    return None
+                self.cv.wait(0.05)
             blk = self.blocks[0]
-            while not blk.done:
-                self.cv.wait()
             # Word-level compare / store (~1 us instead of get_state / set_state) is exact whenever no cached Gaussian
             # is involved: with has_gauss == 0 on both sides of the block the words ARE the state (nobody can set the
             # flag without consuming words).  Uniform chains never touch the flag at all.
@@ -134,10 +150,13 @@ class DrawAhead(object):
             self.thread.start()
 
     def _run(self):
+        cv = self.cv                    # the condition this worker belongs to; a chain re-created after a fork has another
         while True:
-            with self.cv:
-                while self.producer is None or len(self.blocks) >= self.depth:
-                    self.cv.wait()
+            with cv:
+                while self.cv is cv and (self.producer is None or len(self.blocks) >= self.depth):
+                    cv.wait()
+                if self.cv is not cv:
+                    return
                 gen, producer = self.gen, self.producer
                 state = self.tail.copy()
                 blk = _Block(self.tail, gen)
@@ -152,11 +171,13 @@ class DrawAhead(object):
                 error = exc
             self.produce_s += time.perf_counter() - t0
             self.produced += 1
-            with self.cv:
+            with cv:
+                if self.cv is not cv:
+                    return
                 if gen == self.gen:
                     blk.payload, blk.error, blk.end = payload, error, state
                     self.tail = state.copy()
                     if error is not None:
                         self.producer = None
                 blk.done = True
-                self.cv.notify_all()
+                cv.notify_all()

@@ -95,7 +95,6 @@ class MPCController(Policy, Serializable):
         self._bufs = {}
         self._ahead = None          # DrawAhead chain (parity mode), created on first use
         self._cem_first_chunk = 4   # horizon steps of the first chunk of a pipelined CEM rollout (0: equal chunks)
-        self._ranks_checked = False
         self.last_plan = None       # diagnostics of the latest fused plan (returns, keys, ...)
 
     @property
@@ -172,27 +171,63 @@ class MPCController(Policy, Serializable):
     def _shard_range(n, rank, world):
         return (rank * n) // world, ((rank + 1) * n) // world
 
-    def _check_ranks_agree(self, world):
-        """Sharded planning lets every rank draw the SAME candidate tensor and keep its slice (parity mode), or the
-        same CEM normals (device mode).  Ranks seeded differently (the common ``seed + rank``) would combine keys
-        and returns that refer to different actions - silently.  Once per controller: all-reduce a digest of the
-        generator state and refuse to plan if the ranks disagree."""
-        if world == 1 or self._ranks_checked:
-            return
+    DIGEST_MASK = 0x7FFFFFFFFFFF          # include/l2a.h: L2A_DIGEST_MASK
+
+    def _rank_digest(self):
+        """Fingerprint of what this rank's candidates were drawn from.  Sharded planning lets every rank draw the SAME
+        candidate tensor and keep its slice (parity mode), or the same CEM normals (device mode).  Ranks seeded
+        differently (the common ``seed + rank``) - or one rank whose generator was consumed by something else between
+        two plans (an in-process env reset, a logger) - would combine keys and returns that refer to different
+        actions, silently.  Parity mode: the global MT19937 state as this step's draw left it (~1 us); device mode:
+        ``torch.initial_seed()``.  Travels with EVERY collective of a plan step (two more words), so a disagreement is
+        caught on the step it happens, on all ranks at once."""
         if self.rng == "numpy":
-            st = np.random.get_state()
-            digest = (zlib.crc32(np.asarray(st[1]).tobytes()) ^ (int(st[2]) << 32)) & 0x7FFFFFFFFFFFFFFF
-            what = "np.random global state"
-        else:
-            digest = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-            what = "torch.initial_seed()"
-        t = torch.tensor([digest, -digest], dtype=torch.int64, device=self._device())
+            return fast_rng.global_digest() & self.DIGEST_MASK
+        return int(torch.initial_seed()) & self.DIGEST_MASK
+
+    def _digest_error(self):
+        what = "np.random global state" if self.rng == "numpy" else "torch.initial_seed()"
+        return _lib.L2AError("candidate sharding needs identical %s on every rank (seed all ranks alike and keep other "
+                             "consumers of the generator off the planning process; the shards themselves are disjoint)"
+                             % what)
+
+    def _agree(self, flag, world):
+        """Host-side facts every rank must share before a collective whose inputs depend on them (CEM: the all-gather
+        of the returns): MAX all-reduce of ``[flag, digest, MASK - digest]``.  Returns ``any rank's flag``; raises - on
+        every rank - when the digests differ."""
+        if world == 1:
+            return bool(flag)
+        d = self._rank_digest()
+        t = torch.tensor([1 if flag else 0, d, self.DIGEST_MASK - d], dtype=torch.int64, device=self._device())
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        lo_hi = t.cpu().numpy()
-        if int(lo_hi[0]) != -int(lo_hi[1]):
-            raise _lib.L2AError("candidate sharding needs identical %s on every rank (seed all ranks alike; "
-                                "the shards themselves are disjoint)" % what)
-        self._ranks_checked = True
+        v = t.cpu().numpy()
+        if int(v[1]) + int(v[2]) != self.DIGEST_MASK:
+            raise self._digest_error()
+        return bool(int(v[0]))
+
+    def _force_unsplit(self):
+        """Every rank of a sharded plan switches to the unsplit launch geometry (some rank's launch lost its tile-split
+        partner); the CPU test harness replaces this."""
+        self.dynamics_model.planner_model().ctx.force_unsplit()
+
+    def _pack_payload(self, best, m):
+        """``[keys (m), launch flag, digest, MASK - digest]`` as an int64 tensor on the planning device - packed ON the
+        device behind the launch (``l2a_plan_payload`` reads the status word there), so nothing on the host waits
+        between the launch and the collective."""
+        dev = best.device
+        payload = self._buf("payload", (m + 3,), torch.int64, dev)
+        d = self._rank_digest()
+        if dev.type == "cuda":
+            self.dynamics_model.planner_model().plan_payload(best, m, d, payload)
+        else:                                   # CPU test harness (tests/oracle_backend.py): flags come from its hook
+            payload[:m] = best
+            payload[m] = 1 if self._harness_flag() else 0
+            payload[m + 1] = d
+            payload[m + 2] = self.DIGEST_MASK - d
+        return payload
+
+    def _harness_flag(self):
+        return False
 
     def _fusable(self):
         return (self._reward_spec is not None) and hasattr(self.dynamics_model, "planner_model")
@@ -279,6 +314,11 @@ class MPCController(Policy, Serializable):
         (its tile-split partner was not co-resident); the context has been switched to the unsplit launch
         geometry and the caller must relaunch.  Raises only if launches fail with the split already off."""
         return self.dynamics_model.planner_model().ctx.check_or_degrade()
+
+    def _status_flag(self):
+        """After a stream sync: was a launch since the last read flagged invalid?  Reads and clears the status word
+        WITHOUT switching the geometry (the ranks of a sharded plan decide that together, ``_agree``)."""
+        return self.dynamics_model.planner_model().ctx.launch_status_value() != 0
 
     def _check_blocks(self, m):
         blocks = self.dynamics_model.planner_blocks(m)
@@ -394,7 +434,6 @@ class MPCController(Policy, Serializable):
             return self._get_rs_action_unfused(observations)
 
         rank, world = self._dist()
-        self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         n_local = hi - lo
         act_dim = self.action_space.shape[0]
@@ -448,20 +487,27 @@ class MPCController(Policy, Serializable):
         return out.cpu().numpy().astype(np.float64)
 
     def _combine_keys(self, best, relaunch, world):
-        """Read the arg-max keys back (max all-reduce over the ranks first).  A launch flagged invalid (see
-        ``_check_status``) is repeated with the unsplit geometry - before the collective, so that a rank never
-        contributes a stale key."""
+        """Read the arg-max keys back.  Sharded plan: ONE max all-reduce of ``[keys, launch flag, digest pair]`` enqueued
+        right behind the launch (no host synchronisation, no status read before the collective), then ONE device-to-host
+        copy of ``m + 3`` words.  A set flag means some rank's launch lost its tile-split partner: ALL ranks switch to
+        the unsplit geometry (bit-identical results) and repeat their launch and the collective together, so no rank is
+        ever out of step and a stale key never decides anything."""
         if isinstance(best, np.ndarray):        # blocking launch: keys already on the host, status already handled
             return best
         if world > 1:
-            self._sync()
-            if self._check_status() is False:
-                best = relaunch()
-                self._sync()
-                if self._check_status() is False:
+            m = best.numel()
+            for attempt in (0, 1):
+                payload = self._pack_payload(best, m)
+                torch.distributed.all_reduce(payload, op=torch.distributed.ReduceOp.MAX)
+                host = payload.cpu().numpy()
+                if int(host[m + 1]) + int(host[m + 2]) != self.DIGEST_MASK:
+                    raise self._digest_error()
+                if int(host[m]) == 0:
+                    return host[:m].copy()
+                if attempt == 1:
                     raise _lib.L2AError("rollout launch failed twice")
-            torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MAX)
-            return best.cpu().numpy()
+                self._force_unsplit()           # every rank: the reduced flag is the same everywhere
+                best = relaunch()
         keys = best.cpu().numpy()
         if self._check_status() is False:
             keys = relaunch().cpu().numpy()
@@ -653,10 +699,22 @@ class MPCController(Policy, Serializable):
             else:               # more ranks than candidates: an empty shard still joins the collective
                 rets = torch.zeros((m, 0), dtype=torch.float32, device=self._device())
             if world > 1:
+                # every rank must gather VALID returns drawn from the SAME normals: the ranks agree on (any launch
+                # flagged?, generator digests equal?) first - one more 3-word collective per iteration beside a 2.8 ms
+                # rollout - and repeat the rollout unsplit TOGETHER when any of them lost a tile-split partner
+                bad = False
                 if n_local > 0:
                     self._sync()
-                    if self._check_status() is False:
+                    bad = self._status_flag()
+                if self._agree(bad, world):
+                    self._force_unsplit()
+                    bad = False
+                    if n_local > 0:
                         _, rets = self._rollout(observations, a_dev, n_local, lo, want_returns=True)
+                        self._sync()
+                        bad = self._status_flag()
+                    if self._agree(bad, world):
+                        raise _lib.L2AError("rollout launch failed twice")
                 # all-gather needs equal shapes: shards are padded to the widest one (they differ by at most one
                 # candidate) and cut back to their own width afterwards
                 widths = [self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] for r in range(world)]
@@ -790,7 +848,6 @@ class MPCController(Policy, Serializable):
         mean = self._buf("cem_mean", (m, D), torch.float32, dev).zero_()
         std = self._buf("cem_std", (m, D), torch.float32, dev).fill_(1.0)
         rank, world = self._dist()
-        self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         n_local = hi - lo
         widths = [self._shard_range(n, r, world)[1] - self._shard_range(n, r, world)[0] for r in range(world)]
@@ -836,11 +893,17 @@ class MPCController(Policy, Serializable):
         cand = a_raw.reshape(m, n, D) if reference else a_clip.permute(1, 0, 2)
         first = cand[torch.arange(m, device=dev), idx, :act_dim]
         out = first.cpu().numpy().astype(np.float64)
-        bad = self._check_status() is False     # a launch lost its tile-split partner: the context is unsplit now
-        if world > 1:                           # every rank gathered that rank's returns: all of them replay
-            flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=dev)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            bad = bool(int(flag.cpu()[0]))
+        if world > 1:
+            # every rank gathered every rank's returns: all of them replay when any launch lost its tile-split partner;
+            # the same collective carries the seed digests (ranks seeded differently sampled different normals)
+            if self._agree(self._status_flag(), world):
+                bad = True
+                if not retry:
+                    self._force_unsplit()
+            else:
+                bad = False
+        else:
+            bad = self._check_status() is False     # a launch lost its tile-split partner: the context is unsplit now
         if bad:
             if retry:
                 raise _lib.L2AError("rollout launch failed twice")
@@ -866,7 +929,6 @@ class MPCController(Policy, Serializable):
         clip_high = np.concatenate([self.action_space.high] * h)
 
         rank, world = self._dist()
-        self._check_ranks_agree(world)
         lo, hi = self._shard_range(n, rank, world)
         trace = []
         cand_a = None

@@ -70,6 +70,26 @@ AntEnv = _env_stub("AntEnv", "ant")
 Arm7DofEnv = _env_stub("Arm7DofEnv", "arm_7dof")
 
 
+def _tf_op(name):
+    """Named stand-in for a TensorFlow activation function found among recorded constructor arguments
+    (``hidden_nonlinearity=tf.nn.tanh`` is ``RNNDynamicsModel``'s default, ``rnn_dynamics.py:21``, and
+    ``run_rebal.py`` does not override it, so every ReBAL snapshot holds that global).  Never called: the drop-in
+    constructors read its ``__name__`` (``dynamics/core.nonlinearity_name``)."""
+    def op(*args, **kwargs):
+        raise RuntimeError("tensorflow stand-in %r is a name tag, not a function" % name)
+    op.__name__ = op.__qualname__ = name
+    op.__module__ = __name__
+    return op
+
+
+# module-level (picklable by this module's path when a rebuilt object is dumped again)
+tanh, relu, sigmoid, swish = _tf_op("tanh"), _tf_op("relu"), _tf_op("sigmoid"), _tf_op("swish")
+# where TensorFlow 1.x defines / re-exports them: a pickled function is `module.qualname` of its definition
+_TF_OP_MODULES = ("tensorflow.python.ops.math_ops", "tensorflow.python.ops.gen_math_ops",
+                  "tensorflow.python.ops.nn_ops", "tensorflow.python.ops.gen_nn_ops",
+                  "tensorflow.python.ops.nn_impl", "tensorflow.python.ops.nn", "tensorflow.nn", "tensorflow")
+
+
 class AdamOptimizer(object):
     """Placeholder for ``tf.train.AdamOptimizer`` found among recorded constructor arguments (never instantiated:
     the drop-in models train with ``torch.optim.Adam``)."""
@@ -128,6 +148,14 @@ def _alias_modules():
         adam = types.ModuleType("tensorflow.python.training.adam")
         adam.AdamOptimizer = AdamOptimizer
         out[adam.__name__] = adam
+        # ... and `hidden_nonlinearity=tf.nn.tanh` / `tf.nn.relu` (rnn_dynamics.py:21, mlp_dynamics.py:29,
+        # meta_mlp_dynamics.py:30): function references into TensorFlow's op modules
+        for name in _TF_OP_MODULES:
+            mod = types.ModuleType(name)
+            mod.__path__ = []
+            mod._l2a_alias = True
+            mod.tanh, mod.relu, mod.sigmoid, mod.swish = tanh, relu, sigmoid, swish
+            out[name] = mod
     norm = types.ModuleType("%s.envs.normalized_env" % _PREFIX_REF)
     norm.NormalizedEnv = NormalizedEnv
     norm.normalize = NormalizedEnv

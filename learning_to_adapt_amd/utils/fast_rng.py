@@ -56,7 +56,7 @@ def _load():
             c = ctypes
             vp, ll, i32 = c.c_void_p, c.c_longlong, c.c_int
             ip = c.POINTER(i32)
-            if lib.l2a_rng_version() < 5:
+            if lib.l2a_rng_version() < 6:
                 return None
             lib.l2a_mt19937_fill_double_mt.argtypes = [vp, ip, vp, ll, i32]
             lib.l2a_mt19937_fill_double_mt.restype = i32
@@ -80,6 +80,8 @@ def _load():
             lib.l2a_mt19937_state_store.restype = None
             lib.l2a_mt19937_state_load.argtypes = [vp, vp, ip]
             lib.l2a_mt19937_state_load.restype = None
+            lib.l2a_mt19937_state_digest.argtypes = [vp]
+            lib.l2a_mt19937_state_digest.restype = c.c_ulonglong
             _state["lib"] = lib
         except (OSError, AttributeError):
             _state["lib"] = None
@@ -95,6 +97,25 @@ def _global_addr():
         return int(bg.ctypes.state_address)
     except Exception:
         return None
+
+
+def _global_lock():
+    """The bit generator's own lock: every NumPy draw holds it, so the 624 words + position are never read or written
+    half way through another thread's draw (``get_state`` / ``set_state``, which the direct path replaces, hold it too)."""
+    return np.random.mtrand._rand._bit_generator.lock
+
+
+def global_digest():
+    """Fingerprint (< 2**47) of the global legacy generator's state - what the ranks of a sharded plan compare every
+    step (``MPCController._combine_keys``).  ~1 us through the helper library, ``get_state`` + crc32 otherwise."""
+    if available("direct"):
+        addr = _global_addr()
+        if addr is not None:
+            with _global_lock():
+                return int(_state["lib"].l2a_mt19937_state_digest(addr)) & 0x7FFFFFFFFFFF
+    import zlib
+    st = np.random.get_state()
+    return (zlib.crc32(np.asarray(st[1]).tobytes()) ^ (int(st[2]) << 32)) & 0x7FFFFFFFFFFF
 
 
 class State(object):
@@ -133,7 +154,8 @@ class State(object):
         if available("direct"):
             addr = _global_addr()
             if addr is not None:
-                return bool(_state["lib"].l2a_mt19937_state_equal(addr, self.key.ctypes.data, self.pos.value))
+                with _global_lock():
+                    return bool(_state["lib"].l2a_mt19937_state_equal(addr, self.key.ctypes.data, self.pos.value))
         st = np.random.get_state()
         return st[0] == "MT19937" and st[2] == self.pos.value and np.array_equal(st[1], self.key)
 
@@ -141,7 +163,8 @@ class State(object):
         if available("direct"):
             addr = _global_addr()
             if addr is not None:
-                _state["lib"].l2a_mt19937_state_store(addr, self.key.ctypes.data, self.pos.value)
+                with _global_lock():
+                    _state["lib"].l2a_mt19937_state_store(addr, self.key.ctypes.data, self.pos.value)
                 return
         st = np.random.get_state()
         np.random.set_state(("MT19937", self.key, self.pos.value, st[3], st[4]))

@@ -14,6 +14,24 @@ from oracle.planner import rollout_returns
 import cases
 
 
+def _install_status_hooks(controller):
+    """Launch-status hooks of the sharded paths: ``controller.harness_flags`` is a list of booleans handed out one per
+    launch-status read (empty = every launch fine); ``controller.harness_unsplit`` counts the collective "switch to the
+    unsplit geometry" decisions this rank took part in."""
+    controller.harness_flags = []
+    controller.harness_unsplit = 0
+
+    def flag():
+        return bool(controller.harness_flags.pop(0)) if controller.harness_flags else False
+
+    def force_unsplit():
+        controller.harness_unsplit += 1
+
+    controller._harness_flag = flag
+    controller._status_flag = flag
+    controller._force_unsplit = force_unsplit
+
+
 def install(controller, case):
     lib = _lib.load()
     env, _, _ = cases.recipe(case)
@@ -40,6 +58,7 @@ def install(controller, case):
         return torch.from_numpy(keys), (torch.from_numpy(rets) if want_returns else None)
 
     controller._check_status = lambda: None
+    _install_status_hooks(controller)
     controller.pipeline_chunks = 1            # the chunked launches bypass `_rollout`; the harness replaces that
     controller._upload_obs = lambda observations: None
     controller._device = _device
@@ -75,6 +94,7 @@ def install_rnn(controller, case):
         return dyn.predict(obs, act, hidden)
 
     controller._check_status = lambda: None
+    _install_status_hooks(controller)
     controller._upload_obs = lambda observations: None
     controller._device = lambda: cpu
     controller._upload = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))

@@ -85,6 +85,35 @@ def test_recurrent_snapshot_loads():
     for got, want in zip(model.get_param_values().values(), params):
         assert np.array_equal(got, np.asarray(want, dtype=np.float32))
     assert type(snap["policy"]).__name__ == "RNNMPCController" and snap["policy"].percent_elites == 0.05
+    # run_rebal.py leaves hidden_nonlinearity at its default, the FUNCTION tf.nn.tanh (rnn_dynamics.py:21): the file holds
+    # a global of TensorFlow's op module, which the loader resolves by name
+    assert model.hidden_nonlinearity == "tanh"
+    pickle.loads(pickle.dumps(snap["policy"]))
+
+
+def test_the_recurrent_fixture_records_the_tensorflow_function_reference():
+    import zlib
+    raw = open(os.path.join(cases.GOLDEN_DIR, "ref_snapshot_rebal.pkl"), "rb").read()
+    text = None
+    for off in range(0, 64):
+        try:
+            text = zlib.decompress(raw[off:])
+            break
+        except zlib.error:
+            continue
+    assert text is not None and b"tensorflow.python.ops.gen_math_ops" in text and b"tanh" in text
+
+
+def test_callable_nonlinearities_are_resolved_by_name():
+    """The drop-in constructors take the reference's defaults (``tf.nn.relu`` / ``tf.nn.tanh`` function objects) as well
+    as the strings the run scripts pass; an unknown callable is refused with the usual message."""
+    from learning_to_adapt_amd.dynamics import MLPDynamicsModel, RNNDynamicsModel
+    from learning_to_adapt_amd.envs import SyntheticEnv
+    env = SyntheticEnv("half_cheetah")
+    assert RNNDynamicsModel("d", env, hidden_sizes=(64,), hidden_nonlinearity=checkpoint.tanh).hidden_nonlinearity == "tanh"
+    assert MLPDynamicsModel("d", env, hidden_sizes=(64,), hidden_nonlinearity=checkpoint.relu).hidden_nonlinearity == "relu"
+    with pytest.raises(ValueError):
+        RNNDynamicsModel("d", env, hidden_sizes=(64,), hidden_nonlinearity=len)
 
 
 @pytest.mark.gpu

@@ -194,3 +194,91 @@ def test_ranks_seeded_differently_are_refused(tmp_path):
     for r in range(world):
         with open(os.path.join(str(tmp_path), "rank%d.txt" % r)) as f:
             assert f.read().startswith("refused: candidate sharding needs identical")
+
+
+def _worker_drift(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        import oracle_backend
+        from learning_to_adapt_amd import _lib
+        case = cases.CASES["hc_rs_m3_n64_h5"]
+        gold = cases.load_golden("hc_rs_m3_n64_h5_s0")
+        ctrl = oracle_backend.install(cases.product_controller(case), case)
+        np.random.seed(3)
+        verdicts = []
+        for step in range(4):
+            if step == 2 and rank == 1:
+                np.random.uniform()               # e.g. an in-process env reset on ONE rank (envs/mujoco_env.py:85-87)
+            try:
+                ctrl.get_actions(gold["obs0"])
+                verdicts.append("planned")
+            except _lib.L2AError as exc:
+                verdicts.append("refused: %s" % exc)
+                break
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write("\n".join(verdicts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_whose_generator_drifts_mid_run_is_caught_on_that_step(tmp_path):
+    """The generator digest travels with EVERY step's collective: a rank that consumes np.random on its
+    own after the first plan is noticed on the very next plan - on both ranks, so neither is left in a collective."""
+    world = 2
+    mp.spawn(_worker_drift, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        with open(os.path.join(str(tmp_path), "rank%d.txt" % r)) as f:
+            lines = f.read().split("\n")
+        assert lines[:2] == ["planned", "planned"]
+        assert len(lines) == 3 and lines[2].startswith("refused: candidate sharding needs identical")
+
+
+def _worker_flagged(rank, world, port, cid, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        import oracle_backend
+        case, seed = cases.split_id(cid)
+        gold = cases.load_golden(cid)
+        ctrl = oracle_backend.install(cases.product_controller(case), case)
+        calls = {"n": 0}
+        stock = ctrl._rollout
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return stock(*a, **k)
+        ctrl._rollout = counting
+        if rank == 1:
+            ctrl.harness_flags = [True]           # this rank's first launch "lost its tile-split partner"
+        np.random.seed(seed)
+        actions, _ = ctrl.get_actions(gold["obs0"])
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), actions=actions, best=np.asarray(ctrl.last_plan["best_index"]),
+                 launches=calls["n"], unsplit=ctrl.harness_unsplit)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cid,launches", [("hc_rs_m3_n64_h5_s0", 2), ("hc_cem_m2_n100_h4_s0", 3 + 1)])
+def test_a_flagged_launch_on_one_rank_makes_every_rank_relaunch_unsplit(cid, launches, tmp_path):
+    """The launch flag is part of the reduced payload: when ONE rank's launch is invalid, ALL ranks switch to the unsplit
+    geometry and repeat launch + collective together (no rank contributes a stale key, none is left behind in a
+    collective), and the plan is still the single-process plan.  CEM: only the flagged iteration is repeated."""
+    world = 2
+    mp.spawn(_worker_flagged, args=(world, _free_port(), cid, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import cases
+    gold = cases.load_golden(cid)
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(o["best"], gold["best"])
+        np.testing.assert_array_equal(o["actions"], gold["chosen"])
+        assert int(o["unsplit"]) == 1 and int(o["launches"]) == launches

@@ -239,3 +239,52 @@ def test_long_threaded_draw_uses_the_jump_and_matches_numpy():
         assert np.array_equal(want, got) and _state_tuple() == after
     finally:
         fast_rng.set_threads(old)
+
+
+def test_draw_ahead_take_never_waits_for_a_worker_that_is_not_there():
+    """after os.fork() the child inherits the chain's bookkeeping but not its worker thread, and a worker may
+    die; take() must then fall back to the synchronous draw (None) instead of waiting on the condition for ever."""
+    import threading
+    import time
+    from learning_to_adapt_amd.policies.draw_ahead import DrawAhead
+    if not fast_rng.available("double"):
+        pytest.skip("host RNG helper not built")
+    release = threading.Event()
+
+    def slow_producer(state, slot):
+        release.wait(5.0)
+        return state.random_sample(4)
+
+    # (a) dead worker: the block is never finished
+    chain = DrawAhead(depth=1)
+    np.random.seed(1)
+    chain.start("sig", slow_producer)
+    dead = threading.Thread(target=lambda: None)
+    dead.start()
+    dead.join()
+    chain.thread = dead                                   # as if the worker had died mid-block
+    t0 = time.perf_counter()
+    assert chain.take("sig") is None
+    assert time.perf_counter() - t0 < 2.0
+    release.set()
+
+    # (b) forked child: same object, another pid
+    chain2 = DrawAhead(depth=1)
+    chain2.start("sig", lambda state, slot: state.random_sample(4))
+    old_cv = chain2.cv
+    chain2.pid = -1                                       # what the child of a fork sees: pid != os.getpid()
+    t0 = time.perf_counter()
+    assert chain2.take("sig") is None
+    assert time.perf_counter() - t0 < 1.0
+    with old_cv:
+        old_cv.notify_all()                               # (in-process stand-in for the fork: let the old worker retire)
+    # ... and the chain works again in "the child" once restarted
+    np.random.seed(2)
+    want = np.random.random_sample(4)
+    np.random.seed(2)
+    chain2.start("sig", lambda state, slot: state.random_sample(4))
+    got = chain2.take("sig")
+    assert got is not None and np.array_equal(got, want)
+    after = np.random.random_sample(3)                    # the global generator continues right behind the block
+    np.random.seed(2)
+    assert np.array_equal(after, np.random.random_sample(7)[4:])

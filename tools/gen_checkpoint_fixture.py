@@ -43,6 +43,21 @@ def ref_class(module, name, extra_state=None):
     return cls
 
 
+def ref_function(module, name):
+    """A function that pickles as the global `module.name` (how `tf.nn.tanh` & co. appear among recorded arguments)."""
+    if module not in sys.modules:
+        parts = module.split(".")
+        for i in range(1, len(parts) + 1):
+            sys.modules.setdefault(".".join(parts[:i]), types.ModuleType(".".join(parts[:i])))
+
+    def fn(*args, **kwargs):
+        raise RuntimeError("fixture stand-in")
+    fn.__name__ = fn.__qualname__ = name
+    fn.__module__ = module
+    setattr(sys.modules[module], name, fn)
+    return fn
+
+
 def dynamics_state(self, base):         # meta_mlp_dynamics.py:434-440 / mlp_dynamics.py / rnn_dynamics.py:319-324
     return {"init_args": base, "normalization": self.normalization,
             "networks": [{"network_params": self.network_params}]}       # core/layers.py:103-108
@@ -119,7 +134,10 @@ def main():
     # rnn_dynamics.py:16-30: name, env, hidden_sizes, cell_type, hidden_nonlinearity, output_nonlinearity,
     # batch_size, learning_rate, normalize_input, optimizer, valid_split_ratio, rolling_average_persitency,
     # backprop_steps
-    rnn = Rnn("dyn", env, (case["units"],), "lstm", "tanh", None, 10, 0.001, True, Adam, 0.2, 0.99, 50)
+    # run_rebal.py:77-99 never passes hidden_nonlinearity, so quick_init records the DEFAULT - the function object
+    # tf.nn.tanh (rnn_dynamics.py:21,32) - which pickles as a global of TensorFlow's generated op module
+    tf_tanh = ref_function("tensorflow.python.ops.gen_math_ops", "tanh")
+    rnn = Rnn("dyn", env, (case["units"],), "lstm", tf_tanh, None, 10, 0.001, True, Adam, 0.2, 0.99, 50)
     rnn.normalization = OrderedDict((k, (np.asarray(v[0]), np.asarray(v[1]))) for k, v in norm.items())
     rnn.network_params = named(params, ["rnn/lstm_cell/kernel", "rnn/lstm_cell/bias", "output/kernel", "output/bias"])
     RPol = ref_class("learning_to_adapt.policies.rnn_mpc_controller", "RNNMPCController",

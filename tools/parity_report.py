@@ -33,6 +33,47 @@ for cid in cases.case_ids(planner="rs"):
     marg = np.min(gold["margin"] / np.maximum(1.0, np.abs(want[np.arange(case["m"]), gold["best"]])))
     print("%-36s %10.2e %10.2e %8s %.2e" % (cid, rel, np.max(np.abs(got - want)), "equal" if ok else "DIFF", marg))
 
+# ---- CEM: every iteration teacher-forced from the reference's mean / std (what test_cem_iterations_teacher_forced asserts):
+#      error of the returns, rank swaps against the reference's ranking, elite-mask flips (reference :101), and the
+#      largest gap - in the REFERENCE's returns - between the two candidates of a swapped rank (its witness pair) --------
+import cem_ties  # noqa: E402
+
+print("\n%-30s %3s %10s %10s %6s %6s %12s %12s" % ("CEM case (teacher-forced)", "it", "max rel", "max abs", "swaps", "flips",
+                                                   "worst gap", "2 x max abs"))
+for cid in cases.case_ids(planner="cem"):
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    ctrl = cases.product_controller(case)
+    env = ctrl.env
+    m, n, h = case["m"], case["n"], case["h"]
+    act_dim = env.action_space.shape[0]
+    k = max(int(n * 0.1), 1)
+    clip_low = np.concatenate([env.action_space.low] * h)
+    clip_high = np.concatenate([env.action_space.high] * h)
+    np.random.seed(seed)
+    mean, std = np.zeros((m, h * act_dim)), np.ones((m, h * act_dim))
+    for it in range(case["num_cem_iters"]):
+        _, _, got, _ = ctrl._cem_iteration(gold["obs0"], mean, std, k, clip_low, clip_high, 0, n, 1)
+        want = gold["cem_returns"][it]
+        flips = cem_ties.rank_flips(got, want, k)
+        gaps = [f[4] for f in flips]
+        print("%-30s %3d %10.2e %10.2e %6d %6d %12.3e %12.3e"
+              % (cid, it, np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))), np.max(np.abs(got - want)),
+                 len(flips), sum(1 for f in flips if f[6]), max(gaps) if gaps else 0.0, 2 * np.max(np.abs(got - want))))
+        mean, std = gold["cem_mean"][it], gold["cem_std"][it]
+    # end to end (no teacher forcing): where does the first elite-mask flip happen, if any
+    ctrl2 = cases.product_controller(case)
+    np.random.seed(seed)
+    ctrl2.get_actions(gold["obs0"])
+    first = None
+    for it, tr in enumerate(ctrl2.last_plan["cem_trace"]):
+        fl = cem_ties.rank_flips(tr["returns"], gold["cem_returns"][it], k)
+        if any(f[6] for f in fl):
+            first = (it, sum(1 for f in fl if f[6]), max(f[4] for f in fl if f[6]))
+            break
+    print("%-30s end to end: %s" % (cid, "no elite-mask flip, bit-equal plan expected" if first is None else
+                                    "first mask flip at iteration %d (%d positions, widest witness gap %.3e)" % first))
+
 # ---- recurrent planner: the controller replayed over the recorded steps (first step of every case: the
 #      candidate draw is the reference's, so every candidate's return can be compared) ----------------------
 from oracle.rnn_planner import rnn_rollout_returns  # noqa: E402

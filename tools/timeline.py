@@ -43,48 +43,36 @@ native.plan_rs(obs0, a, 1, 2000, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(0)), "dbg")
 d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
-names = ["L0", "bar0", "hidden", "out", "bar1", "reduce"]
-for grp, members in ((0, (0, 1, 2)), (1, (3, 4))):
-    print("group %d members %s" % (grp, members))
+# [grp, t, e, wave, slot]; batched flow (l2a_mfma.h): per step  L0(s0) L0(s1) .. | barrier | GEMM+out(s0) GEMM+out(s1) .. |
+# barrier | reduce(s0) reduce(s1) .. | exchange.  Slots of a set: 0 L0 start, 8 operands requested, 9 MFMAs done,
+# 10 bias / activation done, 1 written to LDS; 2 GEMM start, 3 GEMM + epilogue done, 4 output partials written;
+# 5 reduce start, 6 reduce done.
+for grp, members in ((0, (0, 1, 2)), (1, (3, 4, 2))):
+    print("group %d sets %s (median over steps 2.., clocks)" % (grp, members))
     for e in members:
-        print("  set %d (median over steps 2.., clocks):" % e)
-        for w in range(8):
-            seg = np.diff(d[grp, 2:, e, w, :7], axis=1)
-            med = np.median(seg, axis=0)
-            # arrival offsets relative to wave 0 at the start of the set and at the two barriers
-            off0 = np.median(d[grp, 2:, e, w, 0] - d[grp, 2:, e, 0, 0])
-            off4 = np.median(d[grp, 2:, e, w, 4] - d[grp, 2:, e, 0, 4])
-            sub = [np.median(d[grp, 2:, e, w, 8] - d[grp, 2:, e, w, 0]), np.median(d[grp, 2:, e, w, 9] - d[grp, 2:, e, w, 8]),
-                   np.median(d[grp, 2:, e, w, 10] - d[grp, 2:, e, w, 9]), np.median(d[grp, 2:, e, w, 1] - d[grp, 2:, e, w, 10])]
-            if w >= 4 and d[grp, 2:, e, w, 0].max() == 0:
+        for w in range(4):
+            x = d[grp, 2:, e, w, :]
+            if x[:, 0].max() == 0:
                 continue
-            print("    wave %d: " % w + "  ".join("%s %6.0f" % (n, v) for n, v in zip(names, med)) +
-                  "  | start vs w0 %+6.0f  reach bar1 vs w0 %+6.0f | L0: wait-pfL0 %5.0f  mfma %5.0f  epilogue %5.0f  lds-write %5.0f"
-                  % (off0, off4, sub[0], sub[1], sub[2], sub[3]))
+            med = lambda a, b: np.median(x[:, a] - x[:, b])      # noqa: E731
+            print("  set %d wave %d: L0 %5.0f (issue %4.0f mfma %5.0f epilogue %4.0f lds-write %4.0f)  gemm %6.0f  out %5.0f  reduce %5.0f"
+                  % (e, w, med(1, 0), med(8, 0), med(9, 8), med(10, 9), med(1, 10), med(3, 2), med(4, 3), med(6, 5)))
     step = np.diff(d[grp, :, 7, 0, 7])
-    last_end = d[grp, :, 7, 0, 7] - d[grp, :, members[-1], 0, 6]
-    print("  step period: median %d clk (min %d max %d); set-loop-end -> step end (exchange+reward) %d clk"
-          % (np.median(step), step.min(), step.max(), np.median(last_end)))
+    print("  step period: median %d clk (min %d max %d)" % (np.median(step), step.min(), step.max()))
 
-print("\nper-step schedule, wave 0 (clocks since the step began; median over steps 2..):")
-for grp in (0, 1):
-    sets = [e for e in range(8) if d[grp, 5, e, 0, 0] != 0 and e != 7]
-    t_end_prev = d[grp, 1:-1, 7, 0, 7]                      # end of the previous step
+print("\nper-step schedule, wave 0 (clocks since the previous step ended; median over steps 2..):")
+for grp, members in ((0, (0, 1, 2)), (1, (3, 4, 2))):
+    t_end_prev = d[grp, 1:-1, 7, 0, 7]
     line = []
-    for e in sets:
-        for slot, nm in ((0, "start"), (1, "L0"), (3, "gemm"), (4, "out"), (6, "red")):
+    for slot, nm in ((0, "L0"), (1, "L0.end"), (2, "gemm"), (3, "gemm.end"), (4, "out.end"), (5, "red"), (6, "red.end")):
+        for e in members:
+            if d[grp, 5, e, 0, 0] == 0:
+                continue
             line.append("s%d.%s %6.0f" % (e, nm, np.median(d[grp, 2:, e, 0, slot] - t_end_prev)))
-    line.append("step.end %6.0f" % np.median(d[grp, 2:, 7, 0, 7] - t_end_prev))
-    print("  group %d: " % grp + "  ".join(line))
-
-print("\nexchange (wave 0, clocks since the last set's reduce ended; median over steps 2..):")
-for grp in (0, 1):
-    sets = [e for e in range(8) if d[grp, 5, e, 0, 0] != 0 and e != 7]
-    base = d[grp, 2:, sets[-1], 0, 6]
     x = d[grp, 2:, 7, 0, :]
-    print("  group %d: enter %5.0f  published %5.0f  swept %5.0f (sweeps: median %d max %d)  wave0@barrier %5.0f  past barrier %5.0f  step end %5.0f"
-          % (grp, np.median(x[:, 9] - base), np.median(x[:, 11] - base), np.median(x[:, 12] - base),
-             np.median(x[:, 14]) + 1, x[:, 14].max() + 1, np.median(x[:, 10] - base), np.median(x[:, 13] - base),
-             np.median(x[:, 7] - base)))
-    w = d[grp, 2:, 7, :4, 10] - base[:, None]
-    print("           waves reach the post-exchange barrier at", np.median(w, axis=0).astype(int).tolist())
+    for slot, nm in ((9, "sets.done"), (11, "published"), (12, "swept"), (10, "at.barrier"), (13, "past.barrier"), (7, "step.end")):
+        line.append("%s %6.0f" % (nm, np.median(x[:, slot] - t_end_prev)))
+    print("  group %d: " % grp + "  ".join(line))
+    print("           sweeps: median %d max %d; waves reach the post-exchange barrier at %s"
+          % (np.median(x[:, 14]) + 1, x[:, 14].max() + 1,
+             np.median(d[grp, 2:, 7, :4, 10] - t_end_prev[:, None], axis=0).astype(int).tolist()))
