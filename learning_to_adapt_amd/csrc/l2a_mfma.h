@@ -13,21 +13,25 @@
 // (l2a_kernels.h), the B-fragment layout of the next layer: layers chain through LDS with one
 // 16-byte write and one 16-byte read per lane and tile, no transposes, no bank conflicts.
 //
-// Per (step, weight set):
-//   layer 0      : wave w computes hidden tiles [w*TPW, (w+1)*TPW); B = normalised [obs|act] built
-//                  in registers from the state fragment; K = in_dim (KG0 k-groups); result -> LDS
-//   hidden GEMMs : same tile ownership; B fragments (activations) come from LDS; A fragments
+// Per horizon step the sets a workgroup runs are processed in BATCHES of p.lb sets (l2a_set_batch; as many as the CU's
+// LDS holds side by side when the model has two hidden layers, else one):
+//   layer 0      : of every set of the batch, back to back - wave w computes hidden tiles [w*TPW, (w+1)*TPW); B =
+//                  normalised [obs | act] built in registers from the state fragment; K = in_dim (KG0 k-groups);
+//                  result -> LDS region of the set.  ONE barrier.
+//   hidden GEMMs : set by set, same tile ownership; B fragments (activations) come from LDS; A fragments
 //                  (weights, 1 KiB per wave-level buffer load) stream from L2 into registers, two
 //                  k-groups ahead of the MFMAs, one load issued per four MFMAs
 //   output layer : fused into the last hidden layer - hidden tile c IS k-group c of the output
 //                  layer and its D fragment IS the B fragment, so every wave multiplies its own
-//                  registers; chunk partials go through LDS, one barrier, every wave sums them in
-//                  the canonical order, so all waves hold bit-identical copies of state / return
-//   every phase issues the FIRST operands of the next phase before the barrier that separates them
-// LDS: two activation regions of sa_elems f32x4 each + per-set constants (normalisation vectors and
-// all biases) + 2 KiB per (candidate tile, obs tile) of exchange staging.
+//                  registers; chunk partials go to the set's LDS slot; the next set's GEMM follows without a barrier
+//   reduce       : ONE barrier per batch, then every wave sums every set's chunk partials in the canonical order,
+//                  so all waves hold bit-identical copies of state / return
+//   every phase issues the FIRST operands of the next phase before it ends (and the epilogue's bias vectors under its
+//   last MFMAs), so no phase starts with an exposed L2 or LDS round trip
+// LDS: max(2, lb) activation regions of sa_elems f32x4 | chunk partials of a batch (lb > 1) | per-set constants
+// (normalisation vectors and all biases) | 2 KiB per (candidate tile, obs tile) of exchange staging.
 //
-// Fixed summation order (every launch geometry gives the same bits): sets are summed as (group A)
+// Fixed summation order (every launch geometry and every batch size gives the same bits): sets are summed as (group A)
 // + (group B), A = first ceil(E/2) sets; the output layer's K reduction is cut into 2 * L2A_NW
 // chunks of TPW / 2 k-groups, ((c0+c1)+c2)+c3 + ((c4+c5)+c6)+c7.
 //
@@ -36,15 +40,21 @@
 // hidden layers in full, the last hidden layer and the output layer for one half of the hidden
 // tiles each (this balances odd ensembles and lets a single model use two CUs).  Partial sums
 // travel through 16-byte self-validating {tag, v, tag, v} granules in global memory: write-through
-// (sc1) stores, sc1 loads, no flag and no fence (cdna_hip_programming.md G16 recipe R2); the group
-// sums are published before the half member starts.  Spins are bounded (status word, never a hang).
+// (sc1) stores, sc1 loads, no flag and no fence (cdna_hip_programming.md G16 recipe R2: the 8-byte {tag, value} pair is
+// the unit whose single-copy atomicity the recipe rests on - a {tag, v0, v1, v2} granule would need 16-byte atomicity,
+// which nothing documents).  While the records travel the waves take over the next step's actions.  Spins are bounded
+// (status word, never a hang).
 // Tail split (p.split_from >= 0): in a multi-round plan whose last round would fill under half of the
 // chip only the left-over tiles are shared; their workgroup pairs are dispatched last, back to back.
 //
 // Template parameters: NT candidate tiles per workgroup (1|2), TPW hidden tiles per wave (hidden
 // width = 16 * L2A_NW * TPW), OT = ceil(obs_dim / 16), KG0 = ceil((obs_dim + act_dim) / 16), GACT =
 // generic activation functions (false: relu / identity only, branch-free), K0L = layer-0 MFMAs of the last input
-// k-group that can see non-zero operands (4 unless in_dim mod 16 is 1..3).
+// k-group that can see non-zero operands (4 unless in_dim mod 16 is 1..3), N1 = the model has ONE hidden layer (its
+// own instances: compile-time, so that neither path keeps the other's operand registers alive - with the run-time
+// test the register allocator carried the GEMM's prefetch registers through the whole kernel, 475 instead of ~410
+// VGPRs on the HalfCheetah instance), O4 = the last obs tile has at most four live units (HalfCheetah: 20 = 16 + 4):
+// it is computed with the 4x4x1 MFMA instead of a 16-row tile that is three quarters padding (l2a_out_phase).
 #pragma once
 
 #include <type_traits>
@@ -82,6 +92,28 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
     v.z = fmaxf(v.z, floor); v.w = fmaxf(v.w, floor);
     return v;
 }
+
+// x[l] + x[l ^ 16] and x[l] + x[l ^ 32] over the wave with the gfx950 lane-swap instructions (VALU rate, no LDS
+// crossbar round trip like ds_bpermute): v_permlane16_swap exchanges the odd rows of its first operand with the even
+// rows of the second, v_permlane32_swap the upper half of the first with the lower half of the second; called on two
+// copies of x the two results are {own, other} in one half / row and {other, own} in the other - their sum is the same
+// bits in every lane.
+__device__ __forceinline__ float l2a_sum_xor16(float x) {
+    const unsigned int u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float l2a_sum_xor32(float x) {
+    const unsigned int u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products (one k each) per instruction, block b on lanes
+// 4b .. 4b + 3: lane 4b + i supplies A_b[i], lane 4b + j supplies B_b[j] and holds D_b[i][j] in result register i.
+// Two passes (8 clocks) instead of the eight of the 16x16x4 tile.  Used for an obs tile of which only four units
+// are alive (O4, below).
+#define L2A_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
 // Make `v` opaque to the optimiser at this point (no instructions emitted).  Used on the
 // pre-loop fills of the software-pipeline registers: without it InstCombine folds the
@@ -141,6 +173,8 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }
 
+// olane : per obs tile, the byte offset of the lane whose output-layer fragment this lane fetches (16 lane; see O4)
+// bias_lds : this lane's bias slice of the wave's first output tile (LDS, + 16 floats per tile) -> bias[0 .. TW)
 // TW    : output tiles this wave computes here (TPW, or TPW / 2 for a half member)
 // rs    : descriptor of this layer's packed weights [tile][k-group][64 lanes][4]
 // rsn   : descriptor of the next phase's packed weights (next hidden layer, or the output layer)
@@ -149,14 +183,18 @@ __device__ __forceinline__ f32x4 l2a_actv(f32x4 v, int kind, float floor) {
 // LAST == true : tile0 = global index of this wave's first tile (selects the output fragments)
 // Output-layer fragments fetched a phase ahead: the first L2A_PFT tiles only (the rest are loaded
 // when the output phase starts and land under the MFMAs of the first tiles) - register budget.
-#define L2A_PFT(TW_, OT_) ((OT_) <= 2 ? ((TW_) < 6 ? (TW_) : 6) : ((TW_) < 2 ? (TW_) : 2))
+#ifndef L2A_PFT_MAX
+#define L2A_PFT_MAX 8
+#endif
+#define L2A_PFT(TW_, OT_) ((OT_) <= 2 ? ((TW_) < L2A_PFT_MAX ? (TW_) : L2A_PFT_MAX) : ((TW_) < 2 ? (TW_) : 2))
 
 template <int NT, int TW, int TPW, int OT, bool LAST>
 __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
                                                 const int (&voff)[TPW], const int (&voffn)[TPW], int twn,
                                                 int tile0, const f32x4* hin,
                                                 f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
-                                                f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW], int lane) {
+                                                f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW], int lane,
+                                                const float* bias_lds, f32x4 (&bias)[TPW], const int (&olane)[OT]) {
     constexpr int HT = L2A_NW * TPW;
     static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
     f32x4 aC[TW], aD[TW], bA[NT], bB[NT], bC[NT], bD[NT];
@@ -191,7 +229,7 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
 #pragma unroll
                 for (int c = 0; c < OT; ++c)
                     if (((tt * OT + c) & 1) == 0)
-                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (tile0 + tt) * 1024, c * HT * 1024);
+                        pfO[tt][c] = l2a_ldw(rsn, olane[c] + (tile0 + tt) * 1024, c * HT * 1024);
         } else {
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt)
@@ -200,14 +238,17 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
         L2A_STAGE_MFMA(aC, bC)
         __builtin_amdgcn_sched_barrier(0);
     }
-    {   // stage 3: consume D; aB is free
+    {   // stage 3: consume D; aB is free.  The epilogue's bias vectors (LDS) are requested here, under the last MFMAs:
+        // read where they are used they cost one exposed LDS round trip per tile (~1k clocks per GEMM, timeline r03)
+#pragma unroll
+        for (int tt = 0; tt < TW; ++tt) bias[tt] = *reinterpret_cast<const f32x4*>(bias_lds + 16 * tt);
         if (LAST) {
 #pragma unroll
             for (int tt = 0; tt < L2A_PFT(TW, OT); ++tt)
 #pragma unroll
                 for (int c = 0; c < OT; ++c)
                     if (((tt * OT + c) & 1) == 1)
-                        pfO[tt][c] = l2a_ldw(rsn, lane * 16 + (tile0 + tt) * 1024, c * HT * 1024);
+                        pfO[tt][c] = l2a_ldw(rsn, olane[c] + (tile0 + tt) * 1024, c * HT * 1024);
         } else {
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt)
@@ -225,10 +266,18 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
 // member's wave owns chunk w of its workgroup's half.  `prefetch` issues the NPF operand loads of
 // the phase that follows (the next set's hidden GEMM inside a batch, else the next layer 0), so
 // that they are in flight across the barrier / under the MFMAs here.
-template <int NT, int TW, int TPW, int OT, int NPF, class PF>
+//
+// O4: only four units of the LAST obs tile are alive (HalfCheetah: 20 = 16 + 4).  Its sixteen-row MFMA tile would
+// spend three quarters of its rows on padding; instead the tile is computed with the 4x4x1 MFMA: block b = lane / 4
+// multiplies the four live units by the four candidates 4 (b & 3) .. + 3 for the hidden unit 16 tile + 4 (b >> 2) +
+// ii - the B operand is the hidden fragment as it stands, the A operand the packed output fragment of lane
+// (lane & 48) | (lane & 3) (same packed array, another lane's 16 bytes: `olane`).  A lane's accumulator then holds the
+// sum over ITS quarter of the hidden units (qq = lane >> 4) for candidate lane & 15; the four quarters are added
+// where the chunk partials are reduced (xor-16 / xor-32 lane sums, same order in every launch geometry).
+template <int NT, int TW, int TPW, int OT, int NPF, bool O4, class PF>
 __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x4 (&pfO)[TPW][OT],
                                               __amdgpu_buffer_rsrc_t rs_out, int tile0, PF prefetch,
-                                              f32x4* pbuf, int chunk0, int lane) {
+                                              f32x4* pbuf, int chunk0, int lane, const int (&olane)[OT]) {
     constexpr int HT = L2A_NW * TPW;
     constexpr int CS = TPW / 2;         // tiles per chunk
     constexpr int NCH = TW / CS;        // chunks this wave owns (2 = full member, 1 = half member)
@@ -238,7 +287,7 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
 #pragma unroll
         for (int c = 0; c < OT; ++c)
             a[tt][c] = (tt < L2A_PFT(TW, OT)) ? pfO[tt][c]
-                                              : l2a_ldw(rs_out, lane * 16 + (tile0 + tt) * 1024, c * HT * 1024);
+                                              : l2a_ldw(rs_out, olane[c] + (tile0 + tt) * 1024, c * HT * 1024);
     prefetch();
     f32x4 acc[NCH][NT][OT];
 #pragma unroll
@@ -257,7 +306,9 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int c = 0; c < OT; ++c)
-                        acc[ch][nt][c] = L2A_MFMA(a[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], acc[ch][nt][c]);
+                        acc[ch][nt][c] = (O4 && c == OT - 1)
+                            ? L2A_MFMA4(a[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], acc[ch][nt][c])
+                            : L2A_MFMA(a[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], acc[ch][nt][c]);
     // issue order hint: the late output fragments first (one per 2 MFMAs), then the prefetch loads
     // spread over the remaining MFMAs - 8 VMEM issues in a row would idle the matrix pipe
     {
@@ -283,7 +334,7 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
             for (int c = 0; c < OT; ++c) pbuf[(((chunk0 + ch) * NT + nt) * OT + c) * 64 + lane] = acc[ch][nt][c];
 }
 
-template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false>
+template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = false>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
     constexpr int HT = L2A_NW * TPW;
     constexpr int TH = TPW / 2;         // tiles per wave of a half member
@@ -314,6 +365,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const int jc = lane & 15;
     const int qq = lane >> 4;
     const int c0 = wave * TPW;
+    int olane[OT];              // whose output-layer fragment this lane fetches, per obs tile (O4: see l2a_out_phase)
+#pragma unroll
+    for (int c = 0; c < OT; ++c) olane[c] = ((O4 && c == OT - 1) ? ((lane & 48) | (lane & 3)) : lane) * 16;
 
     // Geometry.  Uniform launches (p.split_from < 0): every tile is run by 1 (split 0) or 2 workgroups, ids
     // remapped XCD-aware.  Tail split (p.split_from >= 0): the first split_from hardware workgroups run whole
@@ -467,13 +521,21 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     f32x4* hcur = buf0;
     f32x4* hoth = buf1;
     const float e_count = (float)e_loop;
+    const float e_inv = 1.0f / e_count;
     double disc_pow = p.disc0;  // discount ** t, carried in float64 like the reference (:126)
     unsigned int spin_left = p.spin_limit;      // exchange polls this workgroup may still spend (whole launch)
+    const unsigned int xtag0 = p.xtag;
     const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
     // barrier that separates them, so a phase never starts with an exposed L2 round trip).
-    f32x4 pfL0[TPW];            // layer-0 A fragments (k-group 0) of the upcoming (step, set)
+    // (-DL2A_L0_PREFETCH_ALL=1: every layer-0 k-group a phase ahead - measured neutral, 21 more registers)
+#ifndef L2A_L0_PREFETCH_ALL
+#define L2A_L0_PREFETCH_ALL 0
+#endif
+    constexpr int KG0P = (L2A_L0_PREFETCH_ALL && KG0 <= 2) ? KG0 : 1;      // layer-0 k-groups fetched a phase ahead (all of them when the input is
+                                                    // at most 32 wide: registers; wider inputs fetch the rest at layer 0)
+    f32x4 pfL0[KG0P][TPW];      // layer-0 A fragments of the upcoming (step, set)
     f32x4 pfA[TPW], pfB[TPW];   // k-groups 0 / 1 of the upcoming hidden->hidden layer
     f32x4 pfO[TPW][OT];         // output-layer A fragments of this wave's k-groups
     // this lane's byte offset of its tiles in a hidden matrix (full member / half member) and in layer 0
@@ -490,7 +552,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     {
         const __amdgpu_buffer_rsrc_t r0 = l2a_rsrc(set_base(seq(0)) + p.pk_w0, w0_bytes);
 #pragma unroll
-        for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0, voff0[tt], 0);
+        for (int g = 0; g < KG0P; ++g)
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0, voff0[tt] + g * 1024, 0);
     }
 
     for (int t = 0; t < p.h; ++t) {
@@ -510,7 +574,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         // the shared set's raw output sum.  A value v of lane l travels as 16-byte self-validating
         // granules {tag, v.x, tag, v.y} {tag, v.z, tag, v.w}: write-through (sc1) stores, sc1 loads,
         // no flag and no fence - a granule is accepted when its tags match (G16 recipe R2).
-        const unsigned int xtag = p.xtag + (unsigned int)(t + 1);
+        const unsigned int xtag = xtag0 + (unsigned int)(t + 1);
         constexpr int XREG = NT * OT * 2 * 64 * 16;             // bytes per region
         auto xbase = [&](int g, int region) { return (((lpair * 2 + g) * 2 + (t & 1)) * 2 + region) * XREG + lane * 16; };
         auto xput = [&](int region, const f32x4 (&v)[NT][OT]) {
@@ -542,6 +606,29 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     }
             return ok;
         };
+        // a sweep = the 16-byte loads of the partner's records (xload) and, once they have returned, the tag check and
+        // the unpacking (xtake); two sweeps are kept in flight half a round trip apart (below)
+        constexpr int XG = NT * OT * 2;                         // granule rows per region
+        auto xload = [&](int region, u32x4 (&g)[XG]) {
+#pragma unroll
+            for (int k = 0; k < XG; ++k)
+                g[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, region) + k * 1024, 0, 16);
+        };
+        auto xtake = [&](const u32x4 (&g)[XG], f32x4 (&v)[NT][OT]) {
+            bool ok = true;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < OT; ++c)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const u32x4 q = g[(nt * OT + c) * 2 + hh];
+                        v[nt][c][2 * hh] = __uint_as_float(q.y);
+                        v[nt][c][2 * hh + 1] = __uint_as_float(q.w);
+                        ok = ok && (q.x == xtag) && (q.z == xtag);
+                    }
+            return ok;
+        };
 
         for (int b0 = 0; b0 < n_seq; b0 += LB) {
             const int nb = (n_seq - b0 < LB) ? n_seq - b0 : LB;
@@ -567,7 +654,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 for (int g = 0; g < KG0; ++g)
 #pragma unroll
                     for (int tt = 0; tt < TPW; ++tt)
-                        a[g][tt] = (g == 0) ? pfL0[tt] : l2a_ldw(r0, voff0[tt] + g * 1024, 0);
+                        a[g][tt] = (g < KG0P) ? pfL0[g < KG0P ? g : 0][tt] : l2a_ldw(r0, voff0[tt] + g * 1024, 0);
                 L2A_TS(8)
                 // normalised inputs of every k-group up front: all 2 KG0 constant reads are issued together (the
                 // register-starved scheduler otherwise puts each LDS round trip right in front of its MFMAs)
@@ -580,12 +667,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
                         if (g == ga0) aa = av[nt][0];
                         if (g == ga0 + 1) aa = av[nt][1];
+                        // a slot holds a state feature OR an action OR padding: the state fragment is exactly zero
+                        // outside the observation (zero-padded weights, biases and denormalisation), the action fragment
+                        // exactly zero outside the action (bounds-checked loads) - their sum is the select, without a lane
+                        // mask per element
 #pragma unroll
-                        for (int ii = 0; ii < 4; ++ii) {
-                            const int k = 16 * g + 4 * qq + ii;
-                            const float v = (k < obs_dim) ? sv[ii] : aa[ii];
-                            x[nt][ii] = (v - mu[ii]) * iv[ii];
-                        }
+                        for (int ii = 0; ii < 4; ++ii) x[nt][ii] = ((sv[ii] + aa[ii]) - mu[ii]) * iv[ii];
                     }
                 };
                 f32x4 xin[XPRE ? KG0 : 1][NT];
@@ -600,6 +687,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                     for (int g = 0; g < KG0; ++g) norm_in(g, mu[g], iv[g], xin[XPRE ? g : 0]);
                 }
+                // the epilogue's bias vectors: requested now, in flight under the MFMAs (read in the epilogue they cost one
+                // exposed LDS round trip per tile)
+                f32x4 bias0[TPW];
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+                    bias0[tt] = *reinterpret_cast<const f32x4*>(nr + CST_BHID + 16 * (c0 + tt) + 4 * qq);
                 f32x4 acc[NT][TPW];
                 // layer-0 MFMAs; called from every branch below so that each branch's operand
                 // prefetch shares a basic block with them and can be interleaved (NPF loads)
@@ -636,7 +729,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     // hint: the a[g >= 1] loads first, then one prefetch load per few MFMAs
                     constexpr int NM = ((KG0 - 1) * 4 + K0L) * NT * TPW;
                     constexpr int PER = NM / (NPF > 0 ? NPF : 1) > 0 ? NM / (NPF > 0 ? NPF : 1) : 1;
-                    __builtin_amdgcn_sched_group_barrier(0x020, (KG0 - 1) * TPW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, (KG0 - KG0P) * TPW, 0);
 #pragma unroll
                     for (int k = 0; k < NPF; ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
@@ -649,14 +742,16 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     for (int tt = 0; tt < L2A_PFT(TPW, OT); ++tt)
 #pragma unroll
                         for (int c = 0; c < OT; ++c)
-                            pfO[tt][c] = l2a_ldw(rs_out, lane * 16 + (c0 + tt) * 1024, c * HT * 1024);
+                            pfO[tt][c] = l2a_ldw(rs_out, olane[c] + (c0 + tt) * 1024, c * HT * 1024);
                     l0_mfma(std::integral_constant<int, L2A_PFT(TPW, OT) * OT>{});
                 } else if (!last_l0) {
                     // the next set's layer 0 follows: its k-group 0
                     const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(set_base(seq(i + 1)) + p.pk_w0, w0_bytes);
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0n, voff0[tt], 0);
-                    l0_mfma(std::integral_constant<int, TPW>{});
+                    for (int g = 0; g < KG0P; ++g)
+#pragma unroll
+                        for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0n, voff0[tt] + g * 1024, 0);
+                    l0_mfma(std::integral_constant<int, KG0P * TPW>{});
                 } else {
                     // the first hidden GEMM of the batch follows (set seq(b0))
                     const int e0 = seq(b0);
@@ -681,10 +776,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 L2A_TS(9)
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt) {
-                    const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BHID + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                        hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias0[tt], p.hidden_act, p.hid_floor);
                 }
                 L2A_TS(10)
                 if (!N1) {
@@ -715,48 +809,46 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 f32x4* pb = (LB > 1) ? pbase + j * PS : hoth;      // LB == 1: re-read below, after the inner layers' swaps
                 L2A_TS(2)
                 if (!N1) {
-                    f32x4 acc[NT][TPW];
+                    f32x4 acc[NT][TPW], bias[TPW];
                     for (int l = 1; last_set && l < n_hidden - 1; ++l) {        // inner layers: LB == 1 only (the set is its batch)
                         const float* wl = wb + p.pk_wmid + (long long)(l - 1) * p.pk_wmid_stride;
                         const bool next_half = is_half && (l == n_hidden - 2);
                         l2a_hidden_gemm<NT, TPW, TPW, OT, false>(l2a_rsrc(wl, wm_bytes), l2a_rsrc(wl + p.pk_wmid_stride, wm_bytes),
                                                                  voff, next_half ? voffh : voff, next_half ? TH : TPW, 0,
-                                                                 hcur, pfA, pfB, pfO, acc, lane);
-                        const float* bl = nr + CST_BHID + l * (16 * HT);
+                                                                 hcur, pfA, pfB, pfO, acc, lane,
+                                                                 nr + CST_BHID + l * (16 * HT) + 16 * c0 + 4 * qq, bias, olane);
 #pragma unroll
                         for (int tt = 0; tt < TPW; ++tt) {
-                            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                hoth[(nt * HT + c0 + tt) * 64 + lane] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                                hoth[(nt * HT + c0 + tt) * 64 + lane] = l2a_actv<GACT>(acc[nt][tt] + bias[tt], p.hidden_act, p.hid_floor);
                         }
                         __syncthreads();
                         f32x4* tmp = hcur; hcur = hoth; hoth = tmp;
                     }
                     if (LB == 1) pb = hoth;
+                    L2A_TS(15)
                     const f32x4* hin = (LB > 1) ? buf0 + j * p.sa_elems : hcur;
                     const __amdgpu_buffer_rsrc_t rs_last =
                         l2a_rsrc(wb + p.pk_wmid + (long long)(n_hidden - 2) * p.pk_wmid_stride, wm_bytes);
                     const float* bl = nr + CST_BHID + (n_hidden - 1) * (16 * HT);
                     if (!is_half) {
                         l2a_hidden_gemm<NT, TPW, TPW, OT, true>(rs_last, rs_out, voff, voff, TPW, c0, hin, pfA, pfB, pfO,
-                                                                acc, lane);
+                                                                acc, lane, bl + 16 * c0 + 4 * qq, bias, olane);
 #pragma unroll
                         for (int tt = 0; tt < TPW; ++tt) {
-                            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (c0 + tt) + 4 * qq);
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                                hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias[tt], p.hidden_act, p.hid_floor);
                         }
                     } else {
                         l2a_hidden_gemm<NT, TH, TPW, OT, true>(rs_last, rs_out, voffh, voffh, TH, tile0h, hin, pfA, pfB,
-                                                               pfO, acc, lane);
+                                                               pfO, acc, lane, bl + 16 * tile0h + 4 * qq, bias, olane);
 #pragma unroll
                         for (int tt = 0; tt < TH; ++tt) {
-                            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * (tile0h + tt) + 4 * qq);
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias, p.hidden_act, p.hid_floor);
+                                hreg[nt][tt] = l2a_actv<GACT>(acc[nt][tt] + bias[tt], p.hidden_act, p.hid_floor);
                         }
                     }
                 }
@@ -767,29 +859,31 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     const __amdgpu_buffer_rsrc_t r0n = l2a_rsrc(set_base(seq((i + 1 < n_seq) ? i + 1 : 0)) + p.pk_w0, w0_bytes);
                     auto pf_l0 = [&]() {
 #pragma unroll
-                        for (int tt = 0; tt < TPW; ++tt) pfL0[tt] = l2a_ldw(r0n, voff0[tt], 0);     // k-group 0 only
+                        for (int g = 0; g < KG0P; ++g)
+#pragma unroll
+                            for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0n, voff0[tt] + g * 1024, 0);
                     };
-                    if (is_half) l2a_out_phase<NT, TH, TPW, OT, TPW>(hreg, pfO, rs_out, tile0h, pf_l0, pb, wave, lane);
-                    else l2a_out_phase<NT, TPW, TPW, OT, TPW>(hreg, pfO, rs_out, c0, pf_l0, pb, 2 * wave, lane);
+                    if (is_half) l2a_out_phase<NT, TH, TPW, OT, KG0P * TPW, O4>(hreg, pfO, rs_out, tile0h, pf_l0, pb, wave, lane, olane);
+                    else l2a_out_phase<NT, TPW, TPW, OT, KG0P * TPW, O4>(hreg, pfO, rs_out, c0, pf_l0, pb, 2 * wave, lane, olane);
                 } else {
                     const int en = seq(i + 1);
                     const __amdgpu_buffer_rsrc_t rsn = l2a_rsrc(set_base(en) + p.pk_wmid, wm_bytes);   // nb > 1: two hidden layers
                     if (en == e_shared) {
-                        l2a_out_phase<NT, TPW, TPW, OT, 2 * TH>(hreg, pfO, rs_out, c0, [&]() {
+                        l2a_out_phase<NT, TPW, TPW, OT, 2 * TH, O4>(hreg, pfO, rs_out, c0, [&]() {
 #pragma unroll
                             for (int tt = 0; tt < TH; ++tt) {
                                 pfA[tt] = l2a_ldw(rsn, voffh[tt], 0);
                                 pfB[tt] = l2a_ldw(rsn, voffh[tt] + 1024, 0);
                             }
-                        }, pb, 2 * wave, lane);
+                        }, pb, 2 * wave, lane, olane);
                     } else {
-                        l2a_out_phase<NT, TPW, TPW, OT, 2 * TPW>(hreg, pfO, rs_out, c0, [&]() {
+                        l2a_out_phase<NT, TPW, TPW, OT, 2 * TPW, O4>(hreg, pfO, rs_out, c0, [&]() {
 #pragma unroll
                             for (int tt = 0; tt < TPW; ++tt) {
                                 pfA[tt] = l2a_ldw(rsn, voff[tt], 0);
                                 pfB[tt] = l2a_ldw(rsn, voff[tt] + 1024, 0);
                             }
-                        }, pb, 2 * wave, lane);
+                        }, pb, 2 * wave, lane, olane);
                     }
                 }
                 L2A_TS(4)
@@ -822,6 +916,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 // which is out of registers kernel-wide, serialises them read-wait-add (~120 cycles each, 22 of
                 // them: the reduce measured 1.4k cycles per set in tools/timeline.py).  The half member's
                 // unwritten upper chunks are read too (branch-free) and simply not used.
+                // (reading all obs tiles of a set up front - one exposed round trip instead of OT - was measured and lost:
+                // 1.434 against 1.431 ms on config 2, profiles/r03_ab_kernel_variants.jsonl)
 #pragma unroll
                 for (int c = 0; c < OT; ++c) {
                     f32x4 part[2 * L2A_NW][NT];
@@ -845,6 +941,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                             for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w][nt];
                             s += s2;
+                            if (O4 && c == OT - 1) {        // the four quarters of the hidden units (l2a_out_phase)
+#pragma unroll
+                                for (int ii = 0; ii < 4; ++ii) s[ii] = l2a_sum_xor32(l2a_sum_xor16(s[ii]));
+                            }
                             s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
                             dgrp[nt][c] += s * osd + omu;
                         }
@@ -890,20 +990,54 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 // single model (E == 1): there are no full sets, region 0 is never written - skip it
                 const bool want0 = (split == 1) || (e_loop > 1);
                 unsigned int spins = 0;
-                while (true) {
-                    // both regions in ONE round trip (an sc1 load sweep costs ~3k cycles whatever its size)
-                    bool ok = true;
-                    if (split == 2) ok = xget(1, oth[1]);
-                    if (want0) ok = xget(0, oth[0]) && ok;
-                    if (__all(ok)) break;
-                    ++spins;
-                    if (spin_left == 0) {           // partner never arrived: flag it, do not hang; the budget is per
-                                                    // launch, so the remaining steps give up after one poll each
+                // Both regions in ONE round trip (an sc1 load sweep costs ~2-3k clocks whatever its size), and TWO sweeps in
+                // flight half a round trip apart: the partner's records become visible ~2k clocks after it published them,
+                // a lone sweep that just misses them costs a whole further round trip (timeline r03: 3.3k clocks when the
+                // first sweep hits, 4.9k when it is the second), the staggered pair at most half of one.
+                auto give_up = [&]() {                  // partner never arrived: flag it, do not hang; the budget is per
+                    ++spins;                            // launch, so the remaining steps give up after one poll each
+                    if (spin_left == 0) {
                         if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
+                        return true;
                     }
                     --spin_left;
-                    __builtin_amdgcn_s_sleep(4);
+                    return false;
+                };
+                // -DL2A_SWEEPS=2: two sweeps in flight half a round trip apart.  Measured and lost (1.457 against 1.448 ms on
+                // config 2, 41 more registers: profiles/r03_ab_kernel_variants.jsonl) - kept as an option, off.
+#ifndef L2A_SWEEPS
+#define L2A_SWEEPS 1
+#endif
+                constexpr bool TWO_SWEEPS = (L2A_SWEEPS == 2) && OT <= 2;     // wider states: no registers for a second sweep
+                if (TWO_SWEEPS) {
+                    u32x4 ga[2][XG], gb[2][XG];
+                    auto issue = [&](u32x4 (&g)[2][XG]) {
+                        if (split == 2) xload(1, g[1]);
+                        if (want0) xload(0, g[0]);
+                    };
+                    auto settle = [&](const u32x4 (&g)[2][XG]) {
+                        bool ok = true;
+                        if (split == 2) ok = xtake(g[1], oth[1]);
+                        if (want0) ok = xtake(g[0], oth[0]) && ok;
+                        return (bool)__all(ok);
+                    };
+                    issue(ga);
+                    __builtin_amdgcn_s_sleep(12);
+                    issue(gb);
+                    while (true) {
+                        if (settle(ga) || give_up()) break;
+                        issue(ga);
+                        if (settle(gb) || give_up()) break;
+                        issue(gb);
+                    }
+                } else {
+                    while (true) {
+                        bool ok = true;
+                        if (split == 2) ok = xget(1, oth[1]);
+                        if (want0) ok = xget(0, oth[0]) && ok;
+                        if (__all(ok) || give_up()) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
@@ -942,6 +1076,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         const f32x4 gb = (grp == 0) ? og[nt][c] : dgrp[nt][c];         // group B
                         if (split == 2) {
                             f32x4 s = qsh[nt][c] + oq[nt][c];                          // S1 + S2
+                            if (O4 && c == OT - 1) {
+#pragma unroll
+                                for (int ii = 0; ii < 4; ++ii) s[ii] = l2a_sum_xor32(l2a_sum_xor16(s[ii]));
+                            }
                             s = l2a_actv<GACT>(s + cb[c], p.output_act, p.out_floor);
                             ga += s * cs[c] + cm[c];        // the shared set is the last member of group A
                         }
@@ -969,7 +1107,15 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
             for (int c = 0; c < OT; ++c) {
                 f32x4 d = dsum[nt][c];
-                if (e_loop > 1) d = d / e_count;
+                if (e_loop > 1) {
+                    // d / E, correctly rounded like the IEEE division it replaces (Markstein: q = RN(d y), r = d - q E exactly
+                    // (fma), q' = RN(q + r y) with y = RN(1 / E)) - three operations instead of the ~11 of v_div_*
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const float q = d[ii] * e_inv;
+                        d[ii] = fmaf(fmaf(-q, e_count, d[ii]), e_inv, q);
+                    }
+                }
                 const f32x4 nx = st[nt][c] + d;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
@@ -981,10 +1127,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 }
                 st[nt][c] = nx;
             }
-            plin += __shfl_xor(plin, 16);
-            plin += __shfl_xor(plin, 32);
-            psq += __shfl_xor(psq, 16);
-            psq += __shfl_xor(psq, 32);
+            plin = l2a_sum_xor32(l2a_sum_xor16(plin));      // (r0 + r1) + (r2 + r3), as the xor-16 / xor-32 shuffles gave
+            psq = l2a_sum_xor32(l2a_sum_xor16(psq));
             float r = plin;
             if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
 #ifdef L2A_RET64

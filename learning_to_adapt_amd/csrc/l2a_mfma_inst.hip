@@ -8,11 +8,11 @@
 
 namespace {
 
-template <int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false>
+template <int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = false>
 int launch_one(const L2AKParams* p, unsigned grid, int smem, hipStream_t stream) {
     // one hidden layer: its own instances (no hidden->hidden GEMM in them), generic activation code only
     if (!N1 && p->n_hidden == 1) return launch_one<OT, KG0, true, 4, true>(p, grid, smem, stream);
-    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L, N1>;
+    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L, N1, O4>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -26,7 +26,12 @@ int launch_shape(int ot, int kg0, const L2AKParams* p, unsigned grid, int smem, 
     switch (ot * 8 + kg0) {
         case 1 * 8 + 1: return launch_one<1, 1, GACT>(p, grid, smem, stream);
         case 1 * 8 + 2: return launch_one<1, 2, GACT>(p, grid, smem, stream);
-        case 2 * 8 + 2: return launch_one<2, 2, GACT>(p, grid, smem, stream);
+        case 2 * 8 + 2:     // HalfCheetah: 20 = 16 + 4 observations - the last obs tile has four live units (O4 instance)
+#ifndef L2A_NO_O4
+            if (p->n_hidden > 1 && p->obs_dim - 16 >= 1 && p->obs_dim - 16 <= 4)
+                return launch_one<2, 2, GACT, 4, false, true>(p, grid, smem, stream);
+#endif
+            return launch_one<2, 2, GACT>(p, grid, smem, stream);
         case 2 * 8 + 3: return launch_one<2, 3, GACT>(p, grid, smem, stream);
         case 3 * 8 + 3: return launch_one<3, 3, GACT>(p, grid, smem, stream);
         case 3 * 8 + 4:     // Ant: 41 + 8 = 49 inputs end one feature into the last k-group (its own instance; relu / identity)

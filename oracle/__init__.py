@@ -33,6 +33,10 @@ Parity status
   padding, pre/post split, mean-square loss, one SGD step).  ``tf.gradients`` is TensorFlow's: **unpinned at the
   TensorFlow boundary**; the hand-written backward pass is pinned against float64 central finite differences
   (``tools/gen_adapt_golden.py``, ``tests/test_adapt_oracle.py``) and by the fixture ``tests/golden/adapt_cases.npz``.
+* training loop (``oracle/fit.py``): restates ``mlp_dynamics.py:140-197`` (epoch / batch structure, loss, TensorFlow's
+  documented Adam update, rolling-average early stop) with the batch order as an input (the ``tf.data`` shuffle cannot
+  be reproduced): **unpinned at the TensorFlow boundary**; ``tests/test_fit_oracle.py`` drives the drop-in's ``fit``
+  with the same split and batch orders.
 * recurrent planner (``oracle/rnn_planner.py``): PINNED against the real
   ``RNNMPCController`` (``policies/rnn_mpc_controller.py``) the same way.
 * LSTM cell arithmetic (``oracle/rnn_dynamics.py``): unpinned at the

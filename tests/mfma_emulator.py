@@ -38,6 +38,16 @@ def mfma_16x16x4(a, b, c):
     return out
 
 
+def mfma_4x4x1(a, b, c):
+    """``v_mfma_f32_4x4x1_16b_f32``: sixteen 4x4 outer products, block ``l >> 2``: lane ``4 blk + i`` supplies ``A[i]``,
+    lane ``4 blk + j`` supplies ``B[j]`` and holds ``D[i][j]`` in result register ``i``."""
+    out = np.array(c, dtype=F32)
+    blk = LANE >> 2
+    for i in range(4):
+        out[:, i] = (a[4 * blk + i].astype(np.float64) * b.astype(np.float64) + out[:, i].astype(np.float64)).astype(F32)
+    return out
+
+
 def act4(v, kind):
     if kind == "relu":
         return np.maximum(v, F32(0))
@@ -136,6 +146,10 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                     dst[nt, s, :, ii] = np.where(ok, v, F32(0))
         return dst
 
+    # O4 (csrc/l2a_mfma.h, l2a_out_phase): the last obs tile has at most four live units -> computed with the 4x4x1 MFMA,
+    # every lane accumulating over ITS quarter of the hidden units; the quarters are added after the chunk reduce
+    O4 = (OT == 2 and KG0 == 2 and ps0.n_hidden > 1 and 1 <= obs_dim - 16 <= 4)
+    LANE4 = (LANE & 48) | (LANE & 3)
     ret = np.zeros((NW, NT, 64), dtype=F32)
     sa = max(NT * HT, 2 * NW * NT * OT)
     lds = [np.zeros((sa, 64, 4), dtype=F32), np.zeros((sa, 64, 4), dtype=F32)]
@@ -218,8 +232,11 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                             for nt in range(NT):
                                 b = hcur[nt * HT + g][:, ii]
                                 for c in range(OT):
-                                    a = ps.wout[c * HT + g, :, ii]
-                                    acc[nt, c] = mfma_16x16x4(a, b, acc[nt, c])
+                                    if O4 and c == OT - 1:
+                                        acc[nt, c] = mfma_4x4x1(ps.wout[c * HT + g, LANE4, ii], b, acc[nt, c])
+                                    else:
+                                        a = ps.wout[c * HT + g, :, ii]
+                                        acc[nt, c] = mfma_16x16x4(a, b, acc[nt, c])
                     for nt in range(NT):
                         for c in range(OT):
                             hoth[((2 * wave + ch) * NT + nt) * OT + c] = acc[nt, c]
@@ -237,6 +254,9 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                         for w in range(1, NW):
                             s2 = (s2 + hoth[((NW + w) * NT + nt) * OT + c]).astype(F32)
                         s = (s1 + s2).astype(F32)
+                        if O4 and c == OT - 1:
+                            s = (s + s[LANE ^ 16]).astype(F32)
+                            s = (s + s[LANE ^ 32]).astype(F32)
                         s = act4((s + bias).astype(F32), output_act)
                         dgrp[wave, nt, c] = (dgrp[wave, nt, c] + (s * osd + omu).astype(F32)).astype(F32)
             # (no barrier; `cur` is NOT flipped: the next layer 0 writes the region it just read)

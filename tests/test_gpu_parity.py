@@ -19,8 +19,9 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
 # CEM: the error bar a rank swap inside the elite mask has to fit in (measured error of a config-5 rollout: 5e-7
-# relative, profiles/r03_parity_report.txt; a swap of two candidates further apart than 2 x this is a ranking bug)
-CEM_TIE_RTOL = 5e-6
+# relative on most iterations, 6e-6 on one - profiles/r03_parity_report.txt; a swap of two candidates further apart than 2 x this
+# bar is a ranking bug)
+CEM_TIE_RTOL = 1e-5
 CEM_TIE_RTOL_ANT = 2e-5      # 41-dimensional state, unclipped CEM samples: RS rollouts of the Ant cases measure up to 9e-6
 
 

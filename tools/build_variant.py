@@ -15,8 +15,9 @@ from learning_to_adapt_amd.csrc import build as b  # noqa: E402
 
 
 def main():
-    name, defs = sys.argv[1], sys.argv[2:]
-    b.build()
+    name, defs = sys.argv[1], [a for a in sys.argv[2:] if a != "--no-base"]
+    if "--no-base" not in sys.argv:         # (developer shortcut: reuse the cached objects of the other units as they are)
+        b.build()
     obj = os.path.join(b.OBJ_DIR, "l2a_mfma_1_8_%s.o" % name)
     subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DL2A_INST_NT=1", "-DL2A_INST_TPW=8"] + defs +
                           ["-c", os.path.join(b.HERE, "l2a_mfma_inst.hip"), "-o", obj], cwd=b.HERE)

@@ -11,8 +11,8 @@ import sys
 
 # the phase stamps exist only in a library built with -DL2A_TIMELINE (they cost the product kernel 0.6 %):
 #   python tools/build_variant.py timeline -DL2A_TIMELINE
-_TL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "learning_to_adapt_amd",
-                   "libl2a_hip_timeline.so")
+_TL = os.environ.get("L2A_TIMELINE_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                          "learning_to_adapt_amd", "libl2a_hip_timeline.so")
 if not os.path.exists(_TL):
     raise SystemExit("build the timeline library first: python tools/build_variant.py timeline -DL2A_TIMELINE")
 os.environ["L2A_LIB_PATH"] = _TL
@@ -25,21 +25,22 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
 
-case = cases.CASES["c2_hc_rs_n2000_h30_e5"]
+name = sys.argv[1] if len(sys.argv) > 1 else "c2_hc_rs_n2000_h30_e5"          # any MLP case of tests/golden/cases.json
+case = cases.CASES[name]
 env, model = cases.product_model(case)
 native = model.planner_model()
 dev = native.device
-gold = cases.load_golden("c2_hc_rs_n2000_h30_e5_s0")
-obs0 = torch.from_numpy(gold["obs0"].astype(np.float32)).to(dev)
-a = (torch.rand((30, 2000, 6), device=dev) * 2 - 1)
-best = torch.zeros(1, dtype=torch.int64, device=dev)
-h = 30
+m, n, h = case["m"], case["n"], case["h"]
+od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+obs0 = torch.randn((m, od), device=dev) * 0.3
+a = (torch.rand((h, m * n, ad), device=dev) * 2 - 1)
+best = torch.zeros(m, dtype=torch.int64, device=dev)
 for _ in range(3):
-    native.plan_rs(obs0, a, 1, 2000, h, 1.0, env.reward_spec, best_key=best)
+    native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
 dbg = torch.zeros((2, h, 8, 8, 16), dtype=torch.int64, device=dev)
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(dbg.data_ptr())), "dbg")
-native.plan_rs(obs0, a, 1, 2000, h, 1.0, env.reward_spec, best_key=best)
+native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(0)), "dbg")
 d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
@@ -47,7 +48,14 @@ d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
 # barrier | reduce(s0) reduce(s1) .. | exchange.  Slots of a set: 0 L0 start, 8 operands requested, 9 MFMAs done,
 # 10 bias / activation done, 1 written to LDS; 2 GEMM start, 3 GEMM + epilogue done, 4 output partials written;
 # 5 reduce start, 6 reduce done.
-for grp, members in ((0, (0, 1, 2)), (1, (3, 4, 2))):
+print("case %s" % name)
+t_mid = min(5, h - 1)
+GROUPS = []
+for grp in (0, 1):
+    ran = [e for e in range(7) if d[grp, t_mid, e, 0, 0] != 0]
+    if ran:
+        GROUPS.append((grp, tuple(sorted(ran, key=lambda e: d[grp, t_mid, e, 0, 0]))))
+for grp, members in GROUPS:
     print("group %d sets %s (median over steps 2.., clocks)" % (grp, members))
     for e in members:
         for w in range(4):
@@ -55,19 +63,17 @@ for grp, members in ((0, (0, 1, 2)), (1, (3, 4, 2))):
             if x[:, 0].max() == 0:
                 continue
             med = lambda a, b: np.median(x[:, a] - x[:, b])      # noqa: E731
-            print("  set %d wave %d: L0 %5.0f (issue %4.0f mfma %5.0f epilogue %4.0f lds-write %4.0f)  gemm %6.0f  out %5.0f  reduce %5.0f"
-                  % (e, w, med(1, 0), med(8, 0), med(9, 8), med(10, 9), med(1, 10), med(3, 2), med(4, 3), med(6, 5)))
+            print("  set %d wave %d: L0 %5.0f (issue %4.0f mfma %5.0f epilogue %4.0f lds-write %4.0f)  inner layers %6.0f  last gemm %6.0f  out %5.0f  reduce %5.0f"
+                  % (e, w, med(1, 0), med(8, 0), med(9, 8), med(10, 9), med(1, 10), med(15, 2), med(3, 15), med(4, 3), med(6, 5)))
     step = np.diff(d[grp, :, 7, 0, 7])
     print("  step period: median %d clk (min %d max %d)" % (np.median(step), step.min(), step.max()))
 
 print("\nper-step schedule, wave 0 (clocks since the previous step ended; median over steps 2..):")
-for grp, members in ((0, (0, 1, 2)), (1, (3, 4, 2))):
+for grp, members in GROUPS:
     t_end_prev = d[grp, 1:-1, 7, 0, 7]
     line = []
     for slot, nm in ((0, "L0"), (1, "L0.end"), (2, "gemm"), (3, "gemm.end"), (4, "out.end"), (5, "red"), (6, "red.end")):
         for e in members:
-            if d[grp, 5, e, 0, 0] == 0:
-                continue
             line.append("s%d.%s %6.0f" % (e, nm, np.median(d[grp, 2:, e, 0, slot] - t_end_prev)))
     x = d[grp, 2:, 7, 0, :]
     for slot, nm in ((9, "sets.done"), (11, "published"), (12, "swept"), (10, "at.barrier"), (13, "past.barrier"), (7, "step.end")):
