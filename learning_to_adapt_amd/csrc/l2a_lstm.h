@@ -254,20 +254,29 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 
     const int ga0 = obs_dim >> 4;
     f32x4 av_next[NT][2];
-    auto load_actions = [&](int t, f32x4 (&dst)[NT][2]) {
+    // (raw buffer loads from a per-step descriptor; slots that hold no action point past the slab and read 0.0 - no lane
+    // mask, no select: see l2a_mfma.h)
+    int aoff[NT][2][4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float* arow = p.actions + ((long long)t * R + row[nt]) * act_dim;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+                const bool in = (ka >= 0) && (ka < act_dim);
+                aoff[nt][s][ii] = in ? (row[nt] * act_dim + ka) * 4 : 0x7ffffff0;
+            }
+    const long long a_step = (long long)R * act_dim;
+    auto load_actions = [&](int t, f32x4 (&dst)[NT][2]) {
+        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
-                    const bool in = (ka >= 0) && (ka < act_dim);
-                    const float v = arow[in ? ka : 0];
-                    dst[nt][s][ii] = in ? v : 0.0f;
-                }
-        }
+                for (int ii = 0; ii < 4; ++ii)
+                    dst[nt][s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[nt][s][ii], 0, 0));
     };
     load_actions(0, av_next);
 
@@ -418,10 +427,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 }
                 st[nt][c] = nx;
             }
-            plin += __shfl_xor(plin, 16);
-            plin += __shfl_xor(plin, 32);
-            psq += __shfl_xor(psq, 16);
-            psq += __shfl_xor(psq, 32);
+            plin = l2a_sum_xor32(l2a_sum_xor16(plin));      // lane-swap sums (l2a_mfma.h): same order as the xor shuffles
+            psq = l2a_sum_xor32(l2a_sum_xor16(psq));
             float r = plin;
             if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
             ret[nt] = fmaf(disc_prev, r, ret[nt]);
@@ -577,12 +584,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                 f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (g == ga0) aa = av[nt][0];
                 if (g == ga0 + 1) aa = av[nt][1];
+                // state OR action OR padding per slot, each fragment exactly zero outside its own range: the sum is the select
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int k = 16 * g + 4 * qq + ii;
-                    const float v = (k < obs_dim) ? sv[ii] : aa[ii];
-                    x[g][nt][ii] = (v - mu[ii]) * iv[ii];
-                }
+                for (int ii = 0; ii < 4; ++ii) x[g][nt][ii] = ((sv[ii] + aa[ii]) - mu[ii]) * iv[ii];
             }
         }
         {

@@ -157,12 +157,15 @@ __device__ __forceinline__ float l2a_sum_xor32(float x) {
             _Pragma("unroll") for (int tt = TW - 1; tt >= 0; --tt)   /* last-loaded tile first: one vmcnt wait per stage */ \
                 acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);
 
-#define L2A_STAGE(CA, CB, FA, FB, SOFF, IMM, GF)                                           \
+#define L2A_STAGE(CA, CB, FA, FB, SOFF, IMM, GF) L2A_STAGE_X(CA, CB, FA, FB, SOFF, IMM, GF, (void)0)
+// SIDE: a statement scheduled INSIDE the stage (after its operand requests, among its MFMAs) - see l2a_hidden_gemm
+#define L2A_STAGE_X(CA, CB, FA, FB, SOFF, IMM, GF, SIDE)                                   \
     {                                                                                      \
         _Pragma("unroll") for (int tt = 0; tt < TW; ++tt)                                  \
             FA[tt] = l2a_ldw(rs, voff[tt] + (IMM), (SOFF));                                \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
             FB[nt] = hin[(nt * HT + (GF)) * 64 + lane];                                    \
+        SIDE;                                                                              \
         L2A_STAGE_MFMA(CA, CB)                                                             \
         /* interleave: one weight load per 4 NT MFMAs (8 back-to-back VMEM issues stall the pipe) */ \
         __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);                                \
@@ -184,17 +187,21 @@ __device__ __forceinline__ float l2a_sum_xor32(float x) {
 // Output-layer fragments fetched a phase ahead: the first L2A_PFT tiles only (the rest are loaded
 // when the output phase starts and land under the MFMAs of the first tiles) - register budget.
 #ifndef L2A_PFT_MAX
-#define L2A_PFT_MAX 8
+#define L2A_PFT_MAX 6
 #endif
 #define L2A_PFT(TW_, OT_) ((OT_) <= 2 ? ((TW_) < L2A_PFT_MAX ? (TW_) : L2A_PFT_MAX) : ((TW_) < 2 ? (TW_) : 2))
 
-template <int NT, int TW, int TPW, int OT, bool LAST>
+//
+// SIDE: work of ANOTHER phase carried in the shadow of this GEMM's MFMAs (layer 0 of the later sets of a batch: one hidden
+// tile per loop iteration - the loop has HT / 4 = TPW iterations, as many as a wave has layer-0 tiles).  `side(it, stage,
+// last)` is called after each of the four stages of iteration `it` (stage and "last iteration" as compile-time tags).
+template <int NT, int TW, int TPW, int OT, bool LAST, class SIDE>
 __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
                                                 const int (&voff)[TPW], const int (&voffn)[TPW], int twn,
                                                 int tile0, const f32x4* hin,
                                                 f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
                                                 f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW], int lane,
-                                                const float* bias_lds, f32x4 (&bias)[TPW], const int (&olane)[OT]) {
+                                                const float* bias_lds, f32x4 (&bias)[TPW], const int (&olane)[OT], SIDE side) {
     constexpr int HT = L2A_NW * TPW;
     static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
     f32x4 aC[TW], aD[TW], bA[NT], bB[NT], bC[NT], bD[NT];
@@ -214,14 +221,15 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
 #pragma unroll 1
     for (int g = 0; g < HT - 4; g += 4) {
         const int soff = (g + 2) * 1024;      // byte offset of k-group g + 2 inside a tile
-        L2A_STAGE(aA, bA, aC, bC, soff, 0, g + 2)
-        L2A_STAGE(aB, bB, aD, bD, soff, 1024, g + 3)
-        L2A_STAGE(aC, bC, aA, bA, soff, 2048, g + 4)
-        L2A_STAGE(aD, bD, aB, bB, soff, 3072, g + 5)
+        const int it = g >> 2;
+        L2A_STAGE_X(aA, bA, aC, bC, soff, 0, g + 2, side(it, std::integral_constant<int, 0>{}, std::false_type{}))
+        L2A_STAGE_X(aB, bB, aD, bD, soff, 1024, g + 3, side(it, std::integral_constant<int, 1>{}, std::false_type{}))
+        L2A_STAGE_X(aC, bC, aA, bA, soff, 2048, g + 4, side(it, std::integral_constant<int, 2>{}, std::false_type{}))
+        L2A_STAGE_X(aD, bD, aB, bB, soff, 3072, g + 5, side(it, std::integral_constant<int, 3>{}, std::false_type{}))
     }
     // ---- peeled last iteration (k-groups HT-4 .. HT-1) ------------------------------------
-    L2A_STAGE(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2)
-    L2A_STAGE(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1)
+    L2A_STAGE_X(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2, side(TPW - 1, std::integral_constant<int, 0>{}, std::true_type{}))
+    L2A_STAGE_X(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1, side(TPW - 1, std::integral_constant<int, 1>{}, std::true_type{}))
     {   // stage 2: consume C; aA is free -> next phase's first operands
         if (LAST) {     // output layer: A fragment (obs tile c, k-group = hidden tile tile0 + tt)
 #pragma unroll
@@ -235,6 +243,7 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
             for (int tt = 0; tt < TPW; ++tt)
                 if (tt < twn) aA[tt] = l2a_ldw(rsn, voffn[tt], 0);
         }
+        side(TPW - 1, std::integral_constant<int, 2>{}, std::true_type{});
         L2A_STAGE_MFMA(aC, bC)
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -254,9 +263,21 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
             for (int tt = 0; tt < TPW; ++tt)
                 if (tt < twn) aB[tt] = l2a_ldw(rsn, voffn[tt] + 1024, 0);
         }
+        side(TPW - 1, std::integral_constant<int, 3>{}, std::true_type{});
         L2A_STAGE_MFMA(aD, bD)
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int NT, int TW, int TPW, int OT, bool LAST>
+__device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
+                                                const int (&voff)[TPW], const int (&voffn)[TPW], int twn,
+                                                int tile0, const f32x4* hin,
+                                                f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
+                                                f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW], int lane,
+                                                const float* bias_lds, f32x4 (&bias)[TPW], const int (&olane)[OT]) {
+    l2a_hidden_gemm<NT, TW, TPW, OT, LAST>(rs, rsn, voff, voffn, twn, tile0, hin, aA, aB, pfO, acc, lane, bias_lds, bias, olane,
+                                           [](int, auto, auto) {});
 }
 
 // Output layer for the TW hidden tiles whose activations `hreg` this wave holds in registers
@@ -790,15 +811,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 }
                 L2A_TS(1)
             };
-            for (int j = 0; j + 1 < nb; ++j) layer0(j, std::false_type{});
-            layer0(nb - 1, std::true_type{});
 
             // ======== phase B: hidden -> hidden layers and the fused output layer, set by set ======
             // the last hidden layer keeps its output in registers and feeds the output layer directly
-            if (!N1) __syncthreads();
             // (again a generic lambda, the batch's last set peeled: a set that is not the last of its batch is a full
             // member and hands over to the next set's GEMM, the last one hands over to a layer 0)
-            auto member = [&](int j, auto last_tag) {
+            auto member = [&](int j, auto last_tag, auto side) {
                 constexpr bool last_set = decltype(last_tag)::value;
                 const int i = b0 + j;
                 const int e = seq(i);
@@ -834,7 +852,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     const float* bl = nr + CST_BHID + (n_hidden - 1) * (16 * HT);
                     if (!is_half) {
                         l2a_hidden_gemm<NT, TPW, TPW, OT, true>(rs_last, rs_out, voff, voff, TPW, c0, hin, pfA, pfB, pfO,
-                                                                acc, lane, bl + 16 * c0 + 4 * qq, bias, olane);
+                                                                acc, lane, bl + 16 * c0 + 4 * qq, bias, olane, side);
 #pragma unroll
                         for (int tt = 0; tt < TPW; ++tt) {
 #pragma unroll
@@ -888,8 +906,116 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 }
                 L2A_TS(4)
             };
-            for (int j = 0; j + 1 < nb; ++j) member(j, std::false_type{});
-            member(nb - 1, std::true_type{});
+            auto no_side = [](int, auto, auto) {};
+#ifndef L2A_EMBED
+#define L2A_EMBED 0
+#endif
+#if L2A_EMBED
+            // Embedded layer 0 (EMB): only the batch's FIRST set runs its layer 0 as a phase of its own; layer 0 of every
+            // later set (its input is the same state) is carried by the hidden GEMM of the set BEFORE it, one hidden tile
+            // per loop iteration - 8 MFMAs, 2 weight loads, 1 bias read, 1 LDS write per iteration, issued between the
+            // GEMM's stages, so that their latencies (operand fetch, bias read, write-out) disappear in the shadow of the
+            // GEMM's MFMAs instead of standing in a phase of 64 MFMAs.  Same operands in the same order: bit-identical.
+            // (One set per GEMM: carrying two at once costs 48 registers and spills the HalfCheetah instance.)
+            // MEASURED AND LOST (profiles/r03_ab_kernel_variants.jsonl, sessions r03g-r03i): a carried layer 0 lengthens its
+            // host GEMM by 3.5k clocks - what the phase of its own costs (3.7k) - whether its instructions sit between the
+            // stages or are interleaved with their MFMAs: with one wave per SIMD every non-MFMA instruction costs issue
+            // time (~6 clocks) wherever it stands, and a layer 0 is 64 MFMAs + ~150 others.  Config 2: 1.428 ms carried
+            // against 1.422 ms as a phase.  Kept behind -DL2A_EMBED=1 for the record; the product does not compile it.
+            constexpr bool EMB = L2A_EMBED && !N1 && KG0 <= 2 && OT <= 2 && NT == 1;
+            if (EMB && nb > 1) {
+                layer0(0, std::true_type{});        // (its tail requests the first operands of the first set's GEMM)
+                __amdgpu_buffer_rsrc_t er0;         // layer-0 weights of the set being carried
+                f32x4 ex[KG0][NT];                  // its normalised inputs
+                f32x4 ea[KG0];                      // A fragments of the tile in flight
+                f32x4 eacc[NT], ebias;
+                const float* ebl;                   // this lane's bias slice of the wave's first tile
+                f32x4* ehd;                         // this lane's slot of the wave's first tile in the set's LDS region
+                const int evoff = lane * 16 + c0 * KG0 * 1024;
+                auto carry = [&](int jn) {          // set jn of the batch is the next to be carried
+                    const int i = b0 + jn;
+                    const float* nr = nrm + i * NRM_SET;
+                    er0 = l2a_rsrc(set_base(seq(i)) + p.pk_w0, w0_bytes);
+#pragma unroll
+                    for (int g = 0; g < KG0; ++g) {
+                        const f32x4 mu = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
+                        const f32x4 iv = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (g < OT) sv = st[nt][g < OT ? g : 0];
+                            f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (g == ga0) aa = av[nt][0];
+                            if (g == ga0 + 1) aa = av[nt][1];
+#pragma unroll
+                            for (int ii = 0; ii < 4; ++ii) ex[g][nt][ii] = ((sv[ii] + aa[ii]) - mu[ii]) * iv[ii];
+                        }
+                    }
+                    ebl = nr + CST_BHID + 16 * c0 + 4 * qq;
+                    ehd = buf0 + jn * p.sa_elems + c0 * 64 + lane;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) eacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                };
+                // Per GEMM iteration `it` (four stages of 32 MFMAs and 8 weight loads each):
+                //   in stage 0: request tile it's layer-0 weights; read the bias of tile it - 1
+                //   in stage 1: bias, activation, write-out of tile it - 1 (its MFMAs ran an iteration ago)
+                //   in stage 3: the 8 MFMAs of tile it - its weights have had three stages (24 younger loads: the wait
+                //                  is vmcnt(24), the GEMM's own operands in flight stay in flight) to arrive
+                // Requesting the weights an ITERATION ahead instead looked natural and cost 3.6k clocks per carried set: the
+                // loop's first trip then reaches the MFMAs with only 8 younger loads behind the request, the wait is
+                // computed for that path (vmcnt(8)) and drains the GEMM's own prefetch every iteration (timeline r03g).
+                auto side = [&](int it, auto stage_tag, auto last_tag) {
+                    constexpr int ST = decltype(stage_tag)::value;
+                    constexpr bool LAST_IT = decltype(last_tag)::value;
+                    auto finish = [&](int tile) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            ehd[(nt * HT + tile) * 64] = l2a_actv<GACT>(eacc[nt] + ebias, p.hidden_act, p.hid_floor);
+                    };
+                    if (ST == 0) {
+#pragma unroll
+                        for (int g = 0; g < KG0; ++g) ea[g] = l2a_ldw(er0, evoff + g * 1024, it * (KG0 * 1024));
+                        ebias = *reinterpret_cast<const f32x4*>(ebl + 16 * (it > 0 ? it - 1 : 0));
+                    } else if (ST == 1) {
+                        // branch-free (a branch would cut the stage's scheduling region in two): the first iteration has no
+                        // finished tile yet and writes zeros + bias into tile 0's slot, which the second iteration overwrites
+                        finish(it > 0 ? it - 1 : 0);
+                    } else if (ST == 2) {
+                        // (nothing: the slot keeps the distance between the request and the MFMAs)
+                    } else {
+                        f32x4 acc_[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc_[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int g = 0; g < KG0; ++g)
+#pragma unroll
+                            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc_[nt] = L2A_MFMA(ea[g][ii], ex[g][nt][ii], acc_[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) eacc[nt] = acc_[nt];
+                        if (LAST_IT) {          // the last tile finishes here (one exposed MFMA latency per carried set)
+                            ebias = *reinterpret_cast<const f32x4*>(ebl + 16 * it);
+                            finish(it);
+                        }
+                    }
+                };
+                for (int j = 0; j + 1 < nb; ++j) {
+                    carry(j + 1);
+                    __syncthreads();                // layer 0 of set j is in LDS (written by the GEMM before, or the phase above)
+                    member(j, std::false_type{}, side);
+                }
+                __syncthreads();
+                member(nb - 1, std::true_type{}, no_side);
+            } else
+#endif
+            {
+                for (int j = 0; j + 1 < nb; ++j) layer0(j, std::false_type{});
+                layer0(nb - 1, std::true_type{});
+                if (!N1) __syncthreads();
+                for (int j = 0; j + 1 < nb; ++j) member(j, std::false_type{}, no_side);
+                member(nb - 1, std::true_type{}, no_side);
+            }
 
             // ======== phase C: canonical reduce of every set of the batch ===========================
             __syncthreads();
