@@ -23,6 +23,13 @@ SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_ins
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# Rollout kernels: MFMA accumulators in architectural VGPRs where the allocator can afford it - every epilogue reads its
+# accumulators with VALU instructions, which cannot address AGPRs, and each v_accvgpr_read costs issue time between MFMAs
+# (536 -> 344 of them in the HalfCheetah instance; config 2 +0.35 %, config 3 +1 %, config 3b +2 %: profiles/r03_ab_kernel_variants.jsonl).
+# NT = 1 instances only: the NT = 2 instances (config 4 on one GPU) LOSE 2.5 % with it (10.44 -> 10.76 ms, same file), and the
+# recurrent kernels get more accumulator moves, not fewer (70 -> 231 in the U = 256 instance).
+KERNEL_FLAGS = ["-mllvm", "--amdgpu-mfma-vgpr-form"]
+LSTM_FLAGS = []
 
 
 def _hipcc():
@@ -73,12 +80,12 @@ def build(force=False, verbose=True, only=None):
             ("l2a_comm.hip", os.path.join(OBJ_DIR, "l2a_comm.o"), []),
             ("l2a_cem.hip", os.path.join(OBJ_DIR, "l2a_cem.o"), [])]
     for utw in LSTM_INSTANCES:
-        jobs.append(("l2a_lstm_inst.hip", os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % utw), ["-DL2A_INST_UTW=%d" % utw]))
+        jobs.append(("l2a_lstm_inst.hip", os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % utw), ["-DL2A_INST_UTW=%d" % utw] + LSTM_FLAGS))
     for nt, tpw in INSTANCES:
         obj = os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % (nt, tpw))
         if only is not None and (nt, tpw) not in only and os.path.exists(obj):
             continue
-        jobs.append(("l2a_mfma_inst.hip", obj, ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw]))
+        jobs.append(("l2a_mfma_inst.hip", obj, ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw] + (KERNEL_FLAGS if nt == 1 else [])))
     if verbose:
         print("[l2a] hipcc %s : %d translation units, %d parallel jobs"
               % (" ".join(FLAGS), len(jobs), min(len(jobs), os.cpu_count() or 1)))

@@ -92,6 +92,26 @@ def main():
         case = C[name]
         env, model = cases.product_model(case)
         report(name + " (single GPU)", case, env, time_plan(model.planner_model(), case, env))
+    # run_mb_mpc.py's own defaults (:77-78,85,97): ONE 2 x 512 model, n = 2000, h = 20, and the Sampler hands get_actions the
+    # observations of all num_rollouts = 10 envs at once - a 1250-tile plan
+    case = dict(C["c1_hc_rs_n500_h10_e1"], n=2000, h=20, m=10)
+    env, model = cases.product_model(case)
+    report("run_mb_mpc.py default (single model, n=2000, h=20, m=10 rollouts)", case, env, time_plan(model.planner_model(), case, env))
+    for mode in ("numpy", "device"):
+        ctrl = cases.product_controller(case, model=model, env=env, rng=mode)
+        obs_np = np.random.RandomState(3).randn(10, 20)
+        np.random.seed(0)
+        for _ in range(5):
+            ctrl.get_actions(obs_np)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            ctrl.get_actions(obs_np)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 50
+        print(json.dumps(dict(config="run_mb_mpc.py default end to end through MPCController.get_actions (10 envs), rng=" + mode,
+                              ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1), env_steps_per_s=round(1e4 / ms, 1))), flush=True)
+        _retire(ctrl)
     # GrBAL default shape: 3 x 512, n = 2000, h = 20, 5 adapted sets
     case = dict(C["c3_ant_rs_n2000_h20_pb5"], hidden=[512, 512, 512])
     env, model = cases.product_model(case)

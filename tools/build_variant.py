@@ -19,7 +19,7 @@ def main():
     if "--no-base" not in sys.argv:         # (developer shortcut: reuse the cached objects of the other units as they are)
         b.build()
     obj = os.path.join(b.OBJ_DIR, "l2a_mfma_1_8_%s.o" % name)
-    subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DL2A_INST_NT=1", "-DL2A_INST_TPW=8"] + defs +
+    subprocess.check_call([b._hipcc()] + b.FLAGS + b.KERNEL_FLAGS + ["-DL2A_INST_NT=1", "-DL2A_INST_TPW=8"] + defs +
                           ["-c", os.path.join(b.HERE, "l2a_mfma_inst.hip"), "-o", obj], cwd=b.HERE)
     objs = [os.path.join(b.OBJ_DIR, "l2a_api.o"), os.path.join(b.OBJ_DIR, "l2a_lstm_api.o"),
             os.path.join(b.OBJ_DIR, "l2a_comm.o"), os.path.join(b.OBJ_DIR, "l2a_cem.o")]
@@ -28,7 +28,7 @@ def main():
         lobj = os.path.join(b.OBJ_DIR, "l2a_lstm_%d.o" % u)
         if u == 4 and any(("L2A_TIMELINE" in d or "L2A_LSTM" in d) for d in defs):     # units 256: the recurrent timeline tool's shape
             lobj = os.path.join(b.OBJ_DIR, "l2a_lstm_%d_%s.o" % (u, name))
-            subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DL2A_INST_UTW=%d" % u] + defs +
+            subprocess.check_call([b._hipcc()] + b.FLAGS + b.LSTM_FLAGS + ["-DL2A_INST_UTW=%d" % u] + defs +
                                   ["-c", os.path.join(b.HERE, "l2a_lstm_inst.hip"), "-o", lobj], cwd=b.HERE)
         objs.append(lobj)
     out = os.path.join(b.PKG, "libl2a_hip_%s.so" % name)

@@ -16,6 +16,8 @@ import cases  # noqa: E402
 
 def main():
     case = cases.CASES[sys.argv[1] if len(sys.argv) > 1 else "c2_hc_rs_n2000_h30_e5"]
+    if os.environ.get("L2A_PROBE_OVER"):        # e.g. '{"n": 2000, "h": 20, "m": 10}' on c1: run_mb_mpc.py's own defaults
+        case = dict(case, **json.loads(os.environ["L2A_PROBE_OVER"]))
     rnn = case["planner"].startswith("rnn")
     env, model = cases.product_rnn_model(case) if rnn else cases.product_model(case)
     obs = np.random.RandomState(1).randn(case["m"], env.observation_space.shape[0])
