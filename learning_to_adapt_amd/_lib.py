@@ -251,12 +251,13 @@ class Context(object):
     def force_unsplit(self):
         """A rank of a sharded plan was told by the collective that SOME rank's launch lost its tile-split partner: all
         ranks clear their status word, switch to the unsplit geometry (bit-identical results) and repeat the launch
-        together.  Raises when the split was already off - a second failure is not a placement problem."""
+        together.  Never raises: a rank that had already degraded on its own (a single-GPU call between two sharded
+        plans) must stay in step with the others - a launch that fails again is caught by the caller's second look at the
+        REDUCED flag, which raises on every rank alike."""
         self.launch_status_value()
-        if getattr(self, "split_degraded", False):
-            raise L2AError("a rollout launch of the sharded plan was flagged invalid with the tile split disabled")
-        self.set_split(0)
-        self.split_degraded = True
+        if not getattr(self, "split_degraded", False):
+            self.set_split(0)
+            self.split_degraded = True
 
     def set_spin_limit(self, polls):
         """Developer / test knob: polls a split workgroup waits for its partner per launch (0 = default)."""

@@ -13,9 +13,16 @@ int launch_one(const L2AKParams* p, unsigned grid, int smem, hipStream_t stream)
     // one hidden layer: its own instances (no hidden->hidden GEMM in them), generic activation code only
     if (!N1 && p->n_hidden == 1) return launch_one<OT, KG0, true, 4, true>(p, grid, smem, stream);
     auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L, N1, O4>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
+    // the dynamic-LDS ceiling of this instance is raised once per device and size, not on every launch (~2 us each)
+    static int smem_set[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || smem > smem_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 16) smem_set[dev] = smem;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * L2A_NW), smem, stream, *p);
     return 0;
 }

@@ -816,6 +816,37 @@ def test_flagged_launch_is_relaunched_unsplit_not_raised(cid, _fresh_split_state
         ctrl.get_actions(gold["obs0"])
 
 
+def test_plan_payload_packs_keys_flag_and_digest_on_the_device(_fresh_split_state):
+    """``l2a_plan_payload`` (what the ranks of a sharded plan all-reduce): keys copied, the launch status word read ON
+    THE DEVICE in stream order behind the launch, the digest pair summing to the mask."""
+    ctx = _fresh_split_state
+    case = cases.CASES["hc_rs_m3_n64_h5"]
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    m = case["m"]
+    a = _rs_actions(case, 0, env)
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    native.plan_rs(torch.from_numpy(np.random.RandomState(1).randn(m, 20).astype(np.float32)).to(dev),
+                   torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev), m, case["n"], case["h"], 1.0,
+                   env.reward_spec, best_key=best)
+    payload = torch.full((m + 3,), -1, dtype=torch.int64, device=dev)
+    mask = 0x7FFFFFFFFFFF
+    digest = 0x123456789ABC
+    native.plan_payload(best, m, digest | (1 << 60), payload)          # bits above the mask are dropped
+    got = payload.cpu().numpy()
+    assert np.array_equal(got[:m], best.cpu().numpy()) and got[m] == 0
+    assert got[m + 1] == digest and got[m + 1] + got[m + 2] == mask
+    ctx.check(ctx.lib.l2a_inject_status(ctx.handle, 1), "l2a_inject_status")        # as if the launch had been flagged
+    native.plan_payload(best, m, digest, payload)
+    assert int(payload.cpu()[m]) == 1
+    assert ctx.launch_status_value() == 1                                           # (read and cleared)
+    # MAX over ranks is what turns the pairs into an agreement test: two different digests cannot sum to the mask
+    other = np.array([digest + 1, mask - (digest + 1)])
+    merged = np.maximum(got[m + 1:], other)
+    assert merged[0] + merged[1] != mask
+
+
 def test_exchange_timeout_in_the_kernel_degrades(_fresh_split_state):
     """The kernel's own time-out path: with one poll allowed per launch a split workgroup almost surely misses its
     partner at some horizon step and flags the launch; whether or not it does, the controller must return the

@@ -128,8 +128,8 @@ def main():
     ob = [rs.randn(16, 41) for _ in range(5)]
     ac = [rs.uniform(-150, 150, (16, 8)) for _ in range(5)]
     nx = [o + 0.1 * rs.randn(16, 41) for o in ob]
-    for mode in ("numpy", "device"):
-        gc = MPCController(name="p", env=env, dynamics_model=gm, n_candidates=2000, horizon=20, rng=mode)
+    for mode, n_c, h_c in (("numpy", 2000, 20), ("device", 2000, 20), ("numpy", 500, 10), ("device", 500, 10)):
+        gc = MPCController(name="p", env=env, dynamics_model=gm, n_candidates=n_c, horizon=h_c, rng=mode)
         obs0 = rs.randn(5, 41)
         t_adapt, t_all = [], []
         for it in range(12):        # the adaptation on its own (with a synchronisation the real loop does not have)
@@ -149,7 +149,8 @@ def main():
             gc.get_actions(obs0)
             if it >= 5:
                 t_all.append(time.perf_counter() - t0)
-        print(json.dumps(dict(config="GrBAL controller step (adapt 5 envs + plan config 3 / 3x512), rng=" + mode,
+        label = "config 3 / 3x512" if n_c == 2000 else "run_grbal.py default n=500 h=10 / 3x512"
+        print(json.dumps(dict(config="GrBAL controller step (adapt 5 envs + plan %s), rng=%s" % (label, mode),
                               adapt_and_upload_ms=round(1e3 * float(np.median(t_adapt)), 3), step_ms=round(1e3 * float(np.median(t_all)), 3),
                               step_ms_mean=round(1e3 * float(np.mean(t_all)), 3), step_ms_max=round(1e3 * float(np.max(t_all)), 3))), flush=True)
         _retire(gc)
