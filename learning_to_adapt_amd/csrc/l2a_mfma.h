@@ -546,6 +546,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     double disc_pow = p.disc0;  // discount ** t, carried in float64 like the reference (:126)
     unsigned int spin_left = p.spin_limit;      // exchange polls this workgroup may still spend (whole launch)
     const unsigned int xtag0 = p.xtag;
+#ifdef L2A_XWAIT
+    unsigned int xwait_q = 0;                   // adaptive delay of the first exchange sweep, in quarter sleep units (below)
+#endif
     const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
@@ -1157,6 +1160,21 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         issue(gb);
                     }
                 } else {
+                    // Timing the FIRST sweep (-DL2A_XWAIT, off: measured and lost).  The workgroup of a pair that finishes its
+                    // sets first sweeps at once, misses (its partner's records become visible ~2.2k clocks after THEY are
+                    // published), sleeps, sweeps again: every miss costs a whole sc1 round trip (~2.5k clocks), and the pair's
+                    // step ends with the later of the two (timeline r03: the early workgroup 6.5k clocks from publish to swept,
+                    // the late one 3.3k).  Letting each workgroup LEARN a delay for its first sweep (+256 clocks per missed
+                    // sweep, -16 per first-sweep hit) made the early one hit at once (4.5k) - and the late one, whose every
+                    // jitter-induced miss adds a delay that takes 16 steps to decay, slower by more: config 2 1.436 against
+                    // 1.429 ms, the tail-split config 3 1.20 against 1.15 ms (profiles/r03_ab_kernel_variants.jsonl, r03p).  The
+                    // shader clocks of two XCDs are not comparable either (s_memtime differs by a drifting offset: tools/
+                    // timeline.py prints it), so the partner's progress cannot be read off a published time stamp.  Nothing
+                    // may be left in flight instead (two staggered sweeps: lost as well): loads retire in order, an abandoned
+                    // sweep would stall the next step's first operand wait by its whole round trip.
+#ifdef L2A_XWAIT
+                    for (unsigned int k = 0; k < (xwait_q >> 2); ++k) __builtin_amdgcn_s_sleep(1);
+#endif
                     while (true) {
                         bool ok = true;
                         if (split == 2) ok = xget(1, oth[1]);
@@ -1164,6 +1182,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         if (__all(ok) || give_up()) break;
                         __builtin_amdgcn_s_sleep(4);
                     }
+#ifdef L2A_XWAIT
+                    if (spins == 0) xwait_q -= (xwait_q > 0) ? 1u : 0u;
+                    else xwait_q = (xwait_q + 16u * spins > 400u) ? 400u : xwait_q + 16u * spins;
+#endif
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k)

@@ -82,3 +82,14 @@ for grp, members in GROUPS:
     print("           sweeps: median %d max %d; waves reach the post-exchange barrier at %s"
           % (np.median(x[:, 14]) + 1, x[:, 14].max() + 1,
              np.median(d[grp, 2:, 7, :4, 10] - t_end_prev[:, None], axis=0).astype(int).tolist()))
+
+if len(GROUPS) == 2:    # are the two workgroups' clocks comparable?  (s_memtime across CUs / XCDs)
+    d0, d1 = d[0, 2:, 7, 0, 7], d[1, 2:, 7, 0, 7]
+    diff = d1 - d0
+    print("\ngroup 1 step end minus group 0 step end (same step, raw stamps): median %d min %d max %d"
+          % (np.median(diff), diff.min(), diff.max()))
+    p0, p1 = d[0, 2:, 7, 0, 11], d[1, 2:, 7, 0, 11]
+    print("group 1 published minus group 0 published: median %d min %d max %d" % (np.median(p1 - p0), (p1 - p0).min(), (p1 - p0).max()))
+    s0, s1 = d[0, 2:, 7, 0, 12], d[1, 2:, 7, 0, 12]
+    print("group 0 swept minus group 1 published: median %d ; group 1 swept minus group 0 published: median %d"
+          % (np.median(s0 - p1), np.median(s1 - p0)))
