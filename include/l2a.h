@@ -101,6 +101,13 @@ int l2a_set_split(l2a_ctx* ctx, int policy);
  * batch held in LDS side by side.  0 (default) = as many as fit the CU's LDS (at most 4), 1 = one set at a time.
  * Arithmetic and summation order do not depend on it: results are bit-identical for every value.       */
 int l2a_set_batch(l2a_ctx* ctx, int sets);
+/* Placement of a uniformly split launch (two workgroups per candidate tile).  1 (default): the grid is padded to a
+ * multiple of eight workgroups so that the workgroups of ensemble group A land on XCDs 0-3 and those of group B on XCDs
+ * 4-7 exactly (hardware workgroup id % 8 = XCD); the up to six spare workgroups return at once.  Without it a tile count
+ * that is not a multiple of four leaves one workgroup alone with its weight sets in a foreign L2, and its tile ends the
+ * launch late (config 2, 125 tiles: 1.431 -> 1.417 ms).  0: the contiguous remap of 2 x tiles workgroups.  Placement
+ * only: results are bit-identical.                                                                          */
+int l2a_set_xcd_align(l2a_ctx* ctx, int on);
 /* Status word of the launches issued since the last call (caller must have synchronised the
  * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch
  * with l2a_set_split(ctx, 0)).  Reading clears it.                                            */

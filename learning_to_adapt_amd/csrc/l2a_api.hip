@@ -225,7 +225,25 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         const int smem = p.cst_off * 16 + cst_bytes_all + x_bytes;
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
-        const dim3 grid((unsigned)(pairs + (p.split ? split_pairs : 0))), block(64 * L2A_NW);
+        long long n_wg = pairs + (p.split ? split_pairs : 0);
+        p.pl_units = 0;
+        if (ctx->xcd_align && p.split_from < 0 && n_wg <= cus) {
+            // one unit of weight-sharing workgroups per XCD (see the kernel's geometry): the two groups of a split
+            // ensemble, the environments of a per-block plan (both workgroups of a split tile stream the same set)
+            int units = 0;
+            long long w = 0;
+            if (p.mode == L2A_MODE_PER_BLOCK) { units = p.m; w = (long long)p.tiles_per_env * (p.split ? 2 : 1); }
+            else if (p.split && e_loop > 1) { units = 2; w = pairs; }
+            if (units >= 2 && units <= 8) {
+                const int f = 8 / units;
+                const long long slots = (w + f - 1) / f;       // per XCD, of the units with f XCDs
+                if (8 * slots <= cus) {
+                    p.pl_units = units; p.pl_f = f; p.pl_r = 8 - units * f; p.pl_w = (int)w;
+                    n_wg = 8 * slots;
+                }
+            }
+        }
+        const dim3 grid((unsigned)n_wg), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
         int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, &p, grid.x, smem, stream);
         if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");
@@ -309,6 +327,8 @@ int l2a_init(int device, l2a_ctx** out) {
     }
     const char* sp = std::getenv("L2A_SPLIT");
     if (sp && sp[0] >= '0' && sp[0] <= '2') ctx->split_policy = sp[0] - '0';
+    const char* xa = std::getenv("L2A_XCD_ALIGN");
+    if (xa && (xa[0] == '0' || xa[0] == '1')) ctx->xcd_align = xa[0] - '0';
     const char* bs = std::getenv("L2A_BATCH");
     if (bs && bs[0] >= '0' && bs[0] <= '4') ctx->batch_sets = bs[0] - '0';
     *out = ctx;
@@ -336,6 +356,13 @@ int l2a_set_batch(l2a_ctx* ctx, int sets) {
     if (!ctx) return L2A_EINVAL;
     if (sets < 0 || sets > 4) return fail(ctx, L2A_EINVAL, "sets per batch must be 0 (automatic) .. 4");
     ctx->batch_sets = sets;
+    return L2A_OK;
+}
+
+int l2a_set_xcd_align(l2a_ctx* ctx, int on) {
+    if (!ctx) return L2A_EINVAL;
+    if (on != 0 && on != 1) return fail(ctx, L2A_EINVAL, "xcd alignment must be 0 or 1");
+    ctx->xcd_align = on;
     return L2A_OK;
 }
 

@@ -20,6 +20,7 @@ struct l2a_ctx {
     int device = 0;
     int kernel_kind = L2A_KERNEL_AUTO;
     int split_policy = 1;                 // 1 = split members over two workgroups when it fills the chip
+    int xcd_align = 1;                    // uniform tile split: pad the grid so that each ensemble group owns four XCDs (L2A_XCD_ALIGN=0: off)
     int batch_sets = 0;                   // MFMA rollout: sets per batch; 0 = as many as fit the LDS, 1 = one at a time
     unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
     unsigned int* status_dev = nullptr;

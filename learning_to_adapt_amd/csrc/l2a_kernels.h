@@ -66,6 +66,11 @@ struct L2AKParams {
     l2a_reward rw;
     // ---- member split (MFMA kernel, mean mode): two workgroups share one candidate tile ----
     int split;                  // 0: one workgroup runs all members; 1: group A | group B; 2: + shared set
+    // XCD placement of a single-round launch (0 units = the contiguous remap of l2a_logical_wg).  A "unit" is a set of
+    // workgroups that stream the same weights: the two ensemble groups of a split mean-mode launch, the environments of a
+    // per-block launch.  The first pl_r units own pl_f + 1 XCDs each, the others pl_f; the grid is 8 ceil(pl_w / pl_f)
+    // workgroups and hardware workgroup i (XCD i % 8, slot i / 8) either finds its place in its XCD's unit or returns.
+    int pl_units, pl_f, pl_r, pl_w;     // units, XCDs per unit (floor), units with one XCD more, workgroups per unit
     int split_from;             // -1: `split` applies to every tile; >= 0: tail split - hardware workgroups
                                 // [0, split_from) run whole tiles, the rest are pairs sharing tiles split_from ..
     unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1

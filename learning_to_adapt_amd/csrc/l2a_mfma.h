@@ -400,7 +400,31 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const int n_tiles = p.m * p.tiles_per_env;
     const int n_pairs = tail ? n_tiles - p.split_from : n_tiles;       // tiles that are shared by two workgroups
     int bid, grp, lpair, pairid;
-    if (!tail) {
+    if (!tail && p.pl_units > 0) {
+        // Every XCD (own 4 MB L2) serves ONE unit - workgroups that stream the same weights: group A of a split ensemble on
+        // XCDs 0-3 and group B on 4-7, each environment of a per-block plan on its own XCD(s).  The contiguous remap cannot
+        // do that when the counts do not divide: config 2 (125 tiles) left one workgroup of group B alone with its sets in
+        // an L2 of group A, and its pair ended the launch 1 % late; config 3b (5 environments x 32 tiles, 2.3 MB of weights
+        // each) had four XCDs thrash between two environments' sets, 5 % slower than the other four.  The grid is padded
+        // (host: launch_rollout); hardware workgroup i sits on XCD i % 8, and the spare ones return here.
+        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        const int f = p.pl_f, wide = p.pl_r * (f + 1);
+        int u, k, xu;
+        if (xcd < wide) { u = xcd / (f + 1); k = xcd - u * (f + 1); xu = f + 1; }
+        else { const int y = xcd - wide; u = y / f; k = y - u * f; u += p.pl_r; xu = f; }
+        const int su = (p.pl_w + xu - 1) / xu;              // workgroups of this unit per XCD
+        const int j = k * su + idx;                         // member of the unit
+        if (idx >= su || j >= p.pl_w) return;
+        if (p.mode == L2A_MODE_PER_BLOCK) {                 // unit = environment: its tiles, both workgroups of each
+            grp = split ? j / p.tiles_per_env : 0;
+            lpair = u * p.tiles_per_env + (j - grp * p.tiles_per_env);
+        } else {                                            // unit = ensemble group
+            grp = u;
+            lpair = j;
+        }
+        bid = grp * n_pairs + lpair;
+        pairid = lpair;
+    } else if (!tail) {
         bid = l2a_logical_wg(blockIdx.x, gridDim.x);
         grp = split ? (bid / n_pairs) : 0;                  // which of the two workgroups of a tile
         lpair = bid - grp * n_pairs;
@@ -413,6 +437,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         grp = bid & 1; lpair = bid >> 1;                    // partners are dispatched back to back
         pairid = p.split_from + lpair;
     }
+#ifdef L2A_TIMELINE
+    unsigned long long wg_t0_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0_) : : "memory");
+#endif
     const int env = pairid / p.tiles_per_env;
     const int tb = pairid - env * p.tiles_per_env;
     const int R = p.m * p.n;
@@ -1323,4 +1351,14 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             }
         }
     }
+#ifdef L2A_TIMELINE
+    if (p.dbg && wave == 0 && lane == 0) {      // per-workgroup record behind the phase stamps: lifetime and placement
+        unsigned long long wg_t1_;
+        unsigned int xcc_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1_) : : "memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        unsigned long long* r = p.dbg + (long long)2 * p.h * 8 * 8 * 16 + (long long)(grp * n_tiles + pairid) * 4;
+        r[0] = wg_t0_; r[1] = wg_t1_; r[2] = xcc_; r[3] = blockIdx.x;
+    }
+#endif
 }

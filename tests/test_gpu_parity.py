@@ -269,14 +269,20 @@ def test_set_batching_is_bit_identical(name, over):
             ctx.set_split(policy)
             for sets in (1, 0, 2, 3, 4):
                 ctx.set_batch(sets)
-                out[(policy, sets)] = _plan_returns(native, case, env, obs0, a)
+                out[(policy, sets, 1)] = _plan_returns(native, case, env, obs0, a)
                 ctx.launch_status()
+            # placement of the split pairs (l2a_set_xcd_align: padded grid, spare workgroups return at once)
+            ctx.set_xcd_align(0)
+            out[(policy, 4, 0)] = _plan_returns(native, case, env, obs0, a)
+            ctx.launch_status()
+            ctx.set_xcd_align(1)
     finally:
         ctx.set_split(1)
         ctx.set_batch(0)
-    ref = out[(0, 1)]
+        ctx.set_xcd_align(1)
+    ref = out[(0, 1, 1)]
     for key, (r, k) in out.items():
-        assert np.array_equal(r, ref[0]) and np.array_equal(k, ref[1]), "split %d, batch %d differs" % key
+        assert np.array_equal(r, ref[0]) and np.array_equal(k, ref[1]), "split %d, batch %d, xcd_align %d differs" % key
 
 
 def test_split_survives_stale_tags_of_short_launches():

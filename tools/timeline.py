@@ -38,7 +38,9 @@ best = torch.zeros(m, dtype=torch.int64, device=dev)
 for _ in range(3):
     native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
-dbg = torch.zeros((2, h, 8, 8, 16), dtype=torch.int64, device=dev)
+n_tiles = m * ((n + 15) // 16)
+dbg_all = torch.zeros(2 * h * 8 * 8 * 16 + 2 * n_tiles * 4, dtype=torch.int64, device=dev)
+dbg = dbg_all[:2 * h * 8 * 8 * 16].view(2, h, 8, 8, 16)
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(dbg.data_ptr())), "dbg")
 native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
@@ -49,6 +51,23 @@ d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
 # 10 bias / activation done, 1 written to LDS; 2 GEMM start, 3 GEMM + epilogue done, 4 output partials written;
 # 5 reduce start, 6 reduce done.
 print("case %s" % name)
+# per-workgroup record (NT = 1 shapes): start, end (own CU's clock), XCC_ID register, hardware workgroup id
+wg = dbg_all[2 * h * 8 * 8 * 16:].cpu().numpy().astype(np.int64).reshape(2, n_tiles, 4)
+ran_wg = wg[:, :, 1] != 0
+if ran_wg.any():
+    life = np.where(ran_wg, wg[:, :, 1] - wg[:, :, 0], 0)
+    xcd = wg[:, :, 2] & 15
+    print("workgroup lifetimes (clocks): median %d, min %d, max %d over %d workgroups"
+          % (np.median(life[ran_wg]), life[ran_wg].min(), life[ran_wg].max(), ran_wg.sum()))
+    for g in (0, 1):
+        for x in range(8):
+            sel = ran_wg[g] & (xcd[g] == x)
+            if sel.any():
+                print("  group %d XCD %d: %3d workgroups, lifetime median %d max %d (hw ids %d..%d)"
+                      % (g, x, sel.sum(), np.median(life[g][sel]), life[g][sel].max(), wg[g][sel, 3].min(), wg[g][sel, 3].max()))
+    slow = np.argsort(-(life * ran_wg).ravel())[:6]
+    print("  slowest: " + ", ".join("g%d tile %d xcd %d hw %d: %d" % (i // n_tiles, i % n_tiles, xcd.ravel()[i], wg.reshape(-1, 4)[i, 3],
+                                                                     life.ravel()[i]) for i in slow))
 t_mid = min(5, h - 1)
 GROUPS = []
 for grp in (0, 1):
