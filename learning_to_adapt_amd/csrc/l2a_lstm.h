@@ -210,6 +210,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
     const int tb = pairid - env * p.tiles_per_env;
     const int R = p.m * p.n;
     const int obs_dim = p.obs_dim, act_dim = p.act_dim;
+#ifdef L2A_TIMELINE
+    unsigned long long wg_t0_, wg_r0_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0_), "=s"(wg_r0_) : : "memory");
+#endif
 
     int cand[NT], row[NT];
     bool valid[NT];
@@ -780,4 +784,14 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             }
         }
     }
+#ifdef L2A_TIMELINE
+    if (p.dbg && wave == 0 && lane == 0) {      // per-workgroup record behind the phase stamps: lifetime and placement
+        unsigned long long wg_t1_, wg_r1_;
+        unsigned int xcc_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1_), "=s"(wg_r1_) : : "memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        unsigned long long* r = p.dbg + (long long)p.h * 4 * 16 + (long long)(grp * n_tiles + pairid) * 6;
+        r[0] = wg_t0_; r[1] = wg_t1_; r[2] = xcc_; r[3] = blockIdx.x; r[4] = wg_r0_; r[5] = wg_r1_;   // [4, 5]: 100 MHz real time
+    }
+#endif
 }

@@ -438,8 +438,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         pairid = p.split_from + lpair;
     }
 #ifdef L2A_TIMELINE
-    unsigned long long wg_t0_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0_) : : "memory");
+    unsigned long long wg_t0_, wg_r0_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0_), "=s"(wg_r0_) : : "memory");
 #endif
     const int env = pairid / p.tiles_per_env;
     const int tb = pairid - env * p.tiles_per_env;
@@ -1353,12 +1353,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     }
 #ifdef L2A_TIMELINE
     if (p.dbg && wave == 0 && lane == 0) {      // per-workgroup record behind the phase stamps: lifetime and placement
-        unsigned long long wg_t1_;
+        unsigned long long wg_t1_, wg_r1_;
         unsigned int xcc_;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1_) : : "memory");
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1_), "=s"(wg_r1_) : : "memory");
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
-        unsigned long long* r = p.dbg + (long long)2 * p.h * 8 * 8 * 16 + (long long)(grp * n_tiles + pairid) * 4;
-        r[0] = wg_t0_; r[1] = wg_t1_; r[2] = xcc_; r[3] = blockIdx.x;
+        unsigned long long* r = p.dbg + (long long)2 * p.h * 8 * 8 * 16 + (long long)(grp * n_tiles + pairid) * 6;
+        r[0] = wg_t0_; r[1] = wg_t1_; r[2] = xcc_; r[3] = blockIdx.x; r[4] = wg_r0_; r[5] = wg_r1_;   // [4, 5]: 100 MHz real time
     }
 #endif
 }

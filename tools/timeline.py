@@ -39,11 +39,17 @@ for _ in range(3):
     native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
 torch.cuda.synchronize()
 n_tiles = m * ((n + 15) // 16)
-dbg_all = torch.zeros(2 * h * 8 * 8 * 16 + 2 * n_tiles * 4, dtype=torch.int64, device=dev)
+dbg_all = torch.zeros(2 * h * 8 * 8 * 16 + 2 * n_tiles * 6, dtype=torch.int64, device=dev)
 dbg = dbg_all[:2 * h * 8 * 8 * 16].view(2, h, 8, 8, 16)
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(dbg.data_ptr())), "dbg")
+for _ in range(int(os.environ.get('L2A_TL_WARM', '20'))):     # clocks up; the stamps of the last launch stay
+    native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
 native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)
+ev1.record()
 torch.cuda.synchronize()
+launch_ms = ev0.elapsed_time(ev1)
 native.ctx.check(native.lib.l2a_set_debug_buffer(native.ctx.handle, ctypes.c_void_p(0)), "dbg")
 d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
 # [grp, t, e, wave, slot]; batched flow (l2a_mfma.h): per step  L0(s0) L0(s1) .. | barrier | GEMM+out(s0) GEMM+out(s1) .. |
@@ -52,10 +58,16 @@ d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
 # 5 reduce start, 6 reduce done.
 print("case %s" % name)
 # per-workgroup record (NT = 1 shapes): start, end (own CU's clock), XCC_ID register, hardware workgroup id
-wg = dbg_all[2 * h * 8 * 8 * 16:].cpu().numpy().astype(np.int64).reshape(2, n_tiles, 4)
+wg = dbg_all[2 * h * 8 * 8 * 16:].cpu().numpy().astype(np.int64).reshape(2, n_tiles, 6)
 ran_wg = wg[:, :, 1] != 0
 if ran_wg.any():
     life = np.where(ran_wg, wg[:, :, 1] - wg[:, :, 0], 0)
+    real = (wg[:, :, 5] - wg[:, :, 4])[ran_wg]          # s_memrealtime: constant 100 MHz
+    print("shader clock over the workgroups' lifetimes (s_memtime ticks per 10 ns of s_memrealtime): median %.1f MHz; "
+          "launch = first start -> last end by real time: %.4f ms"
+          % (np.median(life[ran_wg] / real) * 100.0, (wg[:, :, 5][ran_wg].max() - wg[:, :, 4][ran_wg].min()) / 1e5))
+    print("stamped launch by events: %.4f ms; longest workgroup lifetime %d ticks = %.3f ticks/ns if the launch were nothing else"
+          % (launch_ms, life.max(), life.max() / (launch_ms * 1e6)))
     xcd = wg[:, :, 2] & 15
     print("workgroup lifetimes (clocks): median %d, min %d, max %d over %d workgroups"
           % (np.median(life[ran_wg]), life[ran_wg].min(), life[ran_wg].max(), ran_wg.sum()))
@@ -66,7 +78,7 @@ if ran_wg.any():
                 print("  group %d XCD %d: %3d workgroups, lifetime median %d max %d (hw ids %d..%d)"
                       % (g, x, sel.sum(), np.median(life[g][sel]), life[g][sel].max(), wg[g][sel, 3].min(), wg[g][sel, 3].max()))
     slow = np.argsort(-(life * ran_wg).ravel())[:6]
-    print("  slowest: " + ", ".join("g%d tile %d xcd %d hw %d: %d" % (i // n_tiles, i % n_tiles, xcd.ravel()[i], wg.reshape(-1, 4)[i, 3],
+    print("  slowest: " + ", ".join("g%d tile %d xcd %d hw %d: %d" % (i // n_tiles, i % n_tiles, xcd.ravel()[i], wg.reshape(-1, 6)[i, 3],
                                                                      life.ravel()[i]) for i in slow))
 t_mid = min(5, h - 1)
 GROUPS = []
