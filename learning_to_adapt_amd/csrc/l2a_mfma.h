@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         grp = bid & 1; lpair = bid >> 1;                    // partners are dispatched back to back
         pairid = p.split_from + lpair;
     }
-#ifdef L2A_TIMELINE
+#if defined(L2A_TIMELINE) || defined(L2A_WGREC)
     unsigned long long wg_t0_, wg_r0_;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0_), "=s"(wg_r0_) : : "memory");
 #endif
@@ -1351,7 +1351,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             }
         }
     }
-#ifdef L2A_TIMELINE
+#if defined(L2A_TIMELINE) || defined(L2A_WGREC)
     if (p.dbg && wave == 0 && lane == 0) {      // per-workgroup record behind the phase stamps: lifetime and placement
         unsigned long long wg_t1_, wg_r1_;
         unsigned int xcc_;

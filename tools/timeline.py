@@ -57,6 +57,7 @@ d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
 # 10 bias / activation done, 1 written to LDS; 2 GEMM start, 3 GEMM + epilogue done, 4 output partials written;
 # 5 reduce start, 6 reduce done.
 print("case %s" % name)
+WGREC_ONLY = "wgrec" in os.path.basename(_TL)        # built with -DL2A_WGREC: the per-workgroup record without the phase stamps
 # per-workgroup record (NT = 1 shapes): start, end (own CU's clock), XCC_ID register, hardware workgroup id
 wg = dbg_all[2 * h * 8 * 8 * 16:].cpu().numpy().astype(np.int64).reshape(2, n_tiles, 6)
 ran_wg = wg[:, :, 1] != 0
@@ -80,6 +81,23 @@ if ran_wg.any():
     slow = np.argsort(-(life * ran_wg).ravel())[:6]
     print("  slowest: " + ", ".join("g%d tile %d xcd %d hw %d: %d" % (i // n_tiles, i % n_tiles, xcd.ravel()[i], wg.reshape(-1, 6)[i, 3],
                                                                      life.ravel()[i]) for i in slow))
+if ran_wg.any():
+    # s_memrealtime is one device-wide 100 MHz counter: starts and ends of all workgroups on one axis (10 ns resolution)
+    st = (wg[:, :, 4] - wg[:, :, 4][ran_wg].min()) / 100.0
+    en = (wg[:, :, 5] - wg[:, :, 4][ran_wg].min()) / 100.0
+    q = lambda a: "min %.1f / 10%% %.1f / median %.1f / 90%% %.1f / max %.1f" % tuple(np.percentile(a, [0, 10, 50, 90, 100]))  # noqa: E731
+    print("workgroup starts after the first one (us): " + q(st[ran_wg]))
+    print("workgroup ends after the first start (us):  " + q(en[ran_wg]))
+    print("workgroup durations (us):                   " + q((en - st)[ran_wg]))
+    for g in (0, 1):
+        for x in range(8):
+            sel = ran_wg[g] & (xcd[g] == x)
+            if sel.any():
+                print("  group %d XCD %d: start median %.1f max %.1f | end median %.1f max %.1f | duration median %.1f us"
+                      % (g, x, np.median(st[g][sel]), st[g][sel].max(), np.median(en[g][sel]), en[g][sel].max(),
+                         np.median((en - st)[g][sel])))
+if WGREC_ONLY:
+    raise SystemExit(0)
 t_mid = min(5, h - 1)
 GROUPS = []
 for grp in (0, 1):
