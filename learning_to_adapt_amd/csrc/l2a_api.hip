@@ -178,7 +178,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             const long long need = split_pairs * 2 * 2 * 2 * (long long)(nt * md->OT * 2 * 64 * 16) / 8;   // in 8-byte units
             if (need > md->xbuf_granules) {
                 if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
-                L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));
+                L2A_HIP(ctx, l2a_xbuf_alloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));
                 L2A_HIP(ctx, hipMemsetAsync(md->xbuf, 0, (size_t)need * 8, stream));   // ordered before the launch
                 md->xbuf_granules = need;
                 md->launch_nonce = 0;

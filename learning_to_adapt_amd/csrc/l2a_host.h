@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/l2a.h"
@@ -57,6 +58,18 @@ int l2a_fail(const l2a_ctx* ctx, int code, const std::string& msg);
     } while (0)
 
 inline int l2a_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Exchange granules of the tile splits.  Experiment switch L2A_XBUF_MODE: 0 / unset = hipMalloc (coarse-grained, the kernels'
+// sc1 stores and loads make the granules visible across XCDs), 1 = fine-grained, 3 = uncached device memory.
+inline hipError_t l2a_xbuf_alloc(void** ptr, size_t bytes) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = std::getenv("L2A_XBUF_MODE");
+        mode = (e && (e[0] == '1' || e[0] == '3')) ? e[0] - '0' : 0;
+    }
+    if (mode == 0) return hipMalloc(ptr, bytes);
+    return hipExtMallocWithFlags(ptr, bytes, mode == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+}
 
 // ---- blocking launches through the result mailbox (l2a_plan_rs_sync, l2a_lstm_plan_rs_sync; defined in l2a_api.hip) ----
 struct l2a_mail_ticket {

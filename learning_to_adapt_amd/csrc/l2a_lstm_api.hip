@@ -115,7 +115,7 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
             const long long need = tiles * 4 * (long long)(UT / 2 + md->OT) * 2048;
             if (need > md->xbuf_bytes) {
                 if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
-                L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need));
+                L2A_HIP(ctx, l2a_xbuf_alloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need));
                 L2A_HIP(ctx, hipMemsetAsync(md->xbuf, 0, (size_t)need, stream));
                 md->xbuf_bytes = need;
                 md->launch_nonce = 0;
