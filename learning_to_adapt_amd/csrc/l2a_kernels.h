@@ -25,6 +25,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Everything a rollout launch needs, passed by value (kernarg segment).
+// Cache policy of the exchange granules' stores / loads (aux operand of the raw buffer builtins on gfx950: 1 = sc0, 2 = nt,
+// 16 = sc1).  sc1 alone = write-through / miss-always at device scope; experiment values: 18 = sc1 + nt (streaming: the
+// granules should not displace the weights in L2), 17 = sc0 + sc1 (system scope).
+#ifndef L2A_XAUX_ST
+#define L2A_XAUX_ST 16
+#endif
+#ifndef L2A_XAUX_LD
+#define L2A_XAUX_LD 16
+#endif
+
 struct L2AKParams {
     // ---- model (constant between launches) -------------------------------------------
     const float* wblk;          // base of the weight-set blocks

@@ -339,14 +339,14 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             u32x4 g;
             g.x = xtag; g.y = __float_as_uint(v[2 * hh]);
             g.z = xtag; g.w = __float_as_uint(v[2 * hh + 1]);
-            __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, slot) + (r * 2 + hh) * 1024, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, slot) + (r * 2 + hh) * 1024, 0, L2A_XAUX_ST);
         }
     };
     auto xget = [&](int r, int slot, unsigned int tag, f32x4& v) {
         bool ok = true;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, 16);
+            const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, L2A_XAUX_LD);
             v[2 * hh] = __uint_as_float(g.y);
             v[2 * hh + 1] = __uint_as_float(g.w);
             ok = ok && (g.x == tag) && (g.z == tag);
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
         constexpr int NXG = SPLIT ? 2 * (UTWS + OT) : 1;
         u32x4 xg[NXG];
         auto xraw = [&](int r, int slot, int hh) {
-            return __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, 16);
+            return __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, L2A_XAUX_LD);
         };
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {

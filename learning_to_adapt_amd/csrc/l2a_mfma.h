@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         u32x4 g;
                         g.x = xtag; g.y = __float_as_uint(v[nt][c][2 * hh]);
                         g.z = xtag; g.w = __float_as_uint(v[nt][c][2 * hh + 1]);
-                        __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_XAUX_ST);
                     }
         };
         auto xget = [&](int region, f32x4 (&v)[NT][OT]) {
@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
                         const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(
-                            xrs, xbase(grp ^ 1, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, 16);
+                            xrs, xbase(grp ^ 1, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_XAUX_LD);
                         v[nt][c][2 * hh] = __uint_as_float(g.y);
                         v[nt][c][2 * hh + 1] = __uint_as_float(g.w);
                         ok = ok && (g.x == xtag) && (g.z == xtag);
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         auto xload = [&](int region, u32x4 (&g)[XG]) {
 #pragma unroll
             for (int k = 0; k < XG; ++k)
-                g[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, region) + k * 1024, 0, 16);
+                g[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, region) + k * 1024, 0, L2A_XAUX_LD);
         };
         auto xtake = [&](const u32x4 (&g)[XG], f32x4 (&v)[NT][OT]) {
             bool ok = true;

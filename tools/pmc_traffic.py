@@ -20,9 +20,10 @@ out = {
     "hbm_bytes_per_launch": total,
     "source": "profiles/%s_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py "
               "--steps 5 --no-e2e), mean per launch of l2a_rollout_mfma_k; FETCH_SIZE doubled per MI355X_MICROARCH.md "
-              "(gfx950 counts 128-B requests at 64 B); memory-side (Infinity-Cache-inclusive) bytes: ~%d MB of weight "
-              "re-fetches by the 8 XCD L2s (%.1f %% L2 hit rate) + %d MB of write-through exchange granules; algorithmic "
-              "bytes are 7.17 MB" % (tag, round(2 * fetch / 1000), 100 * hit, round(write / 1000)),
+              "(gfx950 counts 128-B requests at 64 B); memory-side (Infinity-Cache-inclusive) bytes: ~%d MB fetched by the 8 XCD "
+              "L2s (%.1f %% L2 hit rate) = the partner's exchange granules, read with sc1 (>= the %d MB written) + each "
+              "L2's first touch of its weight sets (8 x 2.9 MB) + re-fetches; + %d MB of write-through exchange granules; "
+              "algorithmic bytes are 7.17 MB" % (tag, round(2 * fetch / 1000), 100 * hit, round(write / 1000), round(write / 1000)),
     "fetch_kb_raw": fetch,
     "write_kb": write,
 }
