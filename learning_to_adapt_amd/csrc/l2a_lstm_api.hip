@@ -8,6 +8,7 @@
 #include "l2a_lstm_valu.h"
 #include "l2a_lstm_launch.h"
 #include "l2a_rnn_valu.h"
+#include "l2a_rnn_mfma.h"
 
 #include <cstring>
 #include <string>
@@ -80,24 +81,39 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
     l2a_device_guard guard(ctx->device);
     if (!md->weights_set) return l2a_fail(ctx, L2A_ESTATE, "LSTM weights were never set");
     if (!md->norm_set) return l2a_fail(ctx, L2A_ESTATE, "LSTM normalisation was never set");
+    p.dbg = ctx->dbg;
+    if (md->generic) {
+        // stacks / GRU / BasicRNN: the matrix-core kernel of l2a_rnn_mfma.h unless the caller asked for the VALU one (or
+        // its padded LDS rows do not fit: the VALU kernel's dense rows may still)
+        p.tiles_per_env = l2a_ceil_div(p.n, L2A_LVT);
+        const long long smem_m = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, md->obs_dim, md->n_layers, md->lunits);
+        const int smem_v = (md->in_dim + 3 * md->units + 2 * md->obs_dim + 1) * L2A_LVT * 4;
+        bool mfma = ctx->kernel_kind != L2A_KERNEL_VALU;
+        if (mfma && smem_m > ctx->lds_per_block) {
+            if (ctx->kernel_kind == L2A_KERNEL_MFMA)
+                return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the matrix-core recurrent kernel (" + std::to_string(smem_m) + " B)");
+            mfma = false;
+        }
+        if (!mfma && smem_v > ctx->lds_per_block)
+            return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the generic recurrent kernel (" + std::to_string(smem_v) +
+                                             " B): the layers' units may sum to about 800 at most");
+        if (mfma) {
+            L2A_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l2a_rnn_mfma_k),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
+            hipLaunchKernelGGL(l2a_rnn_mfma_k, dim3((unsigned)(p.m * p.tiles_per_env)), dim3(256), (size_t)smem_m, stream, p);
+        } else {
+            L2A_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l2a_rnn_valu_k),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem_v));
+            hipLaunchKernelGGL(l2a_rnn_valu_k, dim3((unsigned)(p.m * p.tiles_per_env)), dim3(256), smem_v, stream, p);
+        }
+        L2A_HIP(ctx, hipGetLastError());
+        return L2A_OK;
+    }
     int kind = ctx->kernel_kind;
     if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
     if (kind == L2A_KERNEL_MFMA && !md->mfma_ok)
         return l2a_fail(ctx, L2A_EINVAL, "LSTM shape is not eligible for the MFMA kernel "
                                          "(needs a single LSTM layer, units in {128, 256, 512}, obs_dim <= 64, act_dim <= 16)");
-    p.dbg = ctx->dbg;
-    if (md->generic) {
-        p.tiles_per_env = l2a_ceil_div(p.n, L2A_LVT);
-        const int smem = (md->in_dim + 3 * md->units + 2 * md->obs_dim + 1) * L2A_LVT * 4;
-        if (smem > ctx->lds_per_block)
-            return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the generic recurrent kernel (" + std::to_string(smem) +
-                                             " B): the layers' units may sum to about 800 at most");
-        L2A_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l2a_rnn_valu_k),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        hipLaunchKernelGGL(l2a_rnn_valu_k, dim3((unsigned)(p.m * p.tiles_per_env)), dim3(256), smem, stream, p);
-        L2A_HIP(ctx, hipGetLastError());
-        return L2A_OK;
-    }
     if (kind == L2A_KERNEL_MFMA) {
         const int nt = 1;
         const int UT = L2A_NW * md->UTW, U = md->units;

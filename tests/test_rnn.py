@@ -262,8 +262,7 @@ def test_gpu_rnn_returns_table_matches_oracle(name, kernel):
     case = dict(cases.CASES[name])
     if act:
         case["activation"] = act
-    if kernel == "mfma" and "hidden_sizes" in case:
-        pytest.skip("stacks / GRU / RNN cells run on the generic kernel")
+    # "mfma" on stacks / GRU / RNN cells = the generic matrix-core kernel (l2a_rnn_mfma.h), "valu" = l2a_rnn_valu_k
     env, model = cases.product_rnn_model(case)
     dyn = cases.oracle_rnn_dynamics(case)
     reward = make_reward(case["env"], env.dt)
