@@ -33,6 +33,7 @@ struct l2a_lstm {
     int n_layers = 1, cell_type = L2A_CELL_LSTM;
     int lunits[L2A_RNN_MAX_LAYERS] = {0};
     long long lw[L2A_RNN_MAX_LAYERS][2] = {{0}}, lb[L2A_RNN_MAX_LAYERS][2] = {{0}};
+    long long lpk[L2A_RNN_MAX_LAYERS][2] = {{0}};  // the kernels again in MFMA fragment order (l2a_rnn_mfma.h); pk_wout alike
     float* adv_buf = nullptr;                     // l2a_lstm_plan_rs_sync: [64, act_dim] chosen actions + [64, obs_dim] next obs
 };
 
@@ -70,7 +71,7 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
     p.n_layers = md->n_layers; p.cell_type = md->cell_type;
     for (int l = 0; l < L2A_RNN_MAX_LAYERS; ++l) {
         p.layer_units[l] = md->lunits[l];
-        for (int q = 0; q < 2; ++q) { p.layer_w[l][q] = md->lw[l][q]; p.layer_b[l][q] = md->lb[l][q]; }
+        for (int q = 0; q < 2; ++q) { p.layer_w[l][q] = md->lw[l][q]; p.layer_b[l][q] = md->lb[l][q]; p.layer_pk[l][q] = md->lpk[l][q]; }
     }
     p.disc0 = 1.0;
 }
@@ -250,14 +251,17 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
         const int cols0 = (cell_type == L2A_CELL_LSTM) ? 4 * U : (cell_type == L2A_CELL_GRU ? 2 * U : U);
         md->lw[l][0] = take((long long)(kin + U) * cols0);
         md->lb[l][0] = take(cols0);
+        md->lpk[l][0] = take(l2a_rnn_pack_floats(kin, U, cols0 / U, true));
         if (cell_type == L2A_CELL_GRU) {
             md->lw[l][1] = take((long long)(kin + U) * U);
             md->lb[l][1] = take(U);
+            md->lpk[l][1] = take(l2a_rnn_pack_floats(kin, U, 1, true));
         }
         kin = U;
     }
     md->raw_wo = take((long long)kin * obs_dim);
     md->raw_bo = take(obs_dim);
+    md->pk_wout = take(l2a_rnn_pack_floats(kin, obs_dim, 1, false));
     md->pk_bout = take(16 * md->OT);
     md->nm_off = take(32 * md->KG0 + 32 * md->OT);
     md->total = off;
@@ -305,18 +309,32 @@ int l2a_lstm_set_weights(l2a_lstm* md, const void* const* device_ptrs, void* str
         for (int l = 0; l < md->n_layers; ++l) {
             const int Ul = md->lunits[l];
             const int cols0 = (md->cell_type == L2A_CELL_LSTM) ? 4 * Ul : (md->cell_type == L2A_CELL_GRU ? 2 * Ul : Ul);
+            // (the fragment-order copies are made from the block's own raw copies, in stream order behind them)
+            auto pack = [&](long long raw, long long dst, int rows_in, int Uc, int G, int recurrent) {
+                const long long total = l2a_rnn_pack_floats(rows_in, Uc, G, recurrent != 0);
+                hipLaunchKernelGGL(l2a_rnn_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                                   md->wblk + raw, rows_in, Uc, G, recurrent, total, md->wblk + dst);
+            };
             int rc = copy(md->lw[l][0], (size_t)(kin + Ul) * cols0);
+            if (rc == L2A_OK) pack(md->lw[l][0], md->lpk[l][0], kin, Ul, cols0 / Ul, 1);
             if (rc == L2A_OK) rc = copy(md->lb[l][0], (size_t)cols0);
             if (rc == L2A_OK && md->cell_type == L2A_CELL_GRU) {
                 rc = copy(md->lw[l][1], (size_t)(kin + Ul) * Ul);
+                if (rc == L2A_OK) pack(md->lw[l][1], md->lpk[l][1], kin, Ul, 1, 1);
                 if (rc == L2A_OK) rc = copy(md->lb[l][1], (size_t)Ul);
             }
             if (rc != L2A_OK) return rc;
             kin = Ul;
         }
         int rc = copy(md->raw_wo, (size_t)kin * md->obs_dim);
+        if (rc == L2A_OK) {
+            const long long total = l2a_rnn_pack_floats(kin, md->obs_dim, 1, false);
+            hipLaunchKernelGGL(l2a_rnn_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                               md->wblk + md->raw_wo, kin, md->obs_dim, 1, 0, total, md->wblk + md->pk_wout);
+        }
         if (rc == L2A_OK) rc = copy(md->raw_bo, (size_t)md->obs_dim);
         if (rc != L2A_OK) return rc;
+        L2A_HIP(ctx, hipGetLastError());
         md->weights_set = true;
         return L2A_OK;
     }

@@ -10,9 +10,10 @@
 //   B operand  = the layer's input / old h as they lie in LDS, row-major [16 candidates][K]: MFMA ii of k-group g multiplies
 //                k = 16 g + 4 (lane >> 4) + ii, i.e. a lane's four MFMAs of a k-group read ONE ds_read_b128 (rows padded
 //                to a multiple of 16 with zeros + 4 floats of skew against bank conflicts);
-//   A operand  = the reference's TF-layout kernel [K, G U] read in place (dword buffer loads, 16 consecutive columns per
-//                quarter wave; rows past the matrix return 0, rows of an input's zero padding meet a zero B) - no packed
-//                copy: these models are small and not the run scripts' default;
+//   A operand  = a copy of the reference's TF-layout kernel [K, G U] in fragment order (l2a_rnn_pack_k at set_weights:
+//                [unit tile][gate][k-group][lane][4], zero where a row or unit is padding) - one 16-byte buffer load per
+//                gate and k-group; reading the TF layout in place (four dword loads of 64-byte half lines each) ran at
+//                half the speed: every workgroup streams all weights once per step, and the L1 moves whole 128-byte lines;
 //   D          = lane (candidate lane & 15, units 16 T + 4 (lane >> 4) + ii): bias, gates, new h / c written back to the
 //                same row-major LDS rows (padding units masked to zero, so they never feed a later product).
 //
@@ -21,8 +22,14 @@
 // l2a_rnn_valu_k to rounding (tests/test_rnn.py compares them), not bit for bit.
 #pragma once
 
+#include <type_traits>
+
 #include "l2a_lstm.h"
 #include "l2a_lstm_valu.h"
+
+// cell nonlinearity: tanh (the reference default, rnn_dynamics.py:20) as one v_exp_f32 + one v_rcp_f32 like the gates
+// (l2a_lstm.h: the libm forms made the gate arithmetic a quarter of a step); wave-uniform switch
+__device__ __forceinline__ float l2a_rnn_act(float x, int kind) { return kind == L2A_ACT_TANH ? l2a_fast_tanh(x) : l2a_act1(x, kind); }
 
 #define L2A_RNN_SKEW 4      // floats added to every LDS row (rows of 16 k floats would all start in bank 0)
 
@@ -35,28 +42,75 @@ __host__ __device__ inline long long l2a_rnn_mfma_lds_floats(int in_dim, int obs
     return f + 2LL * L2A_LVT * obs_dim + L2A_LVT;
 }
 
-// acc[q] += W[row0 + k][q * gate_stride + col] * B[k]   for k in [0, 16 kgroups)   (one 16 x 16 output tile per gate)
-// W: raw-buffer resource over the whole [rows, ncols] matrix; `colb` = byte offset of this lane's column of gate 0;
-// `bl` = this lane's B row + 4 (lane >> 4).
+// Fragment order of a [kin + U, G U] kernel (TF layout: input rows, then recurrent rows; gate q in columns [q U, (q + 1) U)):
+// float index (((T * G + q) * KG + g) * 64 + lane) * 4 + ii, KG = KGx + UT k-groups (KGx = ceil(kin / 16) input groups, then
+// UT = ceil(U / 16) recurrent groups), = W[row][q U + 16 T + (lane & 15)] with row = 16 g + 4 (lane >> 4) + ii in its part,
+// 0 where the row or the unit is padding.  The output layer is the same with U -> obs_dim, G = 1 and no recurrent part.
+__host__ __device__ inline long long l2a_rnn_pack_floats(int kin, int U, int G, bool recurrent) {
+    const int UT = (U + 15) / 16;
+    return (long long)UT * G * ((kin + 15) / 16 + (recurrent ? UT : 0)) * 256;
+}
+
+__global__ void l2a_rnn_pack_k(const float* w, int kin, int U, int G, int recurrent, long long total, float* dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int UT = (U + 15) / 16, KGx = (kin + 15) / 16, KG = KGx + (recurrent ? UT : 0);
+    const int ii = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const long long rest = idx >> 8;
+    const int g = (int)(rest % KG);
+    const int tq = (int)(rest / KG);
+    const int T = tq / G, q = tq - T * G;
+    const int unit = 16 * T + (lane & 15);
+    int row;
+    if (g < KGx) { row = 16 * g + 4 * (lane >> 4) + ii; if (row >= kin) row = -1; }
+    else { row = 16 * (g - KGx) + 4 * (lane >> 4) + ii; row = (row < U) ? kin + row : -1; }
+    dst[idx] = (row >= 0 && unit < U) ? w[(long long)row * G * U + q * U + unit] : 0.0f;
+}
+
+// acc[q] += sum over the KGx input k-groups (B = bx) and the KGh recurrent ones (B = bh) for unit tile T: one 16 x 16 output
+// tile per gate.  P: raw-buffer resource over the packed kernel; bx / bh = this lane's B row + 4 (lane >> 4).  The A operands
+// of NB - 1 k-groups are in flight ahead of the MFMAs (register ring, all indices static: the compiler tracks the loads).
+#define L2A_RNN_NB 4
 template <int G>
-__device__ __forceinline__ void l2a_rnn_gemm(__amdgpu_buffer_rsrc_t W, int ncols, int gate_stride, int colb, int row0, int kgroups,
-                                             const float* bl, int qq, f32x4 (&acc)[G]) {
-    const int rowb = (row0 + 4 * qq) * ncols * 4 + colb;
-#pragma unroll 2
-    for (int g = 0; g < kgroups; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 16 * g);
-        float a[G][4];
+__device__ __forceinline__ void l2a_rnn_gemm(__amdgpu_buffer_rsrc_t P, int T, int KGx, const float* bx, int KGh, const float* bh,
+                                             int lane, f32x4 (&acc)[G]) {
+    constexpr int NB = L2A_RNN_NB;
+    static_assert(NB == 4, "the stage lists below are written out for a ring of four");
+    const int total = KGx + KGh;
+    const int last = total - 1;
+    const int tile0 = T * G * total * 1024;             // bytes; gate q of this unit tile starts q * total * 1024 further on
+    f32x4 a[NB][G];
+    // (a request past the last k-group re-reads the last one: nobody consumes it, and the loop body stays free of branches -
+    // a conditional load splits the block and the compiler then waits for vmcnt(0) in front of every MFMA group)
+    auto issue = [&](int g, auto slot_tag) {
+        constexpr int slot = decltype(slot_tag)::value;
+        const int gc = g < last ? g : last;
 #pragma unroll
-        for (int q = 0; q < G; ++q)
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-                a[q][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    W, rowb + (16 * g + ii) * ncols * 4 + q * gate_stride * 4, 0, 0));
+        for (int q = 0; q < G; ++q) a[slot][q] = l2a_ldw(P, lane * 16, tile0 + (q * total + gc) * 1024);
+    };
+    auto mfma = [&](int g, auto slot_tag) {
+        constexpr int slot = decltype(slot_tag)::value;
+        const float* bp = (g < KGx) ? bx + 16 * g : bh + 16 * (g - KGx);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-            for (int q = 0; q < G; ++q) acc[q] = L2A_MFMA(a[q][ii], b[ii], acc[q]);
+            for (int q = 0; q < G; ++q) acc[q] = L2A_MFMA(a[slot][q][ii], b[ii], acc[q]);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+    issue(0, S0()); issue(1, S1()); issue(2, S2());
+    const int n4 = total & ~3;
+    for (int g0 = 0; g0 < n4; g0 += NB) {
+        issue(g0 + 3, S3()); mfma(g0, S0());
+        issue(g0 + 4, S0()); mfma(g0 + 1, S1());
+        issue(g0 + 5, S1()); mfma(g0 + 2, S2());
+        issue(g0 + 6, S2()); mfma(g0 + 3, S3());
     }
+    const int r = total - n4;                           // 0 .. 3 k-groups left, already requested
+    if (r > 0) mfma(n4, S0());
+    if (r > 1) mfma(n4 + 1, S1());
+    if (r > 2) mfma(n4 + 2, S2());
 }
 
 __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
@@ -126,14 +180,12 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
             float* hn = lp + nxt * L2A_LVT * SP;
             float* cl = lp + 2 * L2A_LVT * SP;
             const int G0 = lstm ? 4 : (gru ? 2 : 1);
-            const float* w0 = p.wblk + p.layer_w[l][0];
             const float* b0 = p.wblk + p.layer_b[l][0];
-            const __amdgpu_buffer_rsrc_t W0 = l2a_rsrc(w0, (long long)(kin + U) * G0 * U * 4);
+            const __amdgpu_buffer_rsrc_t W0 = l2a_rsrc(p.wblk + p.layer_pk[l][0], l2a_rnn_pack_floats(kin, U, G0, true) * 4);
             const float* bx = xin + jc * xstride + 4 * qq;
             const float* bh = hc + jc * SP + 4 * qq;
             for (int T = wave; T < UT; T += 4) {
                 const int u0 = 16 * T + 4 * qq;                 // this lane's four units of the D tile
-                const int colb = (16 * T + jc) * 4;              // this lane's column of the A tile (gate 0)
                 const int at = jc * SP + u0;                     // ... and their place in a [16][SP] LDS array
                 f32x4 bias[4];
 #pragma unroll
@@ -145,61 +197,56 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
                     f32x4 acc[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<4>(W0, 4 * U, U, colb, 0, KGx, bx, qq, acc);
-                    l2a_rnn_gemm<4>(W0, 4 * U, U, colb, kin, UT, bh, qq, acc);
+                    l2a_rnn_gemm<4>(W0, T, KGx, bx, UT, bh, lane, acc);
                     f32x4 cv = *reinterpret_cast<const f32x4*>(cl + at);
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
-                        const float ig = l2a_sigmoid(acc[0][ii] + bias[0][ii]);
-                        const float jg = l2a_act1(acc[1][ii] + bias[1][ii], p.cell_act);
-                        const float fg = l2a_sigmoid(acc[2][ii] + bias[2][ii] + 1.0f);
-                        const float og = l2a_sigmoid(acc[3][ii] + bias[3][ii]);
+                        const float ig = l2a_fast_sigmoid(acc[0][ii] + bias[0][ii]);
+                        const float jg = l2a_rnn_act(acc[1][ii] + bias[1][ii], p.cell_act);
+                        const float fg = l2a_fast_sigmoid(acc[2][ii] + bias[2][ii] + 1.0f);
+                        const float og = l2a_fast_sigmoid(acc[3][ii] + bias[3][ii]);
                         const float cn = (u0 + ii < U) ? fg * cv[ii] + ig * jg : 0.0f;
                         cv[ii] = cn;
-                        hnew[ii] = (u0 + ii < U) ? og * l2a_act1(cn, p.cell_act) : 0.0f;
+                        hnew[ii] = (u0 + ii < U) ? og * l2a_rnn_act(cn, p.cell_act) : 0.0f;
                     }
                     *reinterpret_cast<f32x4*>(cl + at) = cv;
                 } else if (gru) {
                     f32x4 acc[2];
                     acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<2>(W0, 2 * U, U, colb, 0, KGx, bx, qq, acc);
-                    l2a_rnn_gemm<2>(W0, 2 * U, U, colb, kin, UT, bh, qq, acc);
+                    l2a_rnn_gemm<2>(W0, T, KGx, bx, UT, bh, lane, acc);
                     const f32x4 hv = *reinterpret_cast<const f32x4*>(hc + at);
                     f32x4 rh;
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         const bool live = u0 + ii < U;
-                        rh[ii] = live ? l2a_sigmoid(acc[0][ii] + bias[0][ii]) * hv[ii] : 0.0f;       // r * h
-                        hnew[ii] = live ? l2a_sigmoid(acc[1][ii] + bias[1][ii]) : 0.0f;              // u, parked in the new-h slot
+                        rh[ii] = live ? l2a_fast_sigmoid(acc[0][ii] + bias[0][ii]) * hv[ii] : 0.0f;       // r * h
+                        hnew[ii] = live ? l2a_fast_sigmoid(acc[1][ii] + bias[1][ii]) : 0.0f;              // u, parked in the new-h slot
                     }
                     *reinterpret_cast<f32x4*>(cl + at) = rh;
                 } else {
                     f32x4 acc[1];
                     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<1>(W0, U, U, colb, 0, KGx, bx, qq, acc);
-                    l2a_rnn_gemm<1>(W0, U, U, colb, kin, UT, bh, qq, acc);
+                    l2a_rnn_gemm<1>(W0, T, KGx, bx, UT, bh, lane, acc);
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) hnew[ii] = (u0 + ii < U) ? l2a_act1(acc[0][ii] + bias[0][ii], p.cell_act) : 0.0f;
+                    for (int ii = 0; ii < 4; ++ii) hnew[ii] = (u0 + ii < U) ? l2a_rnn_act(acc[0][ii] + bias[0][ii], p.cell_act) : 0.0f;
                 }
                 *reinterpret_cast<f32x4*>(hn + at) = hnew;
             }
             if (gru) {
                 __syncthreads();            // every unit's r * h before the candidate product
-                const float* w1 = p.wblk + p.layer_w[l][1];
                 const float* b1 = p.wblk + p.layer_b[l][1];
-                const __amdgpu_buffer_rsrc_t W1 = l2a_rsrc(w1, (long long)(kin + U) * U * 4);
+                const __amdgpu_buffer_rsrc_t W1 = l2a_rsrc(p.wblk + p.layer_pk[l][1], l2a_rnn_pack_floats(kin, U, 1, true) * 4);
                 const float* br = cl + jc * SP + 4 * qq;
                 for (int T = wave; T < UT; T += 4) {
-                    const int u0 = 16 * T + 4 * qq, colb = (16 * T + jc) * 4, at = jc * SP + u0;
+                    const int u0 = 16 * T + 4 * qq, at = jc * SP + u0;
                     f32x4 acc[1];
                     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<1>(W1, U, U, colb, 0, KGx, bx, qq, acc);
-                    l2a_rnn_gemm<1>(W1, U, U, colb, kin, UT, br, qq, acc);
+                    l2a_rnn_gemm<1>(W1, T, KGx, bx, UT, br, lane, acc);
                     const f32x4 hv = *reinterpret_cast<const f32x4*>(hc + at);
                     f32x4 ug = *reinterpret_cast<const f32x4*>(hn + at);
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
-                        const float cnd = l2a_act1(acc[0][ii] + ((u0 + ii < U) ? b1[u0 + ii] : 0.0f), p.cell_act);
+                        const float cnd = l2a_rnn_act(acc[0][ii] + ((u0 + ii < U) ? b1[u0 + ii] : 0.0f), p.cell_act);
                         ug[ii] = (u0 + ii < U) ? ug[ii] * hv[ii] + (1.0f - ug[ii]) * cnd : 0.0f;
                     }
                     *reinterpret_cast<f32x4*>(hn + at) = ug;
@@ -213,13 +260,12 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
         }
         {   // output layer: wave c owns obs tile c; K = the top layer's new h
             const int OTn = (obs_dim + 15) >> 4, UTt = (kin + 15) >> 4;
-            const __amdgpu_buffer_rsrc_t WO = l2a_rsrc(p.wblk + p.raw_wo, (long long)kin * obs_dim * 4);
+            const __amdgpu_buffer_rsrc_t WO = l2a_rsrc(p.wblk + p.pk_wout, l2a_rnn_pack_floats(kin, obs_dim, 1, false) * 4);
             const float* bt = xin + jc * xstride + 4 * qq;
             for (int c = wave; c < OTn; c += 4) {
                 f32x4 acc[1];
                 acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // columns past obs_dim read the next row's weights: their D rows are never stored
-                l2a_rnn_gemm<1>(WO, obs_dim, 0, (16 * c + jc) * 4, 0, UTt, bt, qq, acc);
+                l2a_rnn_gemm<1>(WO, c, UTt, bt, 0, bt, lane, acc);
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const int d = 16 * c + 4 * qq + ii;
