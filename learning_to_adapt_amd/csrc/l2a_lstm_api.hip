@@ -87,7 +87,8 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
         // stacks / GRU / BasicRNN: the matrix-core kernel of l2a_rnn_mfma.h unless the caller asked for the VALU one (or
         // its padded LDS rows do not fit: the VALU kernel's dense rows may still)
         p.tiles_per_env = l2a_ceil_div(p.n, L2A_LVT);
-        const long long smem_m = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, md->obs_dim, md->n_layers, md->lunits);
+        const int gates = md->cell_type == L2A_CELL_LSTM ? 4 : (md->cell_type == L2A_CELL_GRU ? 3 : 1);
+        const long long smem_m = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, md->obs_dim, md->n_layers, md->lunits, gates);
         const int smem_v = (md->in_dim + 3 * md->units + 2 * md->obs_dim + 1) * L2A_LVT * 4;
         bool mfma = ctx->kernel_kind != L2A_KERNEL_VALU;
         if (mfma && smem_m > ctx->lds_per_block) {

@@ -36,10 +36,14 @@ __device__ __forceinline__ float l2a_rnn_act(float x, int kind) { return kind ==
 __host__ __device__ inline int l2a_rnn_row(int k) { return 16 * ((k + 15) / 16) + L2A_RNN_SKEW; }
 
 // LDS floats of the kernel for a model (host: launch; device: carve)
-__host__ __device__ inline long long l2a_rnn_mfma_lds_floats(int in_dim, int obs_dim, int n_layers, const int* units) {
+// (gates = 4 LSTM, 3 GRU - two gates + candidate -, 1 BasicRNN: bias floats per unit)
+__host__ __device__ inline long long l2a_rnn_mfma_lds_floats(int in_dim, int obs_dim, int n_layers, const int* units, int gates) {
     long long f = (long long)L2A_LVT * l2a_rnn_row(in_dim);
-    for (int l = 0; l < n_layers; ++l) f += 3LL * L2A_LVT * l2a_rnn_row(units[l]);
-    return f + 2LL * L2A_LVT * obs_dim + L2A_LVT;
+    long long nb = 0;
+    for (int l = 0; l < n_layers; ++l) { f += 3LL * L2A_LVT * l2a_rnn_row(units[l]); nb += (long long)gates * units[l]; }
+    f += 2LL * L2A_LVT * obs_dim + L2A_LVT;                 // state, delta, returns
+    f += (long long)L2A_LVT * (in_dim - obs_dim);           // this step's raw actions (reward)
+    return f + 2LL * in_dim + 3LL * obs_dim + nb;           // constants: input / output normalisation, output bias, cell biases
 }
 
 // Fragment order of a [kin + U, G U] kernel (TF layout: input rows, then recurrent rows; gate q in columns [q U, (q + 1) U)):
@@ -79,23 +83,34 @@ __device__ __forceinline__ void l2a_rnn_gemm(__amdgpu_buffer_rsrc_t P, int T, in
     const int total = KGx + KGh;
     const int last = total - 1;
     const int tile0 = T * G * total * 1024;             // bytes; gate q of this unit tile starts q * total * 1024 further on
-    f32x4 a[NB][G];
+    f32x4 a[NB][G], bq[NB];
     // (a request past the last k-group re-reads the last one: nobody consumes it, and the loop body stays free of branches -
-    // a conditional load splits the block and the compiler then waits for vmcnt(0) in front of every MFMA group)
+    // a conditional load splits the block and the compiler then waits for vmcnt(0) in front of every MFMA group).  The B
+    // fragment travels with its A operands: an LDS read issued right in front of its MFMAs costs its ~130 clocks each time
     auto issue = [&](int g, auto slot_tag) {
         constexpr int slot = decltype(slot_tag)::value;
         const int gc = g < last ? g : last;
 #pragma unroll
         for (int q = 0; q < G; ++q) a[slot][q] = l2a_ldw(P, lane * 16, tile0 + (q * total + gc) * 1024);
+        const float* bp = (gc < KGx) ? bx + 16 * gc : bh + 16 * (gc - KGx);
+        bq[slot] = *reinterpret_cast<const f32x4*>(bp);
     };
+    // fewer than four gates: a second accumulator per gate takes every other MFMA, so that four independent chains are in
+    // the matrix pipe either way (a dependent MFMA waits for its predecessor's eight passes)
+    constexpr bool TWO = G <= 2;
+    f32x4 acc2[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) acc2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto mfma = [&](int g, auto slot_tag) {
         constexpr int slot = decltype(slot_tag)::value;
-        const float* bp = (g < KGx) ? bx + 16 * g : bh + 16 * (g - KGx);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bp);
+        (void)g;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-            for (int q = 0; q < G; ++q) acc[q] = L2A_MFMA(a[slot][q][ii], b[ii], acc[q]);
+            for (int q = 0; q < G; ++q) {
+                if (TWO && (ii & 1)) acc2[q] = L2A_MFMA(a[slot][q][ii], bq[slot][ii], acc2[q]);
+                else acc[q] = L2A_MFMA(a[slot][q][ii], bq[slot][ii], acc[q]);
+            }
     };
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
@@ -111,6 +126,10 @@ __device__ __forceinline__ void l2a_rnn_gemm(__amdgpu_buffer_rsrc_t P, int T, in
     if (r > 0) mfma(n4, S0());
     if (r > 1) mfma(n4 + 1, S1());
     if (r > 2) mfma(n4 + 2, S2());
+    if (TWO) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) acc[q] += acc2[q];
+    }
 }
 
 __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
@@ -124,6 +143,13 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
     float* ss = lbase + lfl;                            // [16][obs_dim] state
     float* ds = ss + L2A_LVT * obs_dim;                 // [16][obs_dim] delta
     float* rs_ = ds + L2A_LVT * obs_dim;                // [16] returns
+    float* araw = rs_ + L2A_LVT;                        // [16][act_dim] this step's raw actions
+    float* c_in_mu = araw + L2A_LVT * act_dim;          // constants, read once from the model block
+    float* c_in_iv = c_in_mu + in_dim;
+    float* c_out_mu = c_in_iv + in_dim;
+    float* c_out_sd = c_out_mu + obs_dim;
+    float* c_bo = c_out_sd + obs_dim;
+    float* c_bias = c_bo + obs_dim;                     // per layer: the kernels' biases as they lie in the block
     const int tid = threadIdx.x;
     const int j = tid & 15, s = tid >> 4;               // element-wise role: candidate j, slice s (as l2a_rnn_valu_k)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,12 +160,22 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
     const bool valid = cand < p.n;
     const int row = env * p.n + (valid ? cand : p.n - 1);
     const int R = p.m * p.n;
-    const float* in_mu = p.wblk + p.nm_off;
-    const float* in_iv = in_mu + 16 * p.KG0;
-    const float* out_mu = in_iv + 16 * p.KG0;
-    const float* out_sd = out_mu + 16 * p.OT;
-    const float* bo = p.wblk + p.raw_bo;
     const bool lstm = (p.cell_type == L2A_CELL_LSTM), gru = (p.cell_type == L2A_CELL_GRU);
+    {
+        const float* in_mu = p.wblk + p.nm_off;
+        const float* in_iv = in_mu + 16 * p.KG0;
+        const float* out_mu = in_iv + 16 * p.KG0;
+        const float* out_sd = out_mu + 16 * p.OT;
+        for (int k = tid; k < in_dim; k += 256) { c_in_mu[k] = in_mu[k]; c_in_iv[k] = in_iv[k]; }
+        for (int d = tid; d < obs_dim; d += 256) { c_out_mu[d] = out_mu[d]; c_out_sd[d] = out_sd[d]; c_bo[d] = p.wblk[p.raw_bo + d]; }
+        float* cb = c_bias;
+        for (int l = 0; l < L; ++l) {
+            const int U = p.layer_units[l], n0 = (lstm ? 4 : (gru ? 2 : 1)) * U;
+            for (int i = tid; i < n0; i += 256) cb[i] = p.wblk[p.layer_b[l][0] + i];
+            if (gru) for (int i = tid; i < U; i += 256) cb[n0 + i] = p.wblk[p.layer_b[l][1] + i];
+            cb += n0 + (gru ? U : 0);
+        }
+    }
 
     for (long long i = tid; i < L2A_LVT * SX + lfl; i += 256) xs[i] = 0.0f;     // padding stays zero for the whole launch
     __syncthreads();
@@ -162,25 +198,52 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
     if (s == 0) rs_[j] = p.ret_in ? p.ret_in[row] : 0.0f;
     __syncthreads();
 
+    // this thread's action elements (k = s, s + 16) of the NEXT step: requested a step ahead, so that the read from HBM
+    // travels under the products instead of in front of them (wider action vectors fall back to reading in place)
+    const bool apf = act_dim <= 32;
+    float apre[2];
+    auto fetch_actions = [&](int tt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = s + 16 * i;
+            apre[i] = (apf && k < act_dim && tt < p.h) ? p.actions[((long long)tt * R + row) * act_dim + k] : 0.0f;
+        }
+    };
+    fetch_actions(0);
     double disc_pow = p.disc0;
     for (int t = 0; t < p.h; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         const float* arow = p.actions + ((long long)t * R + row) * act_dim;
-        for (int k = s; k < in_dim; k += 16) {
-            const float v = (k < obs_dim) ? ss[j * obs_dim + k] : arow[k - obs_dim];
-            xs[j * SX + k] = (v - in_mu[k]) * in_iv[k];
+        for (int k = s; k < obs_dim; k += 16) xs[j * SX + k] = (ss[j * obs_dim + k] - c_in_mu[k]) * c_in_iv[k];
+        if (apf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = s + 16 * i;
+                if (k < act_dim) {
+                    araw[j * act_dim + k] = apre[i];
+                    xs[j * SX + obs_dim + k] = (apre[i] - c_in_mu[obs_dim + k]) * c_in_iv[obs_dim + k];
+                }
+            }
+            fetch_actions(t + 1);
+        } else {
+            for (int k = s; k < act_dim; k += 16) {
+                const float v = arow[k];
+                araw[j * act_dim + k] = v;
+                xs[j * SX + obs_dim + k] = (v - c_in_mu[obs_dim + k]) * c_in_iv[obs_dim + k];
+            }
         }
         __syncthreads();
         const float* xin = xs;          // the current layer's input rows [16][xstride] (zero padded to 16 k-groups)
         int xstride = SX, kin = in_dim;
         float* lp = lbase;
+        const float* cb = c_bias;
         for (int l = 0; l < L; ++l) {
             const int U = p.layer_units[l], SP = l2a_rnn_row(U), UT = (U + 15) >> 4, KGx = (kin + 15) >> 4;
             const float* hc = lp + cur * L2A_LVT * SP;
             float* hn = lp + nxt * L2A_LVT * SP;
             float* cl = lp + 2 * L2A_LVT * SP;
             const int G0 = lstm ? 4 : (gru ? 2 : 1);
-            const float* b0 = p.wblk + p.layer_b[l][0];
+            const float* b0 = cb;
             const __amdgpu_buffer_rsrc_t W0 = l2a_rsrc(p.wblk + p.layer_pk[l][0], l2a_rnn_pack_floats(kin, U, G0, true) * 4);
             const float* bx = xin + jc * xstride + 4 * qq;
             const float* bh = hc + jc * SP + 4 * qq;
@@ -234,7 +297,7 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
             }
             if (gru) {
                 __syncthreads();            // every unit's r * h before the candidate product
-                const float* b1 = p.wblk + p.layer_b[l][1];
+                const float* b1 = cb + 2 * U;
                 const __amdgpu_buffer_rsrc_t W1 = l2a_rsrc(p.wblk + p.layer_pk[l][1], l2a_rnn_pack_floats(kin, U, 1, true) * 4);
                 const float* br = cl + jc * SP + 4 * qq;
                 for (int T = wave; T < UT; T += 4) {
@@ -257,6 +320,7 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
             xstride = SP;
             kin = U;
             lp += 3 * L2A_LVT * SP;
+            cb += G0 * U + (gru ? U : 0);
         }
         {   // output layer: wave c owns obs tile c; K = the top layer's new h
             const int OTn = (obs_dim + 15) >> 4, UTt = (kin + 15) >> 4;
@@ -270,8 +334,8 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
                 for (int ii = 0; ii < 4; ++ii) {
                     const int d = 16 * c + 4 * qq + ii;
                     if (d < obs_dim) {
-                        const float o = l2a_act1(acc[0][ii] + bo[d], p.output_act);
-                        ds[jc * obs_dim + d] = o * out_sd[d] + out_mu[d];
+                        const float o = l2a_act1(acc[0][ii] + c_bo[d], p.output_act);
+                        ds[jc * obs_dim + d] = o * c_out_sd[d] + c_out_mu[d];
                     }
                 }
             }
@@ -279,7 +343,7 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
         __syncthreads();
         if (s == 0) {
             float asq = 0.0f;
-            for (int k = 0; k < act_dim; ++k) asq = fmaf(arow[k], arow[k], asq);
+            for (int k = 0; k < act_dim; ++k) asq = fmaf(araw[j * act_dim + k], araw[j * act_dim + k], asq);
             float r = p.rw.alive - p.rw.ctrl_coef * asq;
             if (p.rw.w_vel != 0.0f) r += p.rw.w_vel * ds[j * obs_dim + p.rw.vel_index] * p.rw.inv_dt;
             if (p.rw.dist_coef != 0.0f) {
