@@ -322,8 +322,9 @@ void l2a_lstm_destroy(l2a_lstm* model);
 
 /* The other recurrent models `create_rnn` (dynamics/core/utils.py:192-236) can build: `cell_type` 'lstm' / 'gru' /
  * 'rnn' and several stacked layers (`len(hidden_sizes) > 1` -> tf.nn.rnn_cell.MultiRNNCell).  One LSTM layer is
- * the model of l2a_lstm_create (MFMA kernel); everything else runs on the generic VALU kernel (the layers' units
- * may sum to about 800).  Cell arithmetic: tensorflow==1.13.1 LSTMCell / GRUCell; 'rnn' = BasicRNNCell
+ * the model of l2a_lstm_create (its own MFMA kernel); everything else runs on the generic matrix-core kernel of
+ * l2a_rnn_mfma.h (l2a_set_kernel VALU: the fp32 VALU kernel of l2a_rnn_valu.h; the layers' units may sum to about 800 -
+ * one candidate tile's states live in a CU's LDS).  Cell arithmetic: tensorflow==1.13.1 LSTMCell / GRUCell; 'rnn' = BasicRNNCell
  * (h = act([x | h] K + b)) - the reference passes the abstract `tf.nn.rnn_cell.RNNCell` there (:209), which cannot
  * be instantiated, so this is the evident intent, not a measured behaviour.
  * Parameters (l2a_lstm_set_weights), in `get_params()` order, kernels row-major [in_l + U_l, .] with the layer's

@@ -135,3 +135,51 @@ def test_random_lstm_shapes_match_oracle(seed):
                    returns_out=rets, best_key=best)
     _check(rets.cpu().numpy(), want, best.cpu().numpy(), n, 7)
     native.close()
+
+
+@pytest.mark.parametrize("seed", range(max(10, _EXTRA)))
+def test_random_recurrent_stacks_matrix_core_matches_valu(seed):
+    """GRU / BasicRNN / LSTM stacks of odd widths (units that are no multiple of 16 or of 4, inputs that straddle k-groups,
+    action vectors wider than the prefetch registers): the matrix-core kernel (l2a_rnn_mfma.h) against the VALU kernel
+    (l2a_rnn_valu.h) - every return, the arg-max keys' consistency, and the states `predict` writes."""
+    rs = np.random.RandomState(900 + seed)
+    cell = str(rs.choice(["gru", "lstm", "rnn"]))
+    n_layers = int(rs.choice([1, 2, 3])) if cell != "lstm" else int(rs.choice([2, 3]))
+    sizes = [int(rs.choice([5, 16, 23, 40, 57, 64, 96, 130])) for _ in range(n_layers)]
+    obs_dim = int(rs.choice([3, 16, 17, 20, 33]))
+    act_dim = int(rs.choice([1, 6, 8, 16, 40]))
+    m = int(rs.choice([1, 2, 3]))
+    n = int(rs.choice([1, 16, 17, 50]))
+    h = int(rs.choice([1, 2, 5]))
+    discount = float(rs.choice([1.0, 0.9]))
+    act = str(rs.choice(["tanh", "tanh", "relu", "sigmoid"]))
+    low, high = -np.ones(act_dim), np.ones(act_dim)
+    params = synthetic.make_rnn_stack_set(obs_dim, act_dim, sizes, cell, int(rs.randint(1 << 30)))
+    norm = _norm(rs, obs_dim, act_dim, low, high)
+    spec = _reward(rs, obs_dim, act_dim)
+    U = sum(sizes)
+    native = NativeLSTM(obs_dim, act_dim, sizes, act, None, cell_type=cell)
+    native.set_weights(params)
+    native.set_norm(norm)
+    dev = native.device
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    obs0, acts = up(rs.randn(m, obs_dim)), up(rs.uniform(low, high, (h, m * n, act_dim)))
+    c0 = up(rs.randn(m, U) * (1.0 if cell == "lstm" else 0.0))
+    h0 = up(np.tanh(rs.randn(m, U)))
+    ctx = _lib.Context.get(0)
+    got = {}
+    try:
+        for kernel in ("mfma", "valu"):
+            ctx.set_kernel(kernel)
+            rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(obs0, c0, h0, acts, m, n, h, discount, spec, cand_offset=3, returns_out=rets, best_key=best)
+            nxt = native.predict(obs0, acts[0, ::n][:m].contiguous(), c0, h0)
+            got[kernel] = (rets.cpu().numpy(), best.cpu().numpy(), [x.cpu().numpy() for x in nxt])
+    finally:
+        ctx.set_kernel("auto")
+    (r_m, k_m, s_m), (r_v, k_v, s_v) = got["mfma"], got["valu"]
+    _check(r_m, r_v, k_m, n, 3)
+    for a, b in zip(s_m, s_v):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
+    native.close()
