@@ -225,7 +225,9 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
         return l2a_fail(ctx, L2A_EINVAL, "l2a_rnn_create: 1 to " + std::to_string(L2A_RNN_MAX_LAYERS) + " layers");
     if (cell_type != L2A_CELL_LSTM && cell_type != L2A_CELL_GRU && cell_type != L2A_CELL_RNN)
         return l2a_fail(ctx, L2A_EINVAL, "l2a_rnn_create: unknown cell type");
-    if (n_layers == 1 && cell_type == L2A_CELL_LSTM)        // the run_rebal.py configuration: MFMA-capable model
+    // the run_rebal.py configuration, at the widths its tuned kernel is instantiated for: the model of l2a_lstm_create;
+    // one LSTM layer of any other width takes the generic matrix-core kernel like the stacks below
+    if (n_layers == 1 && cell_type == L2A_CELL_LSTM && lstm_mfma_eligible(obs_dim, act_dim, units[0]))
         return l2a_lstm_create(ctx, obs_dim, act_dim, units[0], cell_act, output_act, out);
     if (obs_dim < 1 || act_dim < 1) return l2a_fail(ctx, L2A_EINVAL, "obs_dim and act_dim must be >= 1");
     if (cell_act < 0 || cell_act > L2A_ACT_SWISH || output_act < 0 || output_act > L2A_ACT_SWISH)

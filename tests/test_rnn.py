@@ -389,8 +389,17 @@ def test_gpu_rnn_invalid_calls_are_rejected():
         nat.plan_rs(z(1, 20), z(1, 256), z(1, 256), z(2, 16, 6), 1, 16, 2, 1.0, bad, best_key=best)
     with pytest.raises(AssertionError):
         nat.set_weights(params[:3])
+    # a width the tuned LSTM kernel is not instantiated for: the model of l2a_lstm_create refuses kernel='mfma' ...
     ctx = _lib.Context.get(0)
-    odd = NativeLSTM(20, 6, 200)
+    lib = _lib.load()
+    assert lib.l2a_lstm_mfma_eligible(20, 6, 256) == 1 and lib.l2a_lstm_mfma_eligible(20, 6, 200) == 0
+    import ctypes
+    handle = ctypes.c_void_p()
+    ctx.check(lib.l2a_lstm_create(ctx.handle, 20, 6, 200, _lib.ACT_CODES["tanh"], _lib.ACT_CODES[None], ctypes.byref(handle)),
+              "l2a_lstm_create")
+    odd = NativeLSTM.__new__(NativeLSTM)
+    odd.ctx, odd.lib, odd.device, odd.handle, odd._keep = ctx, lib, nat.device, handle, {}
+    odd.layer_units, odd.cell_type, odd.obs_dim, odd.act_dim, odd.units = (200,), "lstm", 20, 6, 200
     odd.set_weights(synthetic_lstm(200))
     odd.set_norm(norm)
     ctx.set_kernel("mfma")
@@ -399,7 +408,22 @@ def test_gpu_rnn_invalid_calls_are_rejected():
             odd.plan_rs(z(1, 20), z(1, 200), z(1, 200), z(2, 16, 6), 1, 16, 2, 1.0, spec, best_key=best)
     finally:
         ctx.set_kernel("auto")
-    assert _lib.load().l2a_lstm_mfma_eligible(20, 6, 256) == 1 and _lib.load().l2a_lstm_mfma_eligible(20, 6, 200) == 0
+    odd.close()
+    # ... while NativeLSTM (l2a_rnn_create) gives such a layer the generic matrix-core kernel: same returns as its VALU twin
+    gen = NativeLSTM(20, 6, 200)
+    gen.set_weights(synthetic_lstm(200))
+    gen.set_norm(norm)
+    a = torch.rand((2, 16, 6), device=nat.device) * 2 - 1
+    out = {}
+    try:
+        for kernel in ("mfma", "valu"):
+            ctx.set_kernel(kernel)
+            rets = torch.empty((1, 16), dtype=torch.float32, device=nat.device)
+            gen.plan_rs(z(1, 20) + 0.1, z(1, 200), z(1, 200) + 0.2, a, 1, 16, 2, 1.0, spec, returns_out=rets, best_key=best)
+            out[kernel] = rets.cpu().numpy()
+    finally:
+        ctx.set_kernel("auto")
+    np.testing.assert_allclose(out["mfma"], out["valu"], rtol=1e-5, atol=1e-6)
 
 
 def synthetic_lstm(units):
