@@ -81,6 +81,7 @@ struct L2AKParams {
     // per-block launch.  The first pl_r units own pl_f + 1 XCDs each, the others pl_f; the grid is 8 ceil(pl_w / pl_f)
     // workgroups and hardware workgroup i (XCD i % 8, slot i / 8) either finds its place in its XCD's unit or returns.
     int pl_units, pl_f, pl_r, pl_w;     // units, XCDs per unit (floor), units with one XCD more, workgroups per unit
+    int pl_il;                          // experiment (L2A_XCD_INTERLEAVE): even hardware XCDs first, i.e. a split pair on XCDs 2k, 2k + 1
     int split_from;             // -1: `split` applies to every tile; >= 0: tail split - hardware workgroups
                                 // [0, split_from) run whole tiles, the rest are pairs sharing tiles split_from ..
     unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1

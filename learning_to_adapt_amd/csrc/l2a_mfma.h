@@ -407,7 +407,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         // an L2 of group A, and its pair ended the launch 1 % late; config 3b (5 environments x 32 tiles, 2.3 MB of weights
         // each) had four XCDs thrash between two environments' sets, 5 % slower than the other four.  The grid is padded
         // (host: launch_rollout); hardware workgroup i sits on XCD i % 8, and the spare ones return here.
-        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        const int hx = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        const int xcd = p.pl_il ? (((hx & 1) << 2) | (hx >> 1)) : hx;
         const int f = p.pl_f, wide = p.pl_r * (f + 1);
         int u, k, xu;
         if (xcd < wide) { u = xcd / (f + 1); k = xcd - u * (f + 1); xu = f + 1; }
