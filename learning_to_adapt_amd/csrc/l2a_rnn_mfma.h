@@ -5,8 +5,9 @@
 // Same semantics, same LDS state and the same thread roles for the element-wise parts as l2a_rnn_valu_k (cell arithmetic:
 // see that header); what changes is who multiplies.  Every [x | h] K product runs on v_mfma_f32_16x16x4_f32:
 //
-//   workgroup = 4 waves = one tile of 16 candidates; wave w owns the unit tiles T = w, w + 4, ... of every layer
-//   (16 units each, all gates of a unit in one wave, so the gate arithmetic is register local);
+//   workgroup = 4 waves = one tile of 16 candidates; wave w owns every fourth BLOCK of unit tiles of a layer (16 units a
+//   tile; a block = four accumulator tiles: one unit tile x four LSTM gates, two x two GRU gates, four x one), all gates
+//   of a unit in one wave, so the gate arithmetic is register local;
 //   B operand  = the layer's input / old h as they lie in LDS, row-major [16 candidates][K]: MFMA ii of k-group g multiplies
 //                k = 16 g + 4 (lane >> 4) + ii, i.e. a lane's four MFMAs of a k-group read ONE ds_read_b128 (rows padded
 //                to a multiple of 16 with zeros + 4 floats of skew against bank conflicts);
@@ -247,72 +248,118 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
             const __amdgpu_buffer_rsrc_t W0 = l2a_rsrc(p.wblk + p.layer_pk[l][0], l2a_rnn_pack_floats(kin, U, G0, true) * 4);
             const float* bx = xin + jc * xstride + 4 * qq;
             const float* bh = hc + jc * SP + 4 * qq;
-            for (int T = wave; T < UT; T += 4) {
-                const int u0 = 16 * T + 4 * qq;                 // this lane's four units of the D tile
-                const int at = jc * SP + u0;                     // ... and their place in a [16][SP] LDS array
-                f32x4 bias[4];
+            // A product call always fills four accumulator tiles - the matrix pipe wants four independent chains, and every
+            // call pays ~1.7k clocks until its first operands arrive: the four gates of ONE unit tile of an LSTM layer, the
+            // 2 x 2 gate tiles of TWO unit tiles of a GRU layer, FOUR unit tiles where a product has a single gate (BasicRNN,
+            // the GRU candidate) - as long as the layer is wide enough to give every wave such a block.  In the packed array
+            // those tiles are consecutive ([unit tile][gate]), so a block of unit tiles is "unit tile b of a kernel with more
+            // gates"; wave w owns blocks w, w + 4, ...  Tiles past the last unit tile read zeros (buffer range) and are
+            // skipped when the results go back to LDS.
+            if (lstm) {
+                for (int T = wave; T < UT; T += 4) {
+                    const int u0 = 16 * T + 4 * qq;             // this lane's four units of the D tile
+                    const int at = jc * SP + u0;                 // ... and their place in a [16][SP] LDS array
+                    f32x4 acc[4], bias[4];          // (the biases and c are requested before the product, not after it)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q) {
+                        acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) bias[q][ii] = (q < G0 && u0 + ii < U) ? b0[q * U + u0 + ii] : 0.0f;
-                f32x4 hnew;
-                if (lstm) {
-                    f32x4 acc[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<4>(W0, T, KGx, bx, UT, bh, lane, acc);
+                        for (int ii = 0; ii < 4; ++ii) bias[q][ii] = b0[q * U + (u0 + ii < U ? u0 + ii : 0)];
+                    }
                     f32x4 cv = *reinterpret_cast<const f32x4*>(cl + at);
+                    l2a_rnn_gemm<4>(W0, T, KGx, bx, UT, bh, lane, acc);
+                    f32x4 hnew;
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
+                        const bool live = u0 + ii < U;
                         const float ig = l2a_fast_sigmoid(acc[0][ii] + bias[0][ii]);
                         const float jg = l2a_rnn_act(acc[1][ii] + bias[1][ii], p.cell_act);
                         const float fg = l2a_fast_sigmoid(acc[2][ii] + bias[2][ii] + 1.0f);
                         const float og = l2a_fast_sigmoid(acc[3][ii] + bias[3][ii]);
-                        const float cn = (u0 + ii < U) ? fg * cv[ii] + ig * jg : 0.0f;
+                        const float cn = live ? fg * cv[ii] + ig * jg : 0.0f;
                         cv[ii] = cn;
-                        hnew[ii] = (u0 + ii < U) ? og * l2a_rnn_act(cn, p.cell_act) : 0.0f;
+                        hnew[ii] = live ? og * l2a_rnn_act(cn, p.cell_act) : 0.0f;
                     }
                     *reinterpret_cast<f32x4*>(cl + at) = cv;
-                } else if (gru) {
-                    f32x4 acc[2];
-                    acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<2>(W0, T, KGx, bx, UT, bh, lane, acc);
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hc + at);
-                    f32x4 rh;
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const bool live = u0 + ii < U;
-                        rh[ii] = live ? l2a_fast_sigmoid(acc[0][ii] + bias[0][ii]) * hv[ii] : 0.0f;       // r * h
-                        hnew[ii] = live ? l2a_fast_sigmoid(acc[1][ii] + bias[1][ii]) : 0.0f;              // u, parked in the new-h slot
-                    }
-                    *reinterpret_cast<f32x4*>(cl + at) = rh;
-                } else {
-                    f32x4 acc[1];
-                    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<1>(W0, T, KGx, bx, UT, bh, lane, acc);
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) hnew[ii] = (u0 + ii < U) ? l2a_rnn_act(acc[0][ii] + bias[0][ii], p.cell_act) : 0.0f;
+                    *reinterpret_cast<f32x4*>(hn + at) = hnew;
                 }
-                *reinterpret_cast<f32x4*>(hn + at) = hnew;
-            }
-            if (gru) {
-                __syncthreads();            // every unit's r * h before the candidate product
-                const float* b1 = cb + 2 * U;
-                const __amdgpu_buffer_rsrc_t W1 = l2a_rsrc(p.wblk + p.layer_pk[l][1], l2a_rnn_pack_floats(kin, U, 1, true) * 4);
-                const float* br = cl + jc * SP + 4 * qq;
-                for (int T = wave; T < UT; T += 4) {
-                    const int u0 = 16 * T + 4 * qq, at = jc * SP + u0;
-                    f32x4 acc[1];
-                    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    l2a_rnn_gemm<1>(W1, T, KGx, bx, UT, br, lane, acc);
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hc + at);
-                    f32x4 ug = *reinterpret_cast<const f32x4*>(hn + at);
+            } else {
+                // (blocks only as far as every wave still gets one: a narrow layer keeps one unit tile per call)
+                // products with ONE gate (BasicRNN, GRU candidate): TB unit tiles per call; epi(T, acc) finishes unit tile T
+                auto prod1 = [&](auto tb_tag, __amdgpu_buffer_rsrc_t W, const float* bsrc, auto&& epi) {
+                    constexpr int TB = decltype(tb_tag)::value;
+                    for (int b = wave; TB * b < UT; b += 4) {
+                        f32x4 acc[TB];
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const float cnd = l2a_rnn_act(acc[0][ii] + ((u0 + ii < U) ? b1[u0 + ii] : 0.0f), p.cell_act);
-                        ug[ii] = (u0 + ii < U) ? ug[ii] * hv[ii] + (1.0f - ug[ii]) * cnd : 0.0f;
+                        for (int q = 0; q < TB; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        l2a_rnn_gemm<TB>(W, b, KGx, bx, UT, bsrc, lane, acc);
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb)
+                            if (TB * b + tb < UT) epi(TB * b + tb, acc[tb]);
                     }
-                    *reinterpret_cast<f32x4*>(hn + at) = ug;
+                };
+                auto run1 = [&](__amdgpu_buffer_rsrc_t W, const float* bsrc, auto&& epi) {
+                    if (UT >= 16) prod1(std::integral_constant<int, 4>(), W, bsrc, epi);
+                    else if (UT >= 8) prod1(std::integral_constant<int, 2>(), W, bsrc, epi);
+                    else prod1(std::integral_constant<int, 1>(), W, bsrc, epi);
+                };
+                if (gru) {
+                    // reset / update gates: TB unit tiles x 2 gates per call
+                    auto prod2 = [&](auto tb_tag) {
+                        constexpr int TB = decltype(tb_tag)::value;
+                        for (int b = wave; TB * b < UT; b += 4) {
+                            f32x4 acc[2 * TB];
+#pragma unroll
+                            for (int q = 0; q < 2 * TB; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            l2a_rnn_gemm<2 * TB>(W0, b, KGx, bx, UT, bh, lane, acc);
+#pragma unroll
+                            for (int tb = 0; tb < TB; ++tb) {
+                                const int T = TB * b + tb;
+                                if (T < UT) {
+                                    const int u0 = 16 * T + 4 * qq, at = jc * SP + u0;
+                                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hc + at);
+                                    f32x4 rh, ug;
+#pragma unroll
+                                    for (int ii = 0; ii < 4; ++ii) {
+                                        const bool live = u0 + ii < U;
+                                        const int ub = live ? u0 + ii : 0;
+                                        rh[ii] = live ? l2a_fast_sigmoid(acc[2 * tb][ii] + b0[ub]) * hv[ii] : 0.0f;       // r * h
+                                        ug[ii] = live ? l2a_fast_sigmoid(acc[2 * tb + 1][ii] + b0[U + ub]) : 0.0f;         // u, parked in the new-h slot
+                                    }
+                                    *reinterpret_cast<f32x4*>(cl + at) = rh;
+                                    *reinterpret_cast<f32x4*>(hn + at) = ug;
+                                }
+                            }
+                        }
+                    };
+                    if (UT >= 8) prod2(std::integral_constant<int, 2>());
+                    else prod2(std::integral_constant<int, 1>());
+                    __syncthreads();            // every unit's r * h before the candidate product
+                    const float* b1 = cb + 2 * U;
+                    const __amdgpu_buffer_rsrc_t W1 = l2a_rsrc(p.wblk + p.layer_pk[l][1], l2a_rnn_pack_floats(kin, U, 1, true) * 4);
+                    run1(W1, cl + jc * SP + 4 * qq, [&](int T, const f32x4& z) {
+                        const int u0 = 16 * T + 4 * qq, at = jc * SP + u0;
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(hc + at);
+                        f32x4 ug = *reinterpret_cast<const f32x4*>(hn + at);
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const bool live = u0 + ii < U;
+                            const float cnd = l2a_rnn_act(z[ii] + b1[live ? u0 + ii : 0], p.cell_act);
+                            ug[ii] = live ? ug[ii] * hv[ii] + (1.0f - ug[ii]) * cnd : 0.0f;
+                        }
+                        *reinterpret_cast<f32x4*>(hn + at) = ug;
+                    });
+                } else {
+                    run1(W0, bh, [&](int T, const f32x4& z) {
+                        const int u0 = 16 * T + 4 * qq, at = jc * SP + u0;
+                        f32x4 hnew;
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const bool live = u0 + ii < U;
+                            hnew[ii] = live ? l2a_rnn_act(z[ii] + b0[live ? u0 + ii : 0], p.cell_act) : 0.0f;
+                        }
+                        *reinterpret_cast<f32x4*>(hn + at) = hnew;
+                    });
                 }
             }
             __syncthreads();

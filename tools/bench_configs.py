@@ -199,6 +199,31 @@ def main():
                                   frac_fp32_peak=round(fl / ms / 1e9 / PEAK, 4),
                                   lstm_steps_per_ms=round(n * m * h / ms, 1))), flush=True)
         _lib.Context.get(0).set_kernel("auto")
+    # the other cells create_rnn builds, at the ReBAL plan size: matrix-core kernel (l2a_rnn_mfma.h) and VALU kernel
+    for label, ctype, sizes in (("GRU 256", "gru", [256]), ("LSTM 2 x 256", "lstm", [256, 256]), ("BasicRNN 256", "rnn", [256])):
+        case = dict(C["hc_rnn_rs_gru2_n48_h4"], n=500, h=10, m=5, cell_type=ctype, hidden_sizes=sizes, units=sum(sizes))
+        case.pop("reset_after", None)
+        env, model = cases.product_rnn_model(case)
+        native = model.planner_model()
+        dev = native.device
+        m, n, h, U = case["m"], case["n"], case["h"], case["units"]
+        obs0 = torch.randn((m, 20), device=dev)
+        c0 = torch.randn((m, U), device=dev) * (1.0 if ctype == "lstm" else 0.0)
+        h0 = torch.tanh(torch.randn((m, U), device=dev))
+        a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
+        best = torch.zeros((m,), dtype=torch.int64, device=dev)
+        macs, kin = 0, 26
+        for u in sizes:
+            macs += (kin + u) * u * {"lstm": 4, "gru": 3, "rnn": 1}[ctype]
+            kin = u
+        fl = 2.0 * (macs + kin * 20) * n * m * h
+        for kernel in ("mfma", "valu"):
+            _lib.Context.get(0).set_kernel(kernel)
+            ms = time_launches(lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best), 10)
+            print(json.dumps(dict(config="ReBAL plan size with %s (generic recurrent kernels), %s kernel" % (label, kernel), n=n, h=h, m=m,
+                                  units=U, kernel_ms=round(ms, 4), tflops=round(fl / ms / 1e9, 2),
+                                  frac_fp32_peak=round(fl / ms / 1e9 / PEAK, 4))), flush=True)
+        _lib.Context.get(0).set_kernel("auto")
     case = C["c6_hc_rnn_rs_n500_h10_m5"]
     for mode in ("numpy", "device"):
         ctrl = cases.product_rnn_controller(case, rng=mode)
