@@ -43,14 +43,16 @@ for name, over in [("c2_hc_rs_n2000_h30_e5", {}), ("c3_ant_rs_n2000_h20_pb5", di
     k, r = run()
     torch.cuda.synchronize()
     plans.append(dict(run=run, run_sync=run_sync, key=k.clone(), rets=r.clone(), keep=(model, env)))
-for over in (dict(n=2000, h=30, m=1), dict(), dict(n=4096, h=6, m=1)):
+for over in (dict(n=2000, h=30, m=1), dict(), dict(n=4096, h=6, m=1),
+             dict(cell_type="gru", hidden_sizes=[96, 40], units=136, n=300, h=5, m=3),          # generic matrix-core kernel
+             dict(cell_type="lstm", hidden_sizes=[128, 64], units=192, n=700, h=4, m=2)):
     case = dict(C["c6_hc_rnn_rs_n500_h10_m5"], **over)
     env, model = cases.product_rnn_model(case)
     nat = model.planner_model()
     dev = nat.device
     m, n, h, U = case["m"], case["n"], case["h"], case["units"]
     obs = np.random.RandomState(7).randn(m, 20).astype(np.float32)
-    c0 = torch.randn((m, U), device=dev)
+    c0 = torch.randn((m, U), device=dev) * (0.0 if case.get("cell_type", "lstm") != "lstm" else 1.0)
     h0 = torch.tanh(torch.randn((m, U), device=dev))
     a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
     best = torch.zeros((m,), dtype=torch.int64, device=dev)
