@@ -93,7 +93,7 @@ int l2a_set_kernel(l2a_ctx* ctx, int kind);
  * single / per-block model - is shared, each workgroup computing the last hidden layer and the
  * output layer for one half of the hidden units (needs >= 2 hidden layers).  Results are
  * bit-identical under all three policies: the summation order is fixed (sets: group A + group B;
- * output layer: eight chunks of hidden units, ((c0+c1)+c2)+c3 + ((c4+c5)+c6)+c7).            */
+ * output layer: eight chunks of hidden units in a balanced tree, ((c0+c1)+(c2+c3)) + ((c4+c5)+(c6+c7))).  */
 int l2a_set_split(l2a_ctx* ctx, int policy);
 /* Set batching of the MFMA kernel (models with two hidden layers).  A workgroup that runs several weight sets per
  * horizon step (an ensemble member group) can run layer 0 of `sets` sets back to back, then their hidden GEMMs and

@@ -121,7 +121,7 @@ int choose_nt(const l2a_model* md, int m, int n, int e_loop, int sa_bytes_nt2, i
 int sa_elems_for(const l2a_model* md, int nt) {
     const int ht = md->H / 16;
     const int a = nt * ht;
-    const int b = 2 * L2A_NW * nt * md->OT;     // output-layer chunk partials
+    const int b = L2A_NW * nt * md->OT;         // output-layer partials (one per wave)
     return (a > b ? a : b) * 64;
 }
 
@@ -201,7 +201,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         const bool uniform_split = p.split && p.split_from < 0;
         const int e_half = (e_loop + 1) / 2;
         const int nseq = uniform_split ? e_half : e_loop;            // sets the busiest workgroup runs in sequence
-        const int ps_bytes = 2 * L2A_NW * nt * md->OT * 64 * 16;     // chunk partials of one set
+        const int ps_bytes = L2A_NW * nt * md->OT * 64 * 16;         // the waves' output-layer partials of one set
         const int x_bytes = 2 * nt * md->OT * 64 * 16;
         const int cst_bytes_all = nseq * p.cst_set * 4;
         p.n_cst = nseq;
@@ -210,10 +210,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         if (md->n_hidden == 2 && ctx->batch_sets != 1) {
             const int cap = ctx->batch_sets > 0 ? ctx->batch_sets : 4;
             for (int lb = (nseq < cap ? nseq : cap); lb >= 2; --lb) {
-                // a shared (half) set writes only the lower half of its partial slot; its reduce still reads the upper
-                // half (branch-free), which then overlays the constants - keep that overlay inside the allocation
-                const bool trim = uniform_split && p.split == 2 && lb == nseq && cst_bytes_all + x_bytes >= ps_bytes / 2;
-                const int pbytes = lb * ps_bytes - (trim ? ps_bytes / 2 : 0);
+                const int pbytes = lb * ps_bytes;
                 if (lb * p.sa_elems * 16 + pbytes + cst_bytes_all + x_bytes <= ctx->lds_per_block) {
                     p.lb = lb;
                     part_bytes = pbytes;

@@ -33,7 +33,7 @@
 //
 // Fixed summation order (every launch geometry and every batch size gives the same bits): sets are summed as (group A)
 // + (group B), A = first ceil(E/2) sets; the output layer's K reduction is cut into 2 * L2A_NW
-// chunks of TPW / 2 k-groups, ((c0+c1)+c2)+c3 + ((c4+c5)+c6)+c7.
+// chunks of TPW / 2 k-groups, summed as the balanced tree ((c0+c1)+(c2+c3)) + ((c4+c5)+(c6+c7)).
 //
 // Tile split (p.split): 1 = workgroup 0 runs group A, workgroup 1 group B; 2 = additionally the
 // last set of group A is SHARED - both workgroups run it as a "half member": layer 0 and the inner
@@ -347,12 +347,12 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
     }
+    // one partial per wave: a full member adds its two chunks here (c_2w + c_2w+1, the first level of the canonical tree)
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int c = 0; c < OT; ++c) pbuf[(((chunk0 + ch) * NT + nt) * OT + c) * 64 + lane] = acc[ch][nt][c];
+        for (int c = 0; c < OT; ++c)
+            pbuf[((chunk0 * NT + nt) * OT + c) * 64 + lane] = (NCH == 2) ? acc[0][nt][c] + acc[NCH - 1][nt][c] : acc[0][nt][c];
 }
 
 template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = false>
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     // workgroup's sequence (slot i = the i-th set it runs).
     constexpr int CST_BOUT = 32 * KG0 + 32 * OT;
     constexpr int CST_BHID = CST_BOUT + 16 * OT;
-    constexpr int PS = 2 * L2A_NW * NT * OT * 64;       // f32x4 of output-layer chunk partials per set
+    constexpr int PS = L2A_NW * NT * OT * 64;           // f32x4 of output-layer partials per set: one per wave
     const int NRM_SET = p.cst_set;
     // LDS: activation regions [max(2, LB)][sa_elems] | (LB > 1: chunk partials of a batch) | constants | exchange staging.
     // LB = sets per batch (p.lb).  LB == 1: one set at a time, two regions used in turn (layer in / layer out, the
@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                             for (int tt = 0; tt < TPW; ++tt) pfL0[g][tt] = l2a_ldw(r0n, voff0[tt] + g * 1024, 0);
                     };
                     if (is_half) l2a_out_phase<NT, TH, TPW, OT, KG0P * TPW, O4>(hreg, pfO, rs_out, tile0h, pf_l0, pb, wave, lane, olane);
-                    else l2a_out_phase<NT, TPW, TPW, OT, KG0P * TPW, O4>(hreg, pfO, rs_out, c0, pf_l0, pb, 2 * wave, lane, olane);
+                    else l2a_out_phase<NT, TPW, TPW, OT, KG0P * TPW, O4>(hreg, pfO, rs_out, c0, pf_l0, pb, wave, lane, olane);
                 } else {
                     const int en = seq(i + 1);
                     const __amdgpu_buffer_rsrc_t rsn = l2a_rsrc(set_base(en) + p.pk_wmid, wm_bytes);   // nb > 1: two hidden layers
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                                 pfA[tt] = l2a_ldw(rsn, voffh[tt], 0);
                                 pfB[tt] = l2a_ldw(rsn, voffh[tt] + 1024, 0);
                             }
-                        }, pb, 2 * wave, lane, olane);
+                        }, pb, wave, lane, olane);
                     } else {
                         l2a_out_phase<NT, TPW, TPW, OT, 2 * TPW, O4>(hreg, pfO, rs_out, c0, [&]() {
 #pragma unroll
@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                                 pfA[tt] = l2a_ldw(rsn, voff[tt], 0);
                                 pfB[tt] = l2a_ldw(rsn, voff[tt] + 1024, 0);
                             }
-                        }, pb, 2 * wave, lane, olane);
+                        }, pb, wave, lane, olane);
                     }
                 }
                 L2A_TS(4)
@@ -1067,20 +1067,22 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                             dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                 }
-                // Sum the chunk partials in the canonical order ((c0+c1)+c2)+c3 [+ ((c4+c5)+c6)+c7].
-                // A half member holds only its own four chunks; the other four arrive at the end of
-                // the step from the partner workgroup.
+                // Sum the waves' partials in the canonical order - a balanced tree over the eight chunks of hidden units,
+                // ((c0+c1)+(c2+c3)) + ((c4+c5)+(c6+c7)): a full member's wave w wrote c_2w + c_2w+1, so (p0+p1)+(p2+p3) is the
+                // whole tree; a half member's wave w wrote chunk w of ITS half, so the same expression is its half of the
+                // tree, and the other half arrives at the end of the step from the partner workgroup.  (Until round 3 the
+                // order was ((c0+c1)+c2)+c3 + ((c4+c5)+c6)+c7, which forced a full member to keep its two chunks apart: eight
+                // partials per set to write and to read back instead of four.)
                 // All LDS reads of an obs tile are issued before the first add: left to itself the compiler,
                 // which is out of registers kernel-wide, serialises them read-wait-add (~120 cycles each, 22 of
-                // them: the reduce measured 1.4k cycles per set in tools/timeline.py).  The half member's
-                // unwritten upper chunks are read too (branch-free) and simply not used.
+                // them: the reduce measured 1.4k cycles per set in tools/timeline.py).
                 // (reading all obs tiles of a set up front - one exposed round trip instead of OT - was measured and lost:
                 // 1.434 against 1.431 ms on config 2, profiles/r03_ab_kernel_variants.jsonl)
 #pragma unroll
                 for (int c = 0; c < OT; ++c) {
-                    f32x4 part[2 * L2A_NW][NT];
+                    f32x4 part[L2A_NW][NT];
 #pragma unroll
-                    for (int ch = 0; ch < 2 * L2A_NW; ++ch)
+                    for (int ch = 0; ch < L2A_NW; ++ch)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) part[ch][nt] = pb[((ch * NT + nt) * OT + c) * 64 + lane];
                     const f32x4 bias = *reinterpret_cast<const f32x4*>(nr + CST_BOUT + 16 * c + 4 * qq);
@@ -1089,16 +1091,11 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        f32x4 s = part[0][nt];
-#pragma unroll
-                        for (int w = 1; w < L2A_NW; ++w) s += part[w][nt];
+                        static_assert(L2A_NW == 4, "the canonical tree below is written out for four waves");
+                        f32x4 s = (part[0][nt] + part[1][nt]) + (part[2][nt] + part[3][nt]);
                         if (is_half) {
                             qsh[nt][c] = s;
                         } else {
-                            f32x4 s2 = part[L2A_NW][nt];
-#pragma unroll
-                            for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w][nt];
-                            s += s2;
                             if (O4 && c == OT - 1) {        // the four quarters of the hidden units (l2a_out_phase)
 #pragma unroll
                                 for (int ii = 0; ii < 4; ++ii) s[ii] = l2a_sum_xor32(l2a_sum_xor16(s[ii]));

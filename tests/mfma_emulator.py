@@ -221,7 +221,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                 # barrier + swap
                 cur ^= 1
                 hcur, hoth = lds[cur], lds[cur ^ 1]
-            # ---- output layer: K cut into 2 * NW chunks of TPW / 2 k-groups (canonical order) ----
+            # ---- output layer: K cut into 2 * NW chunks of TPW / 2 k-groups, summed as a balanced tree (canonical order) ----
             CS = TPW // 2
             for wave in range(NW):
                 for ch in range(2):
@@ -239,7 +239,9 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                                         acc[nt, c] = mfma_16x16x4(a, b, acc[nt, c])
                     for nt in range(NT):
                         for c in range(OT):
-                            hoth[((2 * wave + ch) * NT + nt) * OT + c] = acc[nt, c]
+                            # one partial per wave: chunk 2 wave + chunk 2 wave + 1 (first level of the canonical tree)
+                            k = (wave * NT + nt) * OT + c
+                            hoth[k] = acc[nt, c] if ch == 0 else (np.array(hoth[k]) + acc[nt, c]).astype(F32)
             # barrier
             for wave in range(NW):
                 for c in range(OT):
@@ -247,13 +249,8 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                     omu = ps.out_mu[16 * c + 4 * QQ[:, None] + np.arange(4)[None, :]]
                     osd = ps.out_sd[16 * c + 4 * QQ[:, None] + np.arange(4)[None, :]]
                     for nt in range(NT):
-                        s1 = np.array(hoth[(0 * NT + nt) * OT + c])
-                        for w in range(1, NW):
-                            s1 = (s1 + hoth[(w * NT + nt) * OT + c]).astype(F32)
-                        s2 = np.array(hoth[(NW * NT + nt) * OT + c])
-                        for w in range(1, NW):
-                            s2 = (s2 + hoth[((NW + w) * NT + nt) * OT + c]).astype(F32)
-                        s = (s1 + s2).astype(F32)
+                        part = [np.array(hoth[(w * NT + nt) * OT + c]) for w in range(NW)]
+                        s = ((part[0] + part[1]).astype(F32) + (part[2] + part[3]).astype(F32)).astype(F32)
                         if O4 and c == OT - 1:
                             s = (s + s[LANE ^ 16]).astype(F32)
                             s = (s + s[LANE ^ 32]).astype(F32)
