@@ -27,7 +27,7 @@
 // output columns over the FULL K range (x, then all of h: the same per-tile summation order as the unsplit kernel,
 // so both give the same bits).  Per step the two workgroups swap (a) their halves of the new h - each wave publishes
 // its own tiles right after the gate arithmetic, so they travel under the output layer - and (b) the output layer's
-// half sums S_g = ((c0+c1)+c2)+c3 over their own unit chunks; total = S_0 + S_1 is the unsplit kernel's canonical
+// half sums S_g = (c0+c1)+(c2+c3) over their own unit chunks; total = S_0 + S_1 is the unsplit kernel's canonical
 // reduce.  Same self-validating {tag, v, tag, v} granules, bounded spin and status word as l2a_mfma.h.
 #pragma once
 
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
     constexpr int HT = UT;                      // (name used by the L2A_STAGE macros: LDS stride)
     // LDS: h fragments, double buffered; output-layer chunk partials, double buffered; constants
     constexpr int HB = NT * UT * 64;            // f32x4 per h buffer
-    constexpr int PB = 2 * L2A_NW * NT * OT * 64;
+    constexpr int PB = L2A_NW * NT * OT * 64;           // one output-layer partial per wave (the canonical tree: l2a_mfma.h)
     constexpr int CST_BOUT = 32 * KG0 + 32 * OT;
     constexpr int CST_BG = CST_BOUT + 16 * OT;  // gate bias [4 U], TF order
     extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
@@ -387,9 +387,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
                 for (int ch = 0; ch < L2A_NW; ++ch) part[ch] = pbp[(ch * OT + c) * 64 + lane];
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 sv = part[0];
-#pragma unroll
-                for (int w = 1; w < L2A_NW; ++w) sv += part[w];
+                const f32x4 sv = (part[0] + part[1]) + (part[2] + part[3]);
                 xsum[c] = (grp == 0) ? sv + ps_[c] : ps_[c] + sv;          // S_0 + S_1
             }
         }
@@ -407,17 +405,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
                     s = xsum[c];
                 } else {
                     // all LDS reads of this obs tile first (left alone the scheduler serialises read-wait-add)
-                    f32x4 part[2 * L2A_NW];
+                    f32x4 part[L2A_NW];
 #pragma unroll
-                    for (int ch = 0; ch < 2 * L2A_NW; ++ch) part[ch] = pbp[((ch * NT + nt) * OT + c) * 64 + lane];
+                    for (int ch = 0; ch < L2A_NW; ++ch) part[ch] = pbp[((ch * NT + nt) * OT + c) * 64 + lane];
                     __builtin_amdgcn_sched_barrier(0);
-                    s = part[0];
-#pragma unroll
-                    for (int w = 1; w < L2A_NW; ++w) s += part[w];
-                    f32x4 s2 = part[L2A_NW];
-#pragma unroll
-                    for (int w = 1; w < L2A_NW; ++w) s2 += part[L2A_NW + w];
-                    s += s2;
+                    static_assert(L2A_NW == 4, "the canonical tree is written out for four waves");
+                    s = (part[0] + part[1]) + (part[2] + part[3]);      // wave w wrote c_2w + c_2w+1: the whole balanced tree
                 }
                 s = l2a_act4(s + bias, p.output_act);
                 const f32x4 d = s * osd + omu;
@@ -704,12 +697,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
 #pragma unroll
                             for (int c = 0; c < OT; ++c)
                                 oacc[ch][nt][c] = L2A_MFMA(pfO[ch * CS + t2][c][ii], hreg[nt][ch * CS + t2][ii], oacc[ch][nt][c]);
+            // one partial per wave; an unsplit wave adds its two chunks here (first level of the canonical tree)
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int c = 0; c < OT; ++c) pb[(((NCH * wave + ch) * NT + nt) * OT + c) * 64 + lane] = oacc[ch][nt][c];
+                for (int c = 0; c < OT; ++c)
+                    pb[((wave * NT + nt) * OT + c) * 64 + lane] = (NCH == 2) ? oacc[0][nt][c] + oacc[NCH - 1][nt][c] : oacc[0][nt][c];
         }
         L2A_LTS(5)
 #pragma unroll
@@ -721,16 +714,14 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
         for (int nt = 0; nt < NT; ++nt) asq_prev[nt] = asq[nt];
         disc_prev = disc_t;
         __syncthreads();
-        if (SPLIT && wave == 0) {       // this group's half sum S_g of step t: ((c0+c1)+c2)+c3 over its own chunks
+        if (SPLIT && wave == 0) {       // this group's half sum S_g of step t: (c0+c1)+(c2+c3) over its own chunks
 #pragma unroll
             for (int c = 0; c < OT; ++c) {
                 f32x4 part[L2A_NW];
 #pragma unroll
                 for (int ch = 0; ch < L2A_NW; ++ch) part[ch] = pb[(ch * OT + c) * 64 + lane];
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 sv = part[0];
-#pragma unroll
-                for (int w = 1; w < L2A_NW; ++w) sv += part[w];
+                const f32x4 sv = (part[0] + part[1]) + (part[2] + part[3]);
                 xput(HH + c, t & 1, sv);
             }
         }

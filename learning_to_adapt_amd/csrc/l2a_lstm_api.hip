@@ -120,7 +120,7 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
         const int nt = 1;
         const int UT = L2A_NW * md->UTW, U = md->units;
         p.tiles_per_env = l2a_ceil_div(p.n, 16 * nt);
-        const int smem = 2 * nt * UT * 64 * 16 + 2 * (2 * L2A_NW * nt * md->OT * 64) * 16 +
+        const int smem = 2 * nt * UT * 64 * 16 + 2 * (L2A_NW * nt * md->OT * 64) * 16 +
                          (32 * md->KG0 + 48 * md->OT + 4 * U) * 4;
         if (smem > ctx->lds_per_block)
             return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
