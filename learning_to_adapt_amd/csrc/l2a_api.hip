@@ -236,8 +236,10 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
                 const long long slots = (w + f - 1) / f;       // per XCD, of the units with f XCDs
                 if (8 * slots <= cus) {
                     p.pl_units = units; p.pl_f = f; p.pl_r = 8 - units * f; p.pl_w = (int)w;
-                    static const int il = [] { const char* e = std::getenv("L2A_XCD_INTERLEAVE"); return (e && e[0] == '1') ? 1 : 0; }();
+                    static const int il = [] { const char* e = std::getenv("L2A_XCD_INTERLEAVE"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
                     p.pl_il = il;
+                    if (il == 2 && uniform_split && 16 * ((pairs + 7) / 8) <= cus) n_wg = 16 * ((pairs + 7) / 8);
+                    else if (il == 2) p.pl_il = 0;
                     n_wg = 8 * slots;
                 }
             }

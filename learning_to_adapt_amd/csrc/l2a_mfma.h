@@ -400,7 +400,20 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const int n_tiles = p.m * p.tiles_per_env;
     const int n_pairs = tail ? n_tiles - p.split_from : n_tiles;       // tiles that are shared by two workgroups
     int bid, grp, lpair, pairid;
-    if (!tail && p.pl_units > 0) {
+    if (!tail && p.pl_il == 2 && split) {
+        // experiment (L2A_XCD_INTERLEAVE=2): BOTH workgroups of a pair on one XCD.  Measured (profiles/
+        // r03_ab_kernel_variants.jsonl, r03l2): with the records still travelling through the memory side (sc1) config 2
+        // is 1.3 % SLOWER - all five weight sets stream through every L2 - and workgroup-scope records (sc0 stores / loads,
+        // with and without a buffer_inv sc0 in front of every sweep) never became visible to the partner: the bounded spin
+        // timed out.  grid = 16 ceil(pairs / 8).
+        const int hx = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        const int su = (n_pairs + 7) >> 3;
+        grp = idx >= su ? 1 : 0;
+        lpair = hx * su + (idx - grp * su);
+        if (idx >= 2 * su || lpair >= n_pairs) return;
+        bid = grp * n_pairs + lpair;
+        pairid = lpair;
+    } else if (!tail && p.pl_units > 0) {
         // Every XCD (own 4 MB L2) serves ONE unit - workgroups that stream the same weights: group A of a split ensemble on
         // XCDs 0-3 and group B on 4-7, each environment of a per-block plan on its own XCD(s).  The contiguous remap cannot
         // do that when the counts do not divide: config 2 (125 tiles) left one workgroup of group B alone with its sets in
