@@ -76,6 +76,16 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
     p.disc0 = 1.0;
 }
 
+// generic models (stacks / GRU / BasicRNN / odd LSTM widths): does the launch take the matrix-core kernel of l2a_rnn_mfma.h?
+// (unless the caller asked for the VALU one, or its padded LDS rows do not fit: the VALU kernel's dense rows may still)
+long long generic_mfma_smem(const l2a_lstm* md) {
+    const int gates = md->cell_type == L2A_CELL_LSTM ? 4 : (md->cell_type == L2A_CELL_GRU ? 3 : 1);
+    return 4 * l2a_rnn_mfma_lds_floats(md->in_dim, md->obs_dim, md->n_layers, md->lunits, gates);
+}
+bool generic_uses_mfma(const l2a_lstm* md) {
+    return md->generic && md->ctx->kernel_kind != L2A_KERNEL_VALU && generic_mfma_smem(md) <= md->ctx->lds_per_block;
+}
+
 int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = true) {
     l2a_ctx* ctx = md->ctx;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
@@ -87,8 +97,7 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
         // stacks / GRU / BasicRNN: the matrix-core kernel of l2a_rnn_mfma.h unless the caller asked for the VALU one (or
         // its padded LDS rows do not fit: the VALU kernel's dense rows may still)
         p.tiles_per_env = l2a_ceil_div(p.n, L2A_LVT);
-        const int gates = md->cell_type == L2A_CELL_LSTM ? 4 : (md->cell_type == L2A_CELL_GRU ? 3 : 1);
-        const long long smem_m = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, md->obs_dim, md->n_layers, md->lunits, gates);
+        const long long smem_m = generic_mfma_smem(md);
         const int smem_v = (md->in_dim + 3 * md->units + 2 * md->obs_dim + 1) * L2A_LVT * 4;
         bool mfma = ctx->kernel_kind != L2A_KERNEL_VALU;
         if (mfma && smem_m > ctx->lds_per_block) {
@@ -450,7 +459,8 @@ int l2a_lstm_plan_rs_sync(l2a_lstm* md, const float* obs_host, const float* c0, 
     l2a_device_guard guard(ctx->device);
     int kind = ctx->kernel_kind;
     if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
-    const bool publish = (kind == L2A_KERNEL_MFMA) && !md->generic;   // only the MFMA kernel has the mailbox epilogue
+    // only the matrix-core kernels have the mailbox epilogue
+    const bool publish = md->generic ? generic_uses_mfma(md) : (kind == L2A_KERNEL_MFMA);
     if (c_next && !md->adv_buf)
         L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->adv_buf), sizeof(float) * L2A_MAIL_KEYS * (md->act_dim + md->obs_dim)));
     l2a_mail_ticket tk;

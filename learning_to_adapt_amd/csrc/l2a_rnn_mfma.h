@@ -435,6 +435,9 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
             const unsigned long long other = ((unsigned long long)hi << 32) | lo;
             key = (other > key) ? other : key;
         }
-        if (tid == 0 && key != 0ull) atomicMax(p.best_key + env, key);
+        if (tid == 0) {
+            if (key != 0ull) atomicMax(p.best_key + env, key);
+            l2a_publish_result(p, p.m * p.tiles_per_env);       // blocking plans: the last tile fills the host-mapped mailbox
+        }
     }
 }
