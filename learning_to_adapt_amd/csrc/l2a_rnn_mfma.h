@@ -1,6 +1,7 @@
 // l2a_rnn_mfma.h - matrix-core rollout of the STACKED recurrent cells of l2a_rnn_valu.h (GRU, BasicRNN, LSTM stacks:
-// everything `create_rnn`, reference dynamics/core/utils.py:192-236, builds besides run_rebal.py's single LSTM layer, which
-// has its own tuned kernel in l2a_lstm.h).  Included by l2a_lstm_api.hip only.
+// everything `create_rnn`, reference dynamics/core/utils.py:192-236, builds besides run_rebal.py's single LSTM layer of 128 /
+// 256 / 512 units, which has its own tuned kernel in l2a_lstm.h; a single LSTM layer of any other width runs here too).
+// Included by l2a_lstm_api.hip only.
 //
 // Same semantics, same LDS state and the same thread roles for the element-wise parts as l2a_rnn_valu_k (cell arithmetic:
 // see that header); what changes is who multiplies.  Every [x | h] K product runs on v_mfma_f32_16x16x4_f32:
