@@ -76,7 +76,9 @@ def build(force=False, verbose=True, only=None):
         return OUT
     os.makedirs(OBJ_DIR, exist_ok=True)
     jobs = [("l2a_api.hip", os.path.join(OBJ_DIR, "l2a_api.o"), []),
-            ("l2a_lstm_api.hip", os.path.join(OBJ_DIR, "l2a_lstm_api.o"), []),
+            # (holds the generic recurrent matrix-core kernel, l2a_rnn_mfma.h: its small accumulator tiles are read by the gate
+            # arithmetic right away - in architectural VGPRs that needs no v_accvgpr moves, 590 of them otherwise)
+            ("l2a_lstm_api.hip", os.path.join(OBJ_DIR, "l2a_lstm_api.o"), KERNEL_FLAGS),
             ("l2a_comm.hip", os.path.join(OBJ_DIR, "l2a_comm.o"), []),
             ("l2a_cem.hip", os.path.join(OBJ_DIR, "l2a_cem.o"), [])]
     for utw in LSTM_INSTANCES:
