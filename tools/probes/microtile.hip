@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) micro_k(const float* wpk, float* out, uns
     constexpr int MT = CT / 4;
     extern __shared__ __attribute__((aligned(16))) float act_raw[];
     float (*act)[16][ROW] = reinterpret_cast<float (*)[16][ROW]>(act_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * 16 * ROW; i += 256) (&act[0][0][0])[i] = 0.001f * (float)((i * 7 + blockIdx.x) % 97);
     __syncthreads();
     unsigned long long t0;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) micro_k(const float* wpk, float* out, uns
 __global__ void __launch_bounds__(256) full_k(const float* wpk, float* out, unsigned long long* clocks) {
     extern __shared__ __attribute__((aligned(16))) float act_raw[];
     float (*act)[16][ROW] = reinterpret_cast<float (*)[16][ROW]>(act_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jc = lane & 15, qq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), jc = lane & 15, qq = lane >> 4;
     for (int i = tid; i < 2 * 16 * ROW; i += 256) (&act[0][0][0])[i] = 0.001f * (float)((i * 7 + blockIdx.x) % 97);
     __syncthreads();
     unsigned long long t0;
