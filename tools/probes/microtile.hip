@@ -26,9 +26,14 @@ __device__ __forceinline__ f32x4 ldw(__amdgpu_buffer_rsrc_t r, int voff, int sof
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>()); static_for<I + 1, N>(f); }
+}
+
 // ---- 4x4x1 form: wave w owns the 64-unit tiles 2w, 2w + 1; CT / 4 micro-tiles of four candidates ---------------------------
 // packed A: float (((T * 128 + g) * 64 + lane) * 4 + ii) = W[k = 4 g + ii][unit = 64 T + lane]
-template <int CT>
+template <int CT, int NB>
 __global__ void __launch_bounds__(256) micro_k(const float* wpk, float* out, unsigned long long* clocks) {
     constexpr int MT = CT / 4;
     extern __shared__ __attribute__((aligned(16))) float act_raw[];
@@ -47,7 +52,8 @@ __global__ void __launch_bounds__(256) micro_k(const float* wpk, float* out, uns
 #pragma unroll
             for (int c = 0; c < MT; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* brow = &act[cur][lane & 3][0];
-        constexpr int KG = H / 4, NB = 4;           // k-groups of four; ring of four
+        constexpr int KG = H / 4;                   // k-groups of four; operand ring of NB slots, NB - 1 requests ahead
+        static_assert(KG % NB == 0, "ring depth must divide the k-groups");
         f32x4 a[NB][2], b[NB][MT];
         auto issue = [&](int g, auto slot_tag) {
             constexpr int s = decltype(slot_tag)::value;
@@ -67,15 +73,13 @@ __global__ void __launch_bounds__(256) micro_k(const float* wpk, float* out, uns
                     for (int c = 0; c < MT; ++c)
                         acc[t][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][t][ii], b[s][c][ii], acc[t][c], 0, 0, 0);
         };
-        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
-        using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
-        issue(0, S0()); issue(1, S1()); issue(2, S2());
-        for (int g0 = 0; g0 < KG; g0 += NB) {
-            issue(g0 + 3, S3()); mfma(S0());
-            issue(g0 + 4, S0()); mfma(S1());
-            issue(g0 + 5, S1()); mfma(S2());
-            issue(g0 + 6, S2()); mfma(S3());
-        }
+        static_for<0, NB - 1>([&](auto i) { issue(decltype(i)::value, i); });
+        for (int g0 = 0; g0 < KG; g0 += NB)
+            static_for<0, NB>([&](auto i) {
+                constexpr int I = decltype(i)::value;
+                issue(g0 + I + NB - 1, std::integral_constant<int, (I + NB - 1) % NB>());
+                mfma(i);
+            });
         // D: lane (block b = lane >> 2, candidate lane & 3) holds units 64 T + 4 b + i -> the candidate's LDS row, relu
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -192,11 +196,18 @@ int main(int argc, char** argv) {
     run("full 16x16x4", full_k, 16, 32, w, out, clk);
     run("full 16x16x4", full_k, 16, 160, w, out, clk);
     run("full 16x16x4", full_k, 16, 256, w, out, clk);
-    run("micro 4x4x1", micro_k<16>, 16, 160, w, out, clk);
-    run("micro 4x4x1", micro_k<12>, 12, 209, w, out, clk);
-    run("micro 4x4x1", micro_k<12>, 12, 256, w, out, clk);
-    run("micro 4x4x1", micro_k<8>, 8, 256, w, out, clk);
-    run("micro 4x4x1", micro_k<4>, 4, 125, w, out, clk);
-    run("micro 4x4x1", micro_k<4>, 4, 256, w, out, clk);
+    run("micro 4x4x1 ring 4", micro_k<16, 4>, 16, 160, w, out, clk);
+    run("micro 4x4x1 ring 4", micro_k<12, 4>, 12, 209, w, out, clk);
+    run("micro 4x4x1 ring 4", micro_k<12, 4>, 12, 256, w, out, clk);
+    run("micro 4x4x1 ring 4", micro_k<8, 4>, 8, 256, w, out, clk);
+    run("micro 4x4x1 ring 4", micro_k<4, 4>, 4, 125, w, out, clk);
+    run("micro 4x4x1 ring 4", micro_k<4, 4>, 4, 256, w, out, clk);
+    run("micro 4x4x1 ring 8", micro_k<16, 8>, 16, 160, w, out, clk);
+    run("micro 4x4x1 ring 8", micro_k<12, 8>, 12, 209, w, out, clk);
+    run("micro 4x4x1 ring 8", micro_k<8, 8>, 8, 256, w, out, clk);
+    run("micro 4x4x1 ring 8", micro_k<4, 8>, 4, 125, w, out, clk);
+    run("micro 4x4x1 ring 16", micro_k<12, 16>, 12, 209, w, out, clk);
+    run("micro 4x4x1 ring 16", micro_k<8, 16>, 8, 256, w, out, clk);
+    run("micro 4x4x1 ring 16", micro_k<4, 16>, 4, 125, w, out, clk);
     return 0;
 }
