@@ -108,6 +108,12 @@ int l2a_set_batch(l2a_ctx* ctx, int sets);
  * launch late (config 2, 125 tiles: 1.431 -> 1.417 ms).  0: the contiguous remap of 2 x tiles workgroups.  Placement
  * only: results are bit-identical.                                                                          */
 int l2a_set_xcd_align(l2a_ctx* ctx, int on);
+/* Micro tiles (csrc/l2a_micro.h).  A plan whose 16-candidate tiles would leave CUs idle - e.g. the reference's own default
+ * plans, run_grbal.py:84-85 / run_rebal.py:77-78: 5 x 500 candidates = 160 tiles on 256 CUs - can run in candidate tiles of
+ * FOUR on v_mfma_f32_4x4x1_16b_f32 instead: workgroups of 4, 8 or 12 candidates, every CU busy, no exchange between
+ * workgroups.  0 = never; 1 (default) = where it shortens the launch; 2 = whenever the plan is eligible (testing).  The
+ * arithmetic is ordered like the 16-candidate kernels': results are bit-identical under all three policies.   */
+int l2a_set_micro(l2a_ctx* ctx, int policy);
 /* Status word of the launches issued since the last call (caller must have synchronised the
  * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch
  * with l2a_set_split(ctx, 0)).  Reading clears it.                                            */

@@ -24,7 +24,7 @@ KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
 CELL_CODES = {"lstm": 0, "gru": 1, "rnn": 2}
 
 EXPORTED_SYMBOLS = (
-    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split", "l2a_set_batch", "l2a_set_xcd_align",
+    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split", "l2a_set_batch", "l2a_set_xcd_align", "l2a_set_micro",
     "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_adapt_sgd_raw", "l2a_model_get_weights",
@@ -73,6 +73,11 @@ def load():
     else:
         lib.l2a_set_batch.argtypes = [vp, i32]
         lib.l2a_set_batch.restype = i32
+    if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_set_micro"):
+        lib.l2a_set_micro = lambda handle, policy: 0
+    else:
+        lib.l2a_set_micro.argtypes = [vp, i32]
+        lib.l2a_set_micro.restype = i32
     if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_set_xcd_align"):
         lib.l2a_set_xcd_align = lambda handle, on: 0
     else:
@@ -222,6 +227,10 @@ class Context(object):
     def set_batch(self, sets):
         """Sets per batch of the MFMA rollout: 0 = as many as fit the LDS (default), 1 = one at a time (bit-identical)."""
         self.check(self.lib.l2a_set_batch(self.handle, int(sets)), "l2a_set_batch")
+
+    def set_micro(self, policy):
+        """Micro-tile kernels: 0 = never, 1 = where they fill the chip better (default), 2 = whenever eligible (bit-identical)."""
+        self.check(self.lib.l2a_set_micro(self.handle, int(policy)), "l2a_set_micro")
 
     def set_xcd_align(self, on):
         """Split launches: ensemble group A on XCDs 0-3, B on 4-7 exactly (padded grid; default on; bit-identical)."""

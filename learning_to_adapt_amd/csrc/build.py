@@ -18,8 +18,8 @@ OUT = os.path.join(PKG, "libl2a_hip.so")
 RNG_OUT = os.path.join(PKG, "libl2a_rng.so")        # host-only helper (gcc), see l2a_rng.c
 OBJ_DIR = os.path.join(HERE, "_obj")
 HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_adapt.h", "l2a_mfma.h", "l2a_mfma_launch.h", "l2a_lstm.h",
-           "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", os.path.join("..", "..", "include", "l2a.h")]
-SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_rng.c"]
+           "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", os.path.join("..", "..", "include", "l2a.h")]
+SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_rng.c"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -67,6 +67,21 @@ def _compile(job):
     return obj
 
 
+def relink(units, verbose=True):
+    """Developer shortcut: recompile the named translation units only (``l2a_micro_inst.hip`` ...) and link with the other
+    cached objects."""
+    table = {"l2a_api.hip": ("l2a_api.o", []), "l2a_lstm_api.hip": ("l2a_lstm_api.o", KERNEL_FLAGS), "l2a_comm.hip": ("l2a_comm.o", []),
+             "l2a_cem.hip": ("l2a_cem.o", []), "l2a_micro_inst.hip": ("l2a_micro.o", [])}
+    jobs = [(u, os.path.join(OBJ_DIR, table[u][0]), table[u][1]) for u in units]
+    with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as pool:
+        list(pool.map(_compile, jobs))
+    objs = [os.path.join(OBJ_DIR, o) for o in ("l2a_api.o", "l2a_lstm_api.o", "l2a_comm.o", "l2a_cem.o", "l2a_micro.o")]
+    objs += [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
+    objs += [os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % u) for u in LSTM_INSTANCES]
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"], cwd=HERE)
+    return OUT
+
+
 def build(force=False, verbose=True, only=None):
     """``only``: optional list of (NT, TPW) pairs to (re)compile - the others reuse their cached
     objects (developer shortcut; a clean build compiles all six)."""
@@ -80,7 +95,8 @@ def build(force=False, verbose=True, only=None):
             # arithmetic right away - in architectural VGPRs that needs no v_accvgpr moves, 590 of them otherwise)
             ("l2a_lstm_api.hip", os.path.join(OBJ_DIR, "l2a_lstm_api.o"), KERNEL_FLAGS),
             ("l2a_comm.hip", os.path.join(OBJ_DIR, "l2a_comm.o"), []),
-            ("l2a_cem.hip", os.path.join(OBJ_DIR, "l2a_cem.o"), [])]
+            ("l2a_cem.hip", os.path.join(OBJ_DIR, "l2a_cem.o"), []),
+            ("l2a_micro_inst.hip", os.path.join(OBJ_DIR, "l2a_micro.o"), [])]
     for utw in LSTM_INSTANCES:
         jobs.append(("l2a_lstm_inst.hip", os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % utw), ["-DL2A_INST_UTW=%d" % utw] + LSTM_FLAGS))
     for nt, tpw in INSTANCES:
@@ -94,7 +110,7 @@ def build(force=False, verbose=True, only=None):
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
         list(pool.map(_compile, jobs))
     objs = [os.path.join(OBJ_DIR, "l2a_api.o"), os.path.join(OBJ_DIR, "l2a_lstm_api.o"), os.path.join(OBJ_DIR, "l2a_comm.o"),
-            os.path.join(OBJ_DIR, "l2a_cem.o")]
+            os.path.join(OBJ_DIR, "l2a_cem.o"), os.path.join(OBJ_DIR, "l2a_micro.o")]
     objs += [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
     objs += [os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % u) for u in LSTM_INSTANCES]
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"], cwd=HERE)
@@ -105,6 +121,9 @@ def build(force=False, verbose=True, only=None):
 if __name__ == "__main__":
     only = None
     for a in sys.argv[1:]:
+        if a.startswith("--units="):
+            relink(a[len("--units="):].split(","))
+            sys.exit(0)
         if a.startswith("--only="):
             only = [tuple(int(x) for x in part.split("x")) for part in a[len("--only="):].split(",")]
     build(force="--force" in sys.argv, only=only)

@@ -332,6 +332,8 @@ int l2a_init(int device, l2a_ctx** out) {
     if (xa && (xa[0] == '0' || xa[0] == '1')) ctx->xcd_align = xa[0] - '0';
     const char* bs = std::getenv("L2A_BATCH");
     if (bs && bs[0] >= '0' && bs[0] <= '4') ctx->batch_sets = bs[0] - '0';
+    const char* mc = std::getenv("L2A_MICRO");
+    if (mc && mc[0] >= '0' && mc[0] <= '2') ctx->micro_policy = mc[0] - '0';
     *out = ctx;
     return L2A_OK;
 }
@@ -357,6 +359,13 @@ int l2a_set_batch(l2a_ctx* ctx, int sets) {
     if (!ctx) return L2A_EINVAL;
     if (sets < 0 || sets > 4) return fail(ctx, L2A_EINVAL, "sets per batch must be 0 (automatic) .. 4");
     ctx->batch_sets = sets;
+    return L2A_OK;
+}
+
+int l2a_set_micro(l2a_ctx* ctx, int policy) {
+    if (!ctx) return L2A_EINVAL;
+    if (policy < 0 || policy > 2) return fail(ctx, L2A_EINVAL, "micro-tile policy must be 0, 1 or 2");
+    ctx->micro_policy = policy;
     return L2A_OK;
 }
 

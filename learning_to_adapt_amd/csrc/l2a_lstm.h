@@ -45,6 +45,8 @@ struct L2ALstmParams {
     long long pk_wout;          // packed output layer [OT][UT][64][4]
     long long pk_bout;          // output bias padded to 16 OT
     long long nm_off;           // [in_mu 16 KG0][in_inv 16 KG0][out_mu 16 OT][out_sd 16 OT]
+    long long pk_mg, pk_mo;     // micro-tile kernel (l2a_micro.h): gate matrix / output layer in its fragment order
+    int mc_w, mc_r, mc_hi;      // micro-tile launch: workgroups per env, how many of them take mc_hi micro tiles (the others mc_hi - 1)
     int obs_dim, act_dim, in_dim, units;
     int cell_act, output_act;
     int KG0, OT;

@@ -9,6 +9,8 @@
 #include "l2a_lstm_launch.h"
 #include "l2a_rnn_valu.h"
 #include "l2a_rnn_mfma.h"
+#include "l2a_micro_pack.h"
+#include "l2a_micro_launch.h"
 
 #include <cstring>
 #include <string>
@@ -19,6 +21,8 @@ struct l2a_lstm {
     int obs_dim = 0, act_dim = 0, in_dim = 0, units = 0;
     int cell_act = L2A_ACT_TANH, output_act = L2A_ACT_IDENTITY;
     bool mfma_ok = false;
+    bool micro_ok = false;                        // the micro-tile kernel of l2a_micro.h has an instance (256 / 512 units)
+    long long pk_mg = 0, pk_mo = 0;               // its copies of the gate matrix / output layer
     int UTW = 0, KG0 = 0, OT = 0;
     float* wblk = nullptr;
     long long total = 0;
@@ -65,6 +69,7 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
     p.wblk = md->wblk;
     p.raw_wk = md->raw_wk; p.raw_bk = md->raw_bk; p.raw_wo = md->raw_wo; p.raw_bo = md->raw_bo;
     p.pk_wg = md->pk_wg; p.pk_wout = md->pk_wout; p.pk_bout = md->pk_bout; p.nm_off = md->nm_off;
+    p.pk_mg = md->pk_mg; p.pk_mo = md->pk_mo;
     p.obs_dim = md->obs_dim; p.act_dim = md->act_dim; p.in_dim = md->in_dim; p.units = md->units;
     p.cell_act = md->cell_act; p.output_act = md->output_act;
     p.KG0 = md->KG0; p.OT = md->OT;
@@ -129,6 +134,34 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
         const int nt = 1;
         const int UT = L2A_NW * md->UTW, U = md->units;
         p.tiles_per_env = l2a_ceil_div(p.n, 16 * nt);
+        {
+            // Micro tiles (l2a_micro.h): every env's ceil(n / 4) candidate tiles of four dealt to W workgroups of at most
+            // three - one workgroup per CU, none idle, no exchange.  Plans only (no per-row states, no state written out:
+            // those launches are one step long or chunk continuations and keep the 16-candidate kernel - same bits).
+            const int cus_m = ctx->num_cu > 0 ? ctx->num_cu : 256;
+            const long long tiles16 = (long long)p.m * p.tiles_per_env;
+            const int quads = l2a_ceil_div(p.n, 4);
+            int W = cus_m / p.m;
+            if (W > quads) W = quads;
+            const int hi = W > 0 ? l2a_ceil_div(quads, W) : 99;
+            const bool eligible = md->micro_ok && !p.obs_per_row && !p.state_out && !p.c_out && !p.h_out && hi <= 3 &&
+                                  (p.returns_out || p.best_key);
+            // automatic: the plans the 16-candidate geometries cannot fill - more than CUs / 2 tiles (no unit-tile split)
+            // and fewer than CUs
+            const bool wanted = ctx->micro_policy == 2 || (ctx->micro_policy == 1 && 2 * tiles16 > cus_m && tiles16 < cus_m);
+            if (eligible && wanted) {
+                p.mc_w = W;
+                p.mc_hi = hi;
+                p.mc_r = quads - W * (hi - 1);          // workgroups that take `hi` micro tiles
+                int smem_m = l2a_lstm_micro_smem(U, md->KG0);
+                if (smem_m < 84 * 1024) smem_m = 84 * 1024;     // more than half a CU's LDS: one workgroup per CU
+                const int rc = l2a_launch_lstm_micro(U, &p, (unsigned)(p.m * W), smem_m, stream);
+                if (rc != 0) return l2a_fail(ctx, L2A_EHIP, std::string("micro-tile LSTM kernel launch: ") +
+                                                            (rc > 0 ? hipGetErrorString((hipError_t)rc) : "no instance"));
+                L2A_HIP(ctx, hipGetLastError());
+                return L2A_OK;
+            }
+        }
         const int smem = 2 * nt * UT * 64 * 16 + 2 * (L2A_NW * nt * md->OT * 64) * 16 +
                          (32 * md->KG0 + 48 * md->OT + 4 * U) * 4;
         if (smem > ctx->lds_per_block)
@@ -209,6 +242,11 @@ int l2a_lstm_create(l2a_ctx* ctx, int obs_dim, int act_dim, int units, int cell_
         const int UT = units / 16;
         md->pk_wg = take(4LL * UT * (md->KG0 + UT) * 256);
         md->pk_wout = take((long long)md->OT * UT * 256);
+        md->micro_ok = (units == 256 || units == 512);
+        if (md->micro_ok) {
+            md->pk_mg = take(l2a_lstm_micro_gate_floats(units, md->KG0));
+            md->pk_mo = take((long long)(units / 4) * 256);
+        }
     }
     md->pk_bout = take(16 * md->OT);
     md->nm_off = take(32 * md->KG0 + 32 * md->OT);
@@ -373,6 +411,15 @@ int l2a_lstm_set_weights(l2a_lstm* md, const void* const* device_ptrs, void* str
         hipLaunchKernelGGL(l2a_lstm_pack_out_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wo, U,
                            md->obs_dim, UT, total, md->wblk + md->pk_wout);
         L2A_HIP(ctx, hipGetLastError());
+        if (md->micro_ok) {
+            total = l2a_lstm_micro_gate_floats(U, md->KG0);
+            hipLaunchKernelGGL(l2a_lstm_micro_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wk,
+                               md->in_dim, U, md->KG0, total, md->wblk + md->pk_mg);
+            total = (long long)(U / 4) * 256;
+            hipLaunchKernelGGL(l2a_lstm_micro_pack_out_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wo, U,
+                               md->obs_dim, total, md->wblk + md->pk_mo);
+            L2A_HIP(ctx, hipGetLastError());
+        }
     }
     md->weights_set = true;
     return L2A_OK;

@@ -1,0 +1,449 @@
+// l2a_micro.h - MICRO TILES: candidate tiles of FOUR on v_mfma_f32_4x4x1_16b_f32 (gfx950 / CDNA4 only).
+//
+// Why.  v_mfma_f32_16x16x4_f32 fixes the candidate tile of l2a_mfma.h / l2a_lstm.h at N = 16, so a plan of T tiles keeps
+// T of the 256 CUs busy and a plan between 128 and 256 tiles (the reference's own defaults: run_grbal.py:84-85 and
+// run_rebal.py:77-78 give 5 x 500 candidates = 160 tiles) leaves a third of the chip idle - a tile cannot be cut without a
+// per-step exchange between workgroups.  v_mfma_f32_4x4x1_16b_f32 multiplies sixteen independent 4 x 4 blocks, one k
+// each, in two passes: with the sixteen blocks = 64 output units and the four columns = four candidates (replicated over
+// the blocks) it does 256 MACs in 8 clocks - the 16x16x4 form's 32 MAC/clock - for FOUR candidates.  A workgroup can
+// then own 4, 8 or 12 candidates (MT = 1 .. 3 micro tiles) at full matrix rate, no exchange: 2 500 candidates become 256
+// workgroups of 12 and 8 instead of 160 of 16.  What it costs: the weight stream per candidate grows (every workgroup
+// still streams every weight once per step: 64 B/clock of L1 bandwidth bound a 4-candidate workgroup at ~45 % of its
+// matrix time, an 8-candidate one at ~80 %), and the MFMAs are four times shorter, so the loop has to be free of address
+// arithmetic (tools/probes/microtile2.hip, profiles/r04_probe_microtile2_*.jsonl: 64 % of the matrix time with the
+// compiler's schedule, 86 % with the loop below at 12 candidates).
+//
+// Operands.  Lane L = 4 b + j of a wave (block b, column j):
+//   A  lane L supplies the weight of output SLOT L of a 64-unit tile for one k: a 16-byte load per lane = four consecutive
+//      k of the chain (below); a wave-level load = 1 KiB contiguous (packed at set_weights, l2a_*_micro_pack_k);
+//   B  lane L supplies the activation of candidate j for the same k - the same value in all sixteen blocks: one
+//      ds_read_b128 of the candidate's LDS row (four consecutive chain positions, broadcast);
+//   D  lane L, register i = slot 4 b + i, candidate j.
+// Same bits as the 16-candidate kernels.  v_mfma_f32_16x16x4_f32 is a k-ordered fma chain (guide section 3), and with
+// the packed layout of l2a_kernels.h the chain of a 16-feature k-group runs k = 16 g + 4 kk + ii for ii = 0..3 (MFMA),
+// kk = 0..3 (inside one).  A 4x4x1 MFMA is ONE fma per output, so issuing them in that order reproduces the chain bit
+// for bit: "chain position" p = 16 g + 4 ii + kk <-> feature k = 16 g + 4 kk + ii (l2a_chain_k, an involution).  LDS rows
+// hold activations in chain order, the packed A arrays hold k in chain order, and output slot s of a 64-unit tile is
+// unit l2a_chain_k(s) - so that a lane's D registers (slots 4 b .. 4 b + 3) are four consecutive chain positions of the
+// next layer's row: one ds_write_b128.  Reduction trees, gate arithmetic, reward and key are the 16-candidate kernels'.
+#pragma once
+
+#include <type_traits>
+
+#include "l2a_lstm.h"
+#include "l2a_micro_pack.h"
+
+template <int I, int N, class F>
+__device__ __forceinline__ void l2a_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>()); l2a_static_for<I + 1, N>(f); }
+}
+
+// issue-order hint of one k-group step: its NA weight loads and NB LDS reads spread evenly between its NM MFMAs
+template <int NA, int NB, int NM>
+__device__ __forceinline__ void l2a_micro_hint() {
+    constexpr int NOP = NA + NB, PER = NM / NOP;
+    l2a_static_for<0, NOP>([&](auto it) {
+        constexpr int i = decltype(it)::value;
+        constexpr bool vm = ((i & 1) == 0 ? (i / 2 < NA) : (i / 2 >= NB));      // alternate while both kinds are left
+        if constexpr (vm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (i == NOP - 1) ? NM - PER * (NOP - 1) : PER, 0);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Recurrent planner (one LSTM layer of 256 / 512 units: l2a_lstm.h is the 16-candidate kernel, same arithmetic)
+// ------------------------------------------------------------------------------------------------------------------
+
+template <int MT, int UW>
+__device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, const int env, const int cand0, char* smem) {
+    constexpr int U = 256 * UW;
+    constexpr int ROWF = l2a_micro_row(U);
+    constexpr int NTL = 4 * UW;             // accumulator tiles of a wave: gate q of its 64-unit tile uw -> q * UW + uw
+    constexpr int HG = U / 8;               // k-groups per half of h
+    constexpr int HI = HG / 4;              // loop iterations (four k-groups each) per half
+    constexpr int NGO = 16 * UW;            // output-layer k-groups of this wave's units
+    const int KG0 = p.KG0;
+    const int NIT = 2 * HI + KG0;
+    const int NG = 4 * NIT;
+    float* rows = reinterpret_cast<float*>(smem);                   // [2][4 MT][ROWF]
+    f32x4* pbuf = reinterpret_cast<f32x4*>(rows + 2 * 12 * ROWF);   // [2][4 waves][MT][64]
+    float* c_in_mu = reinterpret_cast<float*>(pbuf + 2 * 4 * 3 * 64);
+    float* c_in_iv = c_in_mu + 16 * KG0;
+    float* c_out_mu = c_in_iv + 16 * KG0;   // [64] each, zero past the observation
+    float* c_out_sd = c_out_mu + 64;
+    float* c_bo = c_out_sd + 64;
+    float* c_gb = c_bo + 64;                // gate bias in slot order [q][U]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = lane >> 2, j = lane & 3;
+    const int qq = b & 3;                   // the lane's role in the 16-candidate kernels' quarter sums (dims 16 c + 4 qq + ii)
+    const int obs_dim = p.obs_dim, act_dim = p.act_dim;
+    const int R = p.m * p.n;
+
+    for (int i = tid; i < 32 * KG0 + 192 + 4 * U; i += 256) {
+        float v;
+        if (i < 32 * KG0) v = p.wblk[p.nm_off + i];
+        else if (i < 32 * KG0 + 192) {
+            const int a = (i - 32 * KG0) >> 6, d = (i - 32 * KG0) & 63;
+            v = (d >= obs_dim) ? 0.0f : (a == 0 ? p.wblk[p.nm_off + 32 * KG0 + d]
+                                                : (a == 1 ? p.wblk[p.nm_off + 32 * KG0 + 16 * p.OT + d] : p.wblk[p.raw_bo + d]));
+        } else {
+            const int o = i - (32 * KG0 + 192), q = o / U, s = o - q * U;
+            v = p.wblk[p.raw_bk + q * U + l2a_chain_k(s)];         // slot s of tile s / 64 is unit chain_k(s)
+        }
+        c_in_mu[i] = v;
+    }
+    for (int i = tid; i < 2 * 12 * ROWF; i += 256) rows[i] = 0.0f;  // padding (and rows of absent micro tiles) stay zero
+    __syncthreads();
+
+    int cand[MT], row[MT];
+    bool valid[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+        cand[c] = cand0 + 4 * c + j;
+        valid[c] = cand[c] < p.n;
+        row[c] = env * p.n + (valid[c] ? cand[c] : p.n - 1);
+    }
+    // state: dims 4 b .. 4 b + 3 of candidate j (every wave keeps a copy, like the 16-candidate kernel)
+    f32x4 st[MT], creg[UW][MT];
+    {
+        const float* orow = p.obs0 + (long long)env * obs_dim;
+        f32x4 s0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dim = 4 * b + i;
+            const float v = orow[dim < obs_dim ? dim : obs_dim - 1];
+            s0[i] = (dim < obs_dim) ? v : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < MT; ++c) st[c] = s0;
+    }
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+        const long long hrow = (p.hid_per_row ? (long long)row[c] : (long long)env) * U;
+#pragma unroll
+        for (int uw = 0; uw < UW; ++uw) {
+            const int tile = wave * UW + uw;
+            f32x4 hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int unit = 64 * tile + l2a_chain_k(4 * b + i);
+                creg[uw][c][i] = p.c0[hrow + unit];
+                hv[i] = p.h0[hrow + unit];
+            }
+            *reinterpret_cast<f32x4*>(rows + (4 * c + j) * ROWF + 64 * tile + 4 * b) = hv;
+        }
+    }
+
+    // raw actions of the lanes that play the 16-candidate kernel's quarter role (b < 4: qq = b): bounds-checked buffer
+    // loads from a per-step descriptor, slots without an action read 0.0 (l2a_mfma.h)
+    const int ga0 = obs_dim >> 4;
+    f32x4 av_next[MT][2];
+    int aoff[MT][2][4];
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+                const bool in = (b < 4) && (ka >= 0) && (ka < act_dim);
+                aoff[c][s][ii] = in ? (row[c] * act_dim + ka) * 4 : 0x7ffffff0;
+            }
+    const long long a_step = (long long)R * act_dim;
+    auto load_actions = [&](int t, f32x4 (&dst)[MT][2]) {
+        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
+#pragma unroll
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    dst[c][s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[c][s][ii], 0, 0));
+    };
+    // normalised inputs of the coming step -> the x section of `dst` rows (chain order); every wave writes all of them
+    // (identical values) and reads them back behind its own writes: no barrier between the state update and the x part
+    f32x4 av[MT][2];
+    float asq[MT];
+    auto write_x = [&](float* dst) {
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            float* xr = dst + (4 * c + j) * ROWF + U;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 4 * b + i;
+                if (k < obs_dim) xr[l2a_chain_k(k)] = ((st[c][i] + 0.0f) - c_in_mu[k]) * c_in_iv[k];
+            }
+            float s = 0.0f;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                s = fmaf(av[c][0][ii], av[c][0][ii], s);
+                s = fmaf(av[c][1][ii], av[c][1][ii], s);
+            }
+            asq[c] = s;
+            if (b < 4) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int k = 16 * (ga0 + s2) + 4 * qq + ii;
+                        if (k >= obs_dim && k < obs_dim + act_dim)
+                            xr[l2a_chain_k(k)] = ((0.0f + av[c][s2][ii]) - c_in_mu[k]) * c_in_iv[k];
+                    }
+            }
+        }
+    };
+    load_actions(0, av_next);
+#pragma unroll
+    for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+    load_actions(p.h > 1 ? 1 : 0, av_next);
+    write_x(rows);
+
+    float ret[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) ret[c] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[c] ? cand[c] : p.n - 1)] : 0.0f;
+    double disc_pow = p.disc0;
+
+    // ---- operand streams ---------------------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsA = l2a_rsrc(p.wblk + p.pk_mg, l2a_lstm_micro_gate_floats(U, KG0) * 4);
+    const __amdgpu_buffer_rsrc_t rsO = l2a_rsrc(p.wblk + p.pk_mo, (long long)(U / 4) * 1024);
+    int voffA[NTL];
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+        const int q = tl / UW, uw = tl - q * UW;
+        voffA[tl] = lane * 16 + (((wave * UW + uw) * 4 + q) * NG) * 1024;
+    }
+    const int voffO = lane * 16 + wave * NGO * 1024;
+    const int own = (wave * UW * 64) / (U / 2);         // which half of h holds this wave's units
+    f32x4 ra[4][NTL];                                   // weight ring: four k-groups, three requested ahead; lives across steps
+    f32x4 rb[2][MT];                                    // activation ring: two k-groups
+    auto issue_a = [&](int soff, auto imm_tag, auto slot_tag) {
+        constexpr int s = decltype(slot_tag)::value, IMM = decltype(imm_tag)::value;
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) ra[s][tl] = l2a_ldw(rsA, voffA[tl] + IMM, soff);
+    };
+    auto issue_b = [&](const float* bp, auto off_tag, auto slot_tag) {
+        constexpr int s = decltype(slot_tag)::value, OFF = decltype(off_tag)::value;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) rb[s][c] = *reinterpret_cast<const f32x4*>(bp + 4 * c * ROWF + OFF);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    issue_a(0, I0(), I0());
+    issue_a(0, std::integral_constant<int, 1024>(), I1());
+    issue_a(0, std::integral_constant<int, 2048>(), I2());
+    __syncthreads();        // every wave's share of h(0) is in the rows
+
+    for (int t = 0; t < p.h; ++t) {
+        float* rows_c = rows + (t & 1) * 12 * ROWF;
+        float* rows_n = rows + ((t + 1) & 1) * 12 * ROWF;
+        f32x4* pb = pbuf + (t & 1) * (4 * 3 * 64);
+        const float* hb_own = rows_c + j * ROWF + own * (U / 2);
+        const float* hb_oth = rows_c + j * ROWF + (1 - own) * (U / 2);
+        const float* xb = rows_c + j * ROWF + U;
+
+        f32x4 acc[NTL][MT];
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+            for (int c = 0; c < MT; ++c) acc[tl][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // ---- gate GEMM: K order own half of h, other half, x (l2a_lstm.h) ------------------------------------------
+        issue_b(hb_own, I0(), I0());
+        int itg = 0;
+        auto segment = [&](const float* bbase, int nit, const float* bnext) {
+#pragma unroll 1
+            for (int it = 0; it < nit; ++it, ++itg) {
+                const int s0 = itg * 4096;
+                const int s1 = (itg + 1 == NIT) ? 0 : s0 + 4096;       // past the last k-group: the NEXT step's first ones
+                const float* bp = bbase + 16 * it;
+                const float* bn = (it + 1 < nit) ? bp + 16 : bnext;
+                l2a_static_for<0, 4>([&](auto iv) {
+                    constexpr int I = decltype(iv)::value;
+                    if constexpr (I == 0) issue_a(s0, std::integral_constant<int, 3072>(), I3());
+                    else issue_a(s1, std::integral_constant<int, (I - 1) * 1024>(), std::integral_constant<int, I - 1>());
+                    if constexpr (I < 3) issue_b(bp, std::integral_constant<int, 4 * (I + 1)>(), std::integral_constant<int, (I + 1) & 1>());
+                    else issue_b(bn, I0(), I0());
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+                            for (int c = 0; c < MT; ++c) acc[tl][c] = L2A_MFMA4(ra[I][tl][e], rb[I & 1][c][e], acc[tl][c]);
+                    l2a_micro_hint<NTL, MT, 4 * NTL * MT>();
+                });
+            }
+        };
+        segment(hb_own, HI, hb_oth);
+        segment(hb_oth, HI, xb);
+        segment(xb, KG0, xb);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // output-layer operands of this wave's first chunk: in flight under the gate arithmetic
+        f32x4 pfo[2][NGO / 2];
+#pragma unroll
+        for (int g = 0; g < NGO / 2; ++g) pfo[0][g] = l2a_ldw(rsO, voffO + g * 1024, 0);
+
+        // ---- gate arithmetic (register local) -> c, h (LDS rows of the next step, this wave's units) ------------------
+#pragma unroll
+        for (int uw = 0; uw < UW; ++uw) {
+            const int tile = wave * UW + uw;
+            f32x4 bias[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias[q] = *reinterpret_cast<const f32x4*>(c_gb + q * U + 64 * tile + 4 * b);
+#pragma unroll
+            for (int c = 0; c < MT; ++c) {
+                f32x4 z[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[q] = acc[q * UW + uw][c] + bias[q];
+                f32x4 cn, hn;
+                if (p.cell_act == L2A_ACT_TANH) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const float ig = l2a_fast_sigmoid(z[0][ii]);
+                        const float jg = l2a_fast_tanh(z[1][ii]);
+                        const float fg = l2a_fast_sigmoid(z[2][ii] + 1.0f);
+                        const float og = l2a_fast_sigmoid(z[3][ii]);
+                        cn[ii] = fmaf(fg, creg[uw][c][ii], ig * jg);
+                        hn[ii] = og * l2a_fast_tanh(cn[ii]);
+                    }
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const float ig = l2a_fast_sigmoid(z[0][ii]);
+                        const float jg = l2a_act1(z[1][ii], p.cell_act);
+                        const float fg = l2a_fast_sigmoid(z[2][ii] + 1.0f);
+                        const float og = l2a_fast_sigmoid(z[3][ii]);
+                        cn[ii] = fmaf(fg, creg[uw][c][ii], ig * jg);
+                        hn[ii] = og * l2a_act1(cn[ii], p.cell_act);
+                    }
+                }
+                creg[uw][c] = cn;
+                *reinterpret_cast<f32x4*>(rows_n + (4 * c + j) * ROWF + 64 * tile + 4 * b) = hn;
+            }
+        }
+
+        // ---- output layer over this wave's units (its two chunks of the canonical tree), B = its own new h -----------
+        {
+#pragma unroll
+            for (int g = 0; g < NGO / 2; ++g) pfo[1][g] = l2a_ldw(rsO, voffO + (NGO / 2 + g) * 1024, 0);
+            const float* hb = rows_n + j * ROWF + 64 * UW * wave;
+            f32x4 oacc[2][MT];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int c = 0; c < MT; ++c) oacc[ch][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int g = 0; g < NGO / 2; ++g) {
+                    f32x4 hb4[MT];
+#pragma unroll
+                    for (int c = 0; c < MT; ++c)
+                        hb4[c] = *reinterpret_cast<const f32x4*>(hb + 4 * c * ROWF + 4 * (ch * (NGO / 2) + g));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < MT; ++c) oacc[ch][c] = L2A_MFMA4(pfo[ch][g][e], hb4[c][e], oacc[ch][c]);
+                }
+#pragma unroll
+            for (int c = 0; c < MT; ++c) pb[(wave * MT + c) * 64 + lane] = oacc[0][c] + oacc[1][c];
+        }
+        __syncthreads();
+
+        // ---- canonical reduce, output activation, denormalisation, reward, state update (every wave, all micro tiles) --
+        const float disc_t = (float)disc_pow;
+        disc_pow *= p.discount;
+        {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(c_bo + 4 * b);
+            const f32x4 omu = *reinterpret_cast<const f32x4*>(c_out_mu + 4 * b);
+            const f32x4 osd = *reinterpret_cast<const f32x4*>(c_out_sd + 4 * b);
+            f32x4 part[MT][4];
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) part[c][w] = pb[(w * MT + c) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < MT; ++c) {
+                f32x4 s = (part[c][0] + part[c][1]) + (part[c][2] + part[c][3]);
+                s = l2a_act4(s + bias, p.output_act);
+                const f32x4 d = s * osd + omu;
+                const f32x4 nx = st[c] + d;
+                // reward in the 16-candidate kernel's order: quarter partials r_qq (lanes b = qq < 4), (r0 + r1) + (r2 + r3)
+                float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[c];
+                float psq = 0.0f;
+                const int vi = p.rw.vel_index;
+                const float dsel = (vi & 2) ? ((vi & 1) ? d[3] : d[2]) : ((vi & 1) ? d[1] : d[0]);
+                const float dvel = __shfl(dsel, (vi & ~3) | j);                 // from the lane that holds dim vel_index
+                if (qq == ((vi >> 2) & 3)) plin += p.rw.w_vel * dvel * p.rw.inv_dt;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int dim = 4 * b + ii;
+                    const bool in_dist = (p.rw.dist_coef != 0.0f) && (dim >= p.rw.dist_index) &&
+                                         (dim < p.rw.dist_index + 3) && (dim < obs_dim);
+                    psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
+                }
+                st[c] = nx;
+                plin = plin + __shfl_xor(plin, 4);
+                plin = plin + __shfl_xor(plin, 8);
+                float r = plin;
+                if (p.rw.dist_coef != 0.0f) {
+                    psq = l2a_sum_xor32(l2a_sum_xor16(psq));                    // over the obs tiles of a quarter (one is non-zero)
+                    psq = psq + __shfl_xor(psq, 4);
+                    psq = psq + __shfl_xor(psq, 8);
+                    r -= p.rw.dist_coef * sqrtf(psq);
+                }
+                ret[c] = fmaf(disc_t, r, ret[c]);
+            }
+        }
+        // the next step's inputs
+#pragma unroll
+        for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+        load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
+        write_x(rows_n);
+    }
+
+    // ---- results: wave 0, lanes of block 0 hold the returns of the candidates cand0 + 4 c + j ----------------------------
+    if (wave == 0) {
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            if (valid[c] && b == 0) {
+                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[c]] = ret[c];
+                const unsigned long long k = l2a_key_pack(ret[c], p.cand_offset + cand[c]);
+                key = (k > key) ? k : key;
+            }
+        }
+        if (p.best_key) {
+#pragma unroll
+            for (int off = 2; off >= 1; off >>= 1) {
+                const unsigned int hi = __shfl_xor((unsigned int)(key >> 32), off);
+                const unsigned int lo = __shfl_xor((unsigned int)(key & 0xffffffffu), off);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key = (other > key) ? other : key;
+            }
+            if (lane == 0) {
+                if (key != 0ull) atomicMax(p.best_key + env, key);
+                l2a_publish_result(p, (int)gridDim.x);
+            }
+        }
+    }
+}
+
+// Workgroup -> (env, first candidate, micro tiles): every env's ceil(n / 4) micro tiles are dealt to p.mc_w workgroups,
+// the first p.mc_r of them take p.mc_hi micro tiles, the others one fewer (host: l2a_lstm_api.hip).
+template <int UW>
+__global__ void __launch_bounds__(256) l2a_lstm_micro_k(const L2ALstmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
+    const int env = (int)blockIdx.x / p.mc_w;
+    const int idx = (int)blockIdx.x - env * p.mc_w;
+    const int mt = idx < p.mc_r ? p.mc_hi : p.mc_hi - 1;
+    const int q0 = idx < p.mc_r ? idx * p.mc_hi : p.mc_r * p.mc_hi + (idx - p.mc_r) * (p.mc_hi - 1);
+    if (mt == 3) l2a_lstm_micro_body<3, UW>(p, env, 4 * q0, l2a_smem);
+    else if (mt == 2) l2a_lstm_micro_body<2, UW>(p, env, 4 * q0, l2a_smem);
+    else l2a_lstm_micro_body<1, UW>(p, env, 4 * q0, l2a_smem);
+}

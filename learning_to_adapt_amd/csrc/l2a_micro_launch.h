@@ -1,0 +1,9 @@
+// l2a_micro_launch.h - host-side entry points of the micro-tile kernel instances (l2a_micro_inst.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+struct L2ALstmParams;
+
+// Returns 0, a hipError_t (> 0) or -100 when no instance exists for the shape.
+int l2a_launch_lstm_micro(int units, const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream);

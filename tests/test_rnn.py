@@ -598,6 +598,55 @@ def test_gpu_rnn_unit_tile_split_is_bit_identical(units, m, n, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("units,m,n,h,env_name", [(256, 5, 500, 10, "hc"), (256, 1, 2000, 6, "hc"), (256, 2, 37, 3, "hc"), (256, 3, 333, 4, "hc"),
+                                                  (256, 1, 5, 2, "hc"), (512, 2, 500, 3, "hc"), (256, 5, 250, 4, "hc"), (256, 64, 12, 2, "hc"),
+                                                  (256, 5, 500, 5, "ant"), (256, 2, 100, 3, "arm")])
+def test_gpu_rnn_micro_tiles_are_bit_identical(units, m, n, h, env_name):
+    """The micro-tile kernel (csrc/l2a_micro.h: candidate tiles of FOUR on the 4x4x1 MFMA, workgroups of 4 / 8 / 12
+    candidates, no exchange) against the 16-candidate kernel, split and unsplit: every return and the arg-max keys bit
+    for bit, from non-zero hidden states, with a discount, ragged last tiles, more envs than a workgroup per CU allows
+    three micro tiles for (falls back), through the plain and the blocking entry point."""
+    from learning_to_adapt_amd import _lib
+    base = {"hc": "hc_rnn_rs_u128_n40_h3"}.get(env_name, "hc_rnn_rs_u128_n40_h3")
+    case = dict(cases.CASES[base], units=units, m=m, n=n, h=h)
+    if env_name != "hc":
+        case["env"] = {"ant": "ant", "arm": "arm_7dof"}[env_name]
+    env, model = cases.product_rnn_model(case)
+    native = model.planner_model()
+    dev = native.device
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    ctx = _lib.Context.get(0)
+    rs = np.random.RandomState(units + n + m)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    obs0, c0 = up(rs.randn(m, od)), up(rs.randn(m, units))
+    h0 = up(np.tanh(rs.randn(m, units)))
+    lo, hi_ = env.action_space.low, env.action_space.high
+    acts = up(rs.uniform(lo, hi_, (h, m * n, ad)))
+    out = {}
+    try:
+        for micro, split in ((0, 0), (0, 1), (2, 1)):
+            ctx.set_micro(micro)
+            ctx.set_split(split)
+            rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(obs0, c0, h0, acts, m, n, h, 0.97, env.reward_spec, cand_offset=11, returns_out=rets, best_key=best)
+            keys_only = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(obs0, c0, h0, acts, m, n, h, 0.97, env.reward_spec, cand_offset=11, best_key=keys_only)
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            out[(micro, split)] = [t.cpu().numpy() for t in (rets, best, keys_only)]
+    finally:
+        ctx.set_micro(1)
+        ctx.set_split(1)
+    ref = out[(0, 0)]
+    assert np.array_equal(ref[1], ref[2])
+    assert np.isfinite(ref[0]).all()
+    for k in ((0, 1), (2, 1)):
+        for a, b in zip(ref, out[k]):
+            assert np.array_equal(a, b), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cell,units,m,n,h", [("lstm", (256,), 5, 500, 10), ("lstm", (256,), 1, 2000, 6),
                                               ("lstm", (128,), 3, 77, 4), ("gru", (64,), 2, 90, 3),
                                               ("lstm", (64, 32), 2, 50, 3)])
