@@ -30,6 +30,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # recurrent kernels get more accumulator moves, not fewer (70 -> 231 in the U = 256 instance).
 KERNEL_FLAGS = ["-mllvm", "--amdgpu-mfma-vgpr-form"]
 LSTM_FLAGS = []
+MICRO_FLAGS = []
 
 
 def _hipcc():
@@ -52,68 +53,114 @@ def build_rng(verbose=True):
     return RNG_OUT
 
 
+def _obj_fresh(obj):
+    """An object is fresh when it is newer than every file its compilation read (hipcc -MD writes the list next to it)
+    and than this script."""
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(obj) or not os.path.exists(dep):
+        return False
+    t = os.path.getmtime(obj)
+    with open(dep) as f:
+        words = f.read().replace("\\\n", " ").split()
+    files = [w for w in words[1:] if not w.endswith(":")]
+    own = [w for w in files if not w.startswith("/opt/") and not w.startswith("/usr/")]     # toolchain headers do not change under us
+    return all(os.path.exists(w) and os.path.getmtime(w) <= t for w in own + [os.path.abspath(__file__)])
+
+
 def up_to_date():
     if not os.path.exists(OUT) or (shutil.which("gcc") and not os.path.exists(RNG_OUT)):
         return False
     t = os.path.getmtime(OUT)
+    if os.path.isdir(OBJ_DIR) and os.listdir(OBJ_DIR):
+        if not all(_obj_fresh(os.path.join(OBJ_DIR, o)) and os.path.getmtime(os.path.join(OBJ_DIR, o)) <= t for o in unit_table()):
+            return False
+        return os.path.getmtime(os.path.join(HERE, "l2a_rng.c")) <= os.path.getmtime(RNG_OUT) if os.path.exists(RNG_OUT) else True
+    # a library that travelled without its objects (the GPU box) is judged by the sources' time stamps
     deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
 def _compile(job):
     src, obj, defs = job
-    cmd = [_hipcc()] + FLAGS + defs + ["-c", os.path.join(HERE, src), "-o", obj]
+    cmd = [_hipcc()] + FLAGS + defs + ["-MD", "-MF", obj[:-2] + ".d", "-c", os.path.join(HERE, src), "-o", obj]
     subprocess.check_call(cmd, cwd=HERE)
     return obj
 
 
+def unit_table():
+    """Every translation unit of libl2a_hip.so: object name -> (source, extra flags)."""
+    t = {"l2a_api.o": ("l2a_api.hip", []),
+         # (holds the generic recurrent matrix-core kernel, l2a_rnn_mfma.h: its small accumulator tiles are read by the gate
+         # arithmetic right away - in architectural VGPRs that needs no v_accvgpr moves, 590 of them otherwise)
+         "l2a_lstm_api.o": ("l2a_lstm_api.hip", KERNEL_FLAGS),
+         "l2a_comm.o": ("l2a_comm.hip", []),
+         "l2a_cem.o": ("l2a_cem.hip", []),
+         "l2a_micro.o": ("l2a_micro_inst.hip", MICRO_FLAGS)}
+    for utw in LSTM_INSTANCES:
+        t["l2a_lstm_%d.o" % utw] = ("l2a_lstm_inst.hip", ["-DL2A_INST_UTW=%d" % utw] + LSTM_FLAGS)
+    for nt, tpw in INSTANCES:
+        t["l2a_mfma_%d_%d.o" % (nt, tpw)] = ("l2a_mfma_inst.hip", ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw] +
+                                               (KERNEL_FLAGS if nt == 1 else []))
+    return t
+
+
+def link(objs, out):
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], cwd=HERE)
+    return out
+
+
 def relink(units, verbose=True):
-    """Developer shortcut: recompile the named translation units only (``l2a_micro_inst.hip`` ...) and link with the other
-    cached objects."""
-    table = {"l2a_api.hip": ("l2a_api.o", []), "l2a_lstm_api.hip": ("l2a_lstm_api.o", KERNEL_FLAGS), "l2a_comm.hip": ("l2a_comm.o", []),
-             "l2a_cem.hip": ("l2a_cem.o", []), "l2a_micro_inst.hip": ("l2a_micro.o", [])}
-    jobs = [(u, os.path.join(OBJ_DIR, table[u][0]), table[u][1]) for u in units]
+    """Developer shortcut: recompile the named objects only (``l2a_micro.o`` ...) and link with the other cached objects."""
+    table = unit_table()
+    jobs = [(table[u][0], os.path.join(OBJ_DIR, u), table[u][1]) for u in units]
     with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as pool:
         list(pool.map(_compile, jobs))
-    objs = [os.path.join(OBJ_DIR, o) for o in ("l2a_api.o", "l2a_lstm_api.o", "l2a_comm.o", "l2a_cem.o", "l2a_micro.o")]
-    objs += [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
-    objs += [os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % u) for u in LSTM_INSTANCES]
-    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"], cwd=HERE)
-    return OUT
+    return link([os.path.join(OBJ_DIR, o) for o in table], OUT)
+
+
+def variant(name, units, defs):
+    """Developer aid for A/B runs on one GPU box: ``libl2a_hip_<name>.so`` whose objects `units` are compiled with the extra
+    flags `defs`; every other object is the regular build's (select the library at run time with L2A_LIB_PATH)."""
+    table = unit_table()
+    jobs, objs = [], []
+    for o, (src, flags) in table.items():
+        if o in units:
+            vo = os.path.join(OBJ_DIR, o[:-2] + "_" + name + ".o")
+            jobs.append((src, vo, flags + list(defs)))
+            objs.append(vo)
+        else:
+            objs.append(os.path.join(OBJ_DIR, o))
+    with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as pool:
+        list(pool.map(_compile, jobs))
+    return link(objs, os.path.join(PKG, "libl2a_hip_%s.so" % name))
 
 
 def build(force=False, verbose=True, only=None):
-    """``only``: optional list of (NT, TPW) pairs to (re)compile - the others reuse their cached
-    objects (developer shortcut; a clean build compiles all six)."""
+    """Compiles the translation units whose object is missing or older than a file it includes (all of them with
+    ``force``) and links.  ``only``: optional list of (NT, TPW) pairs - the other MFMA instances are left as they are even
+    when stale (developer shortcut for A/B work on one instance)."""
     if not force and only is None and up_to_date():
         if verbose:
             print("[l2a] %s is up to date" % OUT)
         return OUT
     os.makedirs(OBJ_DIR, exist_ok=True)
-    jobs = [("l2a_api.hip", os.path.join(OBJ_DIR, "l2a_api.o"), []),
-            # (holds the generic recurrent matrix-core kernel, l2a_rnn_mfma.h: its small accumulator tiles are read by the gate
-            # arithmetic right away - in architectural VGPRs that needs no v_accvgpr moves, 590 of them otherwise)
-            ("l2a_lstm_api.hip", os.path.join(OBJ_DIR, "l2a_lstm_api.o"), KERNEL_FLAGS),
-            ("l2a_comm.hip", os.path.join(OBJ_DIR, "l2a_comm.o"), []),
-            ("l2a_cem.hip", os.path.join(OBJ_DIR, "l2a_cem.o"), []),
-            ("l2a_micro_inst.hip", os.path.join(OBJ_DIR, "l2a_micro.o"), [])]
-    for utw in LSTM_INSTANCES:
-        jobs.append(("l2a_lstm_inst.hip", os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % utw), ["-DL2A_INST_UTW=%d" % utw] + LSTM_FLAGS))
-    for nt, tpw in INSTANCES:
-        obj = os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % (nt, tpw))
-        if only is not None and (nt, tpw) not in only and os.path.exists(obj):
+    table = unit_table()
+    jobs = []
+    for o, (src, flags) in table.items():
+        obj = os.path.join(OBJ_DIR, o)
+        if only is not None and o.startswith("l2a_mfma_") and os.path.exists(obj) and \
+                tuple(int(x) for x in o[len("l2a_mfma_"):-2].split("_")) not in only:
             continue
-        jobs.append(("l2a_mfma_inst.hip", obj, ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw] + (KERNEL_FLAGS if nt == 1 else [])))
+        if not force and only is None and _obj_fresh(obj):
+            continue
+        jobs.append((src, obj, flags))
     if verbose:
-        print("[l2a] hipcc %s : %d translation units, %d parallel jobs"
-              % (" ".join(FLAGS), len(jobs), min(len(jobs), os.cpu_count() or 1)))
-    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
-        list(pool.map(_compile, jobs))
-    objs = [os.path.join(OBJ_DIR, "l2a_api.o"), os.path.join(OBJ_DIR, "l2a_lstm_api.o"), os.path.join(OBJ_DIR, "l2a_comm.o"),
-            os.path.join(OBJ_DIR, "l2a_cem.o"), os.path.join(OBJ_DIR, "l2a_micro.o")]
-    objs += [os.path.join(OBJ_DIR, "l2a_mfma_%d_%d.o" % i) for i in INSTANCES]
-    objs += [os.path.join(OBJ_DIR, "l2a_lstm_%d.o" % u) for u in LSTM_INSTANCES]
-    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"], cwd=HERE)
+        print("[l2a] hipcc %s : %d of %d translation units, %d parallel jobs"
+              % (" ".join(FLAGS), len(jobs), len(table), min(max(len(jobs), 1), os.cpu_count() or 1)))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(_compile, jobs))
+    link([os.path.join(OBJ_DIR, o) for o in table], OUT)
     build_rng(verbose)
     return OUT
 
@@ -122,7 +169,7 @@ if __name__ == "__main__":
     only = None
     for a in sys.argv[1:]:
         if a.startswith("--units="):
-            relink(a[len("--units="):].split(","))
+            relink([u if u.endswith(".o") else u + ".o" for u in a[len("--units="):].split(",")])
             sys.exit(0)
         if a.startswith("--only="):
             only = [tuple(int(x) for x in part.split("x")) for part in a[len("--only="):].split(",")]

@@ -27,6 +27,8 @@
 // Rows beyond `rows` (padding up to 16) carry dZ = 0 and therefore no gradient.
 #pragma once
 
+#include "l2a_micro_pack.h"
+
 #include "l2a_kernels.h"
 #include "l2a_valu.h"
 
@@ -307,6 +309,8 @@ struct L2AAdaptDst {
     long long raw_w[L2A_MAX_LAYERS], raw_b[L2A_MAX_LAYERS], pk[L2A_MAX_LAYERS];
     long long pk_bout;
     int has_pk;
+    int has_mk, mk_H, mk_KG0, mk_o4;        // the micro-tile kernel's copy (l2a_micro_pack.h), at offset mk
+    long long mk;
     float lr;
     int first_block[L2A_MAX_LAYERS + 1];    // prefix sums of the layers' workgroup counts
 };
@@ -347,6 +351,7 @@ __global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p
             const long long pidx = ((((long long)(u >> 4) * KG + (k >> 4)) * 64 + ((u & 15) + 16 * ((k & 15) >> 2))) << 2) + (k & 3);
             dst[d.pk[l] + pidx] = wn;
         }
+        if (d.has_mk) dst[d.mk + l2a_mlp_micro_index(d.mk_H, d.mk_KG0, p.n_layers - 1, d.mk_o4, l, k, u)] = wn;
     }
     if (kc == 0) {
         float gb = 0.0f;

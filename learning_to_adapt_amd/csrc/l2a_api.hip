@@ -9,6 +9,8 @@
 #include "l2a_valu.h"
 #include "l2a_adapt.h"
 #include "l2a_mfma_launch.h"
+#include "l2a_micro_pack.h"
+#include "l2a_micro_launch.h"
 
 #include <chrono>
 #include <cmath>
@@ -46,6 +48,9 @@ struct l2a_model {
     long long raw_w[L2A_MAX_LAYERS] = {0};
     long long raw_b[L2A_MAX_LAYERS] = {0};
     long long pk_w0 = 0, pk_wmid = 0, pk_wmid_stride = 0, pk_wout = 0, pk_bout = 0, nm_off = 0;
+    bool micro_ok = false;                        // the micro-tile kernel of l2a_micro.h has an instance (hidden width 256 / 512)
+    int m_o4 = 0;                                 // ... and sums dims 16 .. 19 per quarter of the hidden units, like the 16-candidate O4 instance
+    long long pk_m = 0;                           // its copy of a set's weights (wave-stream order, l2a_micro_pack.h)
     std::vector<char> weights_set, norm_set;
     std::vector<std::vector<float>> norm_stage;   // host staging, kept alive for async H2D
     unsigned long long* xbuf = nullptr;           // member-split exchange granules
@@ -143,6 +148,43 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         return fail(ctx, L2A_EINVAL, "model shape is not eligible for the MFMA kernel "
                                      "(needs equal hidden widths of 128/256/512, obs_dim<=64, act_dim<=16)");
 
+    if (kind == L2A_KERNEL_MFMA && md->micro_ok && ctx->micro_policy != 0) {
+        // Micro tiles (l2a_micro.h): every env's ceil(n / 4) candidate tiles of four dealt to W workgroups of at most three -
+        // one workgroup per CU, none idle, no exchange between workgroups.  Plans only (no per-row start states, no state
+        // written out: those launches are one step long or chunk continuations and keep the 16-candidate kernel - same bits).
+        const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+        const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
+        const long long tiles16 = (long long)p.m * ceil_div(p.n, 16);
+        const int quads = ceil_div(p.n, 4);
+        int W = cus / p.m;
+        if (W > quads) W = quads;
+        const int hi = W > 0 ? ceil_div(quads, W) : 99;
+        const int smem_need = l2a_mlp_micro_smem(md->H, md->KG0, md->n_hidden, e_loop);
+        const long long span = (long long)((p.mode == L2A_MODE_PER_BLOCK ? p.m : e_loop) - 1) * md->set_stride * 4 +
+                               l2a_mlp_micro_floats(md->H, md->KG0, md->n_hidden) * 4;
+        const bool eligible = !p.obs_per_row && !p.state_out && hi <= 3 && (p.returns_out || p.best_key) &&
+                              smem_need <= ctx->lds_per_block && span < (1LL << 31);
+        // automatic: the plans the 16-candidate geometries cannot fill - more than CUs / 2 tiles (no tile split) and fewer
+        // than CUs - and small single-model plans, whose tile split is bound by its per-step exchange
+        const bool unfilled = 2 * tiles16 > cus && tiles16 < cus;
+        const bool small_single = e_loop == 1 && 2 * tiles16 <= cus;
+        const bool wanted = ctx->micro_policy == 2 || (ctx->micro_policy == 1 && (unfilled || small_single));
+        if (eligible && wanted) {
+            p.mc_w = W;
+            p.mc_hi = hi;
+            p.mc_r = quads - W * (hi - 1);          // workgroups that take `hi` micro tiles
+            p.m_bytes = span;
+            p.dbg = ctx->dbg;
+            int smem_m = smem_need;
+            if (smem_m < 84 * 1024) smem_m = 84 * 1024;     // more than half a CU's LDS: one workgroup per CU
+            const bool gact_m = !(fast_act(md->hidden_act) && fast_act(md->output_act)) || md->n_hidden == 1;
+            const int rc = l2a_launch_mlp_micro(md->H, gact_m ? 1 : 0, &p, (unsigned)(p.m * W), smem_m, stream);
+            if (rc != 0) return fail(ctx, L2A_EHIP, std::string("micro-tile MLP kernel launch: ") +
+                                                        (rc > 0 ? hipGetErrorString((hipError_t)rc) : "no instance"));
+            L2A_HIP(ctx, hipGetLastError());
+            return L2A_OK;
+        }
+    }
     if (kind == L2A_KERNEL_MFMA) {
         const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
         const int cst_bytes = e_loop0 * (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4;
@@ -276,6 +318,8 @@ void fill_model_params(const l2a_model* md, L2AKParams& p) {
     }
     p.pk_w0 = md->pk_w0; p.pk_wmid = md->pk_wmid; p.pk_wmid_stride = md->pk_wmid_stride;
     p.pk_wout = md->pk_wout; p.pk_bout = md->pk_bout; p.nm_off = md->nm_off;
+    p.pk_m = md->pk_m; p.m_o4 = md->m_o4;
+    p.m_nrec = md->micro_ok ? l2a_mlp_micro_nrec(md->H, md->KG0, md->n_hidden) : 0;
     p.n_hidden = md->n_hidden;
     p.obs_dim = md->obs_dim; p.act_dim = md->act_dim; p.in_dim = md->in_dim;
     p.hidden_act = md->hidden_act; p.output_act = md->output_act;
@@ -500,6 +544,12 @@ int l2a_model_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_hidden, const
         md->pk_wmid_stride = packed_floats(md->H, md->H);
         md->pk_wmid = take(md->pk_wmid_stride * (n_hidden - 1));
         md->pk_wout = take(packed_floats(md->H, obs_dim));
+        md->micro_ok = (md->H == 256 || md->H == 512);
+        if (md->micro_ok) {
+            // the quarter sums of the O4 instance (l2a_mfma_inst.hip picks it for exactly these shapes)
+            md->m_o4 = (md->OT == 2 && md->KG0 == 2 && n_hidden > 1 && obs_dim - 16 <= 4) ? 1 : 0;
+            md->pk_m = take(l2a_mlp_micro_floats(md->H, md->KG0, n_hidden));
+        }
     }
     md->pk_bout = take(16 * md->OT);
     md->nm_off = take(32 * md->KG0 + 32 * md->OT);
@@ -576,6 +626,12 @@ int l2a_model_set_weights_strided(l2a_model* md, int first_set, int count, const
             hipLaunchKernelGGL(l2a_pack_layer_k, grid, dim3(256), 0, stream, w, ws, k_in, n_out, KG, total, dst,
                                md->set_stride);
             L2A_HIP(ctx, hipGetLastError());
+            if (md->micro_ok) {
+                const dim3 mgrid((unsigned)(((long long)k_in * n_out + 255) / 256), (unsigned)count);
+                hipLaunchKernelGGL(l2a_mlp_micro_pack_k, mgrid, dim3(256), 0, stream, w, ws, k_in, n_out, l, md->H, md->KG0,
+                                   md->n_hidden, md->m_o4, blk + md->pk_m, md->set_stride);
+                L2A_HIP(ctx, hipGetLastError());
+            }
         }
         if (l == md->n_hidden)      // padded copy of the output bias (the tail beyond obs_dim stays zero)
             L2A_HIP(ctx, copy_sets(blk + md->pk_bout, b, bs, (size_t)n_out));
@@ -643,6 +699,8 @@ int adapt_enqueue(l2a_model* md, const L2AAdaptParams& ap, int m, float lr, hipS
     d.blk = md->wblk;
     d.set_stride = md->set_stride;
     d.has_pk = md->mfma_ok ? 1 : 0;
+    d.has_mk = md->micro_ok ? 1 : 0;
+    d.mk = md->pk_m; d.mk_H = md->H; d.mk_KG0 = md->KG0; d.mk_o4 = md->m_o4;
     d.pk_bout = md->pk_bout;
     d.lr = lr;
     for (int l = 0; l < L; ++l) {

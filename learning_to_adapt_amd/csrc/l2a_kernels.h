@@ -59,6 +59,13 @@ struct L2AKParams {
     int cst_off;                // MFMA: start of the constants in LDS, in f32x4 elements from the base
     int n_cst;                  // MFMA: constant slots laid out (>= the sets any workgroup of the launch runs)
     float hid_floor, out_floor; // MFMA fast activations: relu = max(x, 0), identity = max(x, -inf)
+    // micro-tile kernel (l2a_micro.h): its copy of a set's weights in wave-stream order (l2a_micro_pack.h), records per stream,
+    // whether dims 16 .. 19 are summed per quarter of the hidden units like the 16-candidate O4 instance, bytes the stream
+    // descriptor spans (all sets), and the launch geometry: workgroups per env, how many of them take mc_hi micro tiles
+    long long pk_m;
+    int m_nrec, m_o4;
+    long long m_bytes;
+    int mc_w, mc_r, mc_hi;
     int hmax;                   // VALU: widest hidden layer
     // ---- launch ------------------------------------------------------------------------
     const float* obs0;          // [m, obs_dim] (or [R, obs_dim] when obs_per_row)

@@ -32,6 +32,7 @@
 
 #include "l2a_lstm.h"
 #include "l2a_micro_pack.h"
+#include "l2a_micro_launch.h"
 
 template <int I, int N, class F>
 __device__ __forceinline__ void l2a_static_for(F&& f) {
@@ -50,6 +51,49 @@ __device__ __forceinline__ void l2a_micro_hint() {
         __builtin_amdgcn_sched_group_barrier(0x008, (i == NOP - 1) ? NM - PER * (NOP - 1) : PER, 0);
     });
 }
+
+// Lane moves at VALU rate (no LDS crossbar round trip like ds_bpermute: the reduce tail of a step was 1.8k clocks of
+// dependent __shfl's, timeline r04).  DPP row_shl:n - lane l of a 16-lane row reads lane l + n of its row; only lanes whose
+// source exists are used (block 0 of a row for n = 4, 8).
+template <int N>
+__device__ __forceinline__ float l2a_row_shl(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + N, 0xf, 0xf, true));
+}
+// (x0 + x1) + (x2 + x3) over the four 4-lane blocks of a 16-lane row, valid in the row's block 0
+__device__ __forceinline__ float l2a_row_quarter_sum(float x) {
+    const float t = x + l2a_row_shl<4>(x);
+    return t + l2a_row_shl<8>(t);
+}
+// the value the same lane position holds in 16-lane row `r` (wave uniform), valid in row 0 (l2a_sum_xor16 / 32: the swap
+// instructions return {own, other})
+__device__ __forceinline__ float l2a_from_row(float x, int r) {
+    if (r & 1) {
+        const unsigned int u = __float_as_uint(x);
+        x = __uint_as_float(__builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);
+    }
+    if (r & 2) {
+        const unsigned int u = __float_as_uint(x);
+        x = __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
+    }
+    return x;
+}
+
+// Phase timeline for tools/timeline_micro.py (builds with -DL2A_TIMELINE only): the waves of workgroup 0 stamp the shader
+// clock, dbg[(t * 4 + wave) * 16 + slot].
+#ifndef L2A_TIMELINE
+#define L2A_MTS(slot)
+#define L2A_MTS_AT(step, slot)
+#else
+#define L2A_MTS_AT(step, slot) { const int t = (step); L2A_MTS(slot) }
+#define L2A_MTS(slot)                                                                       \
+    if (p.dbg && blockIdx.x == 0) {                                                         \
+        unsigned long long ts_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (lane == 0) p.dbg[((long long)t * 4 + wave) * 16 + (slot)] = ts_;                \
+    }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // Recurrent planner (one LSTM layer of 256 / 512 units: l2a_lstm.h is the 16-candidate kernel, same arithmetic)
@@ -82,6 +126,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
     const int qq = b & 3;                   // the lane's role in the 16-candidate kernels' quarter sums (dims 16 c + 4 qq + ii)
     const int obs_dim = p.obs_dim, act_dim = p.act_dim;
     const int R = p.m * p.n;
+    L2A_MTS_AT(0, 8)
 
     for (int i = tid; i < 32 * KG0 + 192 + 4 * U; i += 256) {
         float v;
@@ -98,6 +143,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
     }
     for (int i = tid; i < 2 * 12 * ROWF; i += 256) rows[i] = 0.0f;  // padding (and rows of absent micro tiles) stay zero
     __syncthreads();
+    L2A_MTS_AT(0, 9)
 
     int cand[MT], row[MT];
     bool valid[MT];
@@ -165,18 +211,39 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                     dst[c][s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[c][s][ii], 0, 0));
     };
     // normalised inputs of the coming step -> the x section of `dst` rows (chain order); every wave writes all of them
-    // (identical values) and reads them back behind its own writes: no barrier between the state update and the x part
+    // (identical values) and reads them back behind its own writes: no barrier between the state update and the x part.
+    // Branch-free: a lane's normalisation constants and the row offsets of its values are loop invariants (registers); a slot
+    // that holds no feature of this lane goes to the row's padding (floats U + 80 .. U + 87, never read).  (With a guard per
+    // element the compiler serialised read - wait - compute - write behind a branch each: 5.4k clocks per step, timeline r04.)
     f32x4 av[MT][2];
     float asq[MT];
+    int xo_s[4], xo_a[2][4];
+    f32x4 mu_s, iv_s, mu_a[2], iv_a[2];
+    {
+        mu_s = *reinterpret_cast<const f32x4*>(c_in_mu + 4 * b);        // (past the inputs: other constants, unused)
+        iv_s = *reinterpret_cast<const f32x4*>(c_in_iv + 4 * b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * b + i;
+            xo_s[i] = U + ((k < obs_dim) ? l2a_chain_k(k) : 80 + (lane & 7));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            mu_a[s2] = *reinterpret_cast<const f32x4*>(c_in_mu + 16 * (ga0 + s2) + 4 * qq);
+            iv_a[s2] = *reinterpret_cast<const f32x4*>(c_in_iv + 16 * (ga0 + s2) + 4 * qq);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int k = 16 * (ga0 + s2) + 4 * qq + ii;
+                xo_a[s2][ii] = U + ((b < 4 && k >= obs_dim && k < obs_dim + act_dim) ? l2a_chain_k(k) : 80 + (lane & 7));
+            }
+        }
+    }
     auto write_x = [&](float* dst) {
 #pragma unroll
         for (int c = 0; c < MT; ++c) {
-            float* xr = dst + (4 * c + j) * ROWF + U;
+            float* xr = dst + (4 * c + j) * ROWF;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = 4 * b + i;
-                if (k < obs_dim) xr[l2a_chain_k(k)] = ((st[c][i] + 0.0f) - c_in_mu[k]) * c_in_iv[k];
-            }
+            for (int i = 0; i < 4; ++i) xr[xo_s[i]] = ((st[c][i] + 0.0f) - mu_s[i]) * iv_s[i];
             float s = 0.0f;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
@@ -184,16 +251,10 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                 s = fmaf(av[c][1][ii], av[c][1][ii], s);
             }
             asq[c] = s;
-            if (b < 4) {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int k = 16 * (ga0 + s2) + 4 * qq + ii;
-                        if (k >= obs_dim && k < obs_dim + act_dim)
-                            xr[l2a_chain_k(k)] = ((0.0f + av[c][s2][ii]) - c_in_mu[k]) * c_in_iv[k];
-                    }
-            }
+                for (int ii = 0; ii < 4; ++ii) xr[xo_a[s2][ii]] = ((0.0f + av[c][s2][ii]) - mu_a[s2][ii]) * iv_a[s2][ii];
         }
     };
     load_actions(0, av_next);
@@ -236,6 +297,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
     issue_a(0, std::integral_constant<int, 1024>(), I1());
     issue_a(0, std::integral_constant<int, 2048>(), I2());
     __syncthreads();        // every wave's share of h(0) is in the rows
+    L2A_MTS_AT(0, 10)
 
     for (int t = 0; t < p.h; ++t) {
         float* rows_c = rows + (t & 1) * 12 * ROWF;
@@ -245,6 +307,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
         const float* hb_oth = rows_c + j * ROWF + (1 - own) * (U / 2);
         const float* xb = rows_c + j * ROWF + U;
 
+        L2A_MTS(0)
         f32x4 acc[NTL][MT];
 #pragma unroll
         for (int tl = 0; tl < NTL; ++tl)
@@ -281,6 +344,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
         segment(hb_oth, HI, xb);
         segment(xb, KG0, xb);
         __builtin_amdgcn_sched_barrier(0);
+        L2A_MTS(1)
 
         // output-layer operands of this wave's first chunk: in flight under the gate arithmetic
         f32x4 pfo[2][NGO / 2];
@@ -326,6 +390,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
             }
         }
 
+        L2A_MTS(2)
         // ---- output layer over this wave's units (its two chunks of the canonical tree), B = its own new h -----------
         {
 #pragma unroll
@@ -336,23 +401,33 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
             for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
                 for (int c = 0; c < MT; ++c) oacc[ch][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // (the activations of eight k-groups at a time, all reads issued before the first MFMA: read where they are used,
+            // every k-group paid an exposed LDS round trip - 4.1k clocks for 1.5k of MFMA issue, timeline r04)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-                for (int g = 0; g < NGO / 2; ++g) {
-                    f32x4 hb4[MT];
+                for (int g0 = 0; g0 < NGO / 2; g0 += 8) {
+                    f32x4 hb4[8][MT];
 #pragma unroll
-                    for (int c = 0; c < MT; ++c)
-                        hb4[c] = *reinterpret_cast<const f32x4*>(hb + 4 * c * ROWF + 4 * (ch * (NGO / 2) + g));
+                    for (int g = 0; g < 8; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                        for (int c = 0; c < MT; ++c)
+                            hb4[g][c] = *reinterpret_cast<const f32x4*>(hb + 4 * c * ROWF + 4 * (ch * (NGO / 2) + g0 + g));
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int c = 0; c < MT; ++c) oacc[ch][c] = L2A_MFMA4(pfo[ch][g][e], hb4[c][e], oacc[ch][c]);
+                    for (int g = 0; g < 8; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int c = 0; c < MT; ++c) oacc[ch][c] = L2A_MFMA4(pfo[ch][g0 + g][e], hb4[g][c][e], oacc[ch][c]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
             for (int c = 0; c < MT; ++c) pb[(wave * MT + c) * 64 + lane] = oacc[0][c] + oacc[1][c];
         }
+        L2A_MTS(3)
         __syncthreads();
+        L2A_MTS(4)
 
         // ---- canonical reduce, output activation, denormalisation, reward, state update (every wave, all micro tiles) --
         const float disc_t = (float)disc_pow;
@@ -378,7 +453,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                 float psq = 0.0f;
                 const int vi = p.rw.vel_index;
                 const float dsel = (vi & 2) ? ((vi & 1) ? d[3] : d[2]) : ((vi & 1) ? d[1] : d[0]);
-                const float dvel = __shfl(dsel, (vi & ~3) | j);                 // from the lane that holds dim vel_index
+                const float dvel = l2a_from_row(dsel, vi >> 4);         // block (vi >> 2) & 3 of row 0 <- the lane that holds dim vel_index
                 if (qq == ((vi >> 2) & 3)) plin += p.rw.w_vel * dvel * p.rw.inv_dt;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
@@ -388,13 +463,11 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                     psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
                 }
                 st[c] = nx;
-                plin = plin + __shfl_xor(plin, 4);
-                plin = plin + __shfl_xor(plin, 8);
+                plin = l2a_row_quarter_sum(plin);
                 float r = plin;
                 if (p.rw.dist_coef != 0.0f) {
                     psq = l2a_sum_xor32(l2a_sum_xor16(psq));                    // over the obs tiles of a quarter (one is non-zero)
-                    psq = psq + __shfl_xor(psq, 4);
-                    psq = psq + __shfl_xor(psq, 8);
+                    psq = l2a_row_quarter_sum(psq);
                     r -= p.rw.dist_coef * sqrtf(psq);
                 }
                 ret[c] = fmaf(disc_t, r, ret[c]);
@@ -403,8 +476,10 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
         // the next step's inputs
 #pragma unroll
         for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+        L2A_MTS(5)
         load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
         write_x(rows_n);
+        L2A_MTS(6)
     }
 
     // ---- results: wave 0, lanes of block 0 hold the returns of the candidates cand0 + 4 c + j ----------------------------
@@ -446,4 +521,417 @@ __global__ void __launch_bounds__(256) l2a_lstm_micro_k(const L2ALstmParams p) {
     if (mt == 3) l2a_lstm_micro_body<3, UW>(p, env, 4 * q0, l2a_smem);
     else if (mt == 2) l2a_lstm_micro_body<2, UW>(p, env, 4 * q0, l2a_smem);
     else l2a_lstm_micro_body<1, UW>(p, env, 4 * q0, l2a_smem);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// MLP planner (l2a_mfma.h is the 16-candidate kernel: same arithmetic in the same order, so the same bits)
+//
+// Workgroup = 4 waves, MT micro tiles (4 MT candidates) of one env for the whole horizon; wave w owns the 64-unit tiles
+// [w UW, (w + 1) UW) of every hidden layer (UW = H / 256) - i.e. the hidden units of chunks 2 w and 2 w + 1 of the
+// canonical output-layer reduce - and, in the output layer, those two chunks.  Per (step, set): layer 0 (B = the set's
+// normalised inputs, written to LDS once per step for all sets) -> rows A | barrier | hidden layers (rows A -> rows B ->
+// rows A ...) with a barrier between two of them | output layer over the wave's OWN columns of the last rows (its own
+// writes: no barrier) -> one partial per wave | barrier | every wave reduces the four partials (p0 + p1) + (p2 + p3), adds
+// the set to its ensemble group.  The weights of a (step, set) are ONE linear stream per 64-unit tile (l2a_micro_pack.h),
+// so the operand ring (three records requested ahead) runs through every phase boundary and into the next set with a
+// record counter and nothing else.
+// ------------------------------------------------------------------------------------------------------------------
+template <int MT, int UW, bool GACT>
+__device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const int env, const int cand0, char* smem) {
+    constexpr int H = 256 * UW;
+    constexpr int ROWF = l2a_micro_row(H);
+    constexpr int XROWF = 88;               // input rows: 80 floats + 8 (24 mod 32 like ROWF: conflict-free 16-byte accesses)
+    constexpr int HI = H / 16;              // loop iterations (four records each) of a hidden layer
+    constexpr int CIT = H / 128;            // ... of one output-layer chunk (H / 32 records)
+    constexpr int NSEQ = 2 / UW;            // the wave's two chunks: side by side as two streams (UW == 2) or one after the other
+    const int KG0 = p.KG0, n_hidden = p.n_hidden;
+    const int NREC = p.m_nrec;
+    const bool per_block = (p.mode == L2A_MODE_PER_BLOCK);
+    const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
+    const int e_half = (e_loop + 1) >> 1;               // group A = [0, e_half), B = [e_half, e_loop)
+    const int CST = l2a_mlp_micro_cst(H, KG0, n_hidden);
+    const int CST_B = 32 * KG0 + 192;                   // [in_mu 16 KG0][in_iv 16 KG0][out_mu 64][out_sd 64][b_out 64][hidden biases, slot order]
+
+    float* rows = reinterpret_cast<float*>(smem);                   // [2][12][ROWF]
+    f32x4* pbuf = reinterpret_cast<f32x4*>(rows + 2 * 12 * ROWF);   // [2][4 waves][3][64]
+    float* xs = reinterpret_cast<float*>(pbuf + 2 * 4 * 3 * 64);    // [e_loop][12][XROWF]
+    float* cst = xs + e_loop * 12 * XROWF;                          // [e_loop][CST]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = lane >> 2, j = lane & 3;
+    const int qq = b & 3;
+    const int obs_dim = p.obs_dim, act_dim = p.act_dim;
+    const int R = p.m * p.n;
+    auto set_of = [&](int i) { return per_block ? env : i; };       // weight set of the i-th member this workgroup runs
+
+    for (int i = tid; i < e_loop * CST; i += 256) {
+        const int sl = i / CST, o = i - sl * CST;
+        const float* src = p.wblk + (long long)set_of(sl) * p.set_stride;
+        float v;
+        if (o < 32 * KG0) v = src[p.nm_off + o];
+        else if (o < CST_B) {
+            const int a = (o - 32 * KG0) >> 6, d = (o - 32 * KG0) & 63;
+            v = (d >= obs_dim) ? 0.0f : (a == 0 ? src[p.nm_off + 32 * KG0 + d]
+                                                : (a == 1 ? src[p.nm_off + 32 * KG0 + 16 * p.OT + d] : src[p.raw_b[n_hidden] + d]));
+        } else {
+            const int l = (o - CST_B) / H, u = (o - CST_B) - l * H;
+            v = src[p.raw_b[l] + l2a_chain_k(u)];                   // slot u of its 64-unit tile is unit chain_k(u)
+        }
+        cst[i] = v;
+    }
+    for (int i = tid; i < e_loop * 12 * XROWF; i += 256) xs[i] = 0.0f;     // input padding stays zero
+    __syncthreads();
+
+    int cand[MT], row[MT];
+    bool valid[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+        cand[c] = cand0 + 4 * c + j;
+        valid[c] = cand[c] < p.n;
+        row[c] = env * p.n + (valid[c] ? cand[c] : p.n - 1);
+    }
+    // state: dims 4 b .. 4 b + 3 of candidate j (every wave keeps a copy, like the 16-candidate kernel)
+    f32x4 st[MT];
+    {
+        const float* orow = p.obs0 + (long long)env * obs_dim;
+        f32x4 s0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dim = 4 * b + i;
+            const float v = orow[dim < obs_dim ? dim : obs_dim - 1];
+            s0[i] = (dim < obs_dim) ? v : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < MT; ++c) st[c] = s0;
+    }
+
+    // raw actions of the lanes that play the 16-candidate kernel's quarter role (b < 4: qq = b), as in l2a_mfma.h
+    const int ga0 = obs_dim >> 4;
+    f32x4 av_next[MT][2];
+    int aoff[MT][2][4];
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+                const bool in = (b < 4) && (ka >= 0) && (ka < act_dim);
+                aoff[c][s][ii] = in ? (row[c] * act_dim + ka) * 4 : 0x7ffffff0;
+            }
+    const long long a_step = (long long)R * act_dim;
+    auto load_actions = [&](int t, f32x4 (&dst)[MT][2]) {
+        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
+#pragma unroll
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    dst[c][s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[c][s][ii], 0, 0));
+    };
+    // normalised inputs of the coming step, every set's -> xs (chain order); every wave writes all of them (identical
+    // values) and reads them back behind its own writes: no barrier between the state update and the first layer 0.
+    // Branch-free: the row offsets of a lane's values are loop invariants, a slot that holds no feature of this lane goes to
+    // the row's padding (floats 80 .. 87, never read); a set's constants come as 16-byte reads, all issued before the arithmetic.
+    f32x4 av[MT][2];
+    float asq[MT];
+    int xo_s[4], xo_a[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 4 * b + i;
+        xo_s[i] = (k < obs_dim) ? l2a_chain_k(k) : 80 + (lane & 7);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int k = 16 * (ga0 + s2) + 4 * qq + ii;
+            xo_a[s2][ii] = (b < 4 && k >= obs_dim && k < obs_dim + act_dim) ? l2a_chain_k(k) : 80 + (lane & 7);
+        }
+    auto write_x = [&]() {
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            float s = 0.0f;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                s = fmaf(av[c][0][ii], av[c][0][ii], s);
+                s = fmaf(av[c][1][ii], av[c][1][ii], s);
+            }
+            asq[c] = s;
+        }
+        for (int sl = 0; sl < e_loop; ++sl) {
+            const float* mu = cst + sl * CST;
+            const float* iv = mu + 16 * KG0;
+            const f32x4 mu_s = *reinterpret_cast<const f32x4*>(mu + 4 * b);     // (past the inputs: other constants, unused)
+            const f32x4 iv_s = *reinterpret_cast<const f32x4*>(iv + 4 * b);
+            f32x4 mu_a[2], iv_a[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                mu_a[s2] = *reinterpret_cast<const f32x4*>(mu + 16 * (ga0 + s2) + 4 * qq);
+                iv_a[s2] = *reinterpret_cast<const f32x4*>(iv + 16 * (ga0 + s2) + 4 * qq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < MT; ++c) {
+                float* xr = xs + (sl * 12 + 4 * c + j) * XROWF;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[xo_s[i]] = ((st[c][i] + 0.0f) - mu_s[i]) * iv_s[i];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) xr[xo_a[s2][ii]] = ((0.0f + av[c][s2][ii]) - mu_a[s2][ii]) * iv_a[s2][ii];
+            }
+        }
+    };
+    load_actions(0, av_next);
+#pragma unroll
+    for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+    load_actions(p.h > 1 ? 1 : 0, av_next);
+    write_x();
+
+    float ret[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) ret[c] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[c] ? cand[c] : p.n - 1)] : 0.0f;
+    double disc_pow = p.disc0;
+    const float e_count = (float)e_loop;
+    const float e_inv = 1.0f / e_count;
+
+    // ---- operand stream ----------------------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsA = l2a_rsrc(p.wblk + p.pk_m, p.m_bytes);
+    int voffA[UW];
+#pragma unroll
+    for (int tl = 0; tl < UW; ++tl) voffA[tl] = lane * 16 + (wave * UW + tl) * NREC * 1024;
+    const int set_bytes = (int)(p.set_stride * 4);
+    int sbase = set_of(0) * set_bytes;                  // byte offset of the running set's streams
+    int snext = set_of(e_loop > 1 ? 1 : 0) * set_bytes; // ... of the set after it
+    int rec = 0;                                        // records of the running set consumed so far (multiple of 4)
+    f32x4 ra[4][UW];                                    // weight ring: four records, three requested ahead; lives across phases, sets, steps
+    auto issue_a = [&](int soff, auto imm_tag, auto slot_tag) {
+        constexpr int s = decltype(slot_tag)::value, IMM = decltype(imm_tag)::value;
+#pragma unroll
+        for (int tl = 0; tl < UW; ++tl) ra[s][tl] = l2a_ldw(rsA, voffA[tl] + IMM, soff);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    issue_a(sbase, I0(), I0());
+    issue_a(sbase, std::integral_constant<int, 1024>(), I1());
+    issue_a(sbase, std::integral_constant<int, 2048>(), I2());
+
+    // One phase = `nit` iterations of four records for each of the wave's UW streams: acc[tl][c] += A(stream tl) x B.
+    // B = four chain positions of a candidate's LDS row per record: NB == 1: the same row section for every stream (a layer:
+    // the streams are output tiles), NB == UW: stream tl reads 64 floats further (output layer: the streams are chunks of K).
+    // CS = floats between the rows of two micro tiles.  Activation ring: two records.
+    auto run_phase = [&](const float* b0, const int nit, auto cs_tag, auto nb_tag, f32x4 (&acc)[UW][MT]) {
+        constexpr int CS = decltype(cs_tag)::value, NB = decltype(nb_tag)::value;
+        f32x4 rb[2][NB][MT];
+        auto issue_b = [&](const float* bp, auto off_tag, auto slot_tag) {
+            constexpr int s = decltype(slot_tag)::value, OFF = decltype(off_tag)::value;
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+                for (int c = 0; c < MT; ++c) rb[s][tb][c] = *reinterpret_cast<const f32x4*>(bp + 64 * tb + CS * c + OFF);
+        };
+#pragma unroll
+        for (int tl = 0; tl < UW; ++tl)
+#pragma unroll
+            for (int c = 0; c < MT; ++c) acc[tl][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        issue_b(b0, I0(), I0());
+#pragma unroll 1
+        for (int it = 0; it < nit; ++it) {
+            const int s0 = sbase + rec * 1024;
+            rec += 4;
+            const int s1 = (rec == NREC) ? snext : s0 + 4096;      // past the set's last record: the next set's first ones
+            const float* bp = b0 + 16 * it;
+            const float* bn = (it + 1 < nit) ? bp + 16 : b0;        // past the phase's last record: a harmless re-read
+            l2a_static_for<0, 4>([&](auto iv) {
+                constexpr int I = decltype(iv)::value;
+                if constexpr (I == 0) issue_a(s0, std::integral_constant<int, 3072>(), I3());
+                else issue_a(s1, std::integral_constant<int, (I - 1) * 1024>(), std::integral_constant<int, I - 1>());
+                if constexpr (I < 3) issue_b(bp, std::integral_constant<int, 4 * (I + 1)>(), std::integral_constant<int, (I + 1) & 1>());
+                else issue_b(bn, I0(), I0());
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int tl = 0; tl < UW; ++tl)
+#pragma unroll
+                        for (int c = 0; c < MT; ++c)
+                            acc[tl][c] = L2A_MFMA4(ra[I][tl][e], rb[I & 1][NB == 1 ? 0 : tl][c][e], acc[tl][c]);
+                l2a_micro_hint<UW, NB * MT, 4 * UW * MT>();
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // bias, activation, write-out of a layer's tiles (this wave's columns of `dst`, every micro tile's rows)
+    auto epilogue = [&](const f32x4 (&acc)[UW][MT], const float* bl, float* dst) {
+#pragma unroll
+        for (int tl = 0; tl < UW; ++tl) {
+            const int col = 64 * (wave * UW + tl) + 4 * b;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + col);
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+                *reinterpret_cast<f32x4*>(dst + (4 * c + j) * ROWF + col) = l2a_actv<GACT>(acc[tl][c] + bias, p.hidden_act, p.hid_floor);
+        }
+    };
+    using CSX = std::integral_constant<int, 4 * XROWF>;
+    using CSR = std::integral_constant<int, 4 * ROWF>;
+    int pp = 0;                                         // parity of the partials buffer
+
+    for (int t = 0; t < p.h; ++t) {
+        L2A_MTS(0)
+        f32x4 dsum[MT], dgrp[MT];
+#pragma unroll
+        for (int c = 0; c < MT; ++c) { dsum[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dgrp[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+        for (int i = 0; i < e_loop; ++i) {
+            const float* cs = cst + i * CST;
+            f32x4 acc[UW][MT];
+            // ---- layer 0 -> rows A ---------------------------------------------------------------------------------
+            run_phase(xs + (i * 12 + j) * XROWF, KG0, CSX(), I1(), acc);
+            epilogue(acc, cs + CST_B, rows);
+            // ---- hidden layers ----------------------------------------------------------------------------------------
+            for (int l = 1; l < n_hidden; ++l) {
+                __syncthreads();
+                run_phase(rows + ((l - 1) & 1) * 12 * ROWF + j * ROWF, HI, CSR(), I1(), acc);
+                epilogue(acc, cs + CST_B + l * H, rows + (l & 1) * 12 * ROWF);
+            }
+            // ---- output layer over this wave's own columns of the last rows (its two chunks of the canonical tree) -------
+            const float* hl = rows + ((n_hidden - 1) & 1) * 12 * ROWF + j * ROWF + 64 * UW * wave;
+            f32x4 oacc[NSEQ][UW][MT];
+#pragma unroll
+            for (int sq = 0; sq < NSEQ; ++sq) run_phase(hl + 32 * sq, CIT, CSR(), std::integral_constant<int, UW>(), oacc[sq]);
+            f32x4* pb = pbuf + pp * (4 * 3 * 64);
+            pp ^= 1;
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+                pb[(wave * MT + c) * 64 + lane] = (UW == 2) ? oacc[0][0][c] + oacc[0][UW - 1][c] : oacc[0][0][c] + oacc[NSEQ - 1][0][c];
+            // the set's stream is through: the ring already holds the next set's first records
+            rec = 0;
+            sbase = snext;
+            snext = set_of((i + 2 < e_loop) ? i + 2 : (i + 2 - e_loop < e_loop ? i + 2 - e_loop : 0)) * set_bytes;
+            __syncthreads();
+
+            // ---- canonical reduce, output activation, denormalisation; the set joins its ensemble group ------------------
+            if (i == e_half) {          // group A complete: park it, start group B
+#pragma unroll
+                for (int c = 0; c < MT; ++c) { dsum[c] = dgrp[c]; dgrp[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            }
+            {
+                const f32x4 omu = *reinterpret_cast<const f32x4*>(cs + 32 * KG0 + 4 * b);
+                const f32x4 osd = *reinterpret_cast<const f32x4*>(cs + 32 * KG0 + 64 + 4 * b);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(cs + 32 * KG0 + 128 + 4 * b);
+                f32x4 part[MT][4];
+#pragma unroll
+                for (int c = 0; c < MT; ++c)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) part[c][w] = pb[(w * MT + c) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < MT; ++c) {
+                    f32x4 s = (part[c][0] + part[c][1]) + (part[c][2] + part[c][3]);
+                    if (p.m_o4) {
+                        // dims 16 .. 19: blocks 4 .. 7 hold the sums over the four quarters of the hidden units -> (Q0 + Q1) + (Q2 + Q3)
+                        // (valid in block 4, the row's first: the lanes that hold dims 16 .. 19 of the state)
+                        f32x4 t2;
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) t2[ii] = l2a_row_quarter_sum(s[ii]);
+                        if (b >= 4 && b < 8) s = t2;
+                    }
+                    s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
+                    dgrp[c] += s * osd + omu;
+                }
+            }
+        }
+        L2A_MTS(1)
+
+        // ---- group A + group B, ensemble mean, reward, state update (every wave, all micro tiles) ------------------------
+        const float disc_t = (float)disc_pow;
+        disc_pow *= p.discount;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            f32x4 d = dsum[c] + dgrp[c];
+            if (e_loop > 1) {
+                // d / E, correctly rounded (Markstein; l2a_mfma.h)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const float q = d[ii] * e_inv;
+                    d[ii] = fmaf(fmaf(-q, e_count, d[ii]), e_inv, q);
+                }
+            }
+            const f32x4 nx = st[c] + d;
+            // reward in the 16-candidate kernel's order: quarter partials r_qq (lanes b = qq < 4), (r0 + r1) + (r2 + r3)
+            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[c];
+            float psq = 0.0f;
+            const int vi = p.rw.vel_index;
+            const float dsel = (vi & 2) ? ((vi & 1) ? d[3] : d[2]) : ((vi & 1) ? d[1] : d[0]);
+            const float dvel = l2a_from_row(dsel, vi >> 4);         // block (vi >> 2) & 3 of row 0 <- the lane that holds dim vel_index
+            if (qq == ((vi >> 2) & 3)) plin += p.rw.w_vel * dvel * p.rw.inv_dt;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int dim = 4 * b + ii;
+                const bool in_dist = (p.rw.dist_coef != 0.0f) && (dim >= p.rw.dist_index) &&
+                                     (dim < p.rw.dist_index + 3) && (dim < obs_dim);
+                psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
+            }
+            st[c] = nx;
+            plin = l2a_row_quarter_sum(plin);
+            float r = plin;
+            if (p.rw.dist_coef != 0.0f) {
+                psq = l2a_sum_xor32(l2a_sum_xor16(psq));                    // over the obs tiles of a quarter (one is non-zero)
+                psq = l2a_row_quarter_sum(psq);
+                r -= p.rw.dist_coef * sqrtf(psq);
+            }
+            ret[c] = fmaf(disc_t, r, ret[c]);
+        }
+        // the next step's inputs
+#pragma unroll
+        for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+        load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
+        write_x();
+        L2A_MTS(2)
+    }
+
+    // ---- results: wave 0, lanes of block 0 hold the returns of the candidates cand0 + 4 c + j ----------------------------
+    if (wave == 0) {
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            if (valid[c] && b == 0) {
+                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[c]] = ret[c];
+                const unsigned long long k = l2a_key_pack(ret[c], p.cand_offset + cand[c]);
+                key = (k > key) ? k : key;
+            }
+        }
+        if (p.best_key) {
+#pragma unroll
+            for (int off = 2; off >= 1; off >>= 1) {
+                const unsigned int hi = __shfl_xor((unsigned int)(key >> 32), off);
+                const unsigned int lo = __shfl_xor((unsigned int)(key & 0xffffffffu), off);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key = (other > key) ? other : key;
+            }
+            if (lane == 0) {
+                if (key != 0ull) atomicMax(p.best_key + env, key);
+                l2a_publish_result(p, (int)gridDim.x);
+            }
+        }
+    }
+}
+
+// Workgroup -> (env, first candidate, micro tiles) as in l2a_lstm_micro_k; logical ids are contiguous per XCD
+// (l2a_logical_wg), so that the workgroups of one env - one weight set in per-block mode - share an XCD's L2.
+template <int UW, bool GACT>
+__global__ void __launch_bounds__(256) l2a_mlp_micro_k(const L2AKParams p) {
+    extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
+    const int bid = l2a_logical_wg((int)blockIdx.x, (int)gridDim.x);
+    const int env = bid / p.mc_w;
+    const int idx = bid - env * p.mc_w;
+    const int mt = idx < p.mc_r ? p.mc_hi : p.mc_hi - 1;
+    const int q0 = idx < p.mc_r ? idx * p.mc_hi : p.mc_r * p.mc_hi + (idx - p.mc_r) * (p.mc_hi - 1);
+    if (mt == 3) l2a_mlp_micro_body<3, UW, GACT>(p, env, 4 * q0, l2a_smem);
+    else if (mt == 2) l2a_mlp_micro_body<2, UW, GACT>(p, env, 4 * q0, l2a_smem);
+    else l2a_mlp_micro_body<1, UW, GACT>(p, env, 4 * q0, l2a_smem);
 }

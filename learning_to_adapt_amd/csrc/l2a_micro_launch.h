@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 struct L2ALstmParams;
+struct L2AKParams;
 
 // Returns 0, a hipError_t (> 0) or -100 when no instance exists for the shape.
 int l2a_launch_lstm_micro(int units, const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream);
+int l2a_launch_mlp_micro(int hidden, int gact, const L2AKParams* p, unsigned grid, int smem, hipStream_t stream);

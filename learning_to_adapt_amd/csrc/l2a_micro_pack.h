@@ -54,3 +54,53 @@ __host__ __device__ inline int l2a_lstm_micro_smem(int U, int KG0) {
     return (2 * 12 * l2a_micro_row(U) + 32 * KG0 + 192 + 4 * U) * 4 + 2 * 4 * 3 * 64 * 16;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// MLP rollout (l2a_mlp_micro_k): per weight set one array in WAVE-STREAM order.  Stream T (= 64-unit tile of the hidden
+// layers; wave T / UW runs it, UW = H / 256 streams per wave) is the sequence of 1 KiB records [64 lanes][4] that the wave
+// consumes for one (horizon step, set), in consumption order:
+//   [layer 0: 4 KG0 records] [hidden layer 1 .. n_hidden - 1: H / 4 records each] [output layer: 16 records]
+// so that the operand ring runs straight through the phase boundaries with nothing but a record counter (and, at the end of
+// a set, the next set's base).  A record holds four consecutive CHAIN positions (l2a_chain_k) of the layer's K order:
+//   layer l < n_hidden : float [lane][e] = W_l[k = chain_k(4 r + e)][unit = 64 T + chain_k(lane)]
+//   output layer       : chain position p = 64 T + 4 r + e of the hidden units (the wave's own: its two chunks of the canonical
+//                        reduce, l2a_mfma.h), float [lane = slot][e] = W_out[k = chain_k(p)][dim(slot)]; slot = obs dim, except
+//                        with O4 (the 16-candidate kernel's 4x4x1 form of an obs tile with at most four live units, HalfCheetah:
+//                        dims 16 .. 19 are summed per QUARTER of the hidden units - chain positions p with p mod 4 = q - and the
+//                        quarters added afterwards): slot 16 + 4 q + i carries dim 16 + i for the positions of quarter q, zero
+//                        for the others.
+// ------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int l2a_mlp_micro_nrec(int H, int KG0, int n_hidden) { return 4 * KG0 + (n_hidden - 1) * (H / 4) + 16; }
+__host__ __device__ inline long long l2a_mlp_micro_floats(int H, int KG0, int n_hidden) {
+    return (long long)(H / 64) * l2a_mlp_micro_nrec(H, KG0, n_hidden) * 256;
+}
+// Where W_l[k][u] lives (l == n_hidden: the output layer, u = obs dim); every weight has exactly one place, the rest of the
+// array stays zero (the model block is zeroed at creation).
+__host__ __device__ inline long long l2a_mlp_micro_index(int H, int KG0, int n_hidden, int o4, int l, int k, int u) {
+    const int nrec = l2a_mlp_micro_nrec(H, KG0, n_hidden);
+    const int p = l2a_chain_k(k);
+    int T, rec, lane;
+    if (l < n_hidden) {
+        T = u >> 6;
+        lane = l2a_chain_k(u & 63);
+        rec = (l == 0 ? 0 : 4 * KG0 + (l - 1) * (H / 4)) + (p >> 2);
+    } else {
+        T = p >> 6;
+        rec = 4 * KG0 + (n_hidden - 1) * (H / 4) + ((p & 63) >> 2);
+        lane = (o4 && u >= 16) ? 16 + 4 * (p & 3) + (u - 16) : u;
+    }
+    return ((((long long)T * nrec + rec) * 64 + lane) << 2) + (p & 3);
+}
+// one layer of `count` sets: grid (ceil(k_in n_out / 256), count); w = the layer's [k_in, n_out] kernel of the first set
+static __global__ void l2a_mlp_micro_pack_k(const float* __restrict__ w, long long w_stride, int k_in, int n_out, int l, int H, int KG0,
+                                            int n_hidden, int o4, float* dst, long long dst_stride) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)k_in * n_out) return;
+    const int k = (int)(idx / n_out), u = (int)(idx - (long long)k * n_out);
+    dst[(long long)blockIdx.y * dst_stride + l2a_mlp_micro_index(H, KG0, n_hidden, o4, l, k, u)] = w[(long long)blockIdx.y * w_stride + idx];
+}
+// LDS bytes: activation rows [2][12][H + 88] | output partials [2][4 waves][3][64] f32x4 | inputs [sets][12][88] | constants per set
+__host__ __device__ inline int l2a_mlp_micro_cst(int H, int KG0, int n_hidden) { return 32 * KG0 + 192 + n_hidden * H; }
+__host__ __device__ inline int l2a_mlp_micro_smem(int H, int KG0, int n_hidden, int sets) {
+    return (2 * 12 * l2a_micro_row(H) + sets * 12 * 88 + sets * l2a_mlp_micro_cst(H, KG0, n_hidden)) * 4 + 2 * 4 * 3 * 64 * 16;
+}

@@ -241,6 +241,78 @@ def test_tile_split_is_bit_identical_to_single_workgroup(name, over):
     assert rel_err(out[1][0], want) < RTOL
 
 
+MICRO_CASES = [
+    # name, overrides - the micro-tile kernel (csrc/l2a_micro.h) on every code path it has: per-block sets on the reference's
+    # default GrBAL plan, a single model, mean ensembles odd / even (groups A | B), the O4 quarter sums (HalfCheetah, two or
+    # more hidden layers) and their absence (one hidden layer, the Ant's 41 observations), hidden width 256 (one 64-unit
+    # tile per wave, the wave's two chunks one after the other), generic activations, a distance reward, ragged micro tiles,
+    # more envs than a workgroup per CU leaves three micro tiles for (falls back to the 16-candidate kernel), a discount
+    ("c3b_ant_rs_n500_h10_pb5_3x512", dict(h=4)),
+    ("c1_hc_rs_n500_h10_e1", {}),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=700, h=5)),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=300, h=4, E=2)),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=333, h=3, E=3, hidden=[256, 256])),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=90, h=3, E=4, hidden=[512, 512, 512, 512])),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=200, h=5, E=3, hidden=[512])),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=150, h=4, E=2, hidden=[256, 256], activation="tanh")),
+    ("hc_rs_ragged_n37_h3", {}),
+    ("hc_rs_n1_h1", {}),
+    ("hc_rs_m3_n64_h5", {}),
+    ("hc_rs_discount", {}),
+    ("hc_rs_tanh_256", {}),
+    ("arm_rs_n256_h8", {}),
+    ("ant_rs_n300_h6_e3", {}),
+    ("ant_rs_4x256_e2", {}),
+    ("arm_cem_n160_h5_e3", {}),
+    ("hc_rs_m3_n64_h5", dict(m=64, n=12, h=2)),
+    ("c3_ant_rs_n2000_h20_pb5", dict(n=600, h=3)),
+]
+
+
+@pytest.mark.parametrize("name,over", MICRO_CASES)
+def test_micro_tiles_are_bit_identical(name, over):
+    """The micro-tile kernel (candidate tiles of FOUR on the 4x4x1 MFMA, workgroups of 4 / 8 / 12 candidates, no exchange
+    between workgroups) against the 16-candidate kernel, split and unsplit: every return and the arg-max keys bit for bit,
+    with a candidate offset, through the plain launch with and without a returns table; then against the oracle."""
+    case = dict(cases.CASES[name], **over)
+    if case["mode"] == "per_block":
+        case["E"] = max(case["E"], case["m"])
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    a = _rs_actions(case, 3, env)
+    obs0 = np.random.RandomState(13).randn(case["m"], env.observation_space.shape[0])
+    ctx = _lib.Context.get(0)
+    dev = native.device
+    out = {}
+    try:
+        for micro, split in ((0, 0), (0, 1), (2, 1)):
+            ctx.set_micro(micro)
+            ctx.set_split(split)
+            r, k = _plan_returns(native, case, env, obs0, a, cand_offset=11)
+            keys_only = torch.zeros((case["m"],), dtype=torch.int64, device=dev)
+            native.plan_rs(torch.from_numpy(np.ascontiguousarray(obs0, dtype=np.float32)).to(dev),
+                           torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev),
+                           case["m"], case["n"], case["h"], case.get("discount", 1.0), env.reward_spec,
+                           cand_offset=11, best_key=keys_only)
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            out[(micro, split)] = (r, k, keys_only.cpu().numpy())
+    finally:
+        ctx.set_micro(1)
+        ctx.set_split(1)
+    ref = out[(0, 0)]
+    assert np.array_equal(ref[1], ref[2])
+    assert np.isfinite(ref[0]).all()
+    for key in ((0, 1), (2, 1)):
+        for x, y in zip(ref, out[key]):
+            assert np.array_equal(x, y), key
+    from oracle import make_reward
+    from oracle.planner import rollout_returns
+    want = rollout_returns(cases.oracle_dynamics(case), make_reward(case["env"], env.dt), obs0, a, case["n"],
+                           case.get("discount", 1.0)).reshape(case["m"], case["n"])
+    assert rel_err(out[(2, 1)][0], want) < RTOL
+
+
 BATCH_CASES = [
     ("c2_hc_rs_n2000_h30_e5", {}),                                      # split: 2 full sets + the shared one per workgroup
     ("c2_hc_rs_n2000_h30_e5", dict(n=4000, h=4)),                       # unsplit, E = 5: batches straddle the A | B groups

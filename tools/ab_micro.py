@@ -50,5 +50,43 @@ def lstm_rows():
         print(json.dumps(row), flush=True)
 
 
+def mlp_rows():
+    import numpy as np
+    shapes = (("c3b_ant_rs_n500_h10_pb5_3x512", {}), ("c1_hc_rs_n500_h10_e1", {}), ("c3b_ant_rs_n500_h10_pb5_3x512", dict(hidden=[512, 512])),
+              ("c2_hc_rs_n2000_h30_e5", {}), ("c2_hc_rs_n2000_h30_e5", dict(n=2500, h=10)), ("c2_hc_rs_n2000_h30_e5", dict(n=500, h=10)),
+              ("c2_hc_rs_n2000_h30_e5", dict(n=3000, h=10)), ("c1_hc_rs_n500_h10_e1", dict(n=2500, m=1)), ("c1_hc_rs_n500_h10_e1", dict(n=1000)),
+              ("c3_ant_rs_n2000_h20_pb5", dict(n=600, h=10)))
+    for name, over in shapes:
+        case = dict(cases.CASES[name], **over)
+        env, model = cases.product_model(case)
+        native = model.planner_model()
+        dev = native.device
+        ctx = _lib.Context.get(0)
+        m, n, h = case["m"], case["n"], case["h"]
+        od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+        obs0 = torch.randn((m, od), device=dev)
+        a = torch.rand((h, m * n, ad), device=dev) * 2 - 1
+        best = torch.zeros((m,), dtype=torch.int64, device=dev)
+        dims = [od + ad] + list(case["hidden"]) + [od]
+        mac = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+        fl = 2.0 * mac * (case["E"] if case["mode"] == "mean" else 1) * n * m * h
+        row = {"kernel": "mlp", "case": name, "hidden": case["hidden"], "mode": case["mode"], "E": case["E"], "n": n, "h": h, "m": m}
+        for pol in (0, 2, 0, 2):
+            ctx.set_micro(pol)
+            ms = bc.time_launches(lambda: native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best), 30)
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            key = "micro" if pol else "tile16"
+            if key + "_ms" in row:
+                ms = min(ms, row[key + "_ms"])
+            row[key + "_ms"] = round(ms, 4)
+            row[key + "_frac"] = round(fl / ms / 1e9 / bc.PEAK, 4)
+        ctx.set_micro(1)
+        row["ratio"] = round(row["micro_ms"] / row["tile16_ms"], 3)
+        print(json.dumps(row), flush=True)
+
+
 if "lstm" in WHAT:
     lstm_rows()
+if "mlp" in WHAT:
+    mlp_rows()
