@@ -39,17 +39,23 @@ __device__ __forceinline__ void l2a_static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>()); l2a_static_for<I + 1, N>(f); }
 }
 
-// issue-order hint of one k-group step: its NA weight loads and NB LDS reads spread evenly between its NM MFMAs
+// issue-order hint of one k-group step (NM MFMAs): its NB LDS reads first, one per two MFMAs - they are consumed at the top of the
+// NEXT step and need their ~100 clocks - then its NA weight loads (consumed three steps later) spread over the rest
 template <int NA, int NB, int NM>
 __device__ __forceinline__ void l2a_micro_hint() {
-    constexpr int NOP = NA + NB, PER = NM / NOP;
-    l2a_static_for<0, NOP>([&](auto it) {
-        constexpr int i = decltype(it)::value;
-        constexpr bool vm = ((i & 1) == 0 ? (i / 2 < NA) : (i / 2 >= NB));      // alternate while both kinds are left
-        if constexpr (vm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, (i == NOP - 1) ? NM - PER * (NOP - 1) : PER, 0);
+    constexpr int LEAD = (2 * NB + 2 <= NM) ? 2 : 1;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    l2a_static_for<0, NB>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
     });
+    constexpr int REST = NM - 1 - LEAD * NB;
+    constexpr int PER = REST / (NA + 1) > 0 ? REST / (NA + 1) : 1;
+    l2a_static_for<0, NA>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    });
+    __builtin_amdgcn_sched_group_barrier(0x008, REST - PER * NA > 0 ? REST - PER * NA : 0, 0);
 }
 
 // Lane moves at VALU rate (no LDS crossbar round trip like ds_bpermute: the reduce tail of a step was 1.8k clocks of
@@ -293,9 +299,14 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    issue_a(0, I0(), I0());
-    issue_a(0, std::integral_constant<int, 1024>(), I1());
-    issue_a(0, std::integral_constant<int, 2048>(), I2());
+    // (in this order, pinned - see l2a_mlp_micro_body: the loops' s_waitcnt counts have to hold on the path from here too)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) { ra[0][tl] = l2a_ldw(rsA, voffA[tl], 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) { ra[1][tl] = l2a_ldw(rsA, voffA[tl] + 1024, 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) { ra[2][tl] = l2a_ldw(rsA, voffA[tl] + 2048, 0); __builtin_amdgcn_sched_barrier(0); }
     __syncthreads();        // every wave's share of h(0) is in the rows
     L2A_MTS_AT(0, 10)
 
@@ -330,12 +341,14 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                     else issue_a(s1, std::integral_constant<int, (I - 1) * 1024>(), std::integral_constant<int, I - 1>());
                     if constexpr (I < 3) issue_b(bp, std::integral_constant<int, 4 * (I + 1)>(), std::integral_constant<int, (I + 1) & 1>());
                     else issue_b(bn, I0(), I0());
+                    // (the LAST-requested operands first: one s_waitcnt per kind and step instead of one per operand - with MFMAs of
+                    // 8 clocks every instruction between them is paid in matrix time; each accumulator's own chain order is e = 0 .. 3)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int tl = 0; tl < NTL; ++tl)
+                        for (int tl = NTL - 1; tl >= 0; --tl)
 #pragma unroll
-                            for (int c = 0; c < MT; ++c) acc[tl][c] = L2A_MFMA4(ra[I][tl][e], rb[I & 1][c][e], acc[tl][c]);
+                            for (int c = MT - 1; c >= 0; --c) acc[tl][c] = L2A_MFMA4(ra[I][tl][e], rb[I & 1][c][e], acc[tl][c]);
                     l2a_micro_hint<NTL, MT, 4 * NTL * MT>();
                 });
             }
@@ -541,11 +554,14 @@ template <int MT, int UW, bool GACT>
 __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const int env, const int cand0, char* smem) {
     constexpr int H = 256 * UW;
     constexpr int ROWF = l2a_micro_row(H);
-    constexpr int XROWF = 88;               // input rows: 80 floats + 8 (24 mod 32 like ROWF: conflict-free 16-byte accesses)
-    constexpr int HI = H / 16;              // loop iterations (four records each) of a hidden layer
-    constexpr int CIT = H / 128;            // ... of one output-layer chunk (H / 32 records)
+    constexpr int XROWF = 104;              // input rows: 96 floats (six k-groups) + 8 (rows 8 banks apart: conflict-free 16-byte accesses)
+    constexpr int RD = 8;                   // operand ring: eight records, seven requested ahead (~1.3k clocks of matrix work at 12
+                                            // candidates: a workgroup that shares its XCD's L2 with another env's weights misses it)
+    constexpr int HI = H / 32;              // loop iterations (eight records each) of a hidden layer
+    constexpr int CIT = H / 256;            // ... of one output-layer chunk (H / 32 records)
     constexpr int NSEQ = 2 / UW;            // the wave's two chunks: side by side as two streams (UW == 2) or one after the other
     const int KG0 = p.KG0, n_hidden = p.n_hidden;
+    const int KG0E = l2a_mlp_micro_kg0e(KG0);
     const int NREC = p.m_nrec;
     const bool per_block = (p.mode == L2A_MODE_PER_BLOCK);
     const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
@@ -566,6 +582,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     const int obs_dim = p.obs_dim, act_dim = p.act_dim;
     const int R = p.m * p.n;
     auto set_of = [&](int i) { return per_block ? env : i; };       // weight set of the i-th member this workgroup runs
+    L2A_MTS_AT(0, 8)
 
     for (int i = tid; i < e_loop * CST; i += 256) {
         const int sl = i / CST, o = i - sl * CST;
@@ -584,6 +601,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     }
     for (int i = tid; i < e_loop * 12 * XROWF; i += 256) xs[i] = 0.0f;     // input padding stays zero
     __syncthreads();
+    L2A_MTS_AT(0, 9)
 
     int cand[MT], row[MT];
     bool valid[MT];
@@ -636,21 +654,21 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     // normalised inputs of the coming step, every set's -> xs (chain order); every wave writes all of them (identical
     // values) and reads them back behind its own writes: no barrier between the state update and the first layer 0.
     // Branch-free: the row offsets of a lane's values are loop invariants, a slot that holds no feature of this lane goes to
-    // the row's padding (floats 80 .. 87, never read); a set's constants come as 16-byte reads, all issued before the arithmetic.
+    // the row's padding (floats 96 .. 103, never read); a set's constants come as 16-byte reads, all issued before the arithmetic.
     f32x4 av[MT][2];
     float asq[MT];
     int xo_s[4], xo_a[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = 4 * b + i;
-        xo_s[i] = (k < obs_dim) ? l2a_chain_k(k) : 80 + (lane & 7);
+        xo_s[i] = (k < obs_dim) ? l2a_chain_k(k) : 96 + (lane & 7);
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int k = 16 * (ga0 + s2) + 4 * qq + ii;
-            xo_a[s2][ii] = (b < 4 && k >= obs_dim && k < obs_dim + act_dim) ? l2a_chain_k(k) : 80 + (lane & 7);
+            xo_a[s2][ii] = (b < 4 && k >= obs_dim && k < obs_dim + act_dim) ? l2a_chain_k(k) : 96 + (lane & 7);
         }
     auto write_x = [&]() {
 #pragma unroll
@@ -709,25 +727,34 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     int sbase = set_of(0) * set_bytes;                  // byte offset of the running set's streams
     int snext = set_of(e_loop > 1 ? 1 : 0) * set_bytes; // ... of the set after it
     int rec = 0;                                        // records of the running set consumed so far (multiple of 4)
-    f32x4 ra[4][UW];                                    // weight ring: four records, three requested ahead; lives across phases, sets, steps
+    f32x4 ra[RD][UW];                                   // weight ring; lives across phases, sets, steps
     auto issue_a = [&](int soff, auto imm_tag, auto slot_tag) {
         constexpr int s = decltype(slot_tag)::value, IMM = decltype(imm_tag)::value;
 #pragma unroll
         for (int tl = 0; tl < UW; ++tl) ra[s][tl] = l2a_ldw(rsA, voffA[tl] + IMM, soff);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    issue_a(sbase, I0(), I0());
-    issue_a(sbase, std::integral_constant<int, 1024>(), I1());
-    issue_a(sbase, std::integral_constant<int, 2048>(), I2());
+    // (in THIS order, pinned: the loops wait for a ring slot by counting the loads issued after it - s_waitcnt vmcnt - and the
+    // compiler inserts ONE count per wait that has to hold on every path into the loop; left to itself the scheduler issued
+    // the first loads backwards, record 0 last, and every loop iteration then drained the whole ring: 1.7x the time, r04)
+    __builtin_amdgcn_sched_barrier(0);
+    l2a_static_for<0, RD - 1>([&](auto rv) {
+        constexpr int r = decltype(rv)::value;
+#pragma unroll
+        for (int tl = 0; tl < UW; ++tl) {
+            ra[r][tl] = l2a_ldw(rsA, voffA[tl] + (r & 3) * 1024, sbase + (r >> 2) * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
 
-    // One phase = `nit` iterations of four records for each of the wave's UW streams: acc[tl][c] += A(stream tl) x B.
+    // One phase = `nit` iterations of eight records for each of the wave's UW streams: acc[tl][c] += A(stream tl) x B.
     // B = four chain positions of a candidate's LDS row per record: NB == 1: the same row section for every stream (a layer:
     // the streams are output tiles), NB == UW: stream tl reads 64 floats further (output layer: the streams are chunks of K).
-    // CS = floats between the rows of two micro tiles.  Activation ring: two records.
+    // CS = floats between the rows of two micro tiles.  Activation ring: four records, two requested ahead (a step of 8
+    // candidates is 128 clocks of matrix work - less than an LDS round trip).
     auto run_phase = [&](const float* b0, const int nit, auto cs_tag, auto nb_tag, f32x4 (&acc)[UW][MT]) {
         constexpr int CS = decltype(cs_tag)::value, NB = decltype(nb_tag)::value;
-        f32x4 rb[2][NB][MT];
+        f32x4 rb[4][NB][MT];
         auto issue_b = [&](const float* bp, auto off_tag, auto slot_tag) {
             constexpr int s = decltype(slot_tag)::value, OFF = decltype(off_tag)::value;
 #pragma unroll
@@ -740,26 +767,30 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
 #pragma unroll
             for (int c = 0; c < MT; ++c) acc[tl][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         issue_b(b0, I0(), I0());
+        issue_b(b0, std::integral_constant<int, 4>(), I1());
 #pragma unroll 1
         for (int it = 0; it < nit; ++it) {
-            const int s0 = sbase + rec * 1024;
-            rec += 4;
-            const int s1 = (rec == NREC) ? snext : s0 + 4096;      // past the set's last record: the next set's first ones
-            const float* bp = b0 + 16 * it;
-            const float* bn = (it + 1 < nit) ? bp + 16 : b0;        // past the phase's last record: a harmless re-read
-            l2a_static_for<0, 4>([&](auto iv) {
+            const int s0b = sbase + rec * 1024 + 4096;              // records 4 .. 7 of this iteration
+            rec += 8;
+            const int s1a = (rec == NREC) ? snext : s0b + 4096;     // past the set's last record: the next set's first ones
+            const int s1b = s1a + 4096;
+            const float* bp = b0 + 32 * it;
+            l2a_static_for<0, 8>([&](auto iv) {
                 constexpr int I = decltype(iv)::value;
-                if constexpr (I == 0) issue_a(s0, std::integral_constant<int, 3072>(), I3());
-                else issue_a(s1, std::integral_constant<int, (I - 1) * 1024>(), std::integral_constant<int, I - 1>());
-                if constexpr (I < 3) issue_b(bp, std::integral_constant<int, 4 * (I + 1)>(), std::integral_constant<int, (I + 1) & 1>());
-                else issue_b(bn, I0(), I0());
+                // record 8 it + I + 7 -> the slot that was consumed a step ago
+                if constexpr (I == 0) issue_a(s0b, std::integral_constant<int, 3072>(), std::integral_constant<int, 7>());
+                else if constexpr (I <= 4) issue_a(s1a, std::integral_constant<int, (I - 1) * 1024>(), std::integral_constant<int, I - 1>());
+                else issue_a(s1b, std::integral_constant<int, (I - 5) * 1024>(), std::integral_constant<int, I - 1>());
+                // activations two steps ahead (past the phase's last record: a harmless read of what follows in LDS)
+                issue_b(bp, std::integral_constant<int, 4 * (I + 2)>(), std::integral_constant<int, (I + 2) & 3>());
+                // (the LAST-requested operands first: one s_waitcnt per kind and step - see l2a_lstm_micro_body)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int tl = 0; tl < UW; ++tl)
+                    for (int tl = UW - 1; tl >= 0; --tl)
 #pragma unroll
-                        for (int c = 0; c < MT; ++c)
-                            acc[tl][c] = L2A_MFMA4(ra[I][tl][e], rb[I & 1][NB == 1 ? 0 : tl][c][e], acc[tl][c]);
+                        for (int c = MT - 1; c >= 0; --c)
+                            acc[tl][c] = L2A_MFMA4(ra[I][tl][e], rb[I & 3][NB == 1 ? 0 : tl][c][e], acc[tl][c]);
                 l2a_micro_hint<UW, NB * MT, 4 * UW * MT>();
             });
         }
@@ -779,6 +810,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     using CSX = std::integral_constant<int, 4 * XROWF>;
     using CSR = std::integral_constant<int, 4 * ROWF>;
     int pp = 0;                                         // parity of the partials buffer
+    L2A_MTS_AT(0, 10)
 
     for (int t = 0; t < p.h; ++t) {
         L2A_MTS(0)
@@ -790,8 +822,10 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
             const float* cs = cst + i * CST;
             f32x4 acc[UW][MT];
             // ---- layer 0 -> rows A ---------------------------------------------------------------------------------
-            run_phase(xs + (i * 12 + j) * XROWF, KG0, CSX(), I1(), acc);
+            run_phase(xs + (i * 12 + j) * XROWF, KG0E >> 1, CSX(), I1(), acc);
+            if (i == 0) { L2A_MTS(3) }
             epilogue(acc, cs + CST_B, rows);
+            if (i == 0) { L2A_MTS(4) }
             // ---- hidden layers ----------------------------------------------------------------------------------------
             for (int l = 1; l < n_hidden; ++l) {
                 __syncthreads();
@@ -799,6 +833,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                 epilogue(acc, cs + CST_B + l * H, rows + (l & 1) * 12 * ROWF);
             }
             // ---- output layer over this wave's own columns of the last rows (its two chunks of the canonical tree) -------
+            if (i == 0) { L2A_MTS(5) }
             const float* hl = rows + ((n_hidden - 1) & 1) * 12 * ROWF + j * ROWF + 64 * UW * wave;
             f32x4 oacc[NSEQ][UW][MT];
 #pragma unroll
@@ -812,7 +847,9 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
             rec = 0;
             sbase = snext;
             snext = set_of((i + 2 < e_loop) ? i + 2 : (i + 2 - e_loop < e_loop ? i + 2 - e_loop : 0)) * set_bytes;
+            if (i == 0) { L2A_MTS(6) }
             __syncthreads();
+            if (i == 0) { L2A_MTS(7) }
 
             // ---- canonical reduce, output activation, denormalisation; the set joins its ensemble group ------------------
             if (i == e_half) {          // group A complete: park it, start group B
@@ -845,7 +882,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                 }
             }
         }
-        L2A_MTS(1)
+        L2A_MTS(11)
 
         // ---- group A + group B, ensemble mean, reward, state update (every wave, all micro tiles) ------------------------
         const float disc_t = (float)disc_pow;
@@ -890,8 +927,9 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
 #pragma unroll
         for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
         load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
+        L2A_MTS(12)
         write_x();
-        L2A_MTS(2)
+        L2A_MTS(13)
     }
 
     // ---- results: wave 0, lanes of block 0 hold the returns of the candidates cand0 + 4 c + j ----------------------------
@@ -931,7 +969,21 @@ __global__ void __launch_bounds__(256) l2a_mlp_micro_k(const L2AKParams p) {
     const int idx = bid - env * p.mc_w;
     const int mt = idx < p.mc_r ? p.mc_hi : p.mc_hi - 1;
     const int q0 = idx < p.mc_r ? idx * p.mc_hi : p.mc_r * p.mc_hi + (idx - p.mc_r) * (p.mc_hi - 1);
+#ifdef L2A_TIMELINE
+    unsigned long long wg_r0_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_r0_) : : "memory");
+#endif
     if (mt == 3) l2a_mlp_micro_body<3, UW, GACT>(p, env, 4 * q0, l2a_smem);
     else if (mt == 2) l2a_mlp_micro_body<2, UW, GACT>(p, env, 4 * q0, l2a_smem);
     else l2a_mlp_micro_body<1, UW, GACT>(p, env, 4 * q0, l2a_smem);
+#ifdef L2A_TIMELINE
+    if (p.dbg && threadIdx.x == 0) {        // per-workgroup record behind the phase stamps: lifetime (100 MHz real time), XCD, size
+        unsigned long long wg_r1_;
+        unsigned int xcc_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_r1_) : : "memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        unsigned long long* r = p.dbg + (long long)p.h * 4 * 16 + 64 + (long long)blockIdx.x * 4;
+        r[0] = wg_r0_; r[1] = wg_r1_; r[2] = xcc_ & 15; r[3] = (unsigned long long)mt | ((unsigned long long)env << 8);
+    }
+#endif
 }

@@ -59,7 +59,7 @@ __host__ __device__ inline int l2a_lstm_micro_smem(int U, int KG0) {
 // MLP rollout (l2a_mlp_micro_k): per weight set one array in WAVE-STREAM order.  Stream T (= 64-unit tile of the hidden
 // layers; wave T / UW runs it, UW = H / 256 streams per wave) is the sequence of 1 KiB records [64 lanes][4] that the wave
 // consumes for one (horizon step, set), in consumption order:
-//   [layer 0: 4 KG0 records] [hidden layer 1 .. n_hidden - 1: H / 4 records each] [output layer: 16 records]
+//   [layer 0: 4 KG0e records, KG0e = KG0 rounded up to even] [hidden layer 1 .. n_hidden - 1: H / 4 records each] [output layer: 16 records]
 // so that the operand ring runs straight through the phase boundaries with nothing but a record counter (and, at the end of
 // a set, the next set's base).  A record holds four consecutive CHAIN positions (l2a_chain_k) of the layer's K order:
 //   layer l < n_hidden : float [lane][e] = W_l[k = chain_k(4 r + e)][unit = 64 T + chain_k(lane)]
@@ -70,7 +70,12 @@ __host__ __device__ inline int l2a_lstm_micro_smem(int U, int KG0) {
 //                        quarters added afterwards): slot 16 + 4 q + i carries dim 16 + i for the positions of quarter q, zero
 //                        for the others.
 // ------------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline int l2a_mlp_micro_nrec(int H, int KG0, int n_hidden) { return 4 * KG0 + (n_hidden - 1) * (H / 4) + 16; }
+// (layer 0 padded to an EVEN number of 16-feature k-groups - zero records - so that every phase is a whole number of
+// eight-record loop iterations: the operand ring is eight records deep)
+__host__ __device__ inline int l2a_mlp_micro_kg0e(int KG0) { return (KG0 + 1) & ~1; }
+__host__ __device__ inline int l2a_mlp_micro_nrec(int H, int KG0, int n_hidden) {
+    return 4 * l2a_mlp_micro_kg0e(KG0) + (n_hidden - 1) * (H / 4) + 16;
+}
 __host__ __device__ inline long long l2a_mlp_micro_floats(int H, int KG0, int n_hidden) {
     return (long long)(H / 64) * l2a_mlp_micro_nrec(H, KG0, n_hidden) * 256;
 }
@@ -83,10 +88,10 @@ __host__ __device__ inline long long l2a_mlp_micro_index(int H, int KG0, int n_h
     if (l < n_hidden) {
         T = u >> 6;
         lane = l2a_chain_k(u & 63);
-        rec = (l == 0 ? 0 : 4 * KG0 + (l - 1) * (H / 4)) + (p >> 2);
+        rec = (l == 0 ? 0 : 4 * l2a_mlp_micro_kg0e(KG0) + (l - 1) * (H / 4)) + (p >> 2);
     } else {
         T = p >> 6;
-        rec = 4 * KG0 + (n_hidden - 1) * (H / 4) + ((p & 63) >> 2);
+        rec = 4 * l2a_mlp_micro_kg0e(KG0) + (n_hidden - 1) * (H / 4) + ((p & 63) >> 2);
         lane = (o4 && u >= 16) ? 16 + 4 * (p & 3) + (u - 16) : u;
     }
     return ((((long long)T * nrec + rec) * 64 + lane) << 2) + (p & 3);
@@ -99,8 +104,8 @@ static __global__ void l2a_mlp_micro_pack_k(const float* __restrict__ w, long lo
     const int k = (int)(idx / n_out), u = (int)(idx - (long long)k * n_out);
     dst[(long long)blockIdx.y * dst_stride + l2a_mlp_micro_index(H, KG0, n_hidden, o4, l, k, u)] = w[(long long)blockIdx.y * w_stride + idx];
 }
-// LDS bytes: activation rows [2][12][H + 88] | output partials [2][4 waves][3][64] f32x4 | inputs [sets][12][88] | constants per set
+// LDS bytes: activation rows [2][12][H + 88] | output partials [2][4 waves][3][64] f32x4 | inputs [sets][12][104] | constants per set
 __host__ __device__ inline int l2a_mlp_micro_cst(int H, int KG0, int n_hidden) { return 32 * KG0 + 192 + n_hidden * H; }
 __host__ __device__ inline int l2a_mlp_micro_smem(int H, int KG0, int n_hidden, int sets) {
-    return (2 * 12 * l2a_micro_row(H) + sets * 12 * 88 + sets * l2a_mlp_micro_cst(H, KG0, n_hidden)) * 4 + 2 * 4 * 3 * 64 * 16;
+    return (2 * 12 * l2a_micro_row(H) + sets * 12 * 104 + sets * l2a_mlp_micro_cst(H, KG0, n_hidden)) * 4 + 2 * 4 * 3 * 64 * 16;
 }

@@ -26,16 +26,19 @@ from learning_to_adapt_amd import _lib  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "lstm"
 NAMES_LSTM = ["gate GEMM", "gates", "out", "barrier", "reduce+reward", "next x"]
-NAMES_MLP = ["x rows", "sets (all phases)", "mean+reward"]
+# MLP stamps per step: 0 start | 3 layer 0 of the first set done | 4 its rows written | 5 hidden layers done | 6 output partials written |
+# 7 past the barrier | 11 every set reduced | 12 mean / reward / state done | 13 next inputs written
+MLP_SLOTS = [0, 3, 4, 5, 6, 7, 11, 12, 13]
+NAMES_MLP = ["set 0: layer 0", "write", "hidden", "out", "barrier", "reduce + other sets", "mean+reward", "next x"]
 
 
-def run(plan, h, names, nslots):
+def run(plan, h, names, slots):
     ctx = _lib.Context.get(0)
     ctx.set_micro(2)
     for _ in range(3):
         plan()
     torch.cuda.synchronize()
-    dbg = torch.zeros(h * 4 * 16 + 64, dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(h * 4 * 16 + 64 + 4 * 1024, dtype=torch.int64, device="cuda")
     ctx.check(ctx.lib.l2a_set_debug_buffer(ctx.handle, ctypes.c_void_p(dbg.data_ptr())), "dbg")
     for _ in range(int(os.environ.get("L2A_TL_WARM", "200"))):
         plan()
@@ -50,14 +53,31 @@ def run(plan, h, names, nslots):
     print("launch %.4f ms (stamped build)" % ev0.elapsed_time(ev1))
     lo = 2 if h > 4 else 0
     for w in range(4):
-        seg = np.median(np.diff(d[lo:, w, :nslots], axis=1), axis=0)
+        seg = np.median(np.diff(d[lo:, w][:, slots], axis=1), axis=0)
         print("  wave %d: " % w + "  ".join("%s %6.0f" % (nm, v) for nm, v in zip(names, seg)))
     if d[0, 0, 8]:
         print("  prologue (wave 0): entry -> constants in LDS %d, -> state / first operands requested %d, -> first step %d clocks"
               % (d[0, 0, 9] - d[0, 0, 8], d[0, 0, 10] - d[0, 0, 9], d[0, 0, 0] - d[0, 0, 10]))
     step = np.diff(d[:, 0, 0])
     print("  step period: median %d clocks (min %d max %d); first stamp -> last stamp of the launch %d"
-          % (np.median(step), step.min(), step.max(), d[:, :, :nslots].max() - d[0, :, 0].min()))
+          % (np.median(step), step.min(), step.max(), d[:, :, slots].max() - d[0, :, 0].min()))
+    wg = dbg[h * 4 * 16 + 64:].view(1024, 4).cpu().numpy().astype(np.int64)
+    ran = wg[:, 1] != 0
+    if ran.any():
+        life = (wg[:, 1] - wg[:, 0]) * 10        # ns
+        print("  per-workgroup records: %d workgroups; launch (first start -> last end) %.1f us; lifetimes by XCD / micro tiles (us):"
+              % (ran.sum(), (wg[ran, 1].max() - wg[ran, 0].min()) / 100.0))
+        for x in range(8):
+            sel = ran & (wg[:, 2] == x)
+            if not sel.any():
+                continue
+            parts = []
+            for mt in (3, 2, 1):
+                s2 = sel & ((wg[:, 3] & 255) == mt)
+                if s2.any():
+                    parts.append("MT %d: %3d wgs median %.1f max %.1f" % (mt, s2.sum(), np.median(life[s2]) / 1e3, life[s2].max() / 1e3))
+            envs = sorted(set((wg[sel, 3] >> 8).tolist()))
+            print("    XCD %d envs %s: %s" % (x, envs, "; ".join(parts)))
     return d
 
 
@@ -76,9 +96,9 @@ if what == "lstm":
     a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
     best = torch.zeros(m, dtype=torch.int64, device=dev)
     print("micro-tile LSTM rollout, units %d, n %d, m %d, h %d" % (units, n, m, h))
-    run(lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best), h, NAMES_LSTM, 7)
+    run(lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best), h, NAMES_LSTM, list(range(7)))
 else:
-    cid = sys.argv[2] if len(sys.argv) > 2 else "c3b_ant_grbal_n500_h10_m5"
+    cid = sys.argv[2] if len(sys.argv) > 2 else "c3b_ant_rs_n500_h10_pb5_3x512"
     case = dict(cases.CASES[cid])
     if len(sys.argv) > 3:
         case["n"] = int(sys.argv[3])
@@ -86,5 +106,13 @@ else:
         case["m"] = int(sys.argv[4])
     if len(sys.argv) > 5:
         case["h"] = int(sys.argv[5])
-    import bench_configs as bc  # noqa: E402,F401
-    raise SystemExit("mlp timeline: see tools/ab_micro.py mlp (stamps are read there)")
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    m, n, h = case["m"], case["n"], case["h"]
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    obs0 = torch.randn((m, od), device=dev)
+    a = torch.rand((h, m * n, ad), device=dev) * 2 - 1
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    print("micro-tile MLP rollout, %s hidden %s mode %s E %d, n %d, m %d, h %d" % (cid, case["hidden"], case["mode"], case["E"], n, m, h))
+    run(lambda: native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best), h, NAMES_MLP, MLP_SLOTS)
