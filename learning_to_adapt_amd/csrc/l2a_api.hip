@@ -159,16 +159,24 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         int W = cus / p.m;
         if (W > quads) W = quads;
         const int hi = W > 0 ? ceil_div(quads, W) : 99;
+        // ... and the FEWEST workgroups that keep the largest one at `hi` micro tiles: under this kernel the chip is power limited
+        // (2.1 GHz with 255 busy CUs against 2.37 with 125: tools/timeline_micro.py), and a workgroup of fewer micro tiles streams
+        // the same weights for less work - 2 500 candidates on 5 x 42 workgroups of 12 instead of 5 x 51 of 12 and 8: c3b 0.325 ->
+        // 0.304 ms, the ReBAL default 0.195 -> 0.183 ms (profiles/r04_ab_micro.jsonl)
+        if (hi >= 1 && hi <= 3) W = ceil_div(quads, hi);
         const int smem_need = l2a_mlp_micro_smem(md->H, md->KG0, md->n_hidden, e_loop);
         const long long span = (long long)((p.mode == L2A_MODE_PER_BLOCK ? p.m : e_loop) - 1) * md->set_stride * 4 +
                                l2a_mlp_micro_floats(md->H, md->KG0, md->n_hidden) * 4;
         const bool eligible = !p.obs_per_row && !p.state_out && hi <= 3 && (p.returns_out || p.best_key) &&
                               smem_need <= ctx->lds_per_block && span < (1LL << 31);
-        // automatic: the plans the 16-candidate geometries cannot fill - more than CUs / 2 tiles (no tile split) and fewer
-        // than CUs - and small single-model plans, whose tile split is bound by its per-step exchange
+        // automatic (profiles/r04_ab_micro.jsonl, hidden width 512): the plans the 16-candidate geometries cannot fill - more
+        // than CUs / 2 tiles (no tile split) and fewer than CUs: 0.80 - 0.90 of the 16-candidate launch (per-block 3 x 512 /
+        // 2 x 512, mean E = 5, single) - and plans of at most CUs / 2 tiles that run ONE set per candidate (single model,
+        // per-block), whose tile split is bound by its per-step exchange: 0.77 - 0.91.  Small ENSEMBLE plans stay with the tile
+        // split (every workgroup would stream all E sets: 1.2x), and so does hidden width 256 (one 64-unit tile per wave: 1.12x).
         const bool unfilled = 2 * tiles16 > cus && tiles16 < cus;
-        const bool small_single = e_loop == 1 && 2 * tiles16 <= cus;
-        const bool wanted = ctx->micro_policy == 2 || (ctx->micro_policy == 1 && (unfilled || small_single));
+        const bool small_one_set = e_loop == 1 && 2 * tiles16 <= cus;
+        const bool wanted = ctx->micro_policy == 2 || (ctx->micro_policy == 1 && md->H == 512 && (unfilled || small_one_set));
         if (eligible && wanted) {
             p.mc_w = W;
             p.mc_hi = hi;

@@ -144,11 +144,17 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
             int W = cus_m / p.m;
             if (W > quads) W = quads;
             const int hi = W > 0 ? l2a_ceil_div(quads, W) : 99;
+            // ... and the fewest workgroups that keep the largest one at `hi` micro tiles (the chip is power limited under this
+            // kernel, see launch_rollout in l2a_api.hip)
+            if (hi >= 1 && hi <= 3) W = l2a_ceil_div(quads, hi);
             const bool eligible = md->micro_ok && !p.obs_per_row && !p.state_out && !p.c_out && !p.h_out && hi <= 3 &&
                                   (p.returns_out || p.best_key);
-            // automatic: the plans the 16-candidate geometries cannot fill - more than CUs / 2 tiles (no unit-tile split)
-            // and fewer than CUs
-            const bool wanted = ctx->micro_policy == 2 || (ctx->micro_policy == 1 && 2 * tiles16 > cus_m && tiles16 < cus_m);
+            // automatic (profiles/r04_ab_micro.jsonl): the plans the 16-candidate geometries cannot fill - more than CUs / 2
+            // tiles (no unit-tile split) and fewer than CUs (the ReBAL default: 0.91 of the 16-candidate launch; 512 units: 0.85)
+            // - and plans of at most one micro tile per CU (0.87 - 0.95 of the unit-tile split); in between the unit-tile
+            // split wins (1.04 - 1.16).
+            const bool unfilled = 2 * tiles16 > cus_m && tiles16 < cus_m;
+            const bool wanted = ctx->micro_policy == 2 || (ctx->micro_policy == 1 && (unfilled || hi == 1));
             if (eligible && wanted) {
                 p.mc_w = W;
                 p.mc_hi = hi;

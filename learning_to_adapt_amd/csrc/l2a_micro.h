@@ -159,19 +159,23 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
         valid[c] = cand[c] < p.n;
         row[c] = env * p.n + (valid[c] ? cand[c] : p.n - 1);
     }
-    // state: dims 4 b .. 4 b + 3 of candidate j (every wave keeps a copy, like the 16-candidate kernel)
-    f32x4 st[MT], creg[UW][MT];
+    // Everything per candidate outside the gate GEMM - the output-layer reduce, reward, state, return, the next step's actions
+    // and input rows - is done for micro tile c by wave c alone (a wave beyond the micro tiles repeats the last one's work, same
+    // values to the same places: no divergence); one barrier per step hands the input rows to the other waves.
+    const int ct = wave < MT ? wave : MT - 1;
+    const int cand_t = cand0 + 4 * ct + j;
+    const bool valid_t = cand_t < p.n;
+    const int row_t = env * p.n + (valid_t ? cand_t : p.n - 1);
+    // state: dims 4 b .. 4 b + 3 of candidate j of this wave's micro tile
+    f32x4 st, creg[UW][MT];
     {
         const float* orow = p.obs0 + (long long)env * obs_dim;
-        f32x4 s0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int dim = 4 * b + i;
             const float v = orow[dim < obs_dim ? dim : obs_dim - 1];
-            s0[i] = (dim < obs_dim) ? v : 0.0f;
+            st[i] = (dim < obs_dim) ? v : 0.0f;
         }
-#pragma unroll
-        for (int c = 0; c < MT; ++c) st[c] = s0;
     }
 #pragma unroll
     for (int c = 0; c < MT; ++c) {
@@ -193,36 +197,31 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
     // raw actions of the lanes that play the 16-candidate kernel's quarter role (b < 4: qq = b): bounds-checked buffer
     // loads from a per-step descriptor, slots without an action read 0.0 (l2a_mfma.h)
     const int ga0 = obs_dim >> 4;
-    f32x4 av_next[MT][2];
-    int aoff[MT][2][4];
+    f32x4 av_next[2];
+    int aoff[2][4];
 #pragma unroll
-    for (int c = 0; c < MT; ++c)
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+            const bool in = (b < 4) && (ka >= 0) && (ka < act_dim);
+            aoff[s][ii] = in ? (row_t * act_dim + ka) * 4 : 0x7ffffff0;
+        }
+    const long long a_step = (long long)R * act_dim;
+    auto load_actions = [&](int t, f32x4 (&dst)[2]) {
+        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
-                const bool in = (b < 4) && (ka >= 0) && (ka < act_dim);
-                aoff[c][s][ii] = in ? (row[c] * act_dim + ka) * 4 : 0x7ffffff0;
-            }
-    const long long a_step = (long long)R * act_dim;
-    auto load_actions = [&](int t, f32x4 (&dst)[MT][2]) {
-        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
-#pragma unroll
-        for (int c = 0; c < MT; ++c)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    dst[c][s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[c][s][ii], 0, 0));
+            for (int ii = 0; ii < 4; ++ii)
+                dst[s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[s][ii], 0, 0));
     };
-    // normalised inputs of the coming step -> the x section of `dst` rows (chain order); every wave writes all of them
-    // (identical values) and reads them back behind its own writes: no barrier between the state update and the x part.
+    // normalised inputs of the coming step -> the x section of `dst` rows (chain order), the rows of this wave's micro tile.
     // Branch-free: a lane's normalisation constants and the row offsets of its values are loop invariants (registers); a slot
     // that holds no feature of this lane goes to the row's padding (floats U + 80 .. U + 87, never read).  (With a guard per
     // element the compiler serialised read - wait - compute - write behind a branch each: 5.4k clocks per step, timeline r04.)
-    f32x4 av[MT][2];
-    float asq[MT];
+    f32x4 av[2];
+    float asq;
     int xo_s[4], xo_a[2][4];
     f32x4 mu_s, iv_s, mu_a[2], iv_a[2];
     {
@@ -245,33 +244,27 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
         }
     }
     auto write_x = [&](float* dst) {
+        float* xr = dst + (4 * ct + j) * ROWF;
 #pragma unroll
-        for (int c = 0; c < MT; ++c) {
-            float* xr = dst + (4 * c + j) * ROWF;
+        for (int i = 0; i < 4; ++i) xr[xo_s[i]] = ((st[i] + 0.0f) - mu_s[i]) * iv_s[i];
+        float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xr[xo_s[i]] = ((st[c][i] + 0.0f) - mu_s[i]) * iv_s[i];
-            float s = 0.0f;
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                s = fmaf(av[c][0][ii], av[c][0][ii], s);
-                s = fmaf(av[c][1][ii], av[c][1][ii], s);
-            }
-            asq[c] = s;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) xr[xo_a[s2][ii]] = ((0.0f + av[c][s2][ii]) - mu_a[s2][ii]) * iv_a[s2][ii];
+        for (int ii = 0; ii < 4; ++ii) {
+            s = fmaf(av[0][ii], av[0][ii], s);
+            s = fmaf(av[1][ii], av[1][ii], s);
         }
+        asq = s;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) xr[xo_a[s2][ii]] = ((0.0f + av[s2][ii]) - mu_a[s2][ii]) * iv_a[s2][ii];
     };
     load_actions(0, av_next);
-#pragma unroll
-    for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+    av[0] = av_next[0]; av[1] = av_next[1];
     load_actions(p.h > 1 ? 1 : 0, av_next);
     write_x(rows);
 
-    float ret[MT];
-#pragma unroll
-    for (int c = 0; c < MT; ++c) ret[c] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[c] ? cand[c] : p.n - 1)] : 0.0f;
+    float ret = p.ret_in ? p.ret_in[(long long)env * p.n + (valid_t ? cand_t : p.n - 1)] : 0.0f;
     double disc_pow = p.disc0;
 
     // ---- operand streams ---------------------------------------------------------------------------------------------
@@ -307,7 +300,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
     for (int tl = 0; tl < NTL; ++tl) { ra[1][tl] = l2a_ldw(rsA, voffA[tl] + 1024, 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) { ra[2][tl] = l2a_ldw(rsA, voffA[tl] + 2048, 0); __builtin_amdgcn_sched_barrier(0); }
-    __syncthreads();        // every wave's share of h(0) is in the rows
+    __syncthreads();        // every wave's share of h(0) and every micro tile's input rows are in the rows
     L2A_MTS_AT(0, 10)
 
     for (int t = 0; t < p.h; ++t) {
@@ -442,27 +435,24 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
         __syncthreads();
         L2A_MTS(4)
 
-        // ---- canonical reduce, output activation, denormalisation, reward, state update (every wave, all micro tiles) --
+        // ---- canonical reduce, output activation, denormalisation, reward, state update (this wave's micro tile) ---------
         const float disc_t = (float)disc_pow;
         disc_pow *= p.discount;
         {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(c_bo + 4 * b);
             const f32x4 omu = *reinterpret_cast<const f32x4*>(c_out_mu + 4 * b);
             const f32x4 osd = *reinterpret_cast<const f32x4*>(c_out_sd + 4 * b);
-            f32x4 part[MT][4];
+            f32x4 part[4];
 #pragma unroll
-            for (int c = 0; c < MT; ++c)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) part[c][w] = pb[(w * MT + c) * 64 + lane];
+            for (int w = 0; w < 4; ++w) part[w] = pb[(w * MT + ct) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < MT; ++c) {
-                f32x4 s = (part[c][0] + part[c][1]) + (part[c][2] + part[c][3]);
+            {
+                f32x4 s = (part[0] + part[1]) + (part[2] + part[3]);
                 s = l2a_act4(s + bias, p.output_act);
                 const f32x4 d = s * osd + omu;
-                const f32x4 nx = st[c] + d;
+                const f32x4 nx = st + d;
                 // reward in the 16-candidate kernel's order: quarter partials r_qq (lanes b = qq < 4), (r0 + r1) + (r2 + r3)
-                float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[c];
+                float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq;
                 float psq = 0.0f;
                 const int vi = p.rw.vel_index;
                 const float dsel = (vi & 2) ? ((vi & 1) ? d[3] : d[2]) : ((vi & 1) ? d[1] : d[0]);
@@ -475,7 +465,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                                          (dim < p.rw.dist_index + 3) && (dim < obs_dim);
                     psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
                 }
-                st[c] = nx;
+                st = nx;
                 plin = l2a_row_quarter_sum(plin);
                 float r = plin;
                 if (p.rw.dist_coef != 0.0f) {
@@ -483,28 +473,24 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                     psq = l2a_row_quarter_sum(psq);
                     r -= p.rw.dist_coef * sqrtf(psq);
                 }
-                ret[c] = fmaf(disc_t, r, ret[c]);
+                ret = fmaf(disc_t, r, ret);
             }
         }
         // the next step's inputs
-#pragma unroll
-        for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+        av[0] = av_next[0]; av[1] = av_next[1];
         L2A_MTS(5)
         load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
         write_x(rows_n);
+        __syncthreads();        // every micro tile's input rows are written
         L2A_MTS(6)
     }
 
-    // ---- results: wave 0, lanes of block 0 hold the returns of the candidates cand0 + 4 c + j ----------------------------
-    if (wave == 0) {
+    // ---- results: lanes of block 0 of wave c hold the returns of the candidates cand0 + 4 c + j; the keys meet in LDS ------
+    {
         unsigned long long key = 0ull;
-#pragma unroll
-        for (int c = 0; c < MT; ++c) {
-            if (valid[c] && b == 0) {
-                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[c]] = ret[c];
-                const unsigned long long k = l2a_key_pack(ret[c], p.cand_offset + cand[c]);
-                key = (k > key) ? k : key;
-            }
+        if (valid_t && b == 0 && wave < MT) {
+            if (p.returns_out) p.returns_out[(long long)env * p.n + cand_t] = ret;
+            key = l2a_key_pack(ret, p.cand_offset + cand_t);
         }
         if (p.best_key) {
 #pragma unroll
@@ -514,7 +500,12 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
                 const unsigned long long other = ((unsigned long long)hi << 32) | lo;
                 key = (other > key) ? other : key;
             }
-            if (lane == 0) {
+            unsigned long long* kbuf = reinterpret_cast<unsigned long long*>(pbuf);     // (the partials are through)
+            if (lane == 0) kbuf[wave] = (wave < MT) ? key : 0ull;
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int w = 1; w < 4; ++w) key = (kbuf[w] > key) ? kbuf[w] : key;
                 if (key != 0ull) atomicMax(p.best_key + env, key);
                 l2a_publish_result(p, (int)gridDim.x);
             }
@@ -545,8 +536,10 @@ __global__ void __launch_bounds__(256) l2a_lstm_micro_k(const L2ALstmParams p) {
 // canonical output-layer reduce - and, in the output layer, those two chunks.  Per (step, set): layer 0 (B = the set's
 // normalised inputs, written to LDS once per step for all sets) -> rows A | barrier | hidden layers (rows A -> rows B ->
 // rows A ...) with a barrier between two of them | output layer over the wave's OWN columns of the last rows (its own
-// writes: no barrier) -> one partial per wave | barrier | every wave reduces the four partials (p0 + p1) + (p2 + p3), adds
-// the set to its ensemble group.  The weights of a (step, set) are ONE linear stream per 64-unit tile (l2a_micro_pack.h),
+// writes: no barrier) -> one partial per wave | barrier | the four partials are reduced (p0 + p1) + (p2 + p3), the set joins
+// its ensemble group.  Everything per candidate - this reduce, the ensemble mean, reward, state, return, the next step's
+// actions and input rows - is done for micro tile c by wave c alone (a wave beyond the micro tiles repeats the last one's
+// work, same values to the same places: no divergence); one barrier per step hands the input rows to the other waves.  The weights of a (step, set) are ONE linear stream per 64-unit tile (l2a_micro_pack.h),
 // so the operand ring (three records requested ahead) runs through every phase boundary and into the next set with a
 // record counter and nothing else.
 // ------------------------------------------------------------------------------------------------------------------
@@ -603,60 +596,49 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     __syncthreads();
     L2A_MTS_AT(0, 9)
 
-    int cand[MT], row[MT];
-    bool valid[MT];
-#pragma unroll
-    for (int c = 0; c < MT; ++c) {
-        cand[c] = cand0 + 4 * c + j;
-        valid[c] = cand[c] < p.n;
-        row[c] = env * p.n + (valid[c] ? cand[c] : p.n - 1);
-    }
-    // state: dims 4 b .. 4 b + 3 of candidate j (every wave keeps a copy, like the 16-candidate kernel)
-    f32x4 st[MT];
+    // this wave's micro tile
+    const int ct = wave < MT ? wave : MT - 1;
+    const int cand = cand0 + 4 * ct + j;
+    const bool valid = cand < p.n;
+    const int row = env * p.n + (valid ? cand : p.n - 1);
+    // state: dims 4 b .. 4 b + 3 of candidate j
+    f32x4 st;
     {
         const float* orow = p.obs0 + (long long)env * obs_dim;
-        f32x4 s0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int dim = 4 * b + i;
             const float v = orow[dim < obs_dim ? dim : obs_dim - 1];
-            s0[i] = (dim < obs_dim) ? v : 0.0f;
+            st[i] = (dim < obs_dim) ? v : 0.0f;
         }
-#pragma unroll
-        for (int c = 0; c < MT; ++c) st[c] = s0;
     }
 
     // raw actions of the lanes that play the 16-candidate kernel's quarter role (b < 4: qq = b), as in l2a_mfma.h
     const int ga0 = obs_dim >> 4;
-    f32x4 av_next[MT][2];
-    int aoff[MT][2][4];
+    f32x4 av_next[2];
+    int aoff[2][4];
 #pragma unroll
-    for (int c = 0; c < MT; ++c)
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
+            const bool in = (b < 4) && (ka >= 0) && (ka < act_dim);
+            aoff[s][ii] = in ? (row * act_dim + ka) * 4 : 0x7ffffff0;
+        }
+    const long long a_step = (long long)R * act_dim;
+    auto load_actions = [&](int t, f32x4 (&dst)[2]) {
+        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int ka = 16 * (ga0 + s) + 4 * qq + ii - obs_dim;
-                const bool in = (b < 4) && (ka >= 0) && (ka < act_dim);
-                aoff[c][s][ii] = in ? (row[c] * act_dim + ka) * 4 : 0x7ffffff0;
-            }
-    const long long a_step = (long long)R * act_dim;
-    auto load_actions = [&](int t, f32x4 (&dst)[MT][2]) {
-        const __amdgpu_buffer_rsrc_t ars = l2a_rsrc(p.actions + (long long)t * a_step, a_step * 4);
-#pragma unroll
-        for (int c = 0; c < MT; ++c)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    dst[c][s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[c][s][ii], 0, 0));
+            for (int ii = 0; ii < 4; ++ii)
+                dst[s][ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, aoff[s][ii], 0, 0));
     };
-    // normalised inputs of the coming step, every set's -> xs (chain order); every wave writes all of them (identical
-    // values) and reads them back behind its own writes: no barrier between the state update and the first layer 0.
+    // normalised inputs of the coming step, every set's -> xs (chain order), the rows of this wave's micro tile.
     // Branch-free: the row offsets of a lane's values are loop invariants, a slot that holds no feature of this lane goes to
     // the row's padding (floats 96 .. 103, never read); a set's constants come as 16-byte reads, all issued before the arithmetic.
-    f32x4 av[MT][2];
-    float asq[MT];
+    f32x4 av[2];
+    float asq;
     int xo_s[4], xo_a[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -671,15 +653,14 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
             xo_a[s2][ii] = (b < 4 && k >= obs_dim && k < obs_dim + act_dim) ? l2a_chain_k(k) : 96 + (lane & 7);
         }
     auto write_x = [&]() {
-#pragma unroll
-        for (int c = 0; c < MT; ++c) {
+        {
             float s = 0.0f;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
-                s = fmaf(av[c][0][ii], av[c][0][ii], s);
-                s = fmaf(av[c][1][ii], av[c][1][ii], s);
+                s = fmaf(av[0][ii], av[0][ii], s);
+                s = fmaf(av[1][ii], av[1][ii], s);
             }
-            asq[c] = s;
+            asq = s;
         }
         for (int sl = 0; sl < e_loop; ++sl) {
             const float* mu = cst + sl * CST;
@@ -693,27 +674,21 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                 iv_a[s2] = *reinterpret_cast<const f32x4*>(iv + 16 * (ga0 + s2) + 4 * qq);
             }
             __builtin_amdgcn_sched_barrier(0);
+            float* xr = xs + (sl * 12 + 4 * ct + j) * XROWF;
 #pragma unroll
-            for (int c = 0; c < MT; ++c) {
-                float* xr = xs + (sl * 12 + 4 * c + j) * XROWF;
+            for (int i = 0; i < 4; ++i) xr[xo_s[i]] = ((st[i] + 0.0f) - mu_s[i]) * iv_s[i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xr[xo_s[i]] = ((st[c][i] + 0.0f) - mu_s[i]) * iv_s[i];
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) xr[xo_a[s2][ii]] = ((0.0f + av[c][s2][ii]) - mu_a[s2][ii]) * iv_a[s2][ii];
-            }
+                for (int ii = 0; ii < 4; ++ii) xr[xo_a[s2][ii]] = ((0.0f + av[s2][ii]) - mu_a[s2][ii]) * iv_a[s2][ii];
         }
     };
     load_actions(0, av_next);
-#pragma unroll
-    for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+    av[0] = av_next[0]; av[1] = av_next[1];
     load_actions(p.h > 1 ? 1 : 0, av_next);
     write_x();
 
-    float ret[MT];
-#pragma unroll
-    for (int c = 0; c < MT; ++c) ret[c] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[c] ? cand[c] : p.n - 1)] : 0.0f;
+    float ret = p.ret_in ? p.ret_in[(long long)env * p.n + (valid ? cand : p.n - 1)] : 0.0f;
     double disc_pow = p.disc0;
     const float e_count = (float)e_loop;
     const float e_inv = 1.0f / e_count;
@@ -810,13 +785,12 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     using CSX = std::integral_constant<int, 4 * XROWF>;
     using CSR = std::integral_constant<int, 4 * ROWF>;
     int pp = 0;                                         // parity of the partials buffer
+    __syncthreads();                                    // every micro tile's input rows are written
     L2A_MTS_AT(0, 10)
 
     for (int t = 0; t < p.h; ++t) {
         L2A_MTS(0)
-        f32x4 dsum[MT], dgrp[MT];
-#pragma unroll
-        for (int c = 0; c < MT; ++c) { dsum[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dgrp[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        f32x4 dsum = (f32x4){0.f, 0.f, 0.f, 0.f}, dgrp = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int i = 0; i < e_loop; ++i) {
             const float* cs = cst + i * CST;
@@ -852,23 +826,17 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
             if (i == 0) { L2A_MTS(7) }
 
             // ---- canonical reduce, output activation, denormalisation; the set joins its ensemble group ------------------
-            if (i == e_half) {          // group A complete: park it, start group B
-#pragma unroll
-                for (int c = 0; c < MT; ++c) { dsum[c] = dgrp[c]; dgrp[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            }
+            if (i == e_half) { dsum = dgrp; dgrp = (f32x4){0.f, 0.f, 0.f, 0.f}; }      // group A complete: park it, start group B
             {
                 const f32x4 omu = *reinterpret_cast<const f32x4*>(cs + 32 * KG0 + 4 * b);
                 const f32x4 osd = *reinterpret_cast<const f32x4*>(cs + 32 * KG0 + 64 + 4 * b);
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(cs + 32 * KG0 + 128 + 4 * b);
-                f32x4 part[MT][4];
+                f32x4 part[4];
 #pragma unroll
-                for (int c = 0; c < MT; ++c)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) part[c][w] = pb[(w * MT + c) * 64 + lane];
+                for (int w = 0; w < 4; ++w) part[w] = pb[(w * MT + ct) * 64 + lane];
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < MT; ++c) {
-                    f32x4 s = (part[c][0] + part[c][1]) + (part[c][2] + part[c][3]);
+                {
+                    f32x4 s = (part[0] + part[1]) + (part[2] + part[3]);
                     if (p.m_o4) {
                         // dims 16 .. 19: blocks 4 .. 7 hold the sums over the four quarters of the hidden units -> (Q0 + Q1) + (Q2 + Q3)
                         // (valid in block 4, the row's first: the lanes that hold dims 16 .. 19 of the state)
@@ -878,18 +846,17 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                         if (b >= 4 && b < 8) s = t2;
                     }
                     s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
-                    dgrp[c] += s * osd + omu;
+                    dgrp += s * osd + omu;
                 }
             }
         }
         L2A_MTS(11)
 
-        // ---- group A + group B, ensemble mean, reward, state update (every wave, all micro tiles) ------------------------
+        // ---- group A + group B, ensemble mean, reward, state update (this wave's micro tile) ----------------------------------
         const float disc_t = (float)disc_pow;
         disc_pow *= p.discount;
-#pragma unroll
-        for (int c = 0; c < MT; ++c) {
-            f32x4 d = dsum[c] + dgrp[c];
+        {
+            f32x4 d = dsum + dgrp;
             if (e_loop > 1) {
                 // d / E, correctly rounded (Markstein; l2a_mfma.h)
 #pragma unroll
@@ -898,9 +865,9 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                     d[ii] = fmaf(fmaf(-q, e_count, d[ii]), e_inv, q);
                 }
             }
-            const f32x4 nx = st[c] + d;
+            const f32x4 nx = st + d;
             // reward in the 16-candidate kernel's order: quarter partials r_qq (lanes b = qq < 4), (r0 + r1) + (r2 + r3)
-            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq[c];
+            float plin = ((qq == 0) ? p.rw.alive : 0.0f) - p.rw.ctrl_coef * asq;
             float psq = 0.0f;
             const int vi = p.rw.vel_index;
             const float dsel = (vi & 2) ? ((vi & 1) ? d[3] : d[2]) : ((vi & 1) ? d[1] : d[0]);
@@ -913,7 +880,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                                      (dim < p.rw.dist_index + 3) && (dim < obs_dim);
                 psq += in_dist ? nx[ii] * nx[ii] : 0.0f;
             }
-            st[c] = nx;
+            st = nx;
             plin = l2a_row_quarter_sum(plin);
             float r = plin;
             if (p.rw.dist_coef != 0.0f) {
@@ -921,27 +888,23 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                 psq = l2a_row_quarter_sum(psq);
                 r -= p.rw.dist_coef * sqrtf(psq);
             }
-            ret[c] = fmaf(disc_t, r, ret[c]);
+            ret = fmaf(disc_t, r, ret);
         }
         // the next step's inputs
-#pragma unroll
-        for (int c = 0; c < MT; ++c) { av[c][0] = av_next[c][0]; av[c][1] = av_next[c][1]; }
+        av[0] = av_next[0]; av[1] = av_next[1];
         load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
         L2A_MTS(12)
         write_x();
+        __syncthreads();                                // every micro tile's input rows are written
         L2A_MTS(13)
     }
 
-    // ---- results: wave 0, lanes of block 0 hold the returns of the candidates cand0 + 4 c + j ----------------------------
-    if (wave == 0) {
+    // ---- results: lanes of block 0 of wave c hold the returns of the candidates cand0 + 4 c + j; the keys meet in LDS ------
+    {
         unsigned long long key = 0ull;
-#pragma unroll
-        for (int c = 0; c < MT; ++c) {
-            if (valid[c] && b == 0) {
-                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[c]] = ret[c];
-                const unsigned long long k = l2a_key_pack(ret[c], p.cand_offset + cand[c]);
-                key = (k > key) ? k : key;
-            }
+        if (valid && b == 0 && wave < MT) {
+            if (p.returns_out) p.returns_out[(long long)env * p.n + cand] = ret;
+            key = l2a_key_pack(ret, p.cand_offset + cand);
         }
         if (p.best_key) {
 #pragma unroll
@@ -951,7 +914,12 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
                 const unsigned long long other = ((unsigned long long)hi << 32) | lo;
                 key = (other > key) ? other : key;
             }
-            if (lane == 0) {
+            unsigned long long* kbuf = reinterpret_cast<unsigned long long*>(pbuf);     // (the partials are through)
+            if (lane == 0) kbuf[wave] = (wave < MT) ? key : 0ull;
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int w = 1; w < 4; ++w) key = (kbuf[w] > key) ? kbuf[w] : key;
                 if (key != 0ull) atomicMax(p.best_key + env, key);
                 l2a_publish_result(p, (int)gridDim.x);
             }

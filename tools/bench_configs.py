@@ -111,6 +111,13 @@ def main():
         case = C[name]
         env, model = cases.product_model(case)
         report(name + " (single GPU)", case, env, time_plan(model.planner_model(), case, env))
+    # the same default plan sizes on the 16-candidate kernels alone (l2a_set_micro(0): round 3's geometry)
+    _lib.Context.get(0).set_micro(0)
+    for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
+        case = C[name]
+        env, model = cases.product_model(case)
+        report(name + " (single GPU), 16-candidate tiles only", case, env, time_plan(model.planner_model(), case, env))
+    _lib.Context.get(0).set_micro(1)
     # run_mb_mpc.py's own defaults (:77-78,85,97): ONE 2 x 512 model, n = 2000, h = 20, and the Sampler hands get_actions the
     # observations of all num_rollouts = 10 envs at once - a 1250-tile plan
     case = dict(C["c1_hc_rs_n500_h10_e1"], n=2000, h=20, m=10)
@@ -188,11 +195,15 @@ def main():
         h0 = torch.tanh(torch.randn((m, U), device=dev))
         a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
         best = torch.zeros((m,), dtype=torch.int64, device=dev)
-        for kernel in ("mfma", "valu"):
+        for kernel in ("mfma", "mfma, 16-candidate tiles only", "valu"):
             if kernel == "valu" and n * m * h > 30000:
                 continue
-            _lib.Context.get(0).set_kernel(kernel)
+            if kernel.endswith("only") and not label.startswith("c6"):
+                continue
+            _lib.Context.get(0).set_kernel(kernel.split(",")[0])
+            _lib.Context.get(0).set_micro(0 if kernel.endswith("only") else 1)
             ms = time_launches(lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best), 20)
+            _lib.Context.get(0).set_micro(1)
             fl = 2.0 * ((26 + U) * 4 * U + U * 20) * n * m * h
             print(json.dumps(dict(config=label + ", " + kernel + " kernel", n=n, h=h, m=m, units=U,
                                   kernel_ms=round(ms, 4), tflops=round(fl / ms / 1e9, 2),

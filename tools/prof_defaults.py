@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""The reference's own default plan sizes, launched back to back for a rocprofv3 --kernel-trace --stats run (profiles/
+r04_defaults_kernel_stats.csv): run_mb_mpc.py's config-1 shape (one 2 x 512 model, n = 500, h = 10), run_grbal.py's default
+(5 adapted 3 x 512 sets, n = 500, h = 10), run_rebal.py's default (LSTM 256, 5 envs, n = 500, h = 10) - the launches the
+micro-tile kernels of csrc/l2a_micro.h take.  L2A_MICRO=0 in the environment gives the 16-candidate kernels instead."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+plans = []
+for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
+    case = cases.CASES[name]
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    m, n, h = case["m"], case["n"], case["h"]
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    obs0 = torch.randn((m, od), device=dev)
+    a = torch.rand((h, m * n, ad), device=dev) * 2 - 1
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    plans.append((model, lambda native=native, obs0=obs0, a=a, m=m, n=n, h=h, env=env, best=best:
+                  native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
+case = cases.CASES["c6_hc_rnn_rs_n500_h10_m5"]
+env, model = cases.product_rnn_model(case)
+native = model.planner_model()
+dev = native.device
+m, n, h, U = case["m"], case["n"], case["h"], case["units"]
+obs0 = torch.randn((m, 20), device=dev)
+c0 = torch.randn((m, U), device=dev)
+h0 = torch.tanh(torch.randn((m, U), device=dev))
+a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
+best = torch.zeros((m,), dtype=torch.int64, device=dev)
+plans.append((model, lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
+for _, plan in plans:       # one shape after the other, back to back: the clocks are up after the first few dozen launches
+    for _ in range(REPS):
+        plan()
+    torch.cuda.synchronize()
+print("done", REPS)

@@ -65,6 +65,9 @@ def run(plan, h, names, slots):
     ran = wg[:, 1] != 0
     if ran.any():
         life = (wg[:, 1] - wg[:, 0]) * 10        # ns
+        if d[0, 0, 8] and life[0] > 0:
+            print("  shader clock over workgroup 0's lifetime: %.0f MHz (%d clocks from entry to the last stamp, %.1f us of real time)"
+                  % ((d[:, 0, slots].max() - d[0, 0, 8]) / (life[0] / 1e3), d[:, 0, slots].max() - d[0, 0, 8], life[0] / 1e3))
         print("  per-workgroup records: %d workgroups; launch (first start -> last end) %.1f us; lifetimes by XCD / micro tiles (us):"
               % (ran.sum(), (wg[ran, 1].max() - wg[ran, 0].min()) / 100.0))
         for x in range(8):
