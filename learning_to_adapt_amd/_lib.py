@@ -277,6 +277,16 @@ class Context(object):
             self.set_split(0)
             self.split_degraded = True
 
+    def plan_payload(self, best_key, m, digest, payload, stream_ptr):
+        """Pack what a sharded plan all-reduces (``l2a_plan_payload``): keys, this rank's launch flag, the digest pair -
+        on the device, in stream order behind the launch, no host synchronisation.  ``best_key`` / ``payload``: int64 CUDA
+        tensors of ``m`` / ``m + 3`` elements.  Shared by every planner model (MLP and recurrent)."""
+        assert best_key.is_cuda and payload.is_cuda and str(best_key.dtype) == "torch.int64" and str(payload.dtype) == "torch.int64"
+        assert best_key.numel() == m and payload.numel() == m + 3
+        rc = self.lib.l2a_plan_payload(self.handle, ctypes.c_void_p(best_key.data_ptr()), int(m), ctypes.c_ulonglong(int(digest)),
+                                       ctypes.c_void_p(payload.data_ptr()), stream_ptr)
+        self.check(rc, "l2a_plan_payload")
+
     def set_spin_limit(self, polls):
         """Developer / test knob: polls a split workgroup waits for its partner per launch (0 = default)."""
         self.check(self.lib.l2a_set_spin_limit(self.handle, int(polls)), "l2a_set_spin_limit")

@@ -132,6 +132,10 @@ class NativeLSTM(object):
         self.ctx.check(rc, "l2a_lstm_plan_rs_sync")
         return keys
 
+    def plan_payload(self, best_key, m, digest, payload):
+        """As ``NativeModel.plan_payload``: the sharded recurrent planner packs its collective's payload the same way."""
+        self.ctx.plan_payload(best_key, m, digest, payload, _stream_ptr(self.device))
+
     def plan_rs_chunk(self, state, c, h, per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
                       returns_in=None, returns_out=None, state_out=None, c_out=None, h_out=None, best_key=None):
         """Horizon steps ``t0 .. t0 + h_chunk - 1`` of a recurrent plan (``l2a_lstm_plan_rs_chunk``)."""

@@ -236,11 +236,7 @@ class NativeModel(object):
     def plan_payload(self, best_key, m, digest, payload):
         """Pack what a sharded plan all-reduces (``l2a_plan_payload``): keys, this rank's launch flag, the digest pair -
         on the device, in stream order behind the launch, no host synchronisation."""
-        assert best_key.is_cuda and payload.is_cuda and best_key.dtype == torch.int64 and payload.dtype == torch.int64
-        assert best_key.numel() == m and payload.numel() == m + 3
-        rc = self.lib.l2a_plan_payload(self.ctx.handle, _ptr(best_key), int(m), ctypes.c_ulonglong(int(digest)),
-                                       _ptr(payload), _stream_ptr(self.device))
-        self.ctx.check(rc, "l2a_plan_payload")
+        self.ctx.plan_payload(best_key, m, digest, payload, _stream_ptr(self.device))
 
     def plan_rs_chunk(self, state, state_per_row, actions, m, n, h_chunk, t0, discount, reward, cand_offset=0,
                       returns_in=None, returns_out=None, state_out=None, best_key=None):

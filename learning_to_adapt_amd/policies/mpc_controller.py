@@ -205,6 +205,16 @@ class MPCController(Policy, Serializable):
             raise self._digest_error()
         return bool(int(v[0]))
 
+    @staticmethod
+    def _all_gather(mine, world):
+        """``all_gather`` of equally shaped tensors.  RCCL gathers device tensors; gloo implements the collective for host
+        tensors only, so a GPU tensor goes through the host there."""
+        if mine.is_cuda and torch.distributed.get_backend() == "gloo":
+            mine = mine.cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(parts, mine)
+        return parts
+
     def _force_unsplit(self):
         """Every rank of a sharded plan switches to the unsplit launch geometry (some rank's launch lost its tile-split
         partner); the CPU test harness replaces this."""
@@ -721,8 +731,7 @@ class MPCController(Policy, Serializable):
                 wmax = max(widths)
                 mine = rets if n_local == wmax else torch.cat(
                     [rets, torch.zeros((m, wmax - n_local), dtype=rets.dtype, device=rets.device)], dim=1)
-                parts = [torch.empty_like(mine) for _ in range(world)]
-                torch.distributed.all_gather(parts, mine.contiguous())
+                parts = self._all_gather(mine.contiguous(), world)
                 rets = torch.cat([part[:, :w] for part, w in zip(parts, widths)], dim=1)
             returns = rets.cpu().numpy().astype(np.float64).reshape(m, n)
             if world == 1 and self._check_status() is False:
@@ -879,9 +888,8 @@ class MPCController(Policy, Serializable):
             if world > 1:       # shards differ by at most one candidate: pad to the widest for the all-gather
                 mine = r_loc if n_local == wmax else torch.cat(
                     [r_loc, torch.zeros((m, wmax - n_local), dtype=r_loc.dtype, device=dev)], dim=1)
-                parts = [torch.empty_like(mine) for _ in range(world)]
-                torch.distributed.all_gather(parts, mine.contiguous())
-                rets = torch.cat([part[:, :w] for part, w in zip(parts, widths)], dim=1).contiguous()
+                parts = self._all_gather(mine.contiguous(), world)
+                rets = torch.cat([part[:, :w] for part, w in zip(parts, widths)], dim=1).to(dev).contiguous()
             else:
                 rets = r_loc
             ctx.check(lib.l2a_cem_refit(ctx.handle, _ptr(rets), _ptr(a_clip), n, m, D, num_elites,
