@@ -409,6 +409,12 @@ int l2a_mfma_eligible(int obs_dim, int act_dim, int n_hidden, const int* hidden)
  * l2a_packed_layer_floats(k_in, n_out) floats.                                               */
 long long l2a_packed_layer_floats(int k_in, int n_out);
 int l2a_pack_layer_host(const float* w, int k_in, int n_out, float* out);
+/* The micro-tile kernels' copy of a weight set (csrc/l2a_micro_pack.h: wave-stream order), on the host - what tests/
+ * micro_emulator.py consumes.  l2a_micro_layout_floats: floats per set for an MLP obs_dim + act_dim -> n_hidden x hidden ->
+ * obs_dim (0: no micro-tile instance for the shape).  l2a_micro_pack_layer_host: scatter layer `layer`'s row-major
+ * [k_in, n_out] kernel (layer == n_hidden: the output layer) into `out`, which the caller zero-initialised.     */
+long long l2a_micro_layout_floats(int obs_dim, int act_dim, int n_hidden, int hidden);
+int l2a_micro_pack_layer_host(const float* w, int obs_dim, int act_dim, int n_hidden, int hidden, int layer, float* out);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_adapt_sgd_raw", "l2a_model_get_weights",
     "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
-    "l2a_packed_layer_floats", "l2a_pack_layer_host",
+    "l2a_packed_layer_floats", "l2a_pack_layer_host", "l2a_micro_layout_floats", "l2a_micro_pack_layer_host",
     "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best", "l2a_plan_payload",
     "l2a_cem_sample", "l2a_cem_refit",
     "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_sync", "l2a_lstm_plan_rs_chunk",
@@ -128,6 +128,11 @@ def load():
     lib.l2a_packed_layer_floats.restype = c.c_longlong
     lib.l2a_pack_layer_host.argtypes = [c.POINTER(f32), i32, i32, c.POINTER(f32)]
     lib.l2a_pack_layer_host.restype = i32
+    if hasattr(lib, "l2a_micro_layout_floats"):         # (absent from older variant libraries selected with L2A_LIB_PATH)
+        lib.l2a_micro_layout_floats.argtypes = [i32, i32, i32, i32]
+        lib.l2a_micro_layout_floats.restype = c.c_longlong
+        lib.l2a_micro_pack_layer_host.argtypes = [c.POINTER(f32), i32, i32, i32, i32, i32, c.POINTER(f32)]
+        lib.l2a_micro_pack_layer_host.restype = i32
     lib.l2a_comm_unique_id.argtypes = [c.c_char_p]
     lib.l2a_comm_unique_id.restype = i32
     lib.l2a_comm_init.argtypes = [vp, i32, i32, c.c_char_p]

@@ -286,10 +286,6 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
                 const long long slots = (w + f - 1) / f;       // per XCD, of the units with f XCDs
                 if (8 * slots <= cus) {
                     p.pl_units = units; p.pl_f = f; p.pl_r = 8 - units * f; p.pl_w = (int)w;
-                    static const int il = [] { const char* e = std::getenv("L2A_XCD_INTERLEAVE"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
-                    p.pl_il = il;
-                    if (il == 2 && uniform_split && 16 * ((pairs + 7) / 8) <= cus) n_wg = 16 * ((pairs + 7) / 8);
-                    else if (il == 2) p.pl_il = 0;
                     n_wg = 8 * slots;
                 }
             }
@@ -488,6 +484,25 @@ int l2a_pack_layer_host(const float* w, int k_in, int n_out, float* out) {
         l2a_pack_decode(idx, KG, &k, &u);
         out[idx] = (k < k_in && u < n_out) ? w[(long long)k * n_out + u] : 0.0f;
     }
+    return L2A_OK;
+}
+
+long long l2a_micro_layout_floats(int obs_dim, int act_dim, int n_hidden, int hidden) {
+    const int hid[L2A_MAX_LAYERS] = {hidden, hidden, hidden, hidden, hidden, hidden, hidden, hidden, hidden};
+    if (n_hidden < 1 || n_hidden > L2A_MAX_LAYERS - 1 || !mfma_eligible(obs_dim, act_dim, n_hidden, hid)) return 0;
+    if (hidden != 256 && hidden != 512) return 0;
+    return l2a_mlp_micro_floats(hidden, ceil_div(obs_dim + act_dim, 16), n_hidden);
+}
+
+int l2a_micro_pack_layer_host(const float* w, int obs_dim, int act_dim, int n_hidden, int hidden, int layer, float* out) {
+    if (!w || !out || layer < 0 || layer > n_hidden || l2a_micro_layout_floats(obs_dim, act_dim, n_hidden, hidden) == 0)
+        return L2A_EINVAL;
+    const int KG0 = ceil_div(obs_dim + act_dim, 16), OT = ceil_div(obs_dim, 16);
+    const int o4 = (OT == 2 && KG0 == 2 && n_hidden > 1 && obs_dim - 16 <= 4) ? 1 : 0;
+    const int k_in = layer == 0 ? obs_dim + act_dim : hidden, n_out = layer == n_hidden ? obs_dim : hidden;
+    for (int k = 0; k < k_in; ++k)
+        for (int u = 0; u < n_out; ++u)
+            out[l2a_mlp_micro_index(hidden, KG0, n_hidden, o4, layer, k, u)] = w[(long long)k * n_out + u];
     return L2A_OK;
 }
 

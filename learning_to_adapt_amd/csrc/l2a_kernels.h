@@ -24,17 +24,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Everything a rollout launch needs, passed by value (kernarg segment).
-// Cache policy of the exchange granules' stores / loads (aux operand of the raw buffer builtins on gfx950: 1 = sc0, 2 = nt,
-// 16 = sc1).  sc1 alone = write-through / miss-always at device scope; experiment values: 18 = sc1 + nt (streaming: the
-// granules should not displace the weights in L2), 17 = sc0 + sc1 (system scope).
-#ifndef L2A_XAUX_ST
-#define L2A_XAUX_ST 16
-#endif
-#ifndef L2A_XAUX_LD
-#define L2A_XAUX_LD 16
-#endif
+// Cache policy of the tile splits' exchange granules (aux operand of the raw buffer builtins on gfx950: 1 = sc0, 2 = nt,
+// 16 = sc1): sc1 alone = write-through stores / miss-always loads at device scope.  (sc1 + nt cost 1.5 %, sc0 + sc1 changed
+// nothing: profiles/r03_ab_kernel_variants.jsonl.)
+#define L2A_SC1 16
 
+// Everything a rollout launch needs, passed by value (kernarg segment).
 struct L2AKParams {
     // ---- model (constant between launches) -------------------------------------------
     const float* wblk;          // base of the weight-set blocks
@@ -88,7 +83,6 @@ struct L2AKParams {
     // per-block launch.  The first pl_r units own pl_f + 1 XCDs each, the others pl_f; the grid is 8 ceil(pl_w / pl_f)
     // workgroups and hardware workgroup i (XCD i % 8, slot i / 8) either finds its place in its XCD's unit or returns.
     int pl_units, pl_f, pl_r, pl_w;     // units, XCDs per unit (floor), units with one XCD more, workgroups per unit
-    int pl_il;                          // experiment (L2A_XCD_INTERLEAVE): even hardware XCDs first, i.e. a split pair on XCDs 2k, 2k + 1
     int split_from;             // -1: `split` applies to every tile; >= 0: tail split - hardware workgroups
                                 // [0, split_from) run whole tiles, the rest are pairs sharing tiles split_from ..
     unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1

@@ -342,14 +342,14 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
             u32x4 g;
             g.x = xtag; g.y = __float_as_uint(v[2 * hh]);
             g.z = xtag; g.w = __float_as_uint(v[2 * hh + 1]);
-            __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, slot) + (r * 2 + hh) * 1024, 0, L2A_XAUX_ST);
+            __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, slot) + (r * 2 + hh) * 1024, 0, L2A_SC1);
         }
     };
     auto xget = [&](int r, int slot, unsigned int tag, f32x4& v) {
         bool ok = true;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, L2A_XAUX_LD);
+            const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, L2A_SC1);
             v[2 * hh] = __uint_as_float(g.y);
             v[2 * hh + 1] = __uint_as_float(g.w);
             ok = ok && (g.x == tag) && (g.z == tag);
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
         constexpr int NXG = SPLIT ? 2 * (UTWS + OT) : 1;
         u32x4 xg[NXG];
         auto xraw = [&](int r, int slot, int hh) {
-            return __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, L2A_XAUX_LD);
+            return __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, slot) + (r * 2 + hh) * 1024, 0, L2A_SC1);
         };
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {

@@ -157,15 +157,12 @@ __device__ __forceinline__ float l2a_sum_xor32(float x) {
             _Pragma("unroll") for (int tt = TW - 1; tt >= 0; --tt)   /* last-loaded tile first: one vmcnt wait per stage */ \
                 acc[nt][tt] = L2A_MFMA(CA[tt][ii], CB[nt][ii], acc[nt][tt]);
 
-#define L2A_STAGE(CA, CB, FA, FB, SOFF, IMM, GF) L2A_STAGE_X(CA, CB, FA, FB, SOFF, IMM, GF, (void)0)
-// SIDE: a statement scheduled INSIDE the stage (after its operand requests, among its MFMAs) - see l2a_hidden_gemm
-#define L2A_STAGE_X(CA, CB, FA, FB, SOFF, IMM, GF, SIDE)                                   \
+#define L2A_STAGE(CA, CB, FA, FB, SOFF, IMM, GF)                                           \
     {                                                                                      \
         _Pragma("unroll") for (int tt = 0; tt < TW; ++tt)                                  \
             FA[tt] = l2a_ldw(rs, voff[tt] + (IMM), (SOFF));                                \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
             FB[nt] = hin[(nt * HT + (GF)) * 64 + lane];                                    \
-        SIDE;                                                                              \
         L2A_STAGE_MFMA(CA, CB)                                                             \
         /* interleave: one weight load per 4 NT MFMAs (8 back-to-back VMEM issues stall the pipe) */ \
         __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);                                \
@@ -186,22 +183,16 @@ __device__ __forceinline__ float l2a_sum_xor32(float x) {
 // LAST == true : tile0 = global index of this wave's first tile (selects the output fragments)
 // Output-layer fragments fetched a phase ahead: the first L2A_PFT tiles only (the rest are loaded
 // when the output phase starts and land under the MFMAs of the first tiles) - register budget.
-#ifndef L2A_PFT_MAX
 #define L2A_PFT_MAX 6
-#endif
 #define L2A_PFT(TW_, OT_) ((OT_) <= 2 ? ((TW_) < L2A_PFT_MAX ? (TW_) : L2A_PFT_MAX) : ((TW_) < 2 ? (TW_) : 2))
 
-//
-// SIDE: work of ANOTHER phase carried in the shadow of this GEMM's MFMAs (layer 0 of the later sets of a batch: one hidden
-// tile per loop iteration - the loop has HT / 4 = TPW iterations, as many as a wave has layer-0 tiles).  `side(it, stage,
-// last)` is called after each of the four stages of iteration `it` (stage and "last iteration" as compile-time tags).
-template <int NT, int TW, int TPW, int OT, bool LAST, class SIDE>
+template <int NT, int TW, int TPW, int OT, bool LAST>
 __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
                                                 const int (&voff)[TPW], const int (&voffn)[TPW], int twn,
                                                 int tile0, const f32x4* hin,
                                                 f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
                                                 f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW], int lane,
-                                                const float* bias_lds, f32x4 (&bias)[TPW], const int (&olane)[OT], SIDE side) {
+                                                const float* bias_lds, f32x4 (&bias)[TPW], const int (&olane)[OT]) {
     constexpr int HT = L2A_NW * TPW;
     static_assert(HT % 4 == 0, "the k-group pipeline is unrolled by 4");
     f32x4 aC[TW], aD[TW], bA[NT], bB[NT], bC[NT], bD[NT];
@@ -221,15 +212,14 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
 #pragma unroll 1
     for (int g = 0; g < HT - 4; g += 4) {
         const int soff = (g + 2) * 1024;      // byte offset of k-group g + 2 inside a tile
-        const int it = g >> 2;
-        L2A_STAGE_X(aA, bA, aC, bC, soff, 0, g + 2, side(it, std::integral_constant<int, 0>{}, std::false_type{}))
-        L2A_STAGE_X(aB, bB, aD, bD, soff, 1024, g + 3, side(it, std::integral_constant<int, 1>{}, std::false_type{}))
-        L2A_STAGE_X(aC, bC, aA, bA, soff, 2048, g + 4, side(it, std::integral_constant<int, 2>{}, std::false_type{}))
-        L2A_STAGE_X(aD, bD, aB, bB, soff, 3072, g + 5, side(it, std::integral_constant<int, 3>{}, std::false_type{}))
+        L2A_STAGE(aA, bA, aC, bC, soff, 0, g + 2)
+        L2A_STAGE(aB, bB, aD, bD, soff, 1024, g + 3)
+        L2A_STAGE(aC, bC, aA, bA, soff, 2048, g + 4)
+        L2A_STAGE(aD, bD, aB, bB, soff, 3072, g + 5)
     }
     // ---- peeled last iteration (k-groups HT-4 .. HT-1) ------------------------------------
-    L2A_STAGE_X(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2, side(TPW - 1, std::integral_constant<int, 0>{}, std::true_type{}))
-    L2A_STAGE_X(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1, side(TPW - 1, std::integral_constant<int, 1>{}, std::true_type{}))
+    L2A_STAGE(aA, bA, aC, bC, (HT - 2) * 1024, 0, HT - 2)
+    L2A_STAGE(aB, bB, aD, bD, (HT - 2) * 1024, 1024, HT - 1)
     {   // stage 2: consume C; aA is free -> next phase's first operands
         if (LAST) {     // output layer: A fragment (obs tile c, k-group = hidden tile tile0 + tt)
 #pragma unroll
@@ -243,7 +233,6 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
             for (int tt = 0; tt < TPW; ++tt)
                 if (tt < twn) aA[tt] = l2a_ldw(rsn, voffn[tt], 0);
         }
-        side(TPW - 1, std::integral_constant<int, 2>{}, std::true_type{});
         L2A_STAGE_MFMA(aC, bC)
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -263,21 +252,9 @@ __device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amd
             for (int tt = 0; tt < TPW; ++tt)
                 if (tt < twn) aB[tt] = l2a_ldw(rsn, voffn[tt] + 1024, 0);
         }
-        side(TPW - 1, std::integral_constant<int, 3>{}, std::true_type{});
         L2A_STAGE_MFMA(aD, bD)
         __builtin_amdgcn_sched_barrier(0);
     }
-}
-
-template <int NT, int TW, int TPW, int OT, bool LAST>
-__device__ __forceinline__ void l2a_hidden_gemm(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rsn,
-                                                const int (&voff)[TPW], const int (&voffn)[TPW], int twn,
-                                                int tile0, const f32x4* hin,
-                                                f32x4 (&aA)[TPW], f32x4 (&aB)[TPW],
-                                                f32x4 (&pfO)[TPW][OT], f32x4 (&acc)[NT][TPW], int lane,
-                                                const float* bias_lds, f32x4 (&bias)[TPW], const int (&olane)[OT]) {
-    l2a_hidden_gemm<NT, TW, TPW, OT, LAST>(rs, rsn, voff, voffn, twn, tile0, hin, aA, aB, pfO, acc, lane, bias_lds, bias, olane,
-                                           [](int, auto, auto) {});
 }
 
 // Output layer for the TW hidden tiles whose activations `hreg` this wave holds in registers
@@ -400,20 +377,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const int n_tiles = p.m * p.tiles_per_env;
     const int n_pairs = tail ? n_tiles - p.split_from : n_tiles;       // tiles that are shared by two workgroups
     int bid, grp, lpair, pairid;
-    if (!tail && p.pl_il == 2 && split) {
-        // experiment (L2A_XCD_INTERLEAVE=2): BOTH workgroups of a pair on one XCD.  Measured (profiles/
-        // r03_ab_kernel_variants.jsonl, r03l2): with the records still travelling through the memory side (sc1) config 2
-        // is 1.3 % SLOWER - all five weight sets stream through every L2 - and workgroup-scope records (sc0 stores / loads,
-        // with and without a buffer_inv sc0 in front of every sweep) never became visible to the partner: the bounded spin
-        // timed out.  grid = 16 ceil(pairs / 8).
-        const int hx = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-        const int su = (n_pairs + 7) >> 3;
-        grp = idx >= su ? 1 : 0;
-        lpair = hx * su + (idx - grp * su);
-        if (idx >= 2 * su || lpair >= n_pairs) return;
-        bid = grp * n_pairs + lpair;
-        pairid = lpair;
-    } else if (!tail && p.pl_units > 0) {
+    if (!tail && p.pl_units > 0) {
         // Every XCD (own 4 MB L2) serves ONE unit - workgroups that stream the same weights: group A of a split ensemble on
         // XCDs 0-3 and group B on 4-7, each environment of a per-block plan on its own XCD(s).  The contiguous remap cannot
         // do that when the counts do not divide: config 2 (125 tiles) left one workgroup of group B alone with its sets in
@@ -421,7 +385,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         // each) had four XCDs thrash between two environments' sets, 5 % slower than the other four.  The grid is padded
         // (host: launch_rollout); hardware workgroup i sits on XCD i % 8, and the spare ones return here.
         const int hx = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-        const int xcd = p.pl_il ? (((hx & 1) << 2) | (hx >> 1)) : hx;
+        const int xcd = hx;
         const int f = p.pl_f, wide = p.pl_r * (f + 1);
         int u, k, xu;
         if (xcd < wide) { u = xcd / (f + 1); k = xcd - u * (f + 1); xu = f + 1; }
@@ -570,14 +534,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     load_actions(0, av_next);
     take_actions(1);
 
-    // -DL2A_RET64 (experiment, tools/build_variant.py): the per-candidate return accumulated in float64 like the
-    // reference's `returns` (:98,126) and rounded to fp32 once at the end - profiles/r03_parity_report.txt records
-    // what that does to the CEM rank ties (nothing measurable: the error is the fp32 state's, not the sum's)
-#ifdef L2A_RET64
-    double ret[NT];
-#else
     float ret[NT];
-#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ret[nt] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[nt] ? cand[nt] : p.n - 1)] : 0.0f;
 
@@ -588,18 +545,12 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     double disc_pow = p.disc0;  // discount ** t, carried in float64 like the reference (:126)
     unsigned int spin_left = p.spin_limit;      // exchange polls this workgroup may still spend (whole launch)
     const unsigned int xtag0 = p.xtag;
-#ifdef L2A_XWAIT
-    unsigned int xwait_q = 0;                   // adaptive delay of the first exchange sweep, in quarter sleep units (below)
-#endif
     const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
     // barrier that separates them, so a phase never starts with an exposed L2 round trip).
-    // (-DL2A_L0_PREFETCH_ALL=1: every layer-0 k-group a phase ahead - measured neutral, 21 more registers)
-#ifndef L2A_L0_PREFETCH_ALL
-#define L2A_L0_PREFETCH_ALL 0
-#endif
-    constexpr int KG0P = (L2A_L0_PREFETCH_ALL && KG0 <= 2) ? KG0 : 1;      // layer-0 k-groups fetched a phase ahead (all of them when the input is
+    // (every layer-0 k-group a phase ahead was measured neutral for 21 more registers: profiles/r03_ab_kernel_variants.jsonl)
+    constexpr int KG0P = 1;      // layer-0 k-groups fetched a phase ahead (all of them when the input is
                                                     // at most 32 wide: registers; wider inputs fetch the rest at layer 0)
     f32x4 pfL0[KG0P][TPW];      // layer-0 A fragments of the upcoming (step, set)
     f32x4 pfA[TPW], pfB[TPW];   // k-groups 0 / 1 of the upcoming hidden->hidden layer
@@ -653,7 +604,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         u32x4 g;
                         g.x = xtag; g.y = __float_as_uint(v[nt][c][2 * hh]);
                         g.z = xtag; g.w = __float_as_uint(v[nt][c][2 * hh + 1]);
-                        __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_XAUX_ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(g, xrs, xbase(grp, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_SC1);
                     }
         };
         auto xget = [&](int region, f32x4 (&v)[NT][OT]) {
@@ -665,33 +616,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
                         const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(
-                            xrs, xbase(grp ^ 1, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_XAUX_LD);
+                            xrs, xbase(grp ^ 1, region) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_SC1);
                         v[nt][c][2 * hh] = __uint_as_float(g.y);
                         v[nt][c][2 * hh + 1] = __uint_as_float(g.w);
                         ok = ok && (g.x == xtag) && (g.z == xtag);
-                    }
-            return ok;
-        };
-        // a sweep = the 16-byte loads of the partner's records (xload) and, once they have returned, the tag check and
-        // the unpacking (xtake); two sweeps are kept in flight half a round trip apart (below)
-        constexpr int XG = NT * OT * 2;                         // granule rows per region
-        auto xload = [&](int region, u32x4 (&g)[XG]) {
-#pragma unroll
-            for (int k = 0; k < XG; ++k)
-                g[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, region) + k * 1024, 0, L2A_XAUX_LD);
-        };
-        auto xtake = [&](const u32x4 (&g)[XG], f32x4 (&v)[NT][OT]) {
-            bool ok = true;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int c = 0; c < OT; ++c)
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const u32x4 q = g[(nt * OT + c) * 2 + hh];
-                        v[nt][c][2 * hh] = __uint_as_float(q.y);
-                        v[nt][c][2 * hh + 1] = __uint_as_float(q.w);
-                        ok = ok && (q.x == xtag) && (q.z == xtag);
                     }
             return ok;
         };
@@ -861,7 +789,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             // the last hidden layer keeps its output in registers and feeds the output layer directly
             // (again a generic lambda, the batch's last set peeled: a set that is not the last of its batch is a full
             // member and hands over to the next set's GEMM, the last one hands over to a layer 0)
-            auto member = [&](int j, auto last_tag, auto side) {
+            auto member = [&](int j, auto last_tag) {
                 constexpr bool last_set = decltype(last_tag)::value;
                 const int i = b0 + j;
                 const int e = seq(i);
@@ -897,7 +825,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     const float* bl = nr + CST_BHID + (n_hidden - 1) * (16 * HT);
                     if (!is_half) {
                         l2a_hidden_gemm<NT, TPW, TPW, OT, true>(rs_last, rs_out, voff, voff, TPW, c0, hin, pfA, pfB, pfO,
-                                                                acc, lane, bl + 16 * c0 + 4 * qq, bias, olane, side);
+                                                                acc, lane, bl + 16 * c0 + 4 * qq, bias, olane);
 #pragma unroll
                         for (int tt = 0; tt < TPW; ++tt) {
 #pragma unroll
@@ -951,116 +879,13 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 }
                 L2A_TS(4)
             };
-            auto no_side = [](int, auto, auto) {};
-#ifndef L2A_EMBED
-#define L2A_EMBED 0
-#endif
-#if L2A_EMBED
-            // Embedded layer 0 (EMB): only the batch's FIRST set runs its layer 0 as a phase of its own; layer 0 of every
-            // later set (its input is the same state) is carried by the hidden GEMM of the set BEFORE it, one hidden tile
-            // per loop iteration - 8 MFMAs, 2 weight loads, 1 bias read, 1 LDS write per iteration, issued between the
-            // GEMM's stages, so that their latencies (operand fetch, bias read, write-out) disappear in the shadow of the
-            // GEMM's MFMAs instead of standing in a phase of 64 MFMAs.  Same operands in the same order: bit-identical.
-            // (One set per GEMM: carrying two at once costs 48 registers and spills the HalfCheetah instance.)
-            // MEASURED AND LOST (profiles/r03_ab_kernel_variants.jsonl, sessions r03g-r03i): a carried layer 0 lengthens its
-            // host GEMM by 3.5k clocks - what the phase of its own costs (3.7k) - whether its instructions sit between the
-            // stages or are interleaved with their MFMAs: with one wave per SIMD every non-MFMA instruction costs issue
-            // time (~6 clocks) wherever it stands, and a layer 0 is 64 MFMAs + ~150 others.  Config 2: 1.428 ms carried
-            // against 1.422 ms as a phase.  Kept behind -DL2A_EMBED=1 for the record; the product does not compile it.
-            constexpr bool EMB = L2A_EMBED && !N1 && KG0 <= 2 && OT <= 2 && NT == 1;
-            if (EMB && nb > 1) {
-                layer0(0, std::true_type{});        // (its tail requests the first operands of the first set's GEMM)
-                __amdgpu_buffer_rsrc_t er0;         // layer-0 weights of the set being carried
-                f32x4 ex[KG0][NT];                  // its normalised inputs
-                f32x4 ea[KG0];                      // A fragments of the tile in flight
-                f32x4 eacc[NT], ebias;
-                const float* ebl;                   // this lane's bias slice of the wave's first tile
-                f32x4* ehd;                         // this lane's slot of the wave's first tile in the set's LDS region
-                const int evoff = lane * 16 + c0 * KG0 * 1024;
-                auto carry = [&](int jn) {          // set jn of the batch is the next to be carried
-                    const int i = b0 + jn;
-                    const float* nr = nrm + i * NRM_SET;
-                    er0 = l2a_rsrc(set_base(seq(i)) + p.pk_w0, w0_bytes);
-#pragma unroll
-                    for (int g = 0; g < KG0; ++g) {
-                        const f32x4 mu = *reinterpret_cast<const f32x4*>(nr + 16 * g + 4 * qq);
-                        const f32x4 iv = *reinterpret_cast<const f32x4*>(nr + 16 * KG0 + 16 * g + 4 * qq);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (g < OT) sv = st[nt][g < OT ? g : 0];
-                            f32x4 aa = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (g == ga0) aa = av[nt][0];
-                            if (g == ga0 + 1) aa = av[nt][1];
-#pragma unroll
-                            for (int ii = 0; ii < 4; ++ii) ex[g][nt][ii] = ((sv[ii] + aa[ii]) - mu[ii]) * iv[ii];
-                        }
-                    }
-                    ebl = nr + CST_BHID + 16 * c0 + 4 * qq;
-                    ehd = buf0 + jn * p.sa_elems + c0 * 64 + lane;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) eacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                };
-                // Per GEMM iteration `it` (four stages of 32 MFMAs and 8 weight loads each):
-                //   in stage 0: request tile it's layer-0 weights; read the bias of tile it - 1
-                //   in stage 1: bias, activation, write-out of tile it - 1 (its MFMAs ran an iteration ago)
-                //   in stage 3: the 8 MFMAs of tile it - its weights have had three stages (24 younger loads: the wait
-                //                  is vmcnt(24), the GEMM's own operands in flight stay in flight) to arrive
-                // Requesting the weights an ITERATION ahead instead looked natural and cost 3.6k clocks per carried set: the
-                // loop's first trip then reaches the MFMAs with only 8 younger loads behind the request, the wait is
-                // computed for that path (vmcnt(8)) and drains the GEMM's own prefetch every iteration (timeline r03g).
-                auto side = [&](int it, auto stage_tag, auto last_tag) {
-                    constexpr int ST = decltype(stage_tag)::value;
-                    constexpr bool LAST_IT = decltype(last_tag)::value;
-                    auto finish = [&](int tile) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            ehd[(nt * HT + tile) * 64] = l2a_actv<GACT>(eacc[nt] + ebias, p.hidden_act, p.hid_floor);
-                    };
-                    if (ST == 0) {
-#pragma unroll
-                        for (int g = 0; g < KG0; ++g) ea[g] = l2a_ldw(er0, evoff + g * 1024, it * (KG0 * 1024));
-                        ebias = *reinterpret_cast<const f32x4*>(ebl + 16 * (it > 0 ? it - 1 : 0));
-                    } else if (ST == 1) {
-                        // branch-free (a branch would cut the stage's scheduling region in two): the first iteration has no
-                        // finished tile yet and writes zeros + bias into tile 0's slot, which the second iteration overwrites
-                        finish(it > 0 ? it - 1 : 0);
-                    } else if (ST == 2) {
-                        // (nothing: the slot keeps the distance between the request and the MFMAs)
-                    } else {
-                        f32x4 acc_[NT];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc_[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int g = 0; g < KG0; ++g)
-#pragma unroll
-                            for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt) acc_[nt] = L2A_MFMA(ea[g][ii], ex[g][nt][ii], acc_[nt]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) eacc[nt] = acc_[nt];
-                        if (LAST_IT) {          // the last tile finishes here (one exposed MFMA latency per carried set)
-                            ebias = *reinterpret_cast<const f32x4*>(ebl + 16 * it);
-                            finish(it);
-                        }
-                    }
-                };
-                for (int j = 0; j + 1 < nb; ++j) {
-                    carry(j + 1);
-                    __syncthreads();                // layer 0 of set j is in LDS (written by the GEMM before, or the phase above)
-                    member(j, std::false_type{}, side);
-                }
-                __syncthreads();
-                member(nb - 1, std::true_type{}, no_side);
-            } else
-#endif
-            {
-                for (int j = 0; j + 1 < nb; ++j) layer0(j, std::false_type{});
-                layer0(nb - 1, std::true_type{});
-                if (!N1) __syncthreads();
-                for (int j = 0; j + 1 < nb; ++j) member(j, std::false_type{}, no_side);
-                member(nb - 1, std::true_type{}, no_side);
-            }
+            // (layer 0 of a batch's later sets carried inside the previous set's GEMM - one hidden tile per loop iteration - was
+            // measured and lost: it lengthens the host GEMM by what the phase of its own costs, profiles/r03_ab_kernel_variants.jsonl)
+            for (int j = 0; j + 1 < nb; ++j) layer0(j, std::false_type{});
+            layer0(nb - 1, std::true_type{});
+            if (!N1) __syncthreads();
+            for (int j = 0; j + 1 < nb; ++j) member(j, std::false_type{});
+            member(nb - 1, std::true_type{});
 
             // ======== phase C: canonical reduce of every set of the batch ===========================
             __syncthreads();
@@ -1158,10 +983,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 // single model (E == 1): there are no full sets, region 0 is never written - skip it
                 const bool want0 = (split == 1) || (e_loop > 1);
                 unsigned int spins = 0;
-                // Both regions in ONE round trip (an sc1 load sweep costs ~2-3k clocks whatever its size), and TWO sweeps in
-                // flight half a round trip apart: the partner's records become visible ~2k clocks after it published them,
-                // a lone sweep that just misses them costs a whole further round trip (timeline r03: 3.3k clocks when the
-                // first sweep hits, 4.9k when it is the second), the staggered pair at most half of one.
+                // Both regions in ONE round trip (an sc1 load sweep costs ~2-3k clocks whatever its size): the partner's records
+                // become visible ~2.2k clocks after it published them; a sweep that misses them costs a whole further round trip
+                // (timeline r03: 3.3k clocks from publish to swept when the first sweep hits, 4.9k when it is the second).
                 auto give_up = [&]() {                  // partner never arrived: flag it, do not hang; the budget is per
                     ++spins;                            // launch, so the remaining steps give up after one poll each
                     if (spin_left == 0) {
@@ -1171,60 +995,16 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     --spin_left;
                     return false;
                 };
-                // -DL2A_SWEEPS=2: two sweeps in flight half a round trip apart.  Measured and lost (1.457 against 1.448 ms on
-                // config 2, 41 more registers: profiles/r03_ab_kernel_variants.jsonl) - kept as an option, off.
-#ifndef L2A_SWEEPS
-#define L2A_SWEEPS 1
-#endif
-                constexpr bool TWO_SWEEPS = (L2A_SWEEPS == 2) && OT <= 2;     // wider states: no registers for a second sweep
-                if (TWO_SWEEPS) {
-                    u32x4 ga[2][XG], gb[2][XG];
-                    auto issue = [&](u32x4 (&g)[2][XG]) {
-                        if (split == 2) xload(1, g[1]);
-                        if (want0) xload(0, g[0]);
-                    };
-                    auto settle = [&](const u32x4 (&g)[2][XG]) {
-                        bool ok = true;
-                        if (split == 2) ok = xtake(g[1], oth[1]);
-                        if (want0) ok = xtake(g[0], oth[0]) && ok;
-                        return (bool)__all(ok);
-                    };
-                    issue(ga);
-                    __builtin_amdgcn_s_sleep(12);
-                    issue(gb);
-                    while (true) {
-                        if (settle(ga) || give_up()) break;
-                        issue(ga);
-                        if (settle(gb) || give_up()) break;
-                        issue(gb);
-                    }
-                } else {
-                    // Timing the FIRST sweep (-DL2A_XWAIT, off: measured and lost).  The workgroup of a pair that finishes its
-                    // sets first sweeps at once, misses (its partner's records become visible ~2.2k clocks after THEY are
-                    // published), sleeps, sweeps again: every miss costs a whole sc1 round trip (~2.5k clocks), and the pair's
-                    // step ends with the later of the two (timeline r03: the early workgroup 6.5k clocks from publish to swept,
-                    // the late one 3.3k).  Letting each workgroup LEARN a delay for its first sweep (+256 clocks per missed
-                    // sweep, -16 per first-sweep hit) made the early one hit at once (4.5k) - and the late one, whose every
-                    // jitter-induced miss adds a delay that takes 16 steps to decay, slower by more: config 2 1.436 against
-                    // 1.429 ms, the tail-split config 3 1.20 against 1.15 ms (profiles/r03_ab_kernel_variants.jsonl, r03p).  The
-                    // shader clocks of two XCDs are not comparable either (s_memtime differs by a drifting offset: tools/
-                    // timeline.py prints it), so the partner's progress cannot be read off a published time stamp.  Nothing
-                    // may be left in flight instead (two staggered sweeps: lost as well): loads retire in order, an abandoned
-                    // sweep would stall the next step's first operand wait by its whole round trip.
-#ifdef L2A_XWAIT
-                    for (unsigned int k = 0; k < (xwait_q >> 2); ++k) __builtin_amdgcn_s_sleep(1);
-#endif
-                    while (true) {
-                        bool ok = true;
-                        if (split == 2) ok = xget(1, oth[1]);
-                        if (want0) ok = xget(0, oth[0]) && ok;
-                        if (__all(ok) || give_up()) break;
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-#ifdef L2A_XWAIT
-                    if (spins == 0) xwait_q -= (xwait_q > 0) ? 1u : 0u;
-                    else xwait_q = (xwait_q + 16u * spins > 400u) ? 400u : xwait_q + 16u * spins;
-#endif
+                // Measured and lost (profiles/r03_ab_kernel_variants.jsonl; the code is in the history): two sweeps in flight half a
+                // round trip apart (41 more registers, and loads retire in order: the sweep still in flight stalls the next step's
+                // first operand wait); a learnt delay of the first sweep (every jitter-induced miss of the late workgroup then
+                // costs 16 steps); streaming / system-scope granules; both workgroups of a pair on one XCD.
+                while (true) {
+                    bool ok = true;
+                    if (split == 2) ok = xget(1, oth[1]);
+                    if (want0) ok = xget(0, oth[0]) && ok;
+                    if (__all(ok) || give_up()) break;
+                    __builtin_amdgcn_s_sleep(4);
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
@@ -1284,8 +1064,6 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
         // ---- ensemble mean, reward, state update -------------------------------------------
         const float disc_t = (float)disc_pow;
-        const double disc_pow_t = disc_pow;     // (used by the L2A_RET64 experiment build)
-        (void)disc_pow_t;
         disc_pow *= p.discount;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1296,11 +1074,14 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 f32x4 d = dsum[nt][c];
                 if (e_loop > 1) {
                     // d / E, correctly rounded like the IEEE division it replaces (Markstein: q = RN(d y), r = d - q E exactly
-                    // (fma), q' = RN(q + r y) with y = RN(1 / E)) - three operations instead of the ~11 of v_div_*
+                    // (fma), q' = RN(q + r y) with y = RN(1 / E)) - three operations instead of the ~11 of v_div_*.  A diverged
+                    // candidate keeps its +-inf like the division would (the correction term of an infinite q is inf - inf = NaN,
+                    // and NaN ranks highest in the arg-max key: ADVICE r3)
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         const float q = d[ii] * e_inv;
-                        d[ii] = fmaf(fmaf(-q, e_count, d[ii]), e_inv, q);
+                        const float qc = fmaf(fmaf(-q, e_count, d[ii]), e_inv, q);
+                        d[ii] = (fabsf(q) < INFINITY) ? qc : q;
                     }
                 }
                 const f32x4 nx = st[nt][c] + d;
@@ -1318,11 +1099,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             psq = l2a_sum_xor32(l2a_sum_xor16(psq));
             float r = plin;
             if (p.rw.dist_coef != 0.0f) r -= p.rw.dist_coef * sqrtf(psq);
-#ifdef L2A_RET64
-            ret[nt] += disc_pow_t * (double)r;
-#else
             ret[nt] = fmaf(disc_t, r, ret[nt]);
-#endif
         }
         { const int e = 7; L2A_TS(7) }     // end of the step (after exchange, reward, state update)
     }
@@ -1333,8 +1110,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (valid[nt] && qq == 0) {
-                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[nt]] = (float)ret[nt];
-                const unsigned long long k = l2a_key_pack((float)ret[nt], p.cand_offset + cand[nt]);
+                if (p.returns_out) p.returns_out[(long long)env * p.n + cand[nt]] = ret[nt];
+                const unsigned long long k = l2a_key_pack(ret[nt], p.cand_offset + cand[nt]);
                 key = (k > key) ? k : key;
             }
             if (p.state_out && valid[nt]) {

@@ -34,17 +34,13 @@ int launch_shape(int ot, int kg0, const L2AKParams* p, unsigned grid, int smem, 
         case 1 * 8 + 1: return launch_one<1, 1, GACT>(p, grid, smem, stream);
         case 1 * 8 + 2: return launch_one<1, 2, GACT>(p, grid, smem, stream);
         case 2 * 8 + 2:     // HalfCheetah: 20 = 16 + 4 observations - the last obs tile has four live units (O4 instance)
-#ifndef L2A_NO_O4
             if (p->n_hidden > 1 && p->obs_dim - 16 >= 1 && p->obs_dim - 16 <= 4)
                 return launch_one<2, 2, GACT, 4, false, true>(p, grid, smem, stream);
-#endif
             return launch_one<2, 2, GACT>(p, grid, smem, stream);
         case 2 * 8 + 3: return launch_one<2, 3, GACT>(p, grid, smem, stream);
         case 3 * 8 + 3: return launch_one<3, 3, GACT>(p, grid, smem, stream);
         case 3 * 8 + 4:     // Ant: 41 + 8 = 49 inputs end one feature into the last k-group (its own instance; relu / identity)
-#ifndef L2A_NO_K0L
             if (!GACT && p->in_dim == 49) return launch_one<3, 4, GACT, 1>(p, grid, smem, stream);
-#endif
             return launch_one<3, 4, GACT>(p, grid, smem, stream);
         case 4 * 8 + 4: return launch_one<4, 4, GACT>(p, grid, smem, stream);
         case 4 * 8 + 5: return launch_one<4, 5, GACT>(p, grid, smem, stream);

@@ -858,11 +858,12 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
         {
             f32x4 d = dsum + dgrp;
             if (e_loop > 1) {
-                // d / E, correctly rounded (Markstein; l2a_mfma.h)
+                // d / E, correctly rounded, +-inf kept (Markstein; l2a_mfma.h)
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const float q = d[ii] * e_inv;
-                    d[ii] = fmaf(fmaf(-q, e_count, d[ii]), e_inv, q);
+                    const float qc = fmaf(fmaf(-q, e_count, d[ii]), e_inv, q);
+                    d[ii] = (fabsf(q) < INFINITY) ? qc : q;
                 }
             }
             const f32x4 nx = st + d;

@@ -52,9 +52,12 @@ __host__ __device__ inline long long l2a_rnn_mfma_lds_floats(int in_dim, int obs
 // float index (((T * G + q) * KG + g) * 64 + lane) * 4 + ii, KG = KGx + UT k-groups (KGx = ceil(kin / 16) input groups, then
 // UT = ceil(U / 16) recurrent groups), = W[row][q U + 16 T + (lane & 15)] with row = 16 g + 4 (lane >> 4) + ii in its part,
 // 0 where the row or the unit is padding.  The output layer is the same with U -> obs_dim, G = 1 and no recurrent part.
+// The array is padded with zero unit tiles to a multiple of FOUR: the rollout computes blocks of up to four unit tiles per
+// product call and addresses a tile through the SGPR offset of its buffer loads, which the hardware's range check does
+// not cover - a block that reaches past the last unit tile reads these zeros, not what follows the allocation.
 __host__ __device__ inline long long l2a_rnn_pack_floats(int kin, int U, int G, bool recurrent) {
-    const int UT = (U + 15) / 16;
-    return (long long)UT * G * ((kin + 15) / 16 + (recurrent ? UT : 0)) * 256;
+    const int UT = (U + 15) / 16, UTP = (UT + 3) & ~3;
+    return (long long)UTP * G * ((kin + 15) / 16 + (recurrent ? UT : 0)) * 256;
 }
 
 __global__ void l2a_rnn_pack_k(const float* w, int kin, int U, int G, int recurrent, long long total, float* dst) {
@@ -254,8 +257,8 @@ __global__ void __launch_bounds__(256) l2a_rnn_mfma_k(const L2ALstmParams p) {
             // 2 x 2 gate tiles of TWO unit tiles of a GRU layer, FOUR unit tiles where a product has a single gate (BasicRNN,
             // the GRU candidate) - as long as the layer is wide enough to give every wave such a block.  In the packed array
             // those tiles are consecutive ([unit tile][gate]), so a block of unit tiles is "unit tile b of a kernel with more
-            // gates"; wave w owns blocks w, w + 4, ...  Tiles past the last unit tile read zeros (buffer range) and are
-            // skipped when the results go back to LDS.
+            // gates"; wave w owns blocks w, w + 4, ...  Tiles past the last unit tile read the zero tiles the packed array is
+            // padded with (l2a_rnn_pack_floats) and are skipped when the results go back to LDS.
             if (lstm) {
                 for (int T = wave; T < UT; T += 4) {
                     const int u0 = 16 * T + 4 * qq;             // this lane's four units of the D tile

@@ -182,7 +182,7 @@ class MPCController(Policy, Serializable):
         ``torch.initial_seed()``.  Travels with EVERY collective of a plan step (two more words), so a disagreement is
         caught on the step it happens, on all ranks at once."""
         if self.rng == "numpy":
-            return fast_rng.global_digest() & self.DIGEST_MASK
+            return fast_rng.global_digest(with_gauss=bool(self.use_cem)) & self.DIGEST_MASK
         return int(torch.initial_seed()) & self.DIGEST_MASK
 
     def _digest_error(self):
@@ -217,7 +217,7 @@ class MPCController(Policy, Serializable):
 
     def _force_unsplit(self):
         """Every rank of a sharded plan switches to the unsplit launch geometry (some rank's launch lost its tile-split
-        partner); the CPU test harness replaces this."""
+        partner)."""
         self.dynamics_model.planner_model().ctx.force_unsplit()
 
     def _pack_payload(self, best, m):
@@ -226,18 +226,8 @@ class MPCController(Policy, Serializable):
         between the launch and the collective."""
         dev = best.device
         payload = self._buf("payload", (m + 3,), torch.int64, dev)
-        d = self._rank_digest()
-        if dev.type == "cuda":
-            self.dynamics_model.planner_model().plan_payload(best, m, d, payload)
-        else:                                   # CPU test harness (tests/oracle_backend.py): flags come from its hook
-            payload[:m] = best
-            payload[m] = 1 if self._harness_flag() else 0
-            payload[m + 1] = d
-            payload[m + 2] = self.DIGEST_MASK - d
+        self.dynamics_model.planner_model().plan_payload(best, m, self._rank_digest(), payload)
         return payload
-
-    def _harness_flag(self):
-        return False
 
     def _fusable(self):
         return (self._reward_spec is not None) and hasattr(self.dynamics_model, "planner_model")

@@ -105,17 +105,38 @@ def _global_lock():
     return np.random.mtrand._rand._bit_generator.lock
 
 
-def global_digest():
+_FNV_OFFSET, _FNV_PRIME, _M64 = 1469598103934665603, 1099511628211, (1 << 64) - 1
+
+
+def _fnv1a_words(h, words):
+    for w in words:
+        h = ((h ^ int(w)) * _FNV_PRIME) & _M64
+    return h
+
+
+def global_digest(with_gauss=False):
     """Fingerprint (< 2**47) of the global legacy generator's state - what the ranks of a sharded plan compare every
-    step (``MPCController._combine_keys``).  ~1 us through the helper library, ``get_state`` + crc32 otherwise."""
+    step (``MPCController._combine_keys``): 64-bit FNV-1a over (key[624], pos), ~1 us through the helper library
+    (``l2a_mt19937_state_digest``) and the SAME function in Python without it, so that ranks whose helper availability
+    differs (a build or self-test failure on one node) still agree when their states do.  ``with_gauss``:
+    the cached second value of the legacy polar Gaussian is folded in as well - planners that draw normals (CEM in parity
+    mode) would otherwise combine returns of different samples when only that cache differs."""
+    h = None
     if available("direct"):
         addr = _global_addr()
         if addr is not None:
             with _global_lock():
-                return int(_state["lib"].l2a_mt19937_state_digest(addr)) & 0x7FFFFFFFFFFF
-    import zlib
-    st = np.random.get_state()
-    return (zlib.crc32(np.asarray(st[1]).tobytes()) ^ (int(st[2]) << 32)) & 0x7FFFFFFFFFFF
+                h = int(_state["lib"].l2a_mt19937_state_digest(addr))
+    st = None
+    if h is None:
+        st = np.random.get_state()
+        h = _fnv1a_words(_FNV_OFFSET, list(np.asarray(st[1], dtype=np.uint32)) + [int(st[2]) & 0xFFFFFFFF])
+    if with_gauss:
+        if st is None:
+            st = np.random.get_state()
+        g = np.float64(st[4]).view(np.uint64)
+        h = _fnv1a_words(h, [int(st[3]) & 0xFFFFFFFF, int(g) & 0xFFFFFFFF, int(g) >> 32])
+    return h & 0x7FFFFFFFFFFF
 
 
 class State(object):

@@ -48,6 +48,11 @@ def mfma_4x4x1(a, b, c):
     return out
 
 
+def fma(a, b, c):
+    """One rounding: what the compiler's contraction of ``a * b + c`` (and an explicit ``fmaf``) gives on the device."""
+    return (np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64) + np.asarray(c, dtype=np.float64)).astype(F32)
+
+
 def act4(v, kind):
     if kind == "relu":
         return np.maximum(v, F32(0))
@@ -162,8 +167,8 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
         for nt in range(NT):
             s = np.zeros(64, dtype=F32)
             for ii in range(4):
-                s = (av[nt, 0, :, ii] * av[nt, 0, :, ii] + s).astype(F32)
-                s = (av[nt, 1, :, ii] * av[nt, 1, :, ii] + s).astype(F32)
+                s = fma(av[nt, 0, :, ii], av[nt, 0, :, ii], s)
+                s = fma(av[nt, 1, :, ii], av[nt, 1, :, ii], s)
             asq[nt] = s
         dsum = np.zeros((NW, NT, OT, 64, 4), dtype=F32)      # finished group
         dgrp = np.zeros((NW, NT, OT, 64, 4), dtype=F32)      # group being summed (A then B)
@@ -255,7 +260,7 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                             s = (s + s[LANE ^ 16]).astype(F32)
                             s = (s + s[LANE ^ 32]).astype(F32)
                         s = act4((s + bias).astype(F32), output_act)
-                        dgrp[wave, nt, c] = (dgrp[wave, nt, c] + (s * osd + omu).astype(F32)).astype(F32)
+                        dgrp[wave, nt, c] = (dgrp[wave, nt, c] + fma(s, osd, omu)).astype(F32)
             # (no barrier; `cur` is NOT flipped: the next layer 0 writes the region it just read)
 
         dsum = (dsum + dgrp).astype(F32)                     # group A + group B
@@ -263,18 +268,17 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
         disc_pow *= float(F32(discount))
         for wave in range(NW):
             for nt in range(NT):
-                plin = np.where(QQ == 0, F32(reward["alive"]), F32(0)) - F32(reward["ctrl_coef"]) * asq[nt]
-                plin = plin.astype(F32)
+                plin = fma(-F32(reward["ctrl_coef"]), asq[nt], np.where(QQ == 0, F32(reward["alive"]), F32(0)))
                 psq = np.zeros(64, dtype=F32)
                 for c in range(OT):
                     d = dsum[wave, nt, c]
                     if e_loop > 1:
-                        d = (d / F32(e_loop)).astype(F32)
+                        d = (d / F32(e_loop)).astype(F32)       # (the kernel's Markstein sequence is the correctly rounded quotient)
                     nx = (st[wave, nt, c] + d).astype(F32)
                     for ii in range(4):
                         dim = 16 * c + 4 * QQ + ii
                         plin = np.where(dim == reward["vel_index"],
-                                        plin + F32(reward["w_vel"]) * d[:, ii] * F32(reward["inv_dt"]), plin).astype(F32)
+                                        fma((F32(reward["w_vel"]) * d[:, ii]).astype(F32), F32(reward["inv_dt"]), plin), plin).astype(F32)
                         in_dist = (reward["dist_coef"] != 0.0) & (dim >= reward["dist_index"]) & \
                                   (dim < reward["dist_index"] + 3) & (dim < obs_dim)
                         psq = (psq + np.where(in_dist, nx[:, ii] * nx[:, ii], F32(0))).astype(F32)
@@ -285,8 +289,8 @@ def rollout_workgroup(sets, mode, obs0_env, actions, env, tb, n, m, obs_dim, act
                 psq = (psq + psq[LANE ^ 32]).astype(F32)
                 r = plin
                 if reward["dist_coef"] != 0.0:
-                    r = (r - F32(reward["dist_coef"]) * np.sqrt(psq)).astype(F32)
-                ret[wave, nt] = (disc_t * r + ret[wave, nt]).astype(F32)
+                    r = fma(-F32(reward["dist_coef"]), np.sqrt(psq), r)
+                ret[wave, nt] = fma(disc_t, r, ret[wave, nt])
 
     for wave in range(1, NW):
         assert np.array_equal(st[wave], st[0]), "waves diverged"

@@ -27,7 +27,17 @@ def _install_status_hooks(controller):
     def force_unsplit():
         controller.harness_unsplit += 1
 
-    controller._harness_flag = flag
+    def pack_payload(best, m):
+        # what `l2a_plan_payload` packs on the device: [keys, this rank's launch flag, digest, MASK - digest]
+        payload = torch.empty((m + 3,), dtype=torch.int64)
+        d = controller._rank_digest()
+        payload[:m] = best
+        payload[m] = 1 if flag() else 0
+        payload[m + 1] = d
+        payload[m + 2] = controller.DIGEST_MASK - d
+        return payload
+
+    controller._pack_payload = pack_payload
     controller._status_flag = flag
     controller._force_unsplit = force_unsplit
 
