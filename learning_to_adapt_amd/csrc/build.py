@@ -2,7 +2,7 @@
 
     python learning_to_adapt_amd/csrc/build.py [--force]
 
-The MFMA kernel template is instantiated in six translation units (one per (NT, TPW) pair), the
+The MFMA kernel template is instantiated in five translation units (one per (NT, TPW) pair), the
 LSTM kernel in three (one per units / 64); all are compiled in parallel and linked with the two API units.
 """
 
@@ -20,7 +20,7 @@ OBJ_DIR = os.path.join(HERE, "_obj")
 HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_adapt.h", "l2a_mfma.h", "l2a_mfma_launch.h", "l2a_lstm.h",
            "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", os.path.join("..", "..", "include", "l2a.h")]
 SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_rng.c"]
-INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8)]
+INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Rollout kernels: MFMA accumulators in architectural VGPRs where the allocator can afford it - every epilogue reads its

@@ -114,6 +114,14 @@ int split_mode_for(const l2a_model* md, int e_loop) {
 int choose_nt(const l2a_model* md, int m, int n, int e_loop, int sa_bytes_nt2, int other_bytes_nt2) {
     const int cus = md->ctx->num_cu > 0 ? md->ctx->num_cu : 256;
     if (2 * sa_bytes_nt2 + other_bytes_nt2 > md->ctx->lds_per_block) return 1;
+    // Two candidate tiles per workgroup pay only where their instance keeps its registers: at hidden width 512 every NT = 2
+    // instance spilled (55 - 388 VGPRs to scratch) and lost to NT = 1 on every multi-round plan measured - Ant 2 x 512,
+    // n = 8000: 2.51 against 2.13 ms, config 4's 16 000 candidates: 3.53 against 3.50 ms per 10 steps (profiles/r04_ab_nt.jsonl)
+    // - and so do the 49 - 64-dimensional observations at width 256.  Those shapes run NT = 1 (whole rounds + a shared tail);
+    // the (2, 8) instances are no longer built.
+    if (md->TPW >= 8 || md->OT >= 4) return 1;
+    static const int force_nt = [] { const char* e = std::getenv("L2A_FORCE_NT"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+    if (force_nt) return force_nt;      // developer A/B (tools/ab_nt.py)
     const long long wg1 = (long long)m * ceil_div(n, 16);
     const long long wg2 = (long long)m * ceil_div(n, 32);
     const long long t = wg1 % cus;

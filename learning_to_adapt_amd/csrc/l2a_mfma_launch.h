@@ -1,8 +1,9 @@
 // l2a_mfma_launch.h - host-side entry points of the MFMA kernel instances.
 //
-// The kernel template (l2a_mfma.h) is instantiated for 2 x 3 x 8 x 2 parameter combinations;
-// they are spread over one translation unit per (NT, TPW) pair (l2a_mfma_inst.hip compiled six
-// times with different -D flags) so that the library builds in parallel.
+// The kernel template (l2a_mfma.h) is instantiated per (NT, TPW, OT, KG0, GACT) combination; the instances are spread over
+// one translation unit per (NT, TPW) pair (l2a_mfma_inst.hip compiled five times with different -D flags) so that the
+// library builds in parallel.  There is no (2, 8) unit: at hidden width 512 two candidate tiles per workgroup spill
+// registers and lose to NT = 1 (launch_rollout, l2a_api.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -18,7 +19,7 @@ struct L2AKParams;
     int l2a_launch_mfma_##NT_##_##TPW_(int ot, int kg0, int gact, const L2AKParams* p, unsigned grid, \
                                        int smem, hipStream_t stream);
 L2A_DECL_LAUNCH(1, 2) L2A_DECL_LAUNCH(1, 4) L2A_DECL_LAUNCH(1, 8)
-L2A_DECL_LAUNCH(2, 2) L2A_DECL_LAUNCH(2, 4) L2A_DECL_LAUNCH(2, 8)
+L2A_DECL_LAUNCH(2, 2) L2A_DECL_LAUNCH(2, 4)
 #undef L2A_DECL_LAUNCH
 
 inline int l2a_launch_mfma(int nt, int tpw, int ot, int kg0, int gact, const L2AKParams* p, unsigned grid,
@@ -29,6 +30,5 @@ inline int l2a_launch_mfma(int nt, int tpw, int ot, int kg0, int gact, const L2A
     if (nt == 1 && tpw == 8) return l2a_launch_mfma_1_8(ot, kg0, gact, p, grid, smem, stream);
     if (nt == 2 && tpw == 2) return l2a_launch_mfma_2_2(ot, kg0, gact, p, grid, smem, stream);
     if (nt == 2 && tpw == 4) return l2a_launch_mfma_2_4(ot, kg0, gact, p, grid, smem, stream);
-    if (nt == 2 && tpw == 8) return l2a_launch_mfma_2_8(ot, kg0, gact, p, grid, smem, stream);
     return -100;
 }
