@@ -24,5 +24,9 @@ tail -12 $SRC/pytest_gpu.log | grep -v amdgpu.ids > $DST/${TAG}_pytest_gpu_tail.
 # rocprofv3 --stats: the rollout kernels only (torch's elementwise kernels have kilobyte-long names)
 f=$(find $SRC/prof -name "*kernel_stats.csv" | head -1)
 (head -1 "$f"; grep -E '^"(void )?l2a_' "$f") > $DST/${TAG}_kernel_stats.csv
+for f in $SRC/timeline_micro_*.txt; do [ -f "$f" ] && grep -v amdgpu.ids $f > $DST/${TAG}_$(basename $f); done
+[ -f $SRC/ab_micro.jsonl ] && cp $SRC/ab_micro.jsonl $DST/${TAG}_ab_micro.jsonl
+[ -f $SRC/ab_nt.jsonl ] && cp $SRC/ab_nt.jsonl $DST/${TAG}_ab_nt.jsonl
+[ -f $SRC/defaults_kernel_stats.csv ] && cp $SRC/defaults_kernel_stats.csv $DST/${TAG}_defaults_kernel_stats.csv
 python tools/pmc_traffic.py $SRC > /dev/null 2>&1 || true
 ls -la $DST | grep ${TAG}_ | awk '{print $5, $9}'

@@ -37,6 +37,18 @@ timeout 300 python tools/parity_report.py > $OUT/parity_report.txt 2> $OUT/parit
 timeout 120 python tools/timeline.py > $OUT/timeline.txt 2>&1; echo "timeline rc=$?"
 timeout 120 python tools/timeline_lstm.py 256 4096 > $OUT/timeline_lstm.txt 2>&1; echo "timeline_lstm rc=$?"
 timeout 120 python tools/timeline_lstm.py 256 2000 >> $OUT/timeline_lstm.txt 2>&1; echo "timeline_lstm (split) rc=$?"
+echo "== micro-tile kernels: timelines, A/B against the 16-candidate kernels, rocprof kernel statistics of the default plan sizes"
+for a in "lstm 500 5 10" "mlp c3b_ant_rs_n500_h10_pb5_3x512" "mlp c1_hc_rs_n500_h10_e1" "mlp c2_hc_rs_n2000_h30_e5"; do
+  n=$(echo $a | tr ' ' '_'); timeout 200 python tools/timeline_micro.py $a > $OUT/timeline_micro_$n.txt 2>&1; echo "timeline_micro $a rc=$?"
+done
+timeout 500 python tools/ab_micro.py lstm mlp > $OUT/ab_micro.jsonl 2> $OUT/ab_micro.err; echo "ab_micro rc=$?"
+timeout 300 python tools/ab_nt.py > $OUT/ab_nt.jsonl 2> /dev/null; echo "ab_nt rc=$?"
+for shape in c1 c3b c6; do for mic in 1 0; do
+  (cd /tmp && L2A_MICRO=$mic timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_def -o trace -- python $GRAFT_REPO_ROOT/tools/prof_defaults.py $shape > /dev/null 2>> $GRAFT_REPO_ROOT/$OUT/prof_def.err)
+  f=$(find $OUT/prof_def -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && (echo "# $shape, L2A_MICRO=$mic"; head -1 "$f"; grep -E '^"(void )?l2a_(rollout|lstm|mlp|rnn)' "$f") >> $OUT/defaults_kernel_stats.csv
+  rm -rf $OUT/prof_def
+done; done; echo "defaults rocprof done"; cat $OUT/defaults_kernel_stats.csv | cut -c1-150
 echo "== GrBAL adaptation step"
 timeout 120 python tools/probe_adapt.py 2> /dev/null > $OUT/probe_adapt.json; echo "probe_adapt rc=$?"
 bash tools/adapt_trace.sh > $OUT/adapt_trace.txt 2>&1; echo "adapt_trace rc=$?"; cd $GRAFT_REPO_ROOT

@@ -13,9 +13,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
 
-REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "all"          # c1 | c3b | c6 | all: one shape per rocprof run keeps its row apart
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 plans = []
 for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
+    if WHICH not in ("all", name.split("_")[0]):
+        continue
     case = cases.CASES[name]
     env, model = cases.product_model(case)
     native = model.planner_model()
@@ -27,19 +30,20 @@ for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
     best = torch.zeros((m,), dtype=torch.int64, device=dev)
     plans.append((model, lambda native=native, obs0=obs0, a=a, m=m, n=n, h=h, env=env, best=best:
                   native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
-case = cases.CASES["c6_hc_rnn_rs_n500_h10_m5"]
-env, model = cases.product_rnn_model(case)
-native = model.planner_model()
-dev = native.device
-m, n, h, U = case["m"], case["n"], case["h"], case["units"]
-obs0 = torch.randn((m, 20), device=dev)
-c0 = torch.randn((m, U), device=dev)
-h0 = torch.tanh(torch.randn((m, U), device=dev))
-a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
-best = torch.zeros((m,), dtype=torch.int64, device=dev)
-plans.append((model, lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
+if WHICH in ("all", "c6"):
+    case = cases.CASES["c6_hc_rnn_rs_n500_h10_m5"]
+    env, model = cases.product_rnn_model(case)
+    native = model.planner_model()
+    dev = native.device
+    m, n, h, U = case["m"], case["n"], case["h"], case["units"]
+    obs0 = torch.randn((m, 20), device=dev)
+    c0 = torch.randn((m, U), device=dev)
+    h0 = torch.tanh(torch.randn((m, U), device=dev))
+    a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    plans.append((model, lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
 for _, plan in plans:       # one shape after the other, back to back: the clocks are up after the first few dozen launches
     for _ in range(REPS):
         plan()
     torch.cuda.synchronize()
-print("done", REPS)
+print("done", WHICH, REPS)
