@@ -27,8 +27,6 @@
 // Rows beyond `rows` (padding up to 16) carry dZ = 0 and therefore no gradient.
 #pragma once
 
-#include <hip/hip_cooperative_groups.h>
-
 #include "l2a_micro_pack.h"
 
 #include "l2a_kernels.h"
@@ -69,52 +67,22 @@ __device__ __forceinline__ float l2a_act_grad_from_output(float o, int kind) {
     }
 }
 
-// A task's scratch block (layer inputs A_l, gradients dZ_l).  COH = false: plain loads / stores - the launch-per-layer
-// kernels, whose boundaries make one launch's writes visible to the next.  COH = true (the fused kernel): the phases
-// of ONE launch hand these arrays from the workgroups of one XCD to those of another, whose L2s are not coherent for
-// ordinary accesses - write-through (sc1) stores and miss-always (sc1) loads through a raw buffer descriptor, as for the
-// tile splits' exchange records; the grid barrier then needs no cache maintenance (with acquire / release fences at
-// device scope every workgroup wrote back and invalidated its L2 at every barrier: ~30 us each).
-template <bool COH>
-struct L2AScratch {
-    float* sc;
-    __amdgpu_buffer_rsrc_t rs;
-    __device__ __forceinline__ L2AScratch(float* base, long long floats) : sc(base) {
-        if (COH) rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(floats * 4), 0x00020000);
-    }
-    __device__ __forceinline__ float ld(long long off) const {
-        if (!COH) return sc[off];
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off * 4, 0, 16));
-    }
-    __device__ __forceinline__ float4 ld4(long long off) const {
-        if (!COH) return *reinterpret_cast<const float4*>(sc + off);
-        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off * 4, 0, 16);
-        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    }
-    __device__ __forceinline__ void st(long long off, float v) const {
-        if (!COH) { sc[off] = v; return; }
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)off * 4, 0, 16);
-    }
-};
-
 #define L2A_AW 8        // waves per forward / backward workgroup (each takes 1 / 8 of the reduction)
 #define L2A_SB 8        // MFMA k-steps (of 4) whose operands are fetched before the first MFMA of a batch
 #define L2A_XS_MAX 128  // widest input layer whose batch is staged through LDS in the first forward launch
 
 // Reduce the 8 waves' accumulators (4 unit tiles x f32x4 per lane) through LDS in a fixed order; wave 0 gets the sums.
-template <int T>
-__device__ __forceinline__ void l2a_adapt_reduce(f32x4 (&acc)[T], float (&red)[L2A_AW - 1][64][L2A_AR + 1], int ks, int lane) {
+__device__ __forceinline__ void l2a_adapt_reduce(f32x4 (&acc)[4], float (&red)[L2A_AW - 1][64][L2A_AR + 1], int ks, int lane) {
     if (ks > 0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[ks - 1][lane][4 * t + i] = acc[t][i];
     }
     __syncthreads();
     if (ks == 0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -126,14 +94,15 @@ __device__ __forceinline__ void l2a_adapt_reduce(f32x4 (&acc)[T], float (&red)[L
 // wave w sums its eighth of the k range.  A_0[k][r] = x[task][r][k] (zero beyond `rows`); x may live in host-mapped
 // memory (l2a_model_adapt_sgd_host): one coalesced pass brings it into LDS - a single bus round trip instead of one
 // per element - and workgroup 0 of the task publishes A_0 for the update pass.  grid (ceil(n_out / 64), m).
-template <bool COH>
-__device__ __forceinline__ void l2a_adapt_fwd0_body(const L2AAdaptParams& p, const int bx, const int task,
-                                                    float (&red)[L2A_AW - 1][64][L2A_AR + 1], float* xs) {
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptParams p) {
+    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
+    __shared__ float xs[L2A_XS_MAX * L2A_AR];
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.y;
     const int k_in = p.dims[0], n_out = p.dims[1];
-    const int u = bx * 64 + lane;
+    const int u = blockIdx.x * 64 + lane;
     const bool live = u < n_out;
-    const L2AScratch<COH> sc(p.scratch + (long long)task * p.scratch_stride, p.scratch_stride);
+    float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float* W = p.w[0] + (live ? u : 0);           // dead lanes read unit 0's column and never store
     const int chunk = (k_in + L2A_AW - 1) / L2A_AW;
     const int k0 = ks * chunk, k1 = (k0 + chunk < k_in) ? k0 + chunk : k_in;
@@ -159,8 +128,8 @@ __device__ __forceinline__ void l2a_adapt_fwd0_body(const L2AAdaptParams& p, con
             xs[kk * L2A_AR + r] = v;
         }
         __syncthreads();
-        if (bx == 0)
-            for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) sc.st(p.a_off[0] + i, xs[i]);
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) sc[p.a_off[0] + i] = xs[i];
     }
     float acc[L2A_AR];
 #pragma unroll
@@ -174,7 +143,7 @@ __device__ __forceinline__ void l2a_adapt_fwd0_body(const L2AAdaptParams& p, con
                 a = xs[k * L2A_AR + r];
             } else {
                 a = (r < p.rows) ? x[r * k_in + k] : 0.0f;
-                if (bx == 0 && lane == r) sc.st(p.a_off[0] + k * L2A_AR + r, a);
+                if (blockIdx.x == 0 && lane == r) sc[p.a_off[0] + k * L2A_AR + r] = a;
             }
             acc[r] = fmaf(w, a, acc[r]);
         }
@@ -186,19 +155,14 @@ __device__ __forceinline__ void l2a_adapt_fwd0_body(const L2AAdaptParams& p, con
     __syncthreads();
     if (ks != 0 || !live) return;
     const float bias = p.b[0][u];
-    const long long dst = p.a_off[1] + u * L2A_AR;
+    float* dst = sc + p.a_off[1] + u * L2A_AR;
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) {
         float v = acc[r];
 #pragma unroll
         for (int w = 0; w < L2A_AW - 1; ++w) v += red[w][lane][r];
-        sc.st(dst + r, l2a_act1(v + bias, p.hidden_act));
+        dst[r] = l2a_act1(v + bias, p.hidden_act);
     }
-}
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptParams p) {
-    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
-    __shared__ float xs[L2A_XS_MAX * L2A_AR];
-    l2a_adapt_fwd0_body<false>(p, blockIdx.x, blockIdx.y, red, xs);
 }
 
 // Forward through layer l >= 1 for 64 output units of one task on the matrix core: D[unit][row] += W^T[unit][k] A_l[k][row]
@@ -206,67 +170,55 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
 // activation rows are one coalesced 256-byte load per k-step).  The 8 waves split the k-steps; operands of 8 k-steps are
 // fetched before the first MFMA; partial tiles meet in LDS in a fixed order.  The last layer writes
 // dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.  grid (ceil(n_out / 64), m).
-// (T = unit tiles of 16 per wave: 4 in the launch-per-layer form, 1 in the fused kernel - four times the workgroups, every operand
-// of a wave's share in flight at once; SB = k-steps per batch of loads.  Same arithmetic per output either way.)
-// `gate()` is called exactly once by every wave, after its first batch of WEIGHT loads has been requested and before the first
-// activation load: the fused kernel passes the grid barrier that ends the previous phase there - the weights do not depend on
-// that phase, so their memory round trip travels under the barrier's.
-template <int T, int SB, bool COH, class GATE>
-__device__ __forceinline__ void l2a_adapt_fwd_body(const L2AAdaptParams& p, const int l, const int bx, const int task,
-                                                   float (&red)[L2A_AW - 1][64][L2A_AR + 1], GATE gate) {
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
+    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.y;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
-    const int u0 = bx * 16 * T;
-    const L2AScratch<COH> sc(p.scratch + (long long)task * p.scratch_stride, p.scratch_stride);
-    const long long A = p.a_off[l];
+    const int u0 = blockIdx.x * 64;
+    float* sc = p.scratch + (long long)task * p.scratch_stride;
+    const float* A = sc + p.a_off[l];
     const float* W = p.w[l];
-    int ucol[T];
-    bool uok[T];
+    int ucol[4];
+    bool uok[4];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < 4; ++t) {
         const int u = u0 + 16 * t + i16;
         uok[t] = u < n_out;
         ucol[t] = uok[t] ? u : 0;
     }
     const int steps = (k_in + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
     const int s0 = ks * per < steps ? ks * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
-    f32x4 acc[T];
+    f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bool gated = false;
-    for (int s = s0; s < s1; s += SB) {
-        float a[SB][T], b[SB];
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; s += L2A_SB) {
+        float a[L2A_SB][4], b[L2A_SB];
 #pragma unroll
-        for (int j = 0; j < SB; ++j) {
-            const int k = 4 * (s + j) + q;
-            const int kk = ((s + j < s1) && (k < k_in)) ? k : 0;
-#pragma unroll
-            for (int t = 0; t < T; ++t) a[j][t] = W[(long long)kk * n_out + ucol[t]];
-        }
-        if (!gated) { __builtin_amdgcn_sched_barrier(0); gate(); gated = true; }
-#pragma unroll
-        for (int j = 0; j < SB; ++j) {
+        for (int j = 0; j < L2A_SB; ++j) {
             const int k = 4 * (s + j) + q;
             const bool ok = (s + j < s1) && (k < k_in);
-            b[j] = sc.ld(A + (ok ? k : 0) * L2A_AR + i16);
+            const int kk = ok ? k : 0;
+            b[j] = A[kk * L2A_AR + i16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[j][t] = W[(long long)kk * n_out + ucol[t]];
             if (!ok) b[j] = 0.0f;           // a zero row annihilates whatever the clamped weight loads returned
         }
-        __builtin_amdgcn_sched_barrier(0);  // all loads of the batch in flight before the first MFMA
+        __builtin_amdgcn_sched_barrier(0);  // all 40 loads of the batch in flight before the first MFMA
 #pragma unroll
-        for (int j = 0; j < SB; ++j)
+        for (int j = 0; j < L2A_SB; ++j)
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = L2A_MFMA(uok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
+            for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(uok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
     }
-    if (!gated) gate();
-    l2a_adapt_reduce<T>(acc, red, ks, lane);
+    l2a_adapt_reduce(acc, red, ks, lane);
     if (ks != 0) return;
     const bool last = (l == p.n_layers - 1);
     const float scale = 2.0f / (float)(p.rows * n_out);
-    const long long dst = last ? p.z_off[l + 1] : p.a_off[l + 1];
+    float* dst = sc + (last ? p.z_off[l + 1] : p.a_off[l + 1]);
     const int r = i16;                      // D fragment: lane (row r, q) holds units u0 + 16 t + 4 q + 0..3
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int u = u0 + 16 * t + 4 * q + i;
@@ -288,79 +240,64 @@ __device__ __forceinline__ void l2a_adapt_fwd_body(const L2AAdaptParams& p, cons
             } else {
                 v = l2a_act1(v, p.hidden_act);
             }
-            sc.st(dst + u * L2A_AR + r, v);
+            dst[u * L2A_AR + r] = v;
         }
-}
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
-    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
-    l2a_adapt_fwd_body<4, L2A_SB, false>(p, l, blockIdx.x, blockIdx.y, red, [] {});
 }
 
 // dZ_l = (W_l dZ_{l+1}) * act'(A_l) for 64 input units k of layer l (1 <= l < L), same scheme: D[k][row] += W[k][u] dZ[u][row],
 // lane (i, q) supplies W[k0 + 16 t + i][u + q] (16 weight rows x 16 bytes per load; a row's line is reused by the next 7
 // u-steps) and dZ_{l+1}[u + q][i]; the waves split the u-steps.  grid (ceil(k_in / 64), m).
-template <int T, int SB, bool COH, class GATE>
-__device__ __forceinline__ void l2a_adapt_bwd_body(const L2AAdaptParams& p, const int l, const int bx, const int task,
-                                                   float (&red)[L2A_AW - 1][64][L2A_AR + 1], GATE gate) {
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwd_k(const L2AAdaptParams p, int l) {
+    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
     const int lane = threadIdx.x & 63, us = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.y;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
-    const int k0 = bx * 16 * T;
-    const L2AScratch<COH> sc(p.scratch + (long long)task * p.scratch_stride, p.scratch_stride);
-    const long long Z = p.z_off[l + 1];
-    const float* wrow[T];
-    bool kok[T];
+    const int k0 = blockIdx.x * 64;
+    float* sc = p.scratch + (long long)task * p.scratch_stride;
+    const float* Z = sc + p.z_off[l + 1];
+    const float* wrow[4];
+    bool kok[4];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < 4; ++t) {
         const int k = k0 + 16 * t + i16;
         kok[t] = k < k_in;
         wrow[t] = p.w[l] + (long long)(kok[t] ? k : 0) * n_out;
     }
     const int steps = (n_out + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
     const int s0 = us * per < steps ? us * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
-    f32x4 acc[T];
+    f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bool gated = false;
-    for (int s = s0; s < s1; s += SB) {
-        float a[SB][T], b[SB];
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; s += L2A_SB) {
+        float a[L2A_SB][4], b[L2A_SB];
 #pragma unroll
-        for (int j = 0; j < SB; ++j) {
-            const int u = 4 * (s + j) + q;
-            const int uu = ((s + j < s1) && (u < n_out)) ? u : 0;
-#pragma unroll
-            for (int t = 0; t < T; ++t) a[j][t] = wrow[t][uu];
-        }
-        if (!gated) { __builtin_amdgcn_sched_barrier(0); gate(); gated = true; }
-#pragma unroll
-        for (int j = 0; j < SB; ++j) {
+        for (int j = 0; j < L2A_SB; ++j) {
             const int u = 4 * (s + j) + q;
             const bool ok = (s + j < s1) && (u < n_out);
-            b[j] = sc.ld(Z + (ok ? u : 0) * L2A_AR + i16);
+            const int uu = ok ? u : 0;
+            b[j] = Z[uu * L2A_AR + i16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[j][t] = wrow[t][uu];
             if (!ok) b[j] = 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < SB; ++j)
+        for (int j = 0; j < L2A_SB; ++j)
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = L2A_MFMA(kok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
+            for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
     }
-    if (!gated) gate();
-    l2a_adapt_reduce<T>(acc, red, us, lane);
+    l2a_adapt_reduce(acc, red, us, lane);
     if (us != 0) return;
     const int r = i16;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + 16 * t + 4 * q + i;
             if (k >= k_in) continue;
-            sc.st(p.z_off[l] + k * L2A_AR + r, acc[t][i] * l2a_act_grad_from_output(sc.ld(p.a_off[l] + k * L2A_AR + r), p.hidden_act));
+            sc[p.z_off[l] + k * L2A_AR + r] = acc[t][i] * l2a_act_grad_from_output(sc[p.a_off[l] + k * L2A_AR + r], p.hidden_act);
         }
-}
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwd_k(const L2AAdaptParams p, int l) {
-    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
-    l2a_adapt_bwd_body<4, L2A_SB, false>(p, l, blockIdx.x, blockIdx.y, red, [] {});
 }
 
 // Where the adapted sets go: the per-block model's weight block (raw reference layout + MFMA fragment order), and
@@ -382,28 +319,27 @@ struct L2AAdaptDst {
 // unit u (its dZ row stays in registers) and walks 16 input rows k; the row-0 workgroups also do the biases.  Writes
 // the raw layout and (has_pk) the MFMA fragment order (inverse of l2a_pack_decode); the last layer's bias also goes
 // to the padded output-bias copy.
-template <bool COH>
-__device__ __forceinline__ void l2a_adapt_update_body(const L2AAdaptParams& p, const L2AAdaptDst& d, const int bx, const int task,
-                                                      const int tid) {
+__global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p, const L2AAdaptDst d) {
     int l = 0;
-    while (l + 1 < p.n_layers && bx >= d.first_block[l + 1]) ++l;
+    while (l + 1 < p.n_layers && (int)blockIdx.x >= d.first_block[l + 1]) ++l;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
     const int ublocks = (n_out + 255) / 256;
-    const int b = bx - d.first_block[l];
+    const int b = blockIdx.x - d.first_block[l];
     const int kc = b / ublocks, ub = b - kc * ublocks;
-    const int u = ub * 256 + tid;
+    const int u = ub * 256 + threadIdx.x;
     if (u >= n_out) return;
-    const L2AScratch<COH> sc(p.scratch + (long long)task * p.scratch_stride, p.scratch_stride);
-    const long long zp = p.z_off[l + 1] + u * L2A_AR;
-    const float4 z0 = sc.ld4(zp), z1 = sc.ld4(zp + 4), z2 = sc.ld4(zp + 8), z3 = sc.ld4(zp + 12);
+    const int task = blockIdx.y;
+    const float* sc = p.scratch + (long long)task * p.scratch_stride;
+    const float4* zp = reinterpret_cast<const float4*>(sc + p.z_off[l + 1] + u * L2A_AR);
+    const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
     float* dst = d.blk + (long long)task * d.set_stride;
     const int KG = (k_in + 15) / 16;
     const int k0 = kc * L2A_UK, k1 = (k0 + L2A_UK < k_in) ? k0 + L2A_UK : k_in;
     const float* wsrc = p.w[l] + u;
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) {
-        const long long ao = p.a_off[l] + k * L2A_AR;
-        const float4 a0 = sc.ld4(ao), a1 = sc.ld4(ao + 4), a2 = sc.ld4(ao + 8), a3 = sc.ld4(ao + 12);
+        const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[l] + k * L2A_AR);
+        const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
         float g = 0.0f;
         g = fmaf(a0.x, z0.x, g); g = fmaf(a0.y, z0.y, g); g = fmaf(a0.z, z0.z, g); g = fmaf(a0.w, z0.w, g);
         g = fmaf(a1.x, z1.x, g); g = fmaf(a1.y, z1.y, g); g = fmaf(a1.z, z1.z, g); g = fmaf(a1.w, z1.w, g);
@@ -426,84 +362,5 @@ __device__ __forceinline__ void l2a_adapt_update_body(const L2AAdaptParams& p, c
         const float bn = p.b[l][u] - d.lr * gb;
         dst[d.raw_b[l] + u] = bn;
         if (d.has_pk && l == p.n_layers - 1) dst[d.pk_bout + u] = bn;
-    }
-}
-__global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p, const L2AAdaptDst d) {
-    l2a_adapt_update_body<false>(p, d, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x);
-}
-
-// The whole step as ONE cooperative launch (round 4): the phases above as loops over work items, a grid barrier between
-// two phases instead of a kernel boundary.  The launch-per-layer form spent ~13 us per phase on 40 workgroups - a launch
-// ramp and two dependent memory round trips for a few microseconds of work (profiles/r04_adapt_trace.txt: 8 phases,
-// 130 us); here a phase's items are 16 units wide (160 workgroups for a 512-unit layer, every operand of a wave's share
-// requested in one batch) and a phase ends with a barrier of the resident grid.  Same arithmetic per output element as the
-// launch-per-layer kernels (same k split over the eight waves, same reduce order): bit-identical, and the old form stays
-// as the fall-back where a cooperative launch is not available (L2A_ADAPT_FUSED=0 selects it).
-// Barrier of the resident grid: one device-scope counter that only grows - barrier k of a launch is passed when the counter
-// has reached bar_base + (k + 1) * gridDim.x (the host knows bar_base: every workgroup adds one per barrier).  The
-// cooperative-groups grid sync of this ROCm measured ~30 us per barrier (the fused step took 245 us against 125 us for
-// eight launches); an atomic add + an sc1 poll is one memory-side round trip each way.
-// YOUNG: vector memory operations requested AFTER this workgroup's last shared-array store that may stay in flight across
-// the barrier (the next phase's weight loads; memory operations complete in order, so waiting for all but the YOUNG youngest
-// covers the stores).
-template <int YOUNG>
-__device__ __forceinline__ void l2a_grid_barrier(unsigned int* ctr, unsigned int target) {
-    // every write-through store of this workgroup has been performed (no L2 write-back: the arrays the phases share are
-    // written with sc1 stores), then ONE relaxed add; the poll is a relaxed device-scope load (sc1, misses by design)
-    static_assert(YOUNG >= 0 && YOUNG < 64, "vmcnt is a six-bit counter");
-    __builtin_amdgcn_s_waitcnt(((YOUNG >> 4) << 14) | 0x0F70 | (YOUNG & 15));       // vmcnt(YOUNG), nothing else
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-}
-
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fused_k(const L2AAdaptParams p, const L2AAdaptDst d, const int m,
-                                                                 unsigned int* bar_ctr, const unsigned int bar_base) {
-    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
-    __shared__ float xs[L2A_XS_MAX * L2A_AR];
-    const int L = p.n_layers;
-    const int G = (int)gridDim.x, wg = (int)blockIdx.x;
-    unsigned int bar_target = bar_base;
-    auto grid_sync = [&]() { bar_target += (unsigned int)G; l2a_grid_barrier<0>(bar_ctr, bar_target); };
-    auto grid_sync_w = [&]() { bar_target += (unsigned int)G; l2a_grid_barrier<16>(bar_ctr, bar_target); };   // 16 weight loads stay in flight
-    {
-        const int nb = (p.dims[1] + 63) / 64;
-        for (int it = wg; it < nb * m; it += G) {
-            l2a_adapt_fwd0_body<true>(p, it % nb, it / nb, red, xs);
-            __syncthreads();
-        }
-    }
-    // (the barrier that ends a phase is taken inside the next phase's first work item, behind its weight requests; a
-    // workgroup without an item in that phase takes it on its own)
-    for (int l = 1; l < L; ++l) {
-        const int nb = (p.dims[l + 1] + 15) / 16;
-        bool first = true;
-        for (int it = wg; it < nb * m; it += G) {
-            if (first) l2a_adapt_fwd_body<1, 16, true>(p, l, it % nb, it / nb, red, [&] { grid_sync_w(); });
-            else l2a_adapt_fwd_body<1, 16, true>(p, l, it % nb, it / nb, red, [] {});
-            first = false;
-            __syncthreads();
-        }
-        if (first) grid_sync();
-    }
-    for (int l = L - 1; l >= 1; --l) {
-        const int nb = (p.dims[l] + 15) / 16;
-        bool first = true;
-        for (int it = wg; it < nb * m; it += G) {
-            if (first) l2a_adapt_bwd_body<1, 16, true>(p, l, it % nb, it / nb, red, [&] { grid_sync_w(); });
-            else l2a_adapt_bwd_body<1, 16, true>(p, l, it % nb, it / nb, red, [] {});
-            first = false;
-            __syncthreads();
-        }
-        if (first) grid_sync();
-    }
-    grid_sync();
-    {
-        const int nb = d.first_block[L];
-        const int half = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
-        for (int it = 2 * wg + half; it < nb * m; it += 2 * G) l2a_adapt_update_body<true>(p, d, it % nb, it / nb, tid);
     }
 }

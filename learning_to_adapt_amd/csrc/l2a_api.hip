@@ -56,8 +56,6 @@ struct l2a_model {
     unsigned long long* xbuf = nullptr;           // member-split exchange granules
     long long xbuf_granules = 0;
     unsigned int launch_nonce = 0;
-    unsigned int* coop_ctr = nullptr;             // fused adaptation step: the grid barrier's counter (device; only grows)
-    unsigned int coop_base = 0;                   // ... and its value when the next cooperative launch starts
     float* adapt_scratch = nullptr;               // l2a_model_adapt_sgd: layer inputs and dZ of every task
     long long adapt_scratch_floats = 0;
     // l2a_model_adapt_sgd_host: two staging slots (host-mapped, read by the kernels directly)
@@ -612,7 +610,6 @@ void l2a_model_destroy(l2a_model* md) {
     }
     if (md->xbuf) (void)hipFree(md->xbuf);
     if (md->adapt_scratch) (void)hipFree(md->adapt_scratch);
-    if (md->coop_ctr) (void)hipFree(md->coop_ctr);
     for (auto& sl : md->aslot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.stage_host) (void)hipHostFree(sl.stage_host);
@@ -746,50 +743,6 @@ int adapt_enqueue(l2a_model* md, const L2AAdaptParams& ap, int m, float lr, hipS
             else d.pk[l] = md->pk_wout;
         }
     }
-    d.first_block[0] = 0;
-    for (int l = 0; l < L; ++l)
-        d.first_block[l + 1] = d.first_block[l] + ((ap.dims[l + 1] + 255) / 256) * ((ap.dims[l] + L2A_UK - 1) / L2A_UK);
-    // One cooperative launch for the whole step where the device offers it (l2a_adapt_fused_k); the launch-per-layer form
-    // otherwise (and with L2A_ADAPT_FUSED=0: the A/B and the bit-identity test).
-    const char* fused_env = std::getenv("L2A_ADAPT_FUSED");         // (read per call: the test toggles it)
-    const int want_fused = (fused_env && fused_env[0] == '0') ? 0 : 1;
-    if (want_fused && ctx->coop_blocks != 0) {
-        if (ctx->coop_blocks < 0) {         // first use: can the grid be resident at once?
-            int coop = 0, per_cu = 0;
-            (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
-            if (coop && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, l2a_adapt_fused_k, 64 * L2A_AW, 0) == hipSuccess && per_cu >= 1)
-                ctx->coop_blocks = (ctx->num_cu > 0 ? ctx->num_cu : 256);
-            else
-                ctx->coop_blocks = 0;
-        }
-        if (ctx->coop_blocks > 0) {
-            int items = 0;
-            for (int l = 1; l < L; ++l) items = ((ap.dims[l + 1] + 15) / 16) * m > items ? ((ap.dims[l + 1] + 15) / 16) * m : items;
-            const int upd = (d.first_block[L] * m + 1) / 2;
-            if (upd > items) items = upd;
-            int G = items < ctx->coop_blocks ? items : ctx->coop_blocks;
-            if (G < 1) G = 1;
-            if (!md->coop_ctr) {           // per model: two models may adapt on two streams at once
-                L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->coop_ctr), sizeof(unsigned int)));
-                L2A_HIP(ctx, hipMemset(md->coop_ctr, 0, sizeof(unsigned int)));
-                md->coop_base = 0;
-            }
-            L2AAdaptParams ap_c = ap;
-            L2AAdaptDst d_c = d;
-            int m_c = m;
-            unsigned int* ctr_c = md->coop_ctr;
-            unsigned int base_c = md->coop_base;
-            void* args[] = {&ap_c, &d_c, &m_c, &ctr_c, &base_c};
-            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(l2a_adapt_fused_k), dim3((unsigned)G),
-                                                            dim3(64 * L2A_AW), args, 0, stream);
-            if (e == hipSuccess) {
-                md->coop_base += (unsigned int)(2 * (L - 1) + 1) * (unsigned int)G;     // one add per workgroup and barrier
-                return L2A_OK;
-            }
-            (void)hipGetLastError();
-            ctx->coop_blocks = 0;           // not launchable here: the launch-per-layer form from now on
-        }
-    }
     hipLaunchKernelGGL(l2a_adapt_fwd0_k, dim3((unsigned)((ap.dims[1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0, stream, ap);
     for (int l = 1; l < L; ++l)
         hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3((unsigned)((ap.dims[l + 1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
@@ -798,6 +751,9 @@ int adapt_enqueue(l2a_model* md, const L2AAdaptParams& ap, int m, float lr, hipS
         hipLaunchKernelGGL(l2a_adapt_bwd_k, dim3((unsigned)((ap.dims[l] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
                            stream, ap, l);
     L2A_HIP(ctx, hipGetLastError());
+    d.first_block[0] = 0;
+    for (int l = 0; l < L; ++l)
+        d.first_block[l + 1] = d.first_block[l] + ((ap.dims[l + 1] + 255) / 256) * ((ap.dims[l] + L2A_UK - 1) / L2A_UK);
     hipLaunchKernelGGL(l2a_adapt_update_k, dim3((unsigned)d.first_block[L], (unsigned)m), dim3(256), 0, stream, ap, d);
     L2A_HIP(ctx, hipGetLastError());
     return L2A_OK;

@@ -41,7 +41,6 @@ struct l2a_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 0;
     int num_cu = 0;
-    int coop_blocks = -1;                 // cooperative launches (the fused adaptation step): -1 = not probed, 0 = unavailable, else the grid limit
     int lds_per_block = 0;
     int clock_khz = 0;
     std::string arch;

@@ -661,59 +661,6 @@ def test_device_adapt_matches_autograd(hidden, act, rows):
     np.testing.assert_allclose(picks[0][2], picks[1][2], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("hidden,od,ad,act", [((512, 512, 512), 41, 8, "relu"), ((256, 256), 20, 6, "tanh"), ((200, 72), 20, 6, "sigmoid"),
-                                              ((512,), 19, 7, "relu")])
-def test_fused_adaptation_step_is_bit_identical_to_the_launch_per_layer_form(hidden, od, ad, act, monkeypatch):
-    """`l2a_adapt_fused_k` - the whole inner step as ONE cooperative launch, grid barriers between the phases, work items
-    a quarter as wide - against the launch-per-layer kernels (`L2A_ADAPT_FUSED=0`): every adapted parameter, raw and
-    in both fragment orders the planners read (the plans that follow are compared as well), bit for bit; full and ragged
-    batches, fewer tasks than sets."""
-    from learning_to_adapt_amd.dynamics.native_model import NativeModel
-    from learning_to_adapt_amd.envs.reward_spec import RewardSpec
-    from learning_to_adapt_amd.utils import synthetic
-    m = 5
-    dev = torch.device("cuda:0")
-    base = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(dev)
-            for w in synthetic.make_weight_set(od, ad, list(hidden), 1000)]
-    models = {f: NativeModel(od, ad, hidden, act, None, m, "per_block") for f in ("1", "0")}
-    rs = np.random.RandomState(3)
-    norm = synthetic.make_norm(od, ad, -np.ones(ad), np.ones(ad), 2000)
-    for mm, rows, lr in [(5, 16, 0.01), (5, 16, 0.03), (3, 9, 0.02), (1, 1, 0.5), (5, 16, 0.01)]:
-        x = torch.from_numpy(rs.randn(mm, rows, od + ad).astype(np.float32)).to(dev)
-        y = torch.from_numpy(rs.randn(mm, rows, od).astype(np.float32)).to(dev)
-        for f, model in models.items():
-            monkeypatch.setenv("L2A_ADAPT_FUSED", f)
-            model.adapt_sgd(base, x, y, lr)
-        torch.cuda.synchronize()
-        for e in range(mm):
-            for a, b in zip(models["1"].get_weights(e), models["0"].get_weights(e)):
-                assert torch.equal(a, b), (mm, rows, e, tuple(a.shape))
-    assert not torch.equal(models["1"].get_weights(0)[0], base[0])
-    # the packed copies: a plan on the adapted sets (16-candidate and, where it has an instance, micro-tile kernels)
-    if od in (20, 41):
-        spec = RewardSpec.half_cheetah(od, 0.05)        # (any closed form: the plan only has to read the adapted sets)
-        n, h = 100, 3
-        obs0 = torch.from_numpy(rs.randn(m, od).astype(np.float32)).to(dev)
-        a = torch.from_numpy(rs.uniform(-1, 1, (h, m * n, ad)).astype(np.float32)).to(dev)
-        ctx = _lib.Context.get(0)
-        try:
-            for micro in (0, 2):
-                ctx.set_micro(micro)
-                outs = []
-                for f in ("1", "0"):
-                    for e in range(m):
-                        models[f].set_norm(e, norm)
-                    rets = torch.empty((m, n), dtype=torch.float32, device=dev)
-                    models[f].plan_rs(obs0, a, m, n, h, 1.0, spec, returns_out=rets)
-                    torch.cuda.synchronize()
-                    outs.append(rets.cpu().numpy())
-                assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]), micro
-        finally:
-            ctx.set_micro(1)
-    for model in models.values():
-        model.close()
-
-
 def test_host_staged_and_raw_adapt_are_bit_identical_to_the_device_pointer_entry():
     """`l2a_model_adapt_sgd_host` (batches copied into host-mapped staging that the kernels read directly, two slots)
     against `l2a_model_adapt_sgd` on device tensors: every adapted parameter bit for bit - over repeated steps with
