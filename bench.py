@@ -276,11 +276,16 @@ def main():
             np.random.seed(0)                   # every rank alike: the shards are slices of ONE candidate tensor
             torch.manual_seed(0)
             ctrl.get_actions(obs_np)
+            first_index = int(ctrl.last_plan["best_index"][0])
+            # two more untimed calls before the clocks are warmed: the second call of a controller starts the draw-ahead chain
+            # (thread pool, pinned staging: ~8 ms with the GPU idle - long enough for the board to drop its clocks again, which
+            # then climb back over the next ~25 calls: tools/probe_first_calls.py: 1.72 -> 1.50 ms per call)
+            ctrl.get_actions(obs_np)
+            ctrl.get_actions(obs_np)
             clock_warm()
             if mode == "numpy" and gold_glob is not None:
-                e2e_index_match = bool(int(ctrl.last_plan["best_index"][0]) == int(gold_glob["best"][0]))
-                assert e2e_index_match, "get_actions picked %d, reference picked %d" % (
-                    int(ctrl.last_plan["best_index"][0]), int(gold_glob["best"][0]))
+                e2e_index_match = bool(first_index == int(gold_glob["best"][0]))
+                assert e2e_index_match, "get_actions picked %d, reference picked %d" % (first_index, int(gold_glob["best"][0]))
             e2e[mode] = max_over_ranks(_timed_calls(lambda: ctrl.get_actions(obs_np), args.steps, args.warmup, sync))
             if mode == "numpy" and ctrl._ahead is not None:
                 e2e["draw_ahead_hits"] = int(ctrl._ahead.hits)
