@@ -94,6 +94,47 @@ def training_device():
     return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
 
+class TFAdam(torch.optim.Optimizer):
+    """``tf.train.AdamOptimizer`` (the ``optimizer`` default of the reference's three dynamics models, e.g.
+    ``mlp_dynamics.py:39,84-85``) as TensorFlow 1.13 documents its update:
+
+        lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2
+        theta -= lr_t * m / (sqrt(v) + epsilon)
+
+    ``epsilon`` is added to the UN-corrected root ("epsilon hat" of Kingma & Ba section 2), which is ``torch.optim.Adam``'s
+    epsilon divided by ``sqrt(1 - beta2^t)`` - 32 x larger on the first step.  For weights whose gradient is below ~1e-6
+    (dead units, inputs that do not matter yet) the two formulas take visibly different steps, which is what
+    ``tests/test_fit_oracle.py`` measured before this class replaced ``torch.optim.Adam`` in the three ``fit`` loops."""
+
+    def __init__(self, params, lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        super().__init__(params, dict(lr=lr, beta1=beta1, beta2=beta2, epsilon=epsilon))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            gs = [p.grad for p in ps]
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
+            ms = [self.state[p]["m"] for p in ps]
+            vs = [self.state[p]["v"] for p in ps]
+            t = group["t"] = group.get("t", 0) + 1
+            b1, b2 = group["beta1"], group["beta2"]
+            lr_t = group["lr"] * float(np.sqrt(1.0 - b2 ** t)) / (1.0 - b1 ** t)
+            torch._foreach_mul_(ms, b1)
+            torch._foreach_add_(ms, gs, alpha=1.0 - b1)
+            torch._foreach_mul_(vs, b2)
+            torch._foreach_addcmul_(vs, gs, gs, value=1.0 - b2)
+            den = torch._foreach_sqrt(vs)
+            torch._foreach_add_(den, group["epsilon"])
+            torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
+
+
 def norm_tensors(normalization, device):
     out = {}
     for key in ("obs", "act", "delta"):

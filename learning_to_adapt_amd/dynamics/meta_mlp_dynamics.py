@@ -408,7 +408,7 @@ class MetaMLPDynamicsModel(Serializable):
         bs, mbs = self.batch_size, self.meta_batch_size
         assert X.shape[1] > 2 * bs, "paths must be longer than 2 * batch_size"
         params = [p.to(dev).requires_grad_(True) for p in self._params]
-        opt = torch.optim.Adam(params, lr=self.learning_rate)
+        opt = core.TFAdam(params, lr=self.learning_rate)
         steps_per_epoch = max(int(np.prod(X.shape[:2]) / (mbs * bs * 2)), 1)                   # :209-210
         steps_test = max(int(np.prod(XT.shape[:2]) / (mbs * bs * 2)), 1)                       # :211-212
         hid, out = self.hidden_nonlinearity, self.output_nonlinearity

@@ -205,7 +205,7 @@ class MLPDynamicsModel(Serializable):
         epoch_times, last_epoch = [], 0
         for e in range(self.ensemble_size):
             params = [p.to(dev).requires_grad_(True) for p in self._param_sets[e]]
-            opt = torch.optim.Adam(params, lr=self.learning_rate)
+            opt = core.TFAdam(params, lr=self.learning_rate)
             rolling, rolling_prev = None, None
             for epoch in range(epochs):
                 t0 = time.time()

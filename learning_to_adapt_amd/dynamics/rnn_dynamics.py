@@ -238,7 +238,7 @@ class RNNDynamicsModel(Serializable):
         y_te = f32(self._dataset_test["delta"])
 
         params = [p.to(dev).requires_grad_(True) for p in self._params]
-        opt = torch.optim.Adam(params, lr=self.learning_rate)
+        opt = core.TFAdam(params, lr=self.learning_rate)
         rolling, rolling_prev = None, None
         epoch_times, last_epoch = [], 0
         zero_state = lambda b: rnn_cells.zero_state(self.cell_type, self.hidden_sizes, b, dev)  # noqa: E731

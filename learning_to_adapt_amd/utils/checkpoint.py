@@ -92,7 +92,7 @@ _TF_OP_MODULES = ("tensorflow.python.ops.math_ops", "tensorflow.python.ops.gen_m
 
 class AdamOptimizer(object):
     """Placeholder for ``tf.train.AdamOptimizer`` found among recorded constructor arguments (never instantiated:
-    the drop-in models train with ``torch.optim.Adam``)."""
+    the drop-in models train with ``dynamics.core.TFAdam``, the same update)."""
 
 
 class NormalizedEnv(Serializable):
