@@ -18,8 +18,8 @@ OUT = os.path.join(PKG, "libl2a_hip.so")
 RNG_OUT = os.path.join(PKG, "libl2a_rng.so")        # host-only helper (gcc), see l2a_rng.c
 OBJ_DIR = os.path.join(HERE, "_obj")
 HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_adapt.h", "l2a_mfma.h", "l2a_mfma_launch.h", "l2a_lstm.h",
-           "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", os.path.join("..", "..", "include", "l2a.h")]
-SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_rng.c"]
+           "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_rnn_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", os.path.join("..", "..", "include", "l2a.h")]
+SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_rnn_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_rng.c"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -95,7 +95,8 @@ def unit_table():
          "l2a_lstm_api.o": ("l2a_lstm_api.hip", KERNEL_FLAGS),
          "l2a_comm.o": ("l2a_comm.hip", []),
          "l2a_cem.o": ("l2a_cem.hip", []),
-         "l2a_micro.o": ("l2a_micro_inst.hip", MICRO_FLAGS)}
+         "l2a_micro.o": ("l2a_micro_inst.hip", MICRO_FLAGS),
+         "l2a_rnn_micro.o": ("l2a_rnn_micro_inst.hip", MICRO_FLAGS)}
     for utw in LSTM_INSTANCES:
         t["l2a_lstm_%d.o" % utw] = ("l2a_lstm_inst.hip", ["-DL2A_INST_UTW=%d" % utw] + LSTM_FLAGS)
     for nt, tpw in INSTANCES:

@@ -55,6 +55,7 @@ struct L2ALstmParams {
     int layer_units[L2A_RNN_MAX_LAYERS];
     long long layer_w[L2A_RNN_MAX_LAYERS][2], layer_b[L2A_RNN_MAX_LAYERS][2];   // offsets of the layer's kernels / biases
     long long layer_pk[L2A_RNN_MAX_LAYERS][2];  // ... of their copies in MFMA fragment order (l2a_rnn_mfma.h), pk_wout alike
+    long long layer_mk[L2A_RNN_MAX_LAYERS][2];  // ... and in the micro-tile kernel's order (l2a_rnn_micro.h; its output layer: pk_mo)
     // ---- launch ------------------------------------------------------------------------
     const float* obs0;          // [m, obs_dim] (or [R, obs_dim] when obs_per_row)
     const float* c0;            // [m, U] (or [R, U] when hid_per_row)

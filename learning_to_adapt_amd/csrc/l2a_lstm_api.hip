@@ -38,6 +38,8 @@ struct l2a_lstm {
     int lunits[L2A_RNN_MAX_LAYERS] = {0};
     long long lw[L2A_RNN_MAX_LAYERS][2] = {{0}}, lb[L2A_RNN_MAX_LAYERS][2] = {{0}};
     long long lpk[L2A_RNN_MAX_LAYERS][2] = {{0}};  // the kernels again in MFMA fragment order (l2a_rnn_mfma.h); pk_wout alike
+    bool gmicro_ok = false;                       // ... and in the micro-tile kernel's (l2a_rnn_micro.h: every layer 256 units wide)
+    long long lmk[L2A_RNN_MAX_LAYERS][2] = {{0}};
     float* adv_buf = nullptr;                     // l2a_lstm_plan_rs_sync: [64, act_dim] chosen actions + [64, obs_dim] next obs
 };
 
@@ -76,7 +78,9 @@ void fill(const l2a_lstm* md, L2ALstmParams& p) {
     p.n_layers = md->n_layers; p.cell_type = md->cell_type;
     for (int l = 0; l < L2A_RNN_MAX_LAYERS; ++l) {
         p.layer_units[l] = md->lunits[l];
-        for (int q = 0; q < 2; ++q) { p.layer_w[l][q] = md->lw[l][q]; p.layer_b[l][q] = md->lb[l][q]; p.layer_pk[l][q] = md->lpk[l][q]; }
+        for (int q = 0; q < 2; ++q) {
+            p.layer_w[l][q] = md->lw[l][q]; p.layer_b[l][q] = md->lb[l][q]; p.layer_pk[l][q] = md->lpk[l][q]; p.layer_mk[l][q] = md->lmk[l][q];
+        }
     }
     p.disc0 = 1.0;
 }
@@ -113,6 +117,30 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
         if (!mfma && smem_v > ctx->lds_per_block)
             return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the generic recurrent kernel (" + std::to_string(smem_v) +
                                              " B): the layers' units may sum to about 800 at most");
+        if (mfma && md->gmicro_ok) {
+            // Micro tiles (l2a_rnn_micro.h; geometry and conditions: the tuned LSTM kernel's branch below).  These models have no
+            // unit-tile split, so every plan that leaves CUs idle under 16-candidate tiles - and every plan of at most three micro
+            // tiles per CU - takes them (policy 1); policy 0 keeps the 16-candidate kernel, 2 forces micro tiles where eligible.
+            const int cus_m = ctx->num_cu > 0 ? ctx->num_cu : 256;
+            const int quads = l2a_ceil_div(p.n, 4);
+            int W = cus_m / p.m;
+            if (W > quads) W = quads;
+            const int hi = W > 0 ? l2a_ceil_div(quads, W) : 99;
+            if (hi >= 1 && hi <= 3) W = l2a_ceil_div(quads, hi);
+            const bool eligible = !p.obs_per_row && !p.state_out && !p.c_out && !p.h_out && hi <= 3 && (p.returns_out || p.best_key);
+            if (eligible && ctx->micro_policy != 0) {
+                p.mc_w = W;
+                p.mc_hi = hi;
+                p.mc_r = quads - W * (hi - 1);
+                int smem_g = (int)l2a_rnn_micro_smem(md->cell_type, md->n_layers, md->lunits[0], md->KG0);
+                if (smem_g < 84 * 1024) smem_g = 84 * 1024;     // more than half a CU's LDS: one workgroup per CU
+                const int rc = l2a_launch_rnn_micro(md->lunits[0], md->cell_type, &p, (unsigned)(p.m * W), smem_g, stream);
+                if (rc != 0) return l2a_fail(ctx, L2A_EHIP, std::string("micro-tile recurrent kernel launch: ") +
+                                                            (rc > 0 ? hipGetErrorString((hipError_t)rc) : "no instance"));
+                L2A_HIP(ctx, hipGetLastError());
+                return L2A_OK;
+            }
+        }
         if (mfma) {
             L2A_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l2a_rnn_mfma_k),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
@@ -300,6 +328,10 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
     md->OT = l2a_ceil_div(obs_dim, 16);
     long long off = 0;
     auto take = [&off](long long n) { long long o = off; off += (n + 15) / 16 * 16; return o; };
+    // micro tiles (l2a_rnn_micro.h): every layer 256 units wide, the input shapes of the tuned LSTM kernel, LDS for the stack
+    md->gmicro_ok = lstm_mfma_eligible(obs_dim, act_dim, 256);
+    for (int l = 0; l < n_layers; ++l) md->gmicro_ok = md->gmicro_ok && units[l] == 256;
+    md->gmicro_ok = md->gmicro_ok && l2a_rnn_micro_smem(cell_type, n_layers, 256, md->KG0) <= ctx->lds_per_block;
     int kin = md->in_dim;
     for (int l = 0; l < n_layers; ++l) {
         const int U = units[l];
@@ -313,11 +345,16 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
             md->lb[l][1] = take(U);
             md->lpk[l][1] = take(l2a_rnn_pack_floats(kin, U, 1, true));
         }
+        if (md->gmicro_ok) {
+            md->lmk[l][0] = take(l2a_rnn_micro_floats(kin, U, cols0 / U));
+            if (cell_type == L2A_CELL_GRU) md->lmk[l][1] = take(l2a_rnn_micro_floats(kin, U, 1));
+        }
         kin = U;
     }
     md->raw_wo = take((long long)kin * obs_dim);
     md->raw_bo = take(obs_dim);
     md->pk_wout = take(l2a_rnn_pack_floats(kin, obs_dim, 1, false));
+    if (md->gmicro_ok) md->pk_mo = take((long long)(kin / 4) * 256);
     md->pk_bout = take(16 * md->OT);
     md->nm_off = take(32 * md->KG0 + 32 * md->OT);
     md->total = off;
@@ -371,12 +408,18 @@ int l2a_lstm_set_weights(l2a_lstm* md, const void* const* device_ptrs, void* str
                 hipLaunchKernelGGL(l2a_rnn_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                                    md->wblk + raw, rows_in, Uc, G, recurrent, total, md->wblk + dst);
             };
+            auto pack_micro = [&](long long raw, long long dst, int rows_in, int Uc, int G) {
+                if (!md->gmicro_ok) return;
+                const long long total = l2a_rnn_micro_floats(rows_in, Uc, G);
+                hipLaunchKernelGGL(l2a_rnn_micro_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                                   md->wblk + raw, rows_in, Uc, G, total, md->wblk + dst);
+            };
             int rc = copy(md->lw[l][0], (size_t)(kin + Ul) * cols0);
-            if (rc == L2A_OK) pack(md->lw[l][0], md->lpk[l][0], kin, Ul, cols0 / Ul, 1);
+            if (rc == L2A_OK) { pack(md->lw[l][0], md->lpk[l][0], kin, Ul, cols0 / Ul, 1); pack_micro(md->lw[l][0], md->lmk[l][0], kin, Ul, cols0 / Ul); }
             if (rc == L2A_OK) rc = copy(md->lb[l][0], (size_t)cols0);
             if (rc == L2A_OK && md->cell_type == L2A_CELL_GRU) {
                 rc = copy(md->lw[l][1], (size_t)(kin + Ul) * Ul);
-                if (rc == L2A_OK) pack(md->lw[l][1], md->lpk[l][1], kin, Ul, 1, 1);
+                if (rc == L2A_OK) { pack(md->lw[l][1], md->lpk[l][1], kin, Ul, 1, 1); pack_micro(md->lw[l][1], md->lmk[l][1], kin, Ul, 1); }
                 if (rc == L2A_OK) rc = copy(md->lb[l][1], (size_t)Ul);
             }
             if (rc != L2A_OK) return rc;
@@ -387,6 +430,11 @@ int l2a_lstm_set_weights(l2a_lstm* md, const void* const* device_ptrs, void* str
             const long long total = l2a_rnn_pack_floats(kin, md->obs_dim, 1, false);
             hipLaunchKernelGGL(l2a_rnn_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                                md->wblk + md->raw_wo, kin, md->obs_dim, 1, 0, total, md->wblk + md->pk_wout);
+            if (md->gmicro_ok) {
+                const long long total_m = (long long)(kin / 4) * 256;
+                hipLaunchKernelGGL(l2a_lstm_micro_pack_out_k, dim3((unsigned)((total_m + 255) / 256)), dim3(256), 0, stream,
+                                   md->wblk + md->raw_wo, kin, md->obs_dim, total_m, md->wblk + md->pk_mo);
+            }
         }
         if (rc == L2A_OK) rc = copy(md->raw_bo, (size_t)md->obs_dim);
         if (rc != L2A_OK) return rc;

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/l2a.h"
+
 // chain position <-> feature inside a 16-feature k-group (swaps the two 2-bit fields: its own inverse)
 __host__ __device__ inline int l2a_chain_k(int p) { return (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3); }
 
@@ -45,6 +47,47 @@ static __global__ void l2a_lstm_micro_pack_out_k(const float* __restrict__ wo, i
     const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     const int gi = (int)(idx >> 8);
     dst[idx] = (lane < obs_dim) ? wo[(long long)l2a_chain_k(4 * gi + e) * obs_dim + lane] : 0.0f;
+}
+
+
+// Generic recurrent cells (l2a_rnn_micro.h): one product of a layer, TF kernel w [kin + U, G U] (input rows, then recurrent rows;
+// gate q in columns [q U, (q + 1) U)) -> [64-unit tile T][gate q][k-group gi][lane][4]: float [lane][e] of record (T, q, gi) =
+// W[row][q U + 64 T + chain_k(lane)], row = the feature at chain position 4 gi + e of the input part (gi < 4 KGx, KGx =
+// ceil(kin / 16); zero past kin) or of the recurrent part; + 1 KiB of zeros.
+__host__ __device__ inline long long l2a_rnn_micro_floats(int kin, int U, int G) {
+    return (long long)(U / 64) * G * (4 * ((kin + 15) / 16) + U / 4) * 256 + 256;
+}
+static __global__ void l2a_rnn_micro_pack_k(const float* __restrict__ w, int kin, int U, int G, long long total, float* dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int NX = 4 * ((kin + 15) / 16), NKG = NX + U / 4;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const long long rest = idx >> 8;
+    const int gi = (int)(rest % NKG);
+    const int tq = (int)(rest / NKG);
+    const int q = tq % G, T = tq / G;
+    if (T >= U / 64) { dst[idx] = 0.0f; return; }
+    const int unit = 64 * T + l2a_chain_k(lane);
+    int row;
+    if (gi < NX) { const int k = l2a_chain_k(4 * gi + e); row = (k < kin) ? k : -1; }
+    else row = kin + l2a_chain_k(4 * (gi - NX) + e);
+    dst[idx] = (row >= 0) ? w[(long long)row * G * U + q * U + unit] : 0.0f;
+}
+
+
+// LDS row of a layer's h / c / r * h: U + 24 = 24 mod 32 floats - the four rows of a micro tile start 24 banks apart
+__host__ __device__ constexpr int l2a_rnn_micro_row(int U) { return U + 24; }
+
+__host__ __device__ inline int l2a_rnn_micro_bias(int cell_type, int U) {
+    return (cell_type == L2A_CELL_LSTM ? 4 : (cell_type == L2A_CELL_GRU ? 3 : 1)) * U;
+}
+// LDS bytes: x rows [12][row] (the layers' row stride: every B read of the loop has an immediate offset; 16 KG0 <= 80 features in
+// chain order, dump slots 80 .. 87 as in l2a_lstm_micro_body) | per layer h [2][12][row], c or r * h [12][row] (not for BasicRNN) |
+// output partials [4][3][64] f32x4 | constants
+__host__ __device__ inline long long l2a_rnn_micro_smem(int cell_type, int n_layers, int U, int KG0) {
+    const long long per_layer = (long long)(cell_type == L2A_CELL_RNN ? 2 : 3) * 12 * l2a_rnn_micro_row(U);
+    return (12LL * l2a_rnn_micro_row(U) + n_layers * per_layer + 32 * KG0 + 192 + (long long)n_layers * l2a_rnn_micro_bias(cell_type, U)) * 4 +
+           4 * 3 * 64 * 16;
 }
 
 

@@ -688,3 +688,61 @@ def test_gpu_blocking_recurrent_plan_matches_the_plain_launches(cell, units, m, 
         c0, h0 = c1, h1
     torch.cuda.synchronize()
     _lib.Context.get(0).launch_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell,hidden,m,n,h,env_name,act", [
+    ("gru", (256,), 5, 500, 10, "hc", "tanh"), ("lstm", (256, 256), 5, 500, 10, "hc", "tanh"), ("rnn", (256,), 5, 500, 10, "hc", "tanh"),
+    ("gru", (256, 256), 1, 2000, 4, "hc", "tanh"), ("rnn", (256, 256, 256), 2, 37, 3, "hc", "relu"), ("lstm", (256, 256, 256), 3, 333, 3, "ant", "tanh"),
+    ("gru", (256,), 64, 12, 2, "arm", "sigmoid"), ("lstm", (256, 256), 1, 5, 2, "hc", "swish"), ("gru", (256, 256, 256), 5, 250, 4, "ant", "tanh")])
+def test_gpu_rnn_generic_micro_tiles_match_the_16_candidate_kernel_and_the_oracle(cell, hidden, m, n, h, env_name, act):
+    """The micro-tile form of the generic recurrent kernel (csrc/l2a_rnn_micro.h: GRU / BasicRNN / LSTM stacks of 256-unit layers on
+    candidate tiles of four) against the 16-candidate kernel (l2a_rnn_mfma.h; the hidden layers sum in the same order, the output
+    layer per wave and then over the waves) and against the oracle's cells (oracle/rnn_cells.py <- dynamics/core/utils.py:192-236):
+    every return, the arg-max key, from non-zero hidden states, with a discount, ragged last tiles, keys-only launches."""
+    from learning_to_adapt_amd import _lib
+    from oracle.rnn_planner import rnn_rollout_returns
+    case = dict(cases.CASES["hc_rnn_rs_gru2_n48_h4"], units=sum(hidden), m=m, n=n, h=h, cell_type=cell, hidden_sizes=list(hidden),
+                activation=act)
+    if env_name != "hc":
+        case["env"] = {"ant": "ant", "arm": "arm_7dof"}[env_name]
+    env, model = cases.product_rnn_model(case)
+    dyn = cases.oracle_rnn_dynamics(case)
+    reward = make_reward(case["env"], env.dt)
+    native = model.planner_model()
+    dev = native.device
+    od, ad, U = env.observation_space.shape[0], env.action_space.shape[0], sum(hidden)
+    rs = np.random.RandomState(U + n + m)
+    obs0 = rs.randn(m, od)
+    flat = LSTMStateTuple((rs.randn(m, U) if cell == "lstm" else np.zeros((m, U))).astype(np.float32), np.tanh(rs.randn(m, U)).astype(np.float32))
+    acts = rs.uniform(env.action_space.low, env.action_space.high, (h, m * n, ad))
+    want = rnn_rollout_returns(dyn, reward, obs0, model.unpack_hidden(flat.c, flat.h), acts, n, 0.97).reshape(m, n)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    ctx = _lib.Context.get(0)
+    out = {}
+    try:
+        for micro in (0, 1, 2):
+            ctx.set_micro(micro)
+            rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(up(obs0), up(flat.c), up(flat.h), up(acts), m, n, h, 0.97, env.reward_spec, cand_offset=11, returns_out=rets, best_key=best)
+            keys_only = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(up(obs0), up(flat.c), up(flat.h), up(acts), m, n, h, 0.97, env.reward_spec, cand_offset=11, best_key=keys_only)
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            out[micro] = [t.cpu().numpy() for t in (rets, best, keys_only)]
+    finally:
+        ctx.set_micro(1)
+    for micro in (0, 1, 2):
+        got, keys, keys_only = out[micro]
+        assert np.isfinite(got).all()
+        assert _tol_returns(got, want) < 1e-4, micro
+        assert np.array_equal(keys, keys_only)
+        for i in range(m):
+            ret, idx = _lib.key_decode(keys[i])
+            assert idx - 11 == int(np.argmax(got[i])) and ret == got[i, idx - 11]
+    assert np.array_equal(out[1][0], out[2][0])                                  # every one of these plans is eligible: policy 1 = 2
+    # the two kernels differ by the output layer's summation order only: a few ulps of the LARGEST partial return (the returns
+    # are sums of up to h rewards of either sign), far inside the bar against the oracle above
+    assert float(np.max(np.abs(out[2][0] - out[0][0])) / max(1.0, float(np.max(np.abs(out[0][0]))))) < 2e-6
+    assert _tol_returns(out[2][0], out[0][0]) < 1e-4
