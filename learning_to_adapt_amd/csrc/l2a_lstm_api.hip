@@ -12,6 +12,7 @@
 #include "l2a_micro_pack.h"
 #include "l2a_micro_launch.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,7 +39,7 @@ struct l2a_lstm {
     int lunits[L2A_RNN_MAX_LAYERS] = {0};
     long long lw[L2A_RNN_MAX_LAYERS][2] = {{0}}, lb[L2A_RNN_MAX_LAYERS][2] = {{0}};
     long long lpk[L2A_RNN_MAX_LAYERS][2] = {{0}};  // the kernels again in MFMA fragment order (l2a_rnn_mfma.h); pk_wout alike
-    bool gmicro_ok = false;                       // ... and in the micro-tile kernel's (l2a_rnn_micro.h: every layer 256 units wide)
+    bool gmicro_ok = false;                       // ... and in the micro-tile kernel's (l2a_rnn_micro.h: every layer 256 or every layer 512 units wide)
     long long lmk[L2A_RNN_MAX_LAYERS][2] = {{0}};
     float* adv_buf = nullptr;                     // l2a_lstm_plan_rs_sync: [64, act_dim] chosen actions + [64, obs_dim] next obs
 };
@@ -308,7 +309,8 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
         return l2a_fail(ctx, L2A_EINVAL, "l2a_rnn_create: unknown cell type");
     // the run_rebal.py configuration, at the widths its tuned kernel is instantiated for: the model of l2a_lstm_create;
     // one LSTM layer of any other width takes the generic matrix-core kernel like the stacks below
-    if (n_layers == 1 && cell_type == L2A_CELL_LSTM && lstm_mfma_eligible(obs_dim, act_dim, units[0]))
+    // (L2A_FORCE_GENERIC: developer switch - A/B of the generic kernels against the tuned one on its own shape)
+    if (n_layers == 1 && cell_type == L2A_CELL_LSTM && lstm_mfma_eligible(obs_dim, act_dim, units[0]) && !getenv("L2A_FORCE_GENERIC"))
         return l2a_lstm_create(ctx, obs_dim, act_dim, units[0], cell_act, output_act, out);
     if (obs_dim < 1 || act_dim < 1) return l2a_fail(ctx, L2A_EINVAL, "obs_dim and act_dim must be >= 1");
     if (cell_act < 0 || cell_act > L2A_ACT_SWISH || output_act < 0 || output_act > L2A_ACT_SWISH)
@@ -328,10 +330,16 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
     md->OT = l2a_ceil_div(obs_dim, 16);
     long long off = 0;
     auto take = [&off](long long n) { long long o = off; off += (n + 15) / 16 * 16; return o; };
-    // micro tiles (l2a_rnn_micro.h): every layer 256 units wide, the input shapes of the tuned LSTM kernel, LDS for the stack
-    md->gmicro_ok = lstm_mfma_eligible(obs_dim, act_dim, 256);
-    for (int l = 0; l < n_layers; ++l) md->gmicro_ok = md->gmicro_ok && units[l] == 256;
-    md->gmicro_ok = md->gmicro_ok && l2a_rnn_micro_smem(cell_type, n_layers, 256, md->KG0) <= ctx->lds_per_block;
+    // micro tiles (l2a_rnn_micro.h): every layer 256 (or every layer 512) units wide, the input shapes of the tuned LSTM kernel,
+    // LDS for the whole stack (256 units: up to three layers; 512: one GRU or BasicRNN layer)
+    md->gmicro_ok = lstm_mfma_eligible(obs_dim, act_dim, 256) && (units[0] == 256 || (units[0] == 512 && cell_type != L2A_CELL_LSTM));
+    for (int l = 0; l < n_layers; ++l) md->gmicro_ok = md->gmicro_ok && units[l] == units[0];
+    md->gmicro_ok = md->gmicro_ok && l2a_rnn_micro_smem(cell_type, n_layers, units[0], md->KG0) <= ctx->lds_per_block;
+    // (and only where the 16-candidate kernel fits too: one-step launches - predict, chunk continuations - stay with it)
+    if (md->gmicro_ok) {
+        const int gates = cell_type == L2A_CELL_LSTM ? 4 : (cell_type == L2A_CELL_GRU ? 3 : 1);
+        md->gmicro_ok = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, obs_dim, n_layers, units, gates) <= ctx->lds_per_block;
+    }
     int kin = md->in_dim;
     for (int l = 0; l < n_layers; ++l) {
         const int U = units[l];

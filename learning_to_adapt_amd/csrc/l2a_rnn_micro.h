@@ -259,7 +259,11 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
         body(std::true_type(), bh + 16 * (HIT - 1), bh, s0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto cell_act = [&](float x) { return p.cell_act == L2A_ACT_TANH ? l2a_fast_tanh(x) : l2a_act1(x, p.cell_act); };
+    struct ActTanh { __device__ __forceinline__ float operator()(float x) const { return l2a_fast_tanh(x); } };
+    struct ActAny { int kind; __device__ __forceinline__ float operator()(float x) const { return l2a_act1(x, kind); } };
+    // (the nonlinearity is chosen once per epilogue, not per element: l2a_lstm_micro_body)
+    auto with_act = [&](auto&& f) { if (p.cell_act == L2A_ACT_TANH) f(ActTanh()); else f(ActAny{p.cell_act}); };
+    f32x4 pfo[2][NGO / 2];                              // output-layer operands of this wave's units (requested under the last layer's gates)
 
     prefetch(stream_of(0, I0(), NT0()), NT0());
     __syncthreads();        // every wave's share of h(0) and every micro tile's input rows are in LDS
@@ -269,14 +273,25 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
         const float* xin = xs + j * HR;
         int nx = KG0;
         L2A_MTS(0)
-#pragma unroll 1
-        for (int l = 0; l < L; ++l) {
+        // one layer; LASTL: the top layer - the next product is the next step's first, and the output layer's operands follow it
+        auto layer = [&](const int l, auto last_tag) {
+            constexpr bool LASTL = decltype(last_tag)::value;
             float* hl = lrows + l * LROWS;
             const float* hc = hl + cur * 12 * HR;
             float* hn = hl + (cur ^ 1) * 12 * HR;
             float* aux = hl + 2 * 12 * HR;              // LSTM: c; GRU: r * h (this step's, every unit: the candidate product's B)
             const float* gb = c_gb + l * NBIAS;
-            const int ln = (l + 1 < L) ? l + 1 : 0;     // whose product 0 comes next (the last layer: the next step's first)
+            const int ln = LASTL ? 0 : l + 1;           // whose product 0 comes next
+            auto next_operands = [&]() {
+                prefetch(stream_of(ln, I0(), NT0()), NT0());
+                if constexpr (LASTL) {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                        for (int g = 0; g < NGO / 2; ++g) pfo[ch][g] = l2a_ldw(rsO, voffO + (ch * (NGO / 2) + g) * 1024, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
             f32x4 acc[NTLM][MT];
 #pragma unroll
             for (int tl = 0; tl < NTLM; ++tl)
@@ -291,6 +306,7 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
                         hv[uw][c] = *reinterpret_cast<const f32x4*>(hc + (4 * c + j) * HR + 64 * (wave * UW + uw) + 4 * b);
             }
             gemm(stream_of(l, I0(), NT0()), NT0(), xin, nx, hc + j * HR, acc);
+            L2A_MTS(6 + 3 * l)
 
             if constexpr (GRU) {
                 const Stream s1 = stream_of(l, I1(), NT1());
@@ -314,74 +330,79 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
                     }
                 }
                 __syncthreads();                        // every unit's r * h before the candidate product
+                L2A_MTS(15)
                 gemm(s1, NT1(), xin, nx, aux + j * HR, acc);
-                prefetch(stream_of(ln, I0(), NT0()), NT0());
+                L2A_MTS(7 + 3 * l)
+                next_operands();
+                with_act([&](auto act) {
 #pragma unroll
-                for (int uw = 0; uw < UW; ++uw) {
-                    const int tile = wave * UW + uw;
-                    const f32x4 bc = *reinterpret_cast<const f32x4*>(gb + 2 * U + 64 * tile + 4 * b);
+                    for (int uw = 0; uw < UW; ++uw) {
+                        const int tile = wave * UW + uw;
+                        const f32x4 bc = *reinterpret_cast<const f32x4*>(gb + 2 * U + 64 * tile + 4 * b);
 #pragma unroll
-                    for (int c = 0; c < MT; ++c) {
-                        f32x4 hnew;
-#pragma unroll
-                        for (int ii = 0; ii < 4; ++ii) {
-                            const float cnd = cell_act(acc[uw][c][ii] + bc[ii]);
-                            hnew[ii] = ug[uw][c][ii] * hv[uw][c][ii] + (1.0f - ug[uw][c][ii]) * cnd;
-                        }
-                        *reinterpret_cast<f32x4*>(hn + (4 * c + j) * HR + 64 * tile + 4 * b) = hnew;
-                    }
-                }
-            } else {
-                prefetch(stream_of(ln, I0(), NT0()), NT0());
-#pragma unroll
-                for (int uw = 0; uw < UW; ++uw) {
-                    const int tile = wave * UW + uw;
-                    f32x4 bias[G0];
-#pragma unroll
-                    for (int q = 0; q < G0; ++q) bias[q] = *reinterpret_cast<const f32x4*>(gb + q * U + 64 * tile + 4 * b);
-#pragma unroll
-                    for (int c = 0; c < MT; ++c) {
-                        float* at_h = hn + (4 * c + j) * HR + 64 * tile + 4 * b;
-                        f32x4 hnew;
-                        if constexpr (LSTM) {
-                            float* at_c = aux + (4 * c + j) * HR + 64 * tile + 4 * b;
-                            f32x4 cv = *reinterpret_cast<const f32x4*>(at_c);
+                        for (int c = 0; c < MT; ++c) {
+                            f32x4 hnew;
 #pragma unroll
                             for (int ii = 0; ii < 4; ++ii) {
-                                const float ig = l2a_fast_sigmoid(acc[uw][c][ii] + bias[0][ii]);
-                                const float jg = cell_act(acc[UW + uw][c][ii] + bias[1][ii]);
-                                const float fg = l2a_fast_sigmoid(acc[2 * UW + uw][c][ii] + bias[2][ii] + 1.0f);
-                                const float og = l2a_fast_sigmoid(acc[3 * UW + uw][c][ii] + bias[3][ii]);
-                                const float cn = fg * cv[ii] + ig * jg;
-                                cv[ii] = cn;
-                                hnew[ii] = og * cell_act(cn);
+                                const float cnd = act(acc[uw][c][ii] + bc[ii]);
+                                hnew[ii] = ug[uw][c][ii] * hv[uw][c][ii] + (1.0f - ug[uw][c][ii]) * cnd;
                             }
-                            *reinterpret_cast<f32x4*>(at_c) = cv;
-                        } else {
-#pragma unroll
-                            for (int ii = 0; ii < 4; ++ii) hnew[ii] = cell_act(acc[uw][c][ii] + bias[0][ii]);
+                            *reinterpret_cast<f32x4*>(hn + (4 * c + j) * HR + 64 * tile + 4 * b) = hnew;
                         }
-                        *reinterpret_cast<f32x4*>(at_h) = hnew;
                     }
-                }
+                });
+            } else {
+                next_operands();
+                with_act([&](auto act) {
+#pragma unroll
+                    for (int uw = 0; uw < UW; ++uw) {
+                        const int tile = wave * UW + uw;
+                        f32x4 bias[G0];
+#pragma unroll
+                        for (int q = 0; q < G0; ++q) bias[q] = *reinterpret_cast<const f32x4*>(gb + q * U + 64 * tile + 4 * b);
+#pragma unroll
+                        for (int c = 0; c < MT; ++c) {
+                            float* at_h = hn + (4 * c + j) * HR + 64 * tile + 4 * b;
+                            f32x4 hnew;
+                            if constexpr (LSTM) {
+                                float* at_c = aux + (4 * c + j) * HR + 64 * tile + 4 * b;
+                                f32x4 cv = *reinterpret_cast<const f32x4*>(at_c);
+#pragma unroll
+                                for (int ii = 0; ii < 4; ++ii) {
+                                    const float ig = l2a_fast_sigmoid(acc[uw][c][ii] + bias[0][ii]);
+                                    const float jg = act(acc[UW + uw][c][ii] + bias[1][ii]);
+                                    const float fg = l2a_fast_sigmoid(acc[2 * UW + uw][c][ii] + bias[2][ii] + 1.0f);
+                                    const float og = l2a_fast_sigmoid(acc[3 * UW + uw][c][ii] + bias[3][ii]);
+                                    const float cn = fg * cv[ii] + ig * jg;
+                                    cv[ii] = cn;
+                                    hnew[ii] = og * act(cn);
+                                }
+                                *reinterpret_cast<f32x4*>(at_c) = cv;
+                            } else {
+#pragma unroll
+                                for (int ii = 0; ii < 4; ++ii) hnew[ii] = act(acc[uw][c][ii] + bias[0][ii]);
+                            }
+                            *reinterpret_cast<f32x4*>(at_h) = hnew;
+                        }
+                    }
+                });
             }
-            if (l + 1 < L) {
+            L2A_MTS(8 + 3 * l)
+            if constexpr (!LASTL) {
                 __syncthreads();                        // the layer above multiplies every unit's new h
                 xin = hn + j * HR;
                 nx = HIT;
             }
-        }
+        };
+#pragma unroll 1
+        for (int l = 0; l + 1 < L; ++l) layer(l, std::false_type());
+        layer(L - 1, std::true_type());
         L2A_MTS(1)
 
         // ---- output layer over this wave's units of the top layer's new h (its own writes: no barrier) -------------------
         f32x4* pb = pbuf;
         {
             const float* hb = lrows + (L - 1) * LROWS + (cur ^ 1) * 12 * HR + j * HR + 64 * UW * wave;
-            f32x4 pfo[2][NGO / 2];
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                for (int g = 0; g < NGO / 2; ++g) pfo[ch][g] = l2a_ldw(rsO, voffO + (ch * (NGO / 2) + g) * 1024, 0);
             f32x4 oacc[2][MT];
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)

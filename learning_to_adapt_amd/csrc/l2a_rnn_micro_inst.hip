@@ -16,9 +16,15 @@ int launch_rnn(const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stre
 }  // namespace
 
 int l2a_launch_rnn_micro(int units, int cell_type, const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream) {
-    if (units != 256) return -100;
-    if (cell_type == L2A_CELL_LSTM) return launch_rnn<1, L2A_CELL_LSTM>(p, grid, smem, stream);
-    if (cell_type == L2A_CELL_GRU) return launch_rnn<1, L2A_CELL_GRU>(p, grid, smem, stream);
-    if (cell_type == L2A_CELL_RNN) return launch_rnn<1, L2A_CELL_RNN>(p, grid, smem, stream);
+    if (units == 256) {
+        if (cell_type == L2A_CELL_LSTM) return launch_rnn<1, L2A_CELL_LSTM>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_GRU) return launch_rnn<1, L2A_CELL_GRU>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_RNN) return launch_rnn<1, L2A_CELL_RNN>(p, grid, smem, stream);
+    }
+    if (units == 512) {
+        // (no LSTM instance: one 512-unit LSTM layer has its tuned kernel, two do not fit the LDS)
+        if (cell_type == L2A_CELL_GRU) return launch_rnn<2, L2A_CELL_GRU>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_RNN) return launch_rnn<2, L2A_CELL_RNN>(p, grid, smem, stream);
+    }
     return -100;
 }

@@ -159,9 +159,11 @@ def _worker_rnn(rank, world, port, cid, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cid,world", [("c6_hc_rnn_rs_n500_h10_m5_s0", 2), ("hc_rnn_rs_gru2_n48_h4_s0", 3)])
+@pytest.mark.parametrize("cid,world", [("c6_hc_rnn_rs_n500_h10_m5_s0", 2), ("hc_rnn_rs_gru2_n48_h4_s0", 3),
+                                       ("c6g_hc_rnn_rs_gru256_n500_h10_m5_s0", 2), ("ant_rnn_cem_gru2x256_n200_h4_m2_s0", 3)])
 def test_sharded_recurrent_plan_on_the_gpu_equals_the_reference_plan(cid, world, tmp_path):
-    """The recurrent planner (ReBAL default: LSTM 256; a GRU stack on the generic kernel) sharded over ranks: the payload is
+    """The recurrent planner (ReBAL default: LSTM 256; a GRU stack on the generic kernel; GRU 256 / a CEM plan on a 2 x 256 GRU stack on
+    the generic micro-tile kernel) sharded over ranks: the payload is
     packed through the recurrent model (`NativeLSTM` had no `plan_payload` - the first sharded step raised) and
     every controller step of the golden replay is the reference's on every rank."""
     mp.spawn(_worker_rnn, args=(world, _free_port(), cid, str(tmp_path)), nprocs=world, join=True)

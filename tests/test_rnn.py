@@ -102,7 +102,7 @@ def test_lstm_restatement_matches_torch_lstm_cell():
 
 
 # ------------------------------------------------------------------------------------------ host logic (CPU)
-@pytest.mark.parametrize("cid", [c for c in RNN_IDS if "c6_" not in c])
+@pytest.mark.parametrize("cid", [c for c in RNN_IDS if cases.split_id(c)[0]["h"] < 6])      # (longer horizons: pipelined launches)
 def test_rnn_controller_host_logic_matches_golden(cid):
     case, seed = cases.split_id(cid)
     gold = cases.load_golden(cid)
@@ -231,6 +231,20 @@ def test_gpu_rnn_controller_matches_golden(cid, kernel):
 
         def step(k, obs):
             chosen, _ = ctrl.get_actions(obs)
+            if case["planner"] == "rnn_cem" and "cem_trace" in ctrl.last_plan:
+                # CEM feeds the returns back through a rank-based elite mask (reference mpc_controller.py:100-104): a rank swap of
+                # two candidates closer than the rollout's fp32 error legitimately changes the later iterations.  Every swap must
+                # be a PROVEN tie (tests/cem_ties.py: a witness pair in the reference's own returns); with one inside the mask the
+                # replay stops here as an xfail - never a silent skip (tests/test_gpu_parity.py does the same for the MLP planner)
+                import cem_ties
+                tie_rtol = 2e-5 if case["env"].startswith("ant") else 1e-5
+                kk = max(int(case["n"] * 0.1), 1)
+                for it, tr in enumerate(ctrl.last_plan["cem_trace"]):
+                    assert _tol_returns(tr["returns"], gold["cem_returns_%d" % k][it]) < tie_rtol
+                    swaps, mask_flips, worst = cem_ties.assert_flips_are_ties(tr["returns"], gold["cem_returns_%d" % k][it], kk, tie_rtol)
+                    if mask_flips:
+                        pytest.xfail("rank tie inside the CEM elite mask at step %d, iteration %d: %d mask flips, largest witness gap "
+                                     "%.1e relative (error bar %.0e)" % (k, it, mask_flips, worst, 2 * tie_rtol))
             margin = gold["margin_%d" % k]
             safe = margin > 1e-4 * np.maximum(1.0, np.abs(gold["returns_%d" % k]).max(axis=1))
             assert np.array_equal(ctrl.last_plan["best_index"][safe], gold["best_%d" % k][safe])

@@ -142,6 +142,16 @@ CASES = [
          hidden_sizes=[80], units=80, steps=2, no_ref_reset=True, activation="tanh", seeds=[0]),
     dict(name="hc_rnn_rs_rnn3_n32_h3", env="half_cheetah", planner="rnn_rs", n=32, h=3, m=2, cell_type="rnn",
          hidden_sizes=[40, 32, 24], units=96, steps=2, activation="relu", seeds=[0]),
+    # ... at the ReBAL default plan size (run_rebal.py:77-78,85) with 256-unit layers: the shapes the micro-tile form of the
+    # generic recurrent kernel takes (csrc/l2a_rnn_micro.h)
+    dict(name="c6g_hc_rnn_rs_gru256_n500_h10_m5", env="half_cheetah", planner="rnn_rs", n=500, h=10, m=5, cell_type="gru",
+         hidden_sizes=[256], units=256, steps=2, no_ref_reset=True, seeds=[0]),
+    dict(name="c6l2_hc_rnn_rs_lstm2x256_n500_h10_m5", env="half_cheetah", planner="rnn_rs", n=500, h=10, m=5, cell_type="lstm",
+         hidden_sizes=[256, 256], units=512, steps=3, reset_after={"1": [False, True, False, False, True]}, seeds=[0]),
+    dict(name="arm_rnn_rs_rnn256_n300_h6_m3", env="arm_7dof", planner="rnn_rs", n=300, h=6, m=3, cell_type="rnn",
+         hidden_sizes=[256], units=256, steps=2, no_ref_reset=True, activation="tanh", discount=0.97, seeds=[0]),
+    dict(name="ant_rnn_cem_gru2x256_n200_h4_m2", env="ant", planner="rnn_cem", n=200, h=4, m=2, cell_type="gru",
+         hidden_sizes=[256, 256], units=512, steps=2, num_cem_iters=3, seeds=[0]),
 ]
 
 

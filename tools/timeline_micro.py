@@ -100,6 +100,39 @@ if what == "lstm":
     best = torch.zeros(m, dtype=torch.int64, device=dev)
     print("micro-tile LSTM rollout, units %d, n %d, m %d, h %d" % (units, n, m, h))
     run(lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best), h, NAMES_LSTM, list(range(7)))
+elif what == "rnn":
+    # generic cells (csrc/l2a_rnn_micro.h): python tools/timeline_micro.py rnn gru|lstm|rnn 256[,256..] [n m h]
+    # stamps: 0 step start | per layer l: 6 + 3 l product 0 done, 15 (GRU, last layer's survives) r * h written + barrier passed,
+    # 7 + 3 l product 1 done, 8 + 3 l gates done | 1 past the layers | 2 output partials written | 3 past the barrier |
+    # 4 reduce / reward done | 5 next inputs written
+    cell = sys.argv[2] if len(sys.argv) > 2 else "gru"
+    hidden = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "256").split(",")]
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 500
+    m = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    h = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+    case = dict(cases.CASES["hc_rnn_rs_gru2_n48_h4"], units=sum(hidden), n=n, m=m, h=h, cell_type=cell, hidden_sizes=hidden)
+    case.pop("reset_after", None)
+    env, model = cases.product_rnn_model(case)
+    native = model.planner_model()
+    dev = native.device
+    U = sum(hidden)
+    obs0 = torch.randn((m, 20), device=dev)
+    c0 = torch.randn((m, U), device=dev) * (1.0 if cell == "lstm" else 0.0)
+    h0 = torch.tanh(torch.randn((m, U), device=dev))
+    a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
+    best = torch.zeros(m, dtype=torch.int64, device=dev)
+    print("micro-tile generic recurrent rollout, %s %s, n %d, m %d, h %d" % (cell, hidden, n, m, h))
+    slots, names = [0], []
+    for l in range(len(hidden)):
+        slots.append(6 + 3 * l); names.append("L%d product 0" % l)
+        if cell == "gru":
+            if l == len(hidden) - 1:
+                slots.append(15); names.append("r*h + barrier")
+            slots.append(7 + 3 * l); names.append("L%d product 1" % l if l == len(hidden) - 1 else "L%d r*h + barrier + product 1" % l)
+        slots.append(8 + 3 * l); names.append("L%d gates" % l)
+    slots += [1, 2, 3, 4, 5]
+    names += ["(layer barrier)", "out", "barrier", "reduce+reward", "next x"]
+    run(lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best), h, names, slots)
 else:
     cid = sys.argv[2] if len(sys.argv) > 2 else "c3b_ant_rs_n500_h10_pb5_3x512"
     case = dict(cases.CASES[cid])
