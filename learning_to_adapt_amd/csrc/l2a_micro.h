@@ -431,6 +431,12 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
 #pragma unroll
             for (int c = 0; c < MT; ++c) pb[(wave * MT + c) * 64 + lane] = oacc[0][c] + oacc[1][c];
         }
+        // the coming steps' actions: requested HERE, behind the last wait of the output operands and two barriers ahead of the next
+        // step's second k-group iteration: memory returns in order, so a read that comes from HBM (the actions of a fresh plan)
+        // requested after the reduce would sit in the queue in front of that iteration's weight requests (with the actions warm
+        // in the L2, as in the launch-loop benchmarks, the two placements measure the same: profiles/r04_ab_action_loads.txt)
+        av[0] = av_next[0]; av[1] = av_next[1];
+        load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
         L2A_MTS(3)
         __syncthreads();
         L2A_MTS(4)
@@ -477,9 +483,7 @@ __device__ __forceinline__ void l2a_lstm_micro_body(const L2ALstmParams& p, cons
             }
         }
         // the next step's inputs
-        av[0] = av_next[0]; av[1] = av_next[1];
         L2A_MTS(5)
-        load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
         write_x(rows_n);
         __syncthreads();        // every micro tile's input rows are written
         L2A_MTS(6)
@@ -821,6 +825,11 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
             rec = 0;
             sbase = snext;
             snext = set_of((i + 2 < e_loop) ? i + 2 : (i + 2 - e_loop < e_loop ? i + 2 - e_loop : 0)) * set_bytes;
+            // (the coming steps' actions: behind the last set's output product, two barriers ahead of the next step - l2a_lstm_micro_body)
+            if (i == e_loop - 1) {
+                av[0] = av_next[0]; av[1] = av_next[1];
+                load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
+            }
             if (i == 0) { L2A_MTS(6) }
             __syncthreads();
             if (i == 0) { L2A_MTS(7) }
@@ -892,8 +901,6 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
             ret = fmaf(disc_t, r, ret);
         }
         // the next step's inputs
-        av[0] = av_next[0]; av[1] = av_next[1];
-        load_actions((t + 2 < p.h) ? t + 2 : p.h - 1, av_next);
         L2A_MTS(12)
         write_x();
         __syncthreads();                                // every micro tile's input rows are written

@@ -53,14 +53,16 @@ static __global__ void l2a_lstm_micro_pack_out_k(const float* __restrict__ wo, i
 // Generic recurrent cells (l2a_rnn_micro.h): one product of a layer, TF kernel w [kin + U, G U] (input rows, then recurrent rows;
 // gate q in columns [q U, (q + 1) U)) -> [64-unit tile T][gate q][k-group gi][lane][4]: float [lane][e] of record (T, q, gi) =
 // W[row][q U + 64 T + chain_k(lane)], row = the feature at chain position 4 gi + e of the input part (gi < 4 KGx, KGx =
-// ceil(kin / 16); zero past kin) or of the recurrent part; + 1 KiB of zeros.
+// ceil(kin / 16) rounded up to EVEN - the operand ring of the products with one or two gate tiles is eight k-groups deep and
+// runs in trips of eight; zero past kin) or of the recurrent part; + 1 KiB of zeros.
+__host__ __device__ inline int l2a_rnn_micro_kgx(int kin) { return (((kin + 15) / 16) + 1) & ~1; }
 __host__ __device__ inline long long l2a_rnn_micro_floats(int kin, int U, int G) {
-    return (long long)(U / 64) * G * (4 * ((kin + 15) / 16) + U / 4) * 256 + 256;
+    return (long long)(U / 64) * G * (4 * l2a_rnn_micro_kgx(kin) + U / 4) * 256 + 256;
 }
 static __global__ void l2a_rnn_micro_pack_k(const float* __restrict__ w, int kin, int U, int G, long long total, float* dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int NX = 4 * ((kin + 15) / 16), NKG = NX + U / 4;
+    const int NX = 4 * l2a_rnn_micro_kgx(kin), NKG = NX + U / 4;
     const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     const long long rest = idx >> 8;
     const int gi = (int)(rest % NKG);

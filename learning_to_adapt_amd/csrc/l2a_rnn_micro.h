@@ -39,6 +39,7 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
     constexpr int HIT = U / 16;             // loop iterations (four k-groups = sixteen features each) of a recurrent part
     constexpr int NGO = 16 * UW;            // output-layer k-groups of this wave's units
     const int KG0 = p.KG0, L = p.n_layers;
+    const int KGX0 = l2a_rnn_micro_kgx(p.in_dim);      // layer 0's input iterations (sixteen features each), padded to even with zeros
     float* xs = reinterpret_cast<float*>(smem);                     // [12][XR]
     float* lrows = xs + 12 * XR;
     f32x4* pbuf = reinterpret_cast<f32x4*>(lrows + L * LROWS);      // [4 waves][3][64]
@@ -149,7 +150,7 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = 4 * b + i;
-            xo_s[i] = (k < obs_dim) ? l2a_chain_k(k) : 80 + (lane & 7);
+            xo_s[i] = (k < obs_dim) ? l2a_chain_k(k) : 96 + (lane & 7);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -158,7 +159,7 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int k = 16 * (ga0 + s2) + 4 * qq + ii;
-                xo_a[s2][ii] = (b < 4 && k >= obs_dim && k < obs_dim + act_dim) ? l2a_chain_k(k) : 80 + (lane & 7);
+                xo_a[s2][ii] = (b < 4 && k >= obs_dim && k < obs_dim + act_dim) ? l2a_chain_k(k) : 96 + (lane & 7);
             }
         }
     }
@@ -189,15 +190,23 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
     // ---- operand streams ---------------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t rsO = l2a_rsrc(p.wblk + p.pk_mo, (long long)(U / 4) * 1024);
     const int voffO = lane * 16 + wave * NGO * 1024;
-    f32x4 ra[4][NTLM];                                  // weight ring: four k-groups, three requested ahead
+    // weight ring: RD k-groups of a product's NTL tiles, RD - 1 requested ahead.  Four deep where a product has four gate tiles (LSTM:
+    // 12 KiB per wave in flight); eight deep for the products with two tiles or one (GRU, BasicRNN: with three k-groups ahead they
+    // had 3 - 6 KiB in flight against the ~8 KiB that 43 B/clock per CU times the L2's latency asks for - 81 - 88 % of their matrix
+    // time, timeline r04)
+    constexpr int RD0 = NTLM >= 4 ? 4 : 8;              // product 0
+    constexpr int RD1 = 8;                              // a GRU layer's candidate product
+    constexpr int RING = RD0 * NTLM;
+    f32x4 ring[RING];
     f32x4 rb[2][MT];                                    // activation ring: two k-groups
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using NT0 = std::integral_constant<int, NTLM>; using NT1 = std::integral_constant<int, UW>;
+    using RDT0 = std::integral_constant<int, RD0>; using RDT1 = std::integral_constant<int, RD1>;
     // a product's stream: resource over its packed array, this wave's tile offsets (tile tl = gate q of its unit tile uw: q UW + uw)
     struct Stream { __amdgpu_buffer_rsrc_t rs; int voff[NTLM]; };
     auto stream_of = [&](int l, auto prod_tag, auto ntl_tag) {
         constexpr int PROD = decltype(prod_tag)::value, NTL = decltype(ntl_tag)::value, G = NTL / UW;
-        const int nkg = (l == 0 ? 4 * KG0 : U / 4) + U / 4;
+        const int nkg = (l == 0 ? 4 * KGX0 : U / 4) + U / 4;
         Stream s;
         s.rs = l2a_rsrc(p.wblk + p.layer_mk[l][PROD], (long long)(U / 64) * G * nkg * 1024);
 #pragma unroll
@@ -207,19 +216,26 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
         }
         return s;
     };
-    // the first three k-groups of a product, requested in this order (pinned: the loops' s_waitcnt counts hold on every path)
-    auto prefetch = [&](const Stream& s, auto ntl_tag) {
-        constexpr int NTL = decltype(ntl_tag)::value;
+    // the first RD - 1 k-groups of a product, requested in this order (pinned: the loops' s_waitcnt counts hold on every path)
+    // (lo_tag .. hi_tag: the requests [lo, hi) of the (RD - 1) NTL, for an epilogue that issues them in portions between its chunks)
+    auto prefetch_part = [&](const Stream& s, auto ntl_tag, auto lo_tag, auto hi_tag) {
+        constexpr int NTL = decltype(ntl_tag)::value, LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int tl = 0; tl < NTL; ++tl) { ra[g][tl] = l2a_ldw(s.rs, s.voff[tl] + g * 1024, 0); __builtin_amdgcn_sched_barrier(0); }
+        l2a_static_for<LO, HI>([&](auto kv) {
+            constexpr int k = decltype(kv)::value, g = k / NTL, tl = k % NTL;
+            ring[g * NTL + tl] = l2a_ldw(s.rs, s.voff[tl] + (g % 4) * 1024, (g / 4) * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto prefetch = [&](const Stream& s, auto ntl_tag, auto rd_tag) {
+        constexpr int NTL = decltype(ntl_tag)::value, RD = decltype(rd_tag)::value;
+        static_assert(RD * NTL <= RING, "ring too small");
+        prefetch_part(s, ntl_tag, I0(), std::integral_constant<int, (RD - 1) * NTL>());
     };
     // acc[tl][c] += the product over [nx iterations of sixteen input features from bx | HIT iterations of the recurrent part from bh]
-    // (bx, bh: this lane's candidate row j of micro tile 0; the other micro tiles lie 4 HR floats apart)
-    auto gemm = [&](const Stream& s, auto ntl_tag, const float* bx, int nx, const float* bh, f32x4 (&acc)[NTLM][MT]) {
-        constexpr int NTL = decltype(ntl_tag)::value;
+    // (bx, bh: this lane's candidate row j of micro tile 0; the other micro tiles lie 4 HR floats apart); a loop trip = RD k-groups
+    auto gemm = [&](const Stream& s, auto ntl_tag, auto rd_tag, const float* bx, int nx, const float* bh, f32x4 (&acc)[NTLM][MT]) {
+        constexpr int NTL = decltype(ntl_tag)::value, RD = decltype(rd_tag)::value, IT = RD / 4;
         auto issue_b = [&](const float* bp, auto off_tag, auto slot_tag) {
             constexpr int sl = decltype(slot_tag)::value, OFF = decltype(off_tag)::value;
 #pragma unroll
@@ -227,16 +243,15 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
         };
         auto body = [&](auto last_tag, const float* bp, const float* bn, int s0) {
             constexpr bool LAST = decltype(last_tag)::value;
-            l2a_static_for<0, 4>([&](auto iv) {
+            l2a_static_for<0, RD>([&](auto iv) {
                 constexpr int I = decltype(iv)::value;
-                if constexpr (I == 0) {
+                constexpr int GA = RD - 1 + I;          // the k-group requested now, counted from the trip's first
+                if constexpr (I == 0 || !LAST) {
 #pragma unroll
-                    for (int tl = 0; tl < NTL; ++tl) ra[3][tl] = l2a_ldw(s.rs, s.voff[tl] + 3072, s0);
-                } else if constexpr (!LAST) {
-#pragma unroll
-                    for (int tl = 0; tl < NTL; ++tl) ra[I - 1][tl] = l2a_ldw(s.rs, s.voff[tl] + (I - 1) * 1024, s0 + 4096);
+                    for (int tl = 0; tl < NTL; ++tl)
+                        ring[(GA % RD) * NTL + tl] = l2a_ldw(s.rs, s.voff[tl] + (GA % 4) * 1024, s0 + (GA / 4) * 4096);
                 }
-                if constexpr (I < 3) issue_b(bp, std::integral_constant<int, 4 * (I + 1)>(), std::integral_constant<int, (I + 1) & 1>());
+                if constexpr (I < RD - 1) issue_b(bp, std::integral_constant<int, 4 * (I + 1)>(), std::integral_constant<int, (I + 1) & 1>());
                 else if constexpr (!LAST) issue_b(bn, I0(), I0());
                 // (the LAST-requested operands first: one s_waitcnt per kind and k-group, l2a_lstm_micro_body)
 #pragma unroll
@@ -244,19 +259,21 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
 #pragma unroll
                     for (int tl = NTL - 1; tl >= 0; --tl)
 #pragma unroll
-                        for (int c = MT - 1; c >= 0; --c) acc[tl][c] = L2A_MFMA4(ra[I][tl][e], rb[I & 1][c][e], acc[tl][c]);
+                        for (int c = MT - 1; c >= 0; --c) acc[tl][c] = L2A_MFMA4(ring[I * NTL + tl][e], rb[I & 1][c][e], acc[tl][c]);
                 constexpr int NA = (I == 0 || !LAST) ? NTL : 0;
-                constexpr int NB = (I < 3 || !LAST) ? MT : 0;
+                constexpr int NB = (I < RD - 1 || !LAST) ? MT : 0;
                 l2a_micro_hint<NA, NB, 4 * NTL * MT>();
             });
         };
         issue_b(bx, I0(), I0());
         int s0 = 0;
+        const int tx = nx / IT;
 #pragma unroll 1
-        for (int it = 0; it < nx; ++it, s0 += 4096) body(std::false_type(), bx + 16 * it, (it + 1 < nx) ? bx + 16 * (it + 1) : bh, s0);
+        for (int it = 0; it < tx; ++it, s0 += 1024 * RD)
+            body(std::false_type(), bx + 4 * RD * it, (it + 1 < tx) ? bx + 4 * RD * (it + 1) : bh, s0);
 #pragma unroll 1
-        for (int it = 0; it < HIT - 1; ++it, s0 += 4096) body(std::false_type(), bh + 16 * it, bh + 16 * (it + 1), s0);
-        body(std::true_type(), bh + 16 * (HIT - 1), bh, s0);
+        for (int it = 0; it < HIT / IT - 1; ++it, s0 += 1024 * RD) body(std::false_type(), bh + 4 * RD * it, bh + 4 * RD * (it + 1), s0);
+        body(std::true_type(), bh + 4 * RD * (HIT / IT - 1), bh, s0);
         __builtin_amdgcn_sched_barrier(0);
     };
     struct ActTanh { __device__ __forceinline__ float operator()(float x) const { return l2a_fast_tanh(x); } };
@@ -265,13 +282,13 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
     auto with_act = [&](auto&& f) { if (p.cell_act == L2A_ACT_TANH) f(ActTanh()); else f(ActAny{p.cell_act}); };
     f32x4 pfo[2][NGO / 2];                              // output-layer operands of this wave's units (requested under the last layer's gates)
 
-    prefetch(stream_of(0, I0(), NT0()), NT0());
+    prefetch(stream_of(0, I0(), NT0()), NT0(), RDT0());
     __syncthreads();        // every wave's share of h(0) and every micro tile's input rows are in LDS
 
     for (int t = 0; t < p.h; ++t) {
         const int cur = t & 1;
         const float* xin = xs + j * HR;
-        int nx = KG0;
+        int nx = KGX0;
         L2A_MTS(0)
         // one layer; LASTL: the top layer - the next product is the next step's first, and the output layer's operands follow it
         auto layer = [&](const int l, auto last_tag) {
@@ -282,14 +299,25 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
             float* aux = hl + 2 * 12 * HR;              // LSTM: c; GRU: r * h (this step's, every unit: the candidate product's B)
             const float* gb = c_gb + l * NBIAS;
             const int ln = LASTL ? 0 : l + 1;           // whose product 0 comes next
-            auto next_operands = [&]() {
-                prefetch(stream_of(ln, I0(), NT0()), NT0());
+            // What the wave multiplies next is requested INSIDE the gate arithmetic, a portion in front of each of its UW MT chunks
+            // (thirty 1 KiB requests in a row wait for queue space - the CU's four waves share one 64 B/clock path - with the VALU
+            // idle, timeline r04): the next layer's first k-groups, or - top layer - the output layer's operands; the next STEP's
+            // first k-groups follow the output product (they have the whole tail to arrive).
+            constexpr int NLOAD = LASTL ? NGO : (RD0 - 1) * NTLM;
+            constexpr int NPART = UW * MT;
+            const Stream sn = stream_of(ln, I0(), NT0());
+            auto next_operands = [&](auto part_tag) {
+                constexpr int PART = decltype(part_tag)::value;
+                constexpr int LO = NLOAD * PART / NPART, HI = NLOAD * (PART + 1) / NPART;
                 if constexpr (LASTL) {
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                        for (int g = 0; g < NGO / 2; ++g) pfo[ch][g] = l2a_ldw(rsO, voffO + (ch * (NGO / 2) + g) * 1024, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    l2a_static_for<LO, HI>([&](auto kv) {
+                        constexpr int k = decltype(kv)::value;
+                        pfo[k / (NGO / 2)][k % (NGO / 2)] = l2a_ldw(rsO, voffO + k * 1024, 0);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    prefetch_part(sn, NT0(), std::integral_constant<int, LO>(), std::integral_constant<int, HI>());
                 }
             };
             f32x4 acc[NTLM][MT];
@@ -305,12 +333,12 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
                     for (int c = 0; c < MT; ++c)
                         hv[uw][c] = *reinterpret_cast<const f32x4*>(hc + (4 * c + j) * HR + 64 * (wave * UW + uw) + 4 * b);
             }
-            gemm(stream_of(l, I0(), NT0()), NT0(), xin, nx, hc + j * HR, acc);
+            gemm(stream_of(l, I0(), NT0()), NT0(), RDT0(), xin, nx, hc + j * HR, acc);
             L2A_MTS(6 + 3 * l)
 
             if constexpr (GRU) {
                 const Stream s1 = stream_of(l, I1(), NT1());
-                prefetch(s1, NT1());
+                prefetch(s1, NT1(), RDT1());
                 f32x4 ug[UW][MT];
 #pragma unroll
                 for (int uw = 0; uw < UW; ++uw) {
@@ -331,16 +359,16 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
                 }
                 __syncthreads();                        // every unit's r * h before the candidate product
                 L2A_MTS(15)
-                gemm(s1, NT1(), xin, nx, aux + j * HR, acc);
+                gemm(s1, NT1(), RDT1(), xin, nx, aux + j * HR, acc);
                 L2A_MTS(7 + 3 * l)
-                next_operands();
                 with_act([&](auto act) {
-#pragma unroll
-                    for (int uw = 0; uw < UW; ++uw) {
+                    l2a_static_for<0, UW>([&](auto uwv) {
+                        constexpr int uw = decltype(uwv)::value;
                         const int tile = wave * UW + uw;
                         const f32x4 bc = *reinterpret_cast<const f32x4*>(gb + 2 * U + 64 * tile + 4 * b);
-#pragma unroll
-                        for (int c = 0; c < MT; ++c) {
+                        l2a_static_for<0, MT>([&](auto cv_) {
+                            constexpr int c = decltype(cv_)::value;
+                            next_operands(std::integral_constant<int, uw * MT + c>());
                             f32x4 hnew;
 #pragma unroll
                             for (int ii = 0; ii < 4; ++ii) {
@@ -348,20 +376,20 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
                                 hnew[ii] = ug[uw][c][ii] * hv[uw][c][ii] + (1.0f - ug[uw][c][ii]) * cnd;
                             }
                             *reinterpret_cast<f32x4*>(hn + (4 * c + j) * HR + 64 * tile + 4 * b) = hnew;
-                        }
-                    }
+                        });
+                    });
                 });
             } else {
-                next_operands();
                 with_act([&](auto act) {
-#pragma unroll
-                    for (int uw = 0; uw < UW; ++uw) {
+                    l2a_static_for<0, UW>([&](auto uwv) {
+                        constexpr int uw = decltype(uwv)::value;
                         const int tile = wave * UW + uw;
                         f32x4 bias[G0];
 #pragma unroll
                         for (int q = 0; q < G0; ++q) bias[q] = *reinterpret_cast<const f32x4*>(gb + q * U + 64 * tile + 4 * b);
-#pragma unroll
-                        for (int c = 0; c < MT; ++c) {
+                        l2a_static_for<0, MT>([&](auto cv_) {
+                            constexpr int c = decltype(cv_)::value;
+                            next_operands(std::integral_constant<int, uw * MT + c>());
                             float* at_h = hn + (4 * c + j) * HR + 64 * tile + 4 * b;
                             f32x4 hnew;
                             if constexpr (LSTM) {
@@ -383,8 +411,8 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
                                 for (int ii = 0; ii < 4; ++ii) hnew[ii] = act(acc[uw][c][ii] + bias[0][ii]);
                             }
                             *reinterpret_cast<f32x4*>(at_h) = hnew;
-                        }
-                    }
+                        });
+                    });
                 });
             }
             L2A_MTS(8 + 3 * l)
@@ -430,6 +458,8 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
 #pragma unroll
             for (int c = 0; c < MT; ++c) pb[(wave * MT + c) * 64 + lane] = oacc[0][c] + oacc[1][c];
         }
+        // the next step's first k-groups (they have the reduce, the input rows and two barriers to arrive), then ...
+        prefetch(stream_of(0, I0(), NT0()), NT0(), RDT0());
         // the coming steps' actions: requested here, behind the last wait of the output operands and two barriers ahead of the
         // next product's first wait - a read from HBM in front of the operand ring would stall the ring (returns are in order)
         av[0] = av_next[0]; av[1] = av_next[1];

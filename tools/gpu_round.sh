@@ -12,7 +12,7 @@ echo "== smoke" | tee $OUT/smoke.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log
 tail -5 $OUT/smoke.log
 echo "== pytest -m gpu"
-timeout 900 python -m pytest tests -m gpu -q --timeout 300 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q --timeout 300 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 tail -25 $OUT/pytest_gpu.log
 echo "== bench"
 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
@@ -41,9 +41,13 @@ echo "== micro-tile kernels: timelines, A/B against the 16-candidate kernels, ro
 for a in "lstm 500 5 10" "mlp c3b_ant_rs_n500_h10_pb5_3x512" "mlp c1_hc_rs_n500_h10_e1" "mlp c2_hc_rs_n2000_h30_e5"; do
   n=$(echo $a | tr ' ' '_'); timeout 200 python tools/timeline_micro.py $a > $OUT/timeline_micro_$n.txt 2>&1; echo "timeline_micro $a rc=$?"
 done
+for a in "gru 256" "lstm 256,256" "rnn 256"; do
+  n=$(echo $a | tr ' ,' '_x'); timeout 200 python tools/timeline_micro.py rnn $a > $OUT/timeline_micro_rnn_$n.txt 2>&1; echo "timeline_micro rnn $a rc=$?"
+done
+timeout 400 python tools/ab_rnn_micro.py > $OUT/ab_rnn_micro.jsonl 2> $OUT/ab_rnn_micro.err; echo "ab_rnn_micro rc=$?"
 timeout 500 python tools/ab_micro.py lstm mlp > $OUT/ab_micro.jsonl 2> $OUT/ab_micro.err; echo "ab_micro rc=$?"
 timeout 300 python tools/ab_nt.py > $OUT/ab_nt.jsonl 2> /dev/null; echo "ab_nt rc=$?"
-for shape in c1 c3b c6; do for mic in 1 0; do
+for shape in c1 c3b c6 gru lstm2; do for mic in 1 0; do
   (cd /tmp && L2A_MICRO=$mic timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_def -o trace -- python $GRAFT_REPO_ROOT/tools/prof_defaults.py $shape > /dev/null 2>> $GRAFT_REPO_ROOT/$OUT/prof_def.err)
   f=$(find $OUT/prof_def -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && (echo "# $shape, L2A_MICRO=$mic"; head -1 "$f"; grep -E '^"(void )?l2a_(rollout|lstm|mlp|rnn)' "$f") >> $OUT/defaults_kernel_stats.csv

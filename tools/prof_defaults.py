@@ -2,7 +2,8 @@
 """The reference's own default plan sizes, launched back to back for a rocprofv3 --kernel-trace --stats run (profiles/
 r04_defaults_kernel_stats.csv): run_mb_mpc.py's config-1 shape (one 2 x 512 model, n = 500, h = 10), run_grbal.py's default
 (5 adapted 3 x 512 sets, n = 500, h = 10), run_rebal.py's default (LSTM 256, 5 envs, n = 500, h = 10) - the launches the
-micro-tile kernels of csrc/l2a_micro.h take.  L2A_MICRO=0 in the environment gives the 16-candidate kernels instead."""
+micro-tile kernels of csrc/l2a_micro.h take; `gru` / `lstm2`: a 256-unit GRU and a 2 x 256 LSTM stack at the ReBAL plan size
+(csrc/l2a_rnn_micro.h).  L2A_MICRO=0 in the environment gives the 16-candidate kernels instead."""
 import os
 import sys
 
@@ -13,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
 
-WHICH = sys.argv[1] if len(sys.argv) > 1 else "all"          # c1 | c3b | c6 | all: one shape per rocprof run keeps its row apart
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "all"          # c1 | c3b | c6 | gru | lstm2 | all: one shape per rocprof run keeps its row apart
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 plans = []
 for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
@@ -42,6 +43,23 @@ if WHICH in ("all", "c6"):
     a = torch.rand((h, m * n, 6), device=dev) * 2 - 1
     best = torch.zeros((m,), dtype=torch.int64, device=dev)
     plans.append((model, lambda: native.plan_rs(obs0, c0, h0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
+for tag, cell, hidden in (("gru", "gru", [256]), ("lstm2", "lstm", [256, 256])):
+    # ... and the other cells of create_rnn at that plan size (csrc/l2a_rnn_micro.h): GRU 256, a 2 x 256 LSTM stack
+    if WHICH not in ("all", tag):
+        continue
+    case = dict(cases.CASES["hc_rnn_rs_gru2_n48_h4"], units=sum(hidden), n=500, m=5, h=10, cell_type=cell, hidden_sizes=hidden)
+    case.pop("reset_after", None)
+    env, model = cases.product_rnn_model(case)
+    native = model.planner_model()
+    dev = native.device
+    U = sum(hidden)
+    obs0 = torch.randn((5, 20), device=dev)
+    c0 = torch.randn((5, U), device=dev) * (1.0 if cell == "lstm" else 0.0)
+    h0 = torch.tanh(torch.randn((5, U), device=dev))
+    a = torch.rand((10, 2500, 6), device=dev) * 2 - 1
+    best = torch.zeros((5,), dtype=torch.int64, device=dev)
+    plans.append((model, lambda native=native, obs0=obs0, c0=c0, h0=h0, a=a, env=env, best=best:
+                  native.plan_rs(obs0, c0, h0, a, 5, 500, 10, 1.0, env.reward_spec, best_key=best)))
 for _, plan in plans:       # one shape after the other, back to back: the clocks are up after the first few dozen launches
     for _ in range(REPS):
         plan()
