@@ -41,6 +41,7 @@ struct l2a_lstm {
     long long lpk[L2A_RNN_MAX_LAYERS][2] = {{0}};  // the kernels again in MFMA fragment order (l2a_rnn_mfma.h); pk_wout alike
     bool gmicro_ok = false;                       // ... and in the micro-tile kernel's (l2a_rnn_micro.h: every layer 256 or every layer 512 units wide)
     long long lmk[L2A_RNN_MAX_LAYERS][2] = {{0}};
+    bool gmicro4_ok = false;                      // ... with workgroups of four micro tiles (plans beyond three per CU)
     float* adv_buf = nullptr;                     // l2a_lstm_plan_rs_sync: [64, act_dim] chosen actions + [64, obs_dim] next obs
 };
 
@@ -126,16 +127,20 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
             const int quads = l2a_ceil_div(p.n, 4);
             int W = cus_m / p.m;
             if (W > quads) W = quads;
-            const int hi = W > 0 ? l2a_ceil_div(quads, W) : 99;
-            if (hi >= 1 && hi <= 3) W = l2a_ceil_div(quads, hi);
-            const bool eligible = !p.obs_per_row && !p.state_out && !p.c_out && !p.h_out && hi <= 3 && (p.returns_out || p.best_key);
+            int hi = W > 0 ? l2a_ceil_div(quads, W) : 99;
+            // Larger plans: workgroups of FOUR micro tiles, ceil(quads / 4) per env, as many rounds as that takes (the instances
+            // with LDS rows for sixteen candidates: 256-unit layers, where the stack still fits)
+            int mtm = 3;
+            if (hi > 3 && md->gmicro4_ok) { hi = 4; mtm = 4; }
+            if (hi >= 1 && hi <= 4) W = l2a_ceil_div(quads, hi);
+            const bool eligible = !p.obs_per_row && !p.state_out && !p.c_out && !p.h_out && hi <= mtm && (p.returns_out || p.best_key);
             if (eligible && ctx->micro_policy != 0) {
                 p.mc_w = W;
                 p.mc_hi = hi;
                 p.mc_r = quads - W * (hi - 1);
-                int smem_g = (int)l2a_rnn_micro_smem(md->cell_type, md->n_layers, md->lunits[0], md->KG0);
+                int smem_g = (int)l2a_rnn_micro_smem(md->cell_type, md->n_layers, md->lunits[0], md->KG0, mtm);
                 if (smem_g < 84 * 1024) smem_g = 84 * 1024;     // more than half a CU's LDS: one workgroup per CU
-                const int rc = l2a_launch_rnn_micro(md->lunits[0], md->cell_type, &p, (unsigned)(p.m * W), smem_g, stream);
+                const int rc = l2a_launch_rnn_micro(md->lunits[0], md->cell_type, mtm, &p, (unsigned)(p.m * W), smem_g, stream);
                 if (rc != 0) return l2a_fail(ctx, L2A_EHIP, std::string("micro-tile recurrent kernel launch: ") +
                                                             (rc > 0 ? hipGetErrorString((hipError_t)rc) : "no instance"));
                 L2A_HIP(ctx, hipGetLastError());
@@ -334,12 +339,13 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
     // LDS for the whole stack (256 units: up to three layers; 512: one GRU or BasicRNN layer)
     md->gmicro_ok = lstm_mfma_eligible(obs_dim, act_dim, 256) && (units[0] == 256 || (units[0] == 512 && cell_type != L2A_CELL_LSTM));
     for (int l = 0; l < n_layers; ++l) md->gmicro_ok = md->gmicro_ok && units[l] == units[0];
-    md->gmicro_ok = md->gmicro_ok && l2a_rnn_micro_smem(cell_type, n_layers, units[0], md->KG0) <= ctx->lds_per_block;
+    md->gmicro_ok = md->gmicro_ok && l2a_rnn_micro_smem(cell_type, n_layers, units[0], md->KG0, 3) <= ctx->lds_per_block;
     // (and only where the 16-candidate kernel fits too: one-step launches - predict, chunk continuations - stay with it)
     if (md->gmicro_ok) {
         const int gates = cell_type == L2A_CELL_LSTM ? 4 : (cell_type == L2A_CELL_GRU ? 3 : 1);
         md->gmicro_ok = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, obs_dim, n_layers, units, gates) <= ctx->lds_per_block;
     }
+    md->gmicro4_ok = md->gmicro_ok && units[0] == 256 && l2a_rnn_micro_smem(cell_type, n_layers, 256, md->KG0, 4) <= ctx->lds_per_block;
     int kin = md->in_dim;
     for (int l = 0; l < n_layers; ++l) {
         const int U = units[l];

@@ -83,15 +83,14 @@ __host__ __device__ constexpr int l2a_rnn_micro_row(int U) { return U + 24; }
 __host__ __device__ inline int l2a_rnn_micro_bias(int cell_type, int U) {
     return (cell_type == L2A_CELL_LSTM ? 4 : (cell_type == L2A_CELL_GRU ? 3 : 1)) * U;
 }
-// LDS bytes: x rows [12][row] (the layers' row stride: every B read of the loop has an immediate offset; 16 KG0 <= 80 features in
-// chain order, dump slots 80 .. 87 as in l2a_lstm_micro_body) | per layer h [2][12][row], c or r * h [12][row] (not for BasicRNN) |
-// output partials [4][3][64] f32x4 | constants
-__host__ __device__ inline long long l2a_rnn_micro_smem(int cell_type, int n_layers, int U, int KG0) {
-    const long long per_layer = (long long)(cell_type == L2A_CELL_RNN ? 2 : 3) * 12 * l2a_rnn_micro_row(U);
-    return (12LL * l2a_rnn_micro_row(U) + n_layers * per_layer + 32 * KG0 + 192 + (long long)n_layers * l2a_rnn_micro_bias(cell_type, U)) * 4 +
-           4 * 3 * 64 * 16;
+// LDS bytes: x rows [4 mtm][row] (the layers' row stride: every B read of the loop has an immediate offset; 16 KG0 <= 80 features in
+// chain order, dump slots 96 .. 103) | per layer h [2][4 mtm][row], c or r * h [4 mtm][row] (not for BasicRNN) |
+// output partials [4][mtm][64] f32x4 | constants; mtm = 3 or 4, the micro tiles of the launch's largest workgroup
+__host__ __device__ inline long long l2a_rnn_micro_smem(int cell_type, int n_layers, int U, int KG0, int mtm) {
+    const long long per_layer = (long long)(cell_type == L2A_CELL_RNN ? 2 : 3) * 4 * mtm * l2a_rnn_micro_row(U);
+    return (4LL * mtm * l2a_rnn_micro_row(U) + n_layers * per_layer + 32 * KG0 + 192 + (long long)n_layers * l2a_rnn_micro_bias(cell_type, U)) * 4 +
+           4 * mtm * 64 * 16;
 }
-
 
 // LDS bytes of the kernel (sized for MT = 3 whatever the workgroup runs; the host asks for at least half a CU's LDS, so
 // that no two workgroups share a CU)

@@ -26,7 +26,7 @@
 
 #include "l2a_micro.h"
 
-template <int MT, int UW, int CELL>
+template <int MT, int UW, int CELL, int MTM>
 __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const int env, const int cand0, char* smem) {
     constexpr int U = 256 * UW;
     constexpr int HR = l2a_rnn_micro_row(U);
@@ -35,15 +35,16 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
     constexpr int G0 = LSTM ? 4 : (GRU ? 2 : 1);
     constexpr int NTLM = G0 * UW;           // accumulator tiles of a wave in product 0 (product 1 of a GRU layer: UW)
     constexpr int NBIAS = (LSTM ? 4 : (GRU ? 3 : 1)) * U;
-    constexpr int LROWS = (CELL == L2A_CELL_RNN ? 2 : 3) * 12 * HR;
+    constexpr int NR = 4 * MTM;             // candidate rows the LDS arrays are laid out for (MTM = the launch's largest workgroup: 3 or 4 micro tiles)
+    constexpr int LROWS = (CELL == L2A_CELL_RNN ? 2 : 3) * NR * HR;
     constexpr int HIT = U / 16;             // loop iterations (four k-groups = sixteen features each) of a recurrent part
     constexpr int NGO = 16 * UW;            // output-layer k-groups of this wave's units
     const int KG0 = p.KG0, L = p.n_layers;
     const int KGX0 = l2a_rnn_micro_kgx(p.in_dim);      // layer 0's input iterations (sixteen features each), padded to even with zeros
     float* xs = reinterpret_cast<float*>(smem);                     // [12][XR]
-    float* lrows = xs + 12 * XR;
-    f32x4* pbuf = reinterpret_cast<f32x4*>(lrows + L * LROWS);      // [4 waves][3][64]
-    float* c_in_mu = reinterpret_cast<float*>(pbuf + 4 * 3 * 64);
+    float* lrows = xs + NR * XR;
+    f32x4* pbuf = reinterpret_cast<f32x4*>(lrows + L * LROWS);      // [4 waves][MTM][64]
+    float* c_in_mu = reinterpret_cast<float*>(pbuf + 4 * MTM * 64);
     float* c_in_iv = c_in_mu + 16 * KG0;
     float* c_out_mu = c_in_iv + 16 * KG0;   // [64] each, zero past the observation
     float* c_out_sd = c_out_mu + 64;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
         }
         c_in_mu[i] = v;
     }
-    for (int i = tid; i < 12 * XR + L * LROWS; i += 256) xs[i] = 0.0f;   // padding (and rows of absent micro tiles) stay zero
+    for (int i = tid; i < NR * XR + L * LROWS; i += 256) xs[i] = 0.0f;   // padding (and rows of absent micro tiles) stay zero
     __syncthreads();
 
     int cand[MT], row[MT];
@@ -114,7 +115,7 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
                     cv[i] = LSTM ? p.c0[hrow + unit] : 0.0f;
                 }
                 *reinterpret_cast<f32x4*>(hl + (4 * c + j) * HR + 64 * tile + 4 * b) = hv;
-                if (LSTM) *reinterpret_cast<f32x4*>(hl + 2 * 12 * HR + (4 * c + j) * HR + 64 * tile + 4 * b) = cv;
+                if (LSTM) *reinterpret_cast<f32x4*>(hl + 2 * NR * HR + (4 * c + j) * HR + 64 * tile + 4 * b) = cv;
             }
         }
     }
@@ -294,9 +295,9 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
         auto layer = [&](const int l, auto last_tag) {
             constexpr bool LASTL = decltype(last_tag)::value;
             float* hl = lrows + l * LROWS;
-            const float* hc = hl + cur * 12 * HR;
-            float* hn = hl + (cur ^ 1) * 12 * HR;
-            float* aux = hl + 2 * 12 * HR;              // LSTM: c; GRU: r * h (this step's, every unit: the candidate product's B)
+            const float* hc = hl + cur * NR * HR;
+            float* hn = hl + (cur ^ 1) * NR * HR;
+            float* aux = hl + 2 * NR * HR;              // LSTM: c; GRU: r * h (this step's, every unit: the candidate product's B)
             const float* gb = c_gb + l * NBIAS;
             const int ln = LASTL ? 0 : l + 1;           // whose product 0 comes next
             // What the wave multiplies next is requested INSIDE the gate arithmetic, a portion in front of each of its UW MT chunks
@@ -430,7 +431,7 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
         // ---- output layer over this wave's units of the top layer's new h (its own writes: no barrier) -------------------
         f32x4* pb = pbuf;
         {
-            const float* hb = lrows + (L - 1) * LROWS + (cur ^ 1) * 12 * HR + j * HR + 64 * UW * wave;
+            const float* hb = lrows + (L - 1) * LROWS + (cur ^ 1) * NR * HR + j * HR + 64 * UW * wave;
             f32x4 oacc[2][MT];
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
@@ -540,15 +541,20 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
     }
 }
 
-// Workgroup -> (env, first candidate, micro tiles): l2a_lstm_micro_k's dealing (host: l2a_lstm_api.hip)
-template <int UW, int CELL>
+// Workgroup -> (env, first candidate, micro tiles): l2a_lstm_micro_k's dealing (host: l2a_lstm_api.hip).  MTM = 3: plans of at most
+// three micro tiles per CU; MTM = 4: larger plans, ceil(quads / 4) workgroups of four (and three) micro tiles per env, as many
+// rounds as that takes - the same loop at 16 candidates a workgroup, in place of l2a_rnn_mfma_k's product calls.
+template <int UW, int CELL, int MTM>
 __global__ void __launch_bounds__(256) l2a_rnn_micro_k(const L2ALstmParams p) {
     extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
     const int env = (int)blockIdx.x / p.mc_w;
     const int idx = (int)blockIdx.x - env * p.mc_w;
     const int mt = idx < p.mc_r ? p.mc_hi : p.mc_hi - 1;
     const int q0 = idx < p.mc_r ? idx * p.mc_hi : p.mc_r * p.mc_hi + (idx - p.mc_r) * (p.mc_hi - 1);
-    if (mt == 3) l2a_rnn_micro_body<3, UW, CELL>(p, env, 4 * q0, l2a_smem);
-    else if (mt == 2) l2a_rnn_micro_body<2, UW, CELL>(p, env, 4 * q0, l2a_smem);
-    else l2a_rnn_micro_body<1, UW, CELL>(p, env, 4 * q0, l2a_smem);
+    if constexpr (MTM == 4) {
+        if (mt == 4) { l2a_rnn_micro_body<4, UW, CELL, MTM>(p, env, 4 * q0, l2a_smem); return; }
+    }
+    if (mt == 3) l2a_rnn_micro_body<3, UW, CELL, MTM>(p, env, 4 * q0, l2a_smem);
+    else if (mt == 2) l2a_rnn_micro_body<2, UW, CELL, MTM>(p, env, 4 * q0, l2a_smem);
+    else l2a_rnn_micro_body<1, UW, CELL, MTM>(p, env, 4 * q0, l2a_smem);
 }

@@ -4,9 +4,9 @@
 
 namespace {
 
-template <int UW, int CELL>
+template <int UW, int CELL, int MTM>
 int launch_rnn(const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream) {
-    auto kernel = l2a_rnn_micro_k<UW, CELL>;
+    auto kernel = l2a_rnn_micro_k<UW, CELL, MTM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), smem, stream, *p);
@@ -15,16 +15,21 @@ int launch_rnn(const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stre
 
 }  // namespace
 
-int l2a_launch_rnn_micro(int units, int cell_type, const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream) {
-    if (units == 256) {
-        if (cell_type == L2A_CELL_LSTM) return launch_rnn<1, L2A_CELL_LSTM>(p, grid, smem, stream);
-        if (cell_type == L2A_CELL_GRU) return launch_rnn<1, L2A_CELL_GRU>(p, grid, smem, stream);
-        if (cell_type == L2A_CELL_RNN) return launch_rnn<1, L2A_CELL_RNN>(p, grid, smem, stream);
+int l2a_launch_rnn_micro(int units, int cell_type, int mtm, const L2ALstmParams* p, unsigned grid, int smem, hipStream_t stream) {
+    if (units == 256 && mtm == 3) {
+        if (cell_type == L2A_CELL_LSTM) return launch_rnn<1, L2A_CELL_LSTM, 3>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_GRU) return launch_rnn<1, L2A_CELL_GRU, 3>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_RNN) return launch_rnn<1, L2A_CELL_RNN, 3>(p, grid, smem, stream);
     }
-    if (units == 512) {
-        // (no LSTM instance: one 512-unit LSTM layer has its tuned kernel, two do not fit the LDS)
-        if (cell_type == L2A_CELL_GRU) return launch_rnn<2, L2A_CELL_GRU>(p, grid, smem, stream);
-        if (cell_type == L2A_CELL_RNN) return launch_rnn<2, L2A_CELL_RNN>(p, grid, smem, stream);
+    if (units == 256 && mtm == 4) {
+        if (cell_type == L2A_CELL_LSTM) return launch_rnn<1, L2A_CELL_LSTM, 4>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_GRU) return launch_rnn<1, L2A_CELL_GRU, 4>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_RNN) return launch_rnn<1, L2A_CELL_RNN, 4>(p, grid, smem, stream);
+    }
+    if (units == 512 && mtm == 3) {
+        // (no LSTM instance: one 512-unit LSTM layer has its tuned kernel, two do not fit the LDS; no four-tile instances: LDS)
+        if (cell_type == L2A_CELL_GRU) return launch_rnn<2, L2A_CELL_GRU, 3>(p, grid, smem, stream);
+        if (cell_type == L2A_CELL_RNN) return launch_rnn<2, L2A_CELL_RNN, 3>(p, grid, smem, stream);
     }
     return -100;
 }

@@ -708,10 +708,13 @@ def test_gpu_blocking_recurrent_plan_matches_the_plain_launches(cell, units, m, 
 @pytest.mark.parametrize("cell,hidden,m,n,h,env_name,act", [
     ("gru", (256,), 5, 500, 10, "hc", "tanh"), ("lstm", (256, 256), 5, 500, 10, "hc", "tanh"), ("rnn", (256,), 5, 500, 10, "hc", "tanh"),
     ("gru", (256, 256), 1, 2000, 4, "hc", "tanh"), ("rnn", (256, 256, 256), 2, 37, 3, "hc", "relu"), ("lstm", (256, 256, 256), 3, 333, 3, "ant", "tanh"),
-    ("gru", (256,), 64, 12, 2, "arm", "sigmoid"), ("lstm", (256, 256), 1, 5, 2, "hc", "swish"), ("gru", (256, 256, 256), 5, 250, 4, "ant", "tanh")])
+    ("gru", (256,), 64, 12, 2, "arm", "sigmoid"), ("lstm", (256, 256), 1, 5, 2, "hc", "swish"), ("gru", (256, 256, 256), 5, 250, 4, "ant", "tanh"),
+    # plans beyond three micro tiles per CU: workgroups of four micro tiles, one round (875 quads on 219 workgroups) and several
+    ("gru", (256, 256), 1, 3500, 3, "hc", "tanh"), ("lstm", (256, 256), 3, 1500, 3, "hc", "tanh"), ("rnn", (256,), 2, 3001, 2, "ant", "relu"),
+    ("gru", (256,), 1, 16000, 2, "hc", "tanh")])
 def test_gpu_rnn_generic_micro_tiles_match_the_16_candidate_kernel_and_the_oracle(cell, hidden, m, n, h, env_name, act):
     """The micro-tile form of the generic recurrent kernel (csrc/l2a_rnn_micro.h: GRU / BasicRNN / LSTM stacks of 256-unit layers on
-    candidate tiles of four) against the 16-candidate kernel (l2a_rnn_mfma.h; the hidden layers sum in the same order, the output
+    candidate tiles of four, workgroups of up to three of them - or, for larger plans, of four, in several rounds) against the 16-candidate kernel (l2a_rnn_mfma.h; the hidden layers sum in the same order, the output
     layer per wave and then over the waves) and against the oracle's cells (oracle/rnn_cells.py <- dynamics/core/utils.py:192-236):
     every return, the arg-max key, from non-zero hidden states, with a discount, ragged last tiles, keys-only launches."""
     from learning_to_adapt_amd import _lib

@@ -17,7 +17,7 @@ import cases  # noqa: E402
 import bench_configs as bc  # noqa: E402
 from learning_to_adapt_amd import _lib  # noqa: E402
 
-PLANS = [(500, 5, 10), (2000, 1, 30), (250, 5, 10), (1000, 1, 10)]
+PLANS = [(500, 5, 10), (2000, 1, 30), (250, 5, 10), (1000, 1, 10), (4000, 1, 30), (2000, 5, 10)]
 if len(sys.argv) > 3:
     PLANS = [tuple(int(v) for v in sys.argv[1:4])]
 ctx = _lib.Context.get(0)
