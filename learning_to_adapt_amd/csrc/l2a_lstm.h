@@ -471,11 +471,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_lstm_mfma_k(const L2ALstmPara
         // (vmcnt retires in order: any earlier and the weight pipeline would wait for the ~2.3k-cycle sc1 round trip),
         // so that it travels under the last two stages' MFMAs instead of in front of an idle matrix pipe (only the other half's
         // k-group-1 operands queue behind it, and those are first used after the sweep has been checked).
-#ifdef L2A_LSTM_NO_EARLY_SWEEP
-        constexpr bool EARLY = false;       // A/B switch (tools/build_variant.py): first sweep after the GEMM, as before
-#else
         constexpr bool EARLY = true;
-#endif
         constexpr int NXG = SPLIT ? 2 * (UTWS + OT) : 1;
         u32x4 xg[NXG];
         auto xraw = [&](int r, int slot, int hh) {

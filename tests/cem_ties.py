@@ -47,3 +47,56 @@ def reference_refit(mean, clipped, returns, k, alpha):
     mask = ((-np.asarray(returns, dtype=np.float64)).argsort(axis=-1) < k).T
     elites = clipped[mask]
     return mean * alpha + (1 - alpha) * np.mean(elites, axis=0), np.std(elites, axis=0)
+
+
+def verify_tail_from_product(rollout, low, high, n, m, h, alpha, k, seed_or_state, trace, it0, best_index, chosen, rtol):
+    """After a PROVEN rank tie inside the elite mask at iteration ``it0`` the product and the reference legitimately part ways -
+    but what the product does from there on is still checkable: the oracle CONTINUED FROM THE PRODUCT'S OWN statistics
+    (``trace[it0]['mean' / 'std']``) with the same normal draws (the stream does not depend on the values).  For every later
+    iteration: the product's returns against the oracle's (``rtol``), every rank swap a witnessed tie, the refit = the reference's
+    arithmetic (``:101-104``) on the product's own returns (1e-9); at the end the chosen index must be the oracle's arg-max up
+    to such a tie and the chosen action the float64 first action of THAT candidate, bit for bit.
+    ``rollout(seq [h, n * m, act_dim]) -> returns [m, n]`` is the oracle's; ``seed_or_state``: the seed the plan started from (int)
+    or the generator state right before its first draw.  Returns the number of later iterations that flipped a mask again."""
+    low = np.asarray(low, dtype=np.float64)
+    high = np.asarray(high, dtype=np.float64)
+    act_dim = low.shape[0]
+    D = h * act_dim
+    clip_low, clip_high = np.concatenate([low] * h), np.concatenate([high] * h)
+    keep = np.random.get_state()
+    try:
+        if isinstance(seed_or_state, (int, np.integer)):
+            np.random.seed(int(seed_or_state))
+        else:
+            np.random.set_state(seed_or_state)
+        for _ in range(it0 + 1):
+            np.random.normal(size=(n, m, D))                       # the draws consumed up to and including iteration it0
+        mean, std = np.array(trace[it0]["mean"]), np.array(trace[it0]["std"])
+        again = 0
+        returns_o = first = None
+        for it in range(it0 + 1, len(trace)):
+            z = np.random.normal(size=(n, m, D))                    # :85
+            raw = mean + z * std
+            clipped = np.clip(raw, clip_low, clip_high)
+            seq = np.transpose(raw.reshape((n * m, h, act_dim)), (1, 0, 2))
+            first = seq[0].reshape((m, n, -1))                      # :94
+            returns_o = np.asarray(rollout(seq), dtype=np.float64).reshape(m, n)
+            got = np.asarray(trace[it]["returns"], dtype=np.float64)
+            err = float(np.max(np.abs(got - returns_o) / np.maximum(1.0, np.abs(returns_o))))
+            assert err < rtol, "iteration %d continued from the product's statistics: returns off by %.2e" % (it, err)
+            _, flips, _ = assert_flips_are_ties(got, returns_o, k, rtol)
+            again += 1 if flips else 0
+            want_mean, want_std = reference_refit(mean, clipped, got, k, alpha)
+            np.testing.assert_allclose(np.broadcast_to(trace[it]["mean"], want_mean.shape), want_mean, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(trace[it]["std"], want_std, rtol=1e-9, atol=1e-12)
+            mean, std = np.array(trace[it]["mean"]), np.array(trace[it]["std"])
+        if returns_o is not None:                                    # (a flip in the LAST iteration leaves nothing to continue)
+            for i in range(m):
+                b = int(best_index[i])
+                gap = float(returns_o[i].max() - returns_o[i, b])
+                assert gap <= 2.0 * rtol * max(1.0, abs(float(returns_o[i].max()))), (
+                    "env %d: the chosen candidate %d is %.3e below the oracle's best - not a tie" % (i, b, gap))
+                np.testing.assert_array_equal(np.asarray(chosen)[i], first[i, b])
+        return again
+    finally:
+        np.random.set_state(keep)

@@ -96,10 +96,22 @@ def test_controller_matches_reference_golden(cid):
             swaps, mask_flips, worst = cem_ties.assert_flips_are_ties(tr["returns"], gold["cem_returns"][it], k, tie_rtol)
             if mask_flips:
                 # PROVEN rank tie: every flipped position has a witness pair of reference returns within the error bar.
-                # From here on the two runs legitimately differ; visible in the -q summary as `x`, never a silent skip,
-                # and every iteration of this very case is checked on its own by test_cem_iterations_teacher_forced
+                # From here on the two runs legitimately differ; visible in the -q summary as `x`, never a silent skip.  Every
+                # iteration of this very case is checked on its own by test_cem_iterations_teacher_forced, and what the product
+                # did AFTER the tie - the later iterations, the index and the action it finally returned - is checked here against
+                # the oracle continued from the product's own statistics (a failure in there is a FAIL, not an `x`)
+                from oracle import make_reward
+                from oracle.planner import rollout_returns
+                dyn, reward_fn = cases.oracle_dynamics(case), make_reward(case["env"], ctrl.env.dt)
+                again = cem_ties.verify_tail_from_product(
+                    lambda seq: rollout_returns(dyn, reward_fn, np.asarray(gold["obs0"], dtype=np.float64), seq, case["n"],
+                                                case.get("discount", 1.0)),
+                    ctrl.env.action_space.low, ctrl.env.action_space.high, case["n"], case["m"], case["h"], ctrl.alpha, k, seed,
+                    trace, it, ctrl.last_plan["best_index"], actions, tie_rtol)
                 pytest.xfail("rank tie inside the CEM elite mask at iteration %d: %d mask flips, largest witness gap %.1e "
-                             "relative (error bar %.0e)" % (it, mask_flips, worst, 2 * tie_rtol))
+                             "relative (error bar %.0e); the %d later iterations, the chosen index and action verified against "
+                             "the oracle continued from the product's statistics (%d of them tied again)"
+                             % (it, mask_flips, worst, 2 * tie_rtol, len(trace) - it - 1, again))
     assert np.array_equal(ctrl.last_plan["best_index"], gold["best"])  # bit-exact index
     np.testing.assert_array_equal(actions, gold["chosen"])             # float64 action, bit for bit
     want_best = gold["returns"][np.arange(case["m"]), gold["best"]]

@@ -230,6 +230,8 @@ def test_gpu_rnn_controller_matches_golden(cid, kernel):
         np.random.seed(seed)
 
         def step(k, obs):
+            hidden_before = ctrl.dynamics_model.unpack_hidden(*[np.array(a) for a in _flat(ctrl._hidden_state)])
+            state_before = np.random.get_state()
             chosen, _ = ctrl.get_actions(obs)
             if case["planner"] == "rnn_cem" and "cem_trace" in ctrl.last_plan:
                 # CEM feeds the returns back through a rank-based elite mask (reference mpc_controller.py:100-104): a rank swap of
@@ -238,13 +240,24 @@ def test_gpu_rnn_controller_matches_golden(cid, kernel):
                 # replay stops here as an xfail - never a silent skip (tests/test_gpu_parity.py does the same for the MLP planner)
                 import cem_ties
                 tie_rtol = 2e-5 if case["env"].startswith("ant") else 1e-5
-                kk = max(int(case["n"] * 0.1), 1)
+                kk = max(int(case["n"] * ctrl.percent_elites), 1)        # (rnn_mpc_controller.py:41: 5 % elites, refit without alpha)
                 for it, tr in enumerate(ctrl.last_plan["cem_trace"]):
                     assert _tol_returns(tr["returns"], gold["cem_returns_%d" % k][it]) < tie_rtol
                     swaps, mask_flips, worst = cem_ties.assert_flips_are_ties(tr["returns"], gold["cem_returns_%d" % k][it], kk, tie_rtol)
                     if mask_flips:
+                        # ... and what the product did after the tie is checked against the oracle continued from ITS statistics
+                        from oracle.rnn_planner import rnn_rollout_returns
+                        dyn, reward_fn = cases.oracle_rnn_dynamics(case), make_reward(case["env"], ctrl.env.dt)
+                        trace = ctrl.last_plan["cem_trace"]
+                        again = cem_ties.verify_tail_from_product(
+                            lambda seq: rnn_rollout_returns(dyn, reward_fn, np.asarray(obs, dtype=np.float64), hidden_before, seq,
+                                                            case["n"], case.get("discount", 1.0)),
+                            ctrl.env.action_space.low, ctrl.env.action_space.high, case["n"], case["m"], case["h"], ctrl.alpha, kk,
+                            state_before, trace, it, ctrl.last_plan["best_index"], chosen, tie_rtol)
                         pytest.xfail("rank tie inside the CEM elite mask at step %d, iteration %d: %d mask flips, largest witness gap "
-                                     "%.1e relative (error bar %.0e)" % (k, it, mask_flips, worst, 2 * tie_rtol))
+                                     "%.1e relative (error bar %.0e); the %d later iterations, the chosen index and action verified "
+                                     "against the oracle continued from the product's statistics (%d tied again)"
+                                     % (k, it, mask_flips, worst, 2 * tie_rtol, len(trace) - it - 1, again))
             margin = gold["margin_%d" % k]
             safe = margin > 1e-4 * np.maximum(1.0, np.abs(gold["returns_%d" % k]).max(axis=1))
             assert np.array_equal(ctrl.last_plan["best_index"][safe], gold["best_%d" % k][safe])
