@@ -284,6 +284,12 @@ int l2a_cem_sample(l2a_ctx* ctx, const float* z, unsigned long long seed, unsign
                    int act_dim, int reference, int lo, int hi, float* a_clip, float* a_raw, float* seq, void* stream);
 int l2a_cem_refit(l2a_ctx* ctx, const float* returns, const float* a_clip, int n, int m, int D, int num_elites,
                   int reference, float alpha, int* elite_rows, float* mean, float* std, void* stream);
+/* l2a_cem_pick: what the plan returns (:106), in one buffer for one read-back: per env the arg-max of the LAST iteration's
+ * `returns` [m, n] (first maximum), the first action of that candidate in `cand` - the unclipped samples read as [m, n, D]
+ * (reference = 1, :92-96) or the clipped samples [n, m, D] (0) - and its return; behind them the final mean / std.
+ * out: m x (act_dim + 2) floats (action | return | index as the bits of an int32), then mean [m, D], std [m, D].       */
+int l2a_cem_pick(l2a_ctx* ctx, const float* returns, const float* cand, const float* mean, const float* std, int n, int m,
+                 int D, int act_dim, int reference, float* out, void* stream);
 
 /* ---- sharded plans: the one collective ------------------------------------------------------
  * Candidates are independent, so G GPUs (one process and one context each) plan disjoint shards of one candidate

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
     "l2a_packed_layer_floats", "l2a_pack_layer_host", "l2a_micro_layout_floats", "l2a_micro_pack_layer_host",
     "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best", "l2a_plan_payload",
-    "l2a_cem_sample", "l2a_cem_refit",
+    "l2a_cem_sample", "l2a_cem_refit", "l2a_cem_pick",
     "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_sync", "l2a_lstm_plan_rs_chunk",
     "l2a_lstm_predict", "l2a_lstm_mfma_eligible",
 )
@@ -158,6 +158,8 @@ def load():
     lib.l2a_cem_sample.restype = i32
     lib.l2a_cem_refit.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]
     lib.l2a_cem_refit.restype = i32
+    lib.l2a_cem_pick.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.l2a_cem_pick.restype = i32
     lib.l2a_lstm_plan_rs_sync.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32, vp, vp, vp, vp]
     lib.l2a_lstm_plan_rs_sync.restype = i32
     lib.l2a_lstm_plan_rs_chunk.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, c.c_double, c.POINTER(RewardSpec), i32,

@@ -180,6 +180,46 @@ __global__ void __launch_bounds__(256) l2a_cem_stats_k(const float* a_clip, cons
     }
 }
 
+// The plan's result in ONE buffer (one read-back instead of five launches and five copies): per env the arg-max of its
+// returns (first maximum, NaN never wins - np.argmax would return a NaN's index; a plan with NaN returns has no meaning
+// either way), the first action of that candidate as the rollout saw it, its return; behind them the final mean / std.
+// out: [m][act_dim + 2] floats (action | return | index as the bit pattern of an int32), then mean [m, D], std [m, D].
+// grid (m + ceil(2 m D / 256)): block i < m is env i.
+__global__ void __launch_bounds__(256) l2a_cem_pick_k(const float* returns, const float* cand, const float* mean, const float* std,
+                                                      int n, int m, int D, int act_dim, int reference, float* out) {
+    const int W = act_dim + 2;
+    if ((int)blockIdx.x >= m) {
+        const long long e = (long long)(blockIdx.x - m) * 256 + threadIdx.x;
+        const long long md = (long long)m * D;
+        if (e < 2 * md) out[(long long)m * W + e] = (e < md) ? mean[e] : std[e - md];
+        return;
+    }
+    const int i = blockIdx.x;
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    float best = -__builtin_inff();
+    int idx = 0x7fffffff;
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float x = returns[(long long)i * n + c];
+        if (x > best || (x == best && c < idx)) { best = x; idx = c; }
+    }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const float x = bv[threadIdx.x + s]; const int c = bi[threadIdx.x + s];
+            if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && c < bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = c; }
+        }
+        __syncthreads();
+    }
+    int j = bi[0];
+    if (j < 0 || j >= n) j = 0;                         // (all returns NaN / -inf)
+    // reference: the sample memory read as [m, n, D] (:92-96), row i * n + j; fixed: candidate j of env i is sample row j * m + i
+    const long long row = reference ? (long long)i * n + j : (long long)j * m + i;
+    if ((int)threadIdx.x < act_dim) out[i * W + threadIdx.x] = cand[row * D + threadIdx.x];
+    if (threadIdx.x == 0) { out[i * W + act_dim] = returns[(long long)i * n + j]; out[i * W + act_dim + 1] = __int_as_float(j); }
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,6 +267,21 @@ int l2a_cem_refit(l2a_ctx* ctx, const float* returns, const float* a_clip, int n
                        n, m, num_elites, reference ? 1 : 0, elite_rows);
     hipLaunchKernelGGL(l2a_cem_stats_k, dim3((unsigned)((D + 31) / 32), (unsigned)(reference ? 1 : m)), dim3(256), 0,
                        stream, a_clip, elite_rows, m, D, num_elites, reference ? 1 : 0, alpha, mean, std);
+    L2A_HIP(ctx, hipGetLastError());
+    return L2A_OK;
+}
+
+int l2a_cem_pick(l2a_ctx* ctx, const float* returns, const float* cand, const float* mean, const float* std, int n, int m, int D,
+                 int act_dim, int reference, float* out, void* stream_v) {
+    if (!ctx) return L2A_EINVAL;
+    if (!returns || !cand || !mean || !std || !out) return l2a_fail(ctx, L2A_EINVAL, "l2a_cem_pick: null pointer");
+    if (n < 1 || m < 1 || D < 1 || act_dim < 1 || act_dim > D || act_dim > 256)
+        return l2a_fail(ctx, L2A_EINVAL, "l2a_cem_pick: bad n / m / D / act_dim");
+    l2a_device_guard guard(ctx->device);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const long long copy_blocks = (2LL * m * D + 255) / 256;
+    hipLaunchKernelGGL(l2a_cem_pick_k, dim3((unsigned)(m + copy_blocks)), dim3(256), 0, stream, returns, cand, mean, std, n, m, D,
+                       act_dim, reference ? 1 : 0, out);
     L2A_HIP(ctx, hipGetLastError());
     return L2A_OK;
 }

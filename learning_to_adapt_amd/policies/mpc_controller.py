@@ -885,12 +885,21 @@ class MPCController(Policy, Serializable):
             ctx.check(lib.l2a_cem_refit(ctx.handle, _ptr(rets), _ptr(a_clip), n, m, D, num_elites,
                                         1 if reference else 0, float(self.alpha), _ptr(elite_rows), _ptr(mean),
                                         _ptr(std), _stream_ptr(dev)), "l2a_cem_refit")
-        idx = torch.argmax(rets, dim=1)                                                       # [m]
         # candidates as the rollout saw them: the reference reads the sample memory as [m, n, D] (:92-96) and returns
-        # the UNCLIPPED first action (:106); the fixed mode's candidate (i, j) is clipped sample row j * m + i
-        cand = a_raw.reshape(m, n, D) if reference else a_clip.permute(1, 0, 2)
-        first = cand[torch.arange(m, device=dev), idx, :act_dim]
-        out = first.cpu().numpy().astype(np.float64)
+        # the UNCLIPPED first action (:106); the fixed mode's candidate (i, j) is clipped sample row j * m + i.  ONE launch packs
+        # arg-max, that candidate's first action, its return and the final mean / std (`l2a_cem_pick`), one copy brings them back
+        # (until round 4: five stock launches and five copies, ~1 % of a config-5 plan step)
+        width = act_dim + 2
+        packed = self._buf("cem_packed", (m * width + 2 * m * D,), torch.float32, dev)
+        ctx.check(lib.l2a_cem_pick(ctx.handle, _ptr(rets), _ptr(a_raw if reference else a_clip), _ptr(mean), _ptr(std), n, m, D,
+                                   act_dim, 1 if reference else 0, _ptr(packed), _stream_ptr(dev)), "l2a_cem_pick")
+        host = packed.cpu().numpy()
+        head = host[:m * width].reshape(m, width)
+        out = head[:, :act_dim].astype(np.float64)
+        best_return = head[:, act_dim].copy()
+        best_index = head[:, act_dim + 1].copy().view(np.int32).astype(np.int64)
+        mean_h = host[m * width:m * width + m * D].reshape(m, D).copy()
+        std_h = host[m * width + m * D:].reshape(m, D).copy()
         if world > 1:
             # every rank gathered every rank's returns: all of them replay when any launch lost its tile-split partner;
             # the same collective carries the seed digests (ranks seeded differently sampled different normals)
@@ -907,8 +916,7 @@ class MPCController(Policy, Serializable):
                 raise _lib.L2AError("rollout launch failed twice")
             return self.get_cem_action_device(observations, retry=True)      # same counters: the same normals again
         self._bufs["cem_calls"] = call0 + self.num_cem_iters
-        self.last_plan = dict(best_index=idx.cpu().numpy(), best_return=rets.max(dim=1).values.cpu().numpy(),
-                              cem_mean=mean.cpu().numpy(), cem_std=std.cpu().numpy())
+        self.last_plan = dict(best_index=best_index, best_return=best_return, cem_mean=mean_h, cem_std=std_h)
         return out
 
     def get_cem_action(self, observations):

@@ -1050,7 +1050,7 @@ def _philox_normal_ref(seed, index):
 
 @pytest.mark.parametrize("reference", [True, False])
 def test_cem_kernels_match_numpy(reference):
-    """`l2a_cem_sample` / `l2a_cem_refit` on their own against NumPy: samples, clip and the rollout's candidate tensor (both
+    """`l2a_cem_sample` / `l2a_cem_refit` / `l2a_cem_pick` on their own against NumPy: samples, clip and the rollout's candidate tensor (both
     row readings, a candidate shard), the library's Philox normals (values of single counters, moments, determinism),
     elite rows and refit - including exact ties in the returns, where the stable descending order decides."""
     from learning_to_adapt_amd.dynamics.native_model import _ptr, _stream_ptr
@@ -1132,3 +1132,24 @@ def test_cem_kernels_match_numpy(reference):
     assert np.array_equal(got_rows, want_rows)
     np.testing.assert_allclose(mean_d.cpu().numpy(), want_mean, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(std_d.cpu().numpy(), want_std, rtol=2e-5, atol=2e-6)
+
+    # l2a_cem_pick: arg-max (first maximum - env 0 has an exact tie at its top), that candidate's first action in the reading of
+    # the mode, its return, and the final mean / std, all in one buffer
+    rets2 = rets.copy()
+    rets2[0, 50] = rets2[0, 300] = np.nanmax(rets2[0]) + 1.0
+    rets2_d = up(rets2)
+    packed = torch.full((m * (ad + 2) + 2 * m * D,), float("nan"), device=dev)
+    cand = a_raw if reference else a_clip
+    ctx.check(lib.l2a_cem_pick(ctx.handle, _ptr(rets2_d), _ptr(cand), _ptr(mean_d), _ptr(std_d), n, m, D, ad, 1 if reference else 0,
+                               _ptr(packed), _stream_ptr(dev)), "l2a_cem_pick")
+    host = packed.cpu().numpy()
+    head = host[:m * (ad + 2)].reshape(m, ad + 2)
+    want_idx = np.array([int(np.nanargmax(rets2[i])) for i in range(m)])
+    assert want_idx[0] == 50
+    assert np.array_equal(head[:, ad + 1].copy().view(np.int32), want_idx)
+    assert np.array_equal(head[:, ad], rets2[np.arange(m), want_idx])
+    cand_h = cand.cpu().numpy()
+    view = cand_h.reshape(m, n, D) if reference else cand_h.transpose(1, 0, 2)       # (:92-96 / candidate j of env i = row j * m + i)
+    assert np.array_equal(head[:, :ad], view[np.arange(m), want_idx, :ad])
+    assert np.array_equal(host[m * (ad + 2):m * (ad + 2) + m * D].reshape(m, D), mean_d.cpu().numpy())
+    assert np.array_equal(host[m * (ad + 2) + m * D:].reshape(m, D), std_d.cpu().numpy())
