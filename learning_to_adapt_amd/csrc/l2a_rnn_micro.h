@@ -191,11 +191,11 @@ __device__ __forceinline__ void l2a_rnn_micro_body(const L2ALstmParams& p, const
     // ---- operand streams ---------------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t rsO = l2a_rsrc(p.wblk + p.pk_mo, (long long)(U / 4) * 1024);
     const int voffO = lane * 16 + wave * NGO * 1024;
-    // weight ring: RD k-groups of a product's NTL tiles, RD - 1 requested ahead.  Four deep where a product has four gate tiles (LSTM:
-    // 12 KiB per wave in flight); eight deep for the products with two tiles or one (GRU, BasicRNN: with three k-groups ahead they
-    // had 3 - 6 KiB in flight against the ~8 KiB that 43 B/clock per CU times the L2's latency asks for - 81 - 88 % of their matrix
-    // time, timeline r04)
-    constexpr int RD0 = NTLM >= 4 ? 4 : 8;              // product 0
+    // weight ring: RD k-groups of a product's NTL tiles, RD - 1 requested ahead: eight deep.  With three k-groups ahead the products
+    // with one or two gate tiles had 3 - 6 KiB per wave in flight against the ~8 KiB that 43 B/clock per CU times the L2's latency asks
+    // for (81 - 88 % of their matrix time, timeline r04); an LSTM layer's four tiles had 12 KiB and still gained 1.2 - 1.8 % from 28
+    // (a stack streams 3.3 MB per step through a 4 MB L2: some k-groups come from further away)
+    constexpr int RD0 = (NTLM >= 4 && !LSTM) ? 4 : 8;   // product 0 (512-unit GRU: four tiles of two gates - eight deep measured 0.3 % slower)
     constexpr int RD1 = 8;                              // a GRU layer's candidate product
     constexpr int RING = RD0 * NTLM;
     f32x4 ring[RING];
