@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc CSVs (one directory per pass) for the rollout kernel."""
+"""Summarise rocprofv3 --pmc CSVs (one directory per pass) for the rollout kernel.
+    python tools/pmc_summary.py <dir> [kernel-name substring, default l2a_rollout] [directory prefix, default pmc_]"""
 import csv
 import glob
 import os
@@ -7,11 +8,13 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "l2a_rollout"
+PREFIX = sys.argv[3] if len(sys.argv) > 3 else "pmc_"
 agg = defaultdict(list)
-for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+for path in glob.glob(os.path.join(out, PREFIX + "*", "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
-            if "l2a_rollout" not in row.get("Kernel_Name", ""):
+            if KERNEL not in row.get("Kernel_Name", ""):
                 continue
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
 print("counter, launches, mean per launch")
@@ -31,3 +34,7 @@ if "FETCH_SIZE" in g:
           % (g["FETCH_SIZE"], 2 * g["FETCH_SIZE"]))
 if "WRITE_SIZE" in g:
     print("WRITE_SIZE per launch = %.1f KB" % g["WRITE_SIZE"])
+if "SQ_VALU_MFMA_BUSY_CYCLES" in g and "GRBM_GUI_ACTIVE" in g:
+    print("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = %.3f" % (g["SQ_VALU_MFMA_BUSY_CYCLES"] / (g["GRBM_GUI_ACTIVE"] * 1024.0)))
+if "SQ_LDS_BANK_CONFLICT" in g and "SQ_LDS_IDX_ACTIVE" in g and g["SQ_LDS_IDX_ACTIVE"] > 0:
+    print("SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.4f" % (g["SQ_LDS_BANK_CONFLICT"] / g["SQ_LDS_IDX_ACTIVE"]))
