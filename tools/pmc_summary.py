@@ -35,6 +35,8 @@ if "FETCH_SIZE" in g:
 if "WRITE_SIZE" in g:
     print("WRITE_SIZE per launch = %.1f KB" % g["WRITE_SIZE"])
 if "SQ_VALU_MFMA_BUSY_CYCLES" in g and "GRBM_GUI_ACTIVE" in g:
-    print("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = %.3f" % (g["SQ_VALU_MFMA_BUSY_CYCLES"] / (g["GRBM_GUI_ACTIVE"] * 1024.0)))
+    # (GRBM_GUI_ACTIVE comes back summed over the 8 XCDs: / 8 = the launch's clocks; 1024 SIMDs)
+    print("matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) = %.3f"
+          % (g["SQ_VALU_MFMA_BUSY_CYCLES"] / (g["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)))
 if "SQ_LDS_BANK_CONFLICT" in g and "SQ_LDS_IDX_ACTIVE" in g and g["SQ_LDS_IDX_ACTIVE"] > 0:
     print("SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.4f" % (g["SQ_LDS_BANK_CONFLICT"] / g["SQ_LDS_IDX_ACTIVE"]))
