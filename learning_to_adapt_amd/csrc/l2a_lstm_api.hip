@@ -110,16 +110,7 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
         p.tiles_per_env = l2a_ceil_div(p.n, L2A_LVT);
         const long long smem_m = generic_mfma_smem(md);
         const int smem_v = (md->in_dim + 3 * md->units + 2 * md->obs_dim + 1) * L2A_LVT * 4;
-        bool mfma = ctx->kernel_kind != L2A_KERNEL_VALU;
-        if (mfma && smem_m > ctx->lds_per_block) {
-            if (ctx->kernel_kind == L2A_KERNEL_MFMA)
-                return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the matrix-core recurrent kernel (" + std::to_string(smem_m) + " B)");
-            mfma = false;
-        }
-        if (!mfma && smem_v > ctx->lds_per_block)
-            return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the generic recurrent kernel (" + std::to_string(smem_v) +
-                                             " B): the layers' units may sum to about 800 at most");
-        if (mfma && md->gmicro_ok) {
+        if (ctx->kernel_kind != L2A_KERNEL_VALU && md->gmicro_ok) {
             // Micro tiles (l2a_rnn_micro.h; geometry and conditions: the tuned LSTM kernel's branch below).  These models have no
             // unit-tile split, so every plan that leaves CUs idle under 16-candidate tiles - and every plan of at most three micro
             // tiles per CU - takes them (policy 1); policy 0 keeps the 16-candidate kernel, 2 forces micro tiles where eligible.
@@ -147,6 +138,15 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
                 return L2A_OK;
             }
         }
+        bool mfma = ctx->kernel_kind != L2A_KERNEL_VALU;
+        if (mfma && smem_m > ctx->lds_per_block) {
+            if (ctx->kernel_kind == L2A_KERNEL_MFMA)
+                return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the matrix-core recurrent kernel (" + std::to_string(smem_m) + " B)");
+            mfma = false;
+        }
+        if (!mfma && smem_v > ctx->lds_per_block)
+            return l2a_fail(ctx, L2A_EINVAL, "LDS budget exceeded by the generic recurrent kernel (" + std::to_string(smem_v) +
+                                             " B): the layers' units may sum to about 800 at most");
         if (mfma) {
             L2A_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(l2a_rnn_mfma_k),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
@@ -340,10 +340,13 @@ int l2a_rnn_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_layers, const i
     md->gmicro_ok = lstm_mfma_eligible(obs_dim, act_dim, 256) && (units[0] == 256 || (units[0] == 512 && cell_type != L2A_CELL_LSTM));
     for (int l = 0; l < n_layers; ++l) md->gmicro_ok = md->gmicro_ok && units[l] == units[0];
     md->gmicro_ok = md->gmicro_ok && l2a_rnn_micro_smem(cell_type, n_layers, units[0], md->KG0, 3) <= ctx->lds_per_block;
-    // (and only where the 16-candidate kernel fits too: one-step launches - predict, chunk continuations - stay with it)
+    // (and only where a 16-candidate kernel fits too - the matrix-core one or, for three-layer stacks, the VALU one: one-step
+    // launches - predict, chunk continuations - stay with those)
     if (md->gmicro_ok) {
         const int gates = cell_type == L2A_CELL_LSTM ? 4 : (cell_type == L2A_CELL_GRU ? 3 : 1);
-        md->gmicro_ok = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, obs_dim, n_layers, units, gates) <= ctx->lds_per_block;
+        const long long smem_v = (long long)(md->in_dim + 3 * width + 2 * obs_dim + 1) * L2A_LVT * 4;
+        md->gmicro_ok = 4 * l2a_rnn_mfma_lds_floats(md->in_dim, obs_dim, n_layers, units, gates) <= ctx->lds_per_block ||
+                        smem_v <= ctx->lds_per_block;
     }
     md->gmicro4_ok = md->gmicro_ok && units[0] == 256 && l2a_rnn_micro_smem(cell_type, n_layers, 256, md->KG0, 4) <= ctx->lds_per_block;
     int kin = md->in_dim;

@@ -183,3 +183,59 @@ def test_random_recurrent_stacks_matrix_core_matches_valu(seed):
     for a, b in zip(s_m, s_v):
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
     native.close()
+
+
+@pytest.mark.parametrize("seed", range(max(12, _EXTRA)))
+def test_random_recurrent_micro_tile_shapes_match_valu(seed):
+    """The micro-tile form of the generic recurrent kernel (csrc/l2a_rnn_micro.h; layers of 256 - GRU / BasicRNN also 512 - units)
+    against the VALU kernel on random input shapes: observation / action widths that end anywhere in a 16-feature group - an ODD
+    number of input groups takes the zero-padded one of the eight-deep operand ring -, 1 - 3 layers, every cell type and reward
+    family, plans of one micro tile up to several rounds of four-tile workgroups, ragged last tiles, discount."""
+    rs = np.random.RandomState(1700 + seed)
+    cell = str(rs.choice(["gru", "lstm", "rnn"]))
+    U = 512 if (cell != "lstm" and rs.rand() < 0.25) else 256
+    n_layers = 1 if U == 512 else (int(rs.choice([1, 2, 3])) if cell != "lstm" else int(rs.choice([2, 3])))
+    sizes = [U] * n_layers
+    obs_dim = int(rs.choice([3, 11, 16, 17, 20, 33, 41, 48, 64]))
+    act_dim = int(rs.choice([1, 2, 6, 8, 13, 16]))
+    if obs_dim + act_dim > 80:
+        act_dim = 80 - obs_dim
+    m = int(rs.choice([1, 2, 5]))
+    n = int(rs.choice([1, 5, 37, 500, 1300, 4100]))
+    h = int(rs.choice([1, 2, 4]))
+    act = str(rs.choice(["tanh", "tanh", "relu", "sigmoid"]))
+    low, high = -np.ones(act_dim), np.ones(act_dim)
+    params = synthetic.make_rnn_stack_set(obs_dim, act_dim, sizes, cell, int(rs.randint(1 << 30)))
+    norm = _norm(rs, obs_dim, act_dim, low, high)
+    spec = _reward(rs, obs_dim, act_dim)
+    W = sum(sizes)
+    native = NativeLSTM(obs_dim, act_dim, sizes, act, None, cell_type=cell)
+    native.set_weights(params)
+    native.set_norm(norm)
+    dev = native.device
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    obs0, acts = up(rs.randn(m, obs_dim)), up(rs.uniform(low, high, (h, m * n, act_dim)))
+    c0 = up(rs.randn(m, W) * (1.0 if cell == "lstm" else 0.0))
+    h0 = up(np.tanh(rs.randn(m, W)))
+    ctx = _lib.Context.get(0)
+    got = {}
+    try:
+        # ("auto": a stack whose 16-candidate matrix-core kernel does not fit the LDS runs the VALU kernel under every policy)
+        for name, kernel, micro in (("micro", "auto", 2), ("tiles16", "auto", 0), ("valu", "valu", 0)):
+            if name == "valu" and m * n * h > 12000:
+                continue
+            ctx.set_kernel(kernel)
+            ctx.set_micro(micro)
+            rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(obs0, c0, h0, acts, m, n, h, 0.95, spec, cand_offset=3, returns_out=rets, best_key=best)
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            got[name] = (rets.cpu().numpy(), best.cpu().numpy())
+    finally:
+        ctx.set_kernel("auto")
+        ctx.set_micro(1)
+    _check(got["micro"][0], got["tiles16"][0], got["micro"][1], n, 3)
+    if "valu" in got:
+        _check(got["micro"][0], got["valu"][0], got["micro"][1], n, 3)
+    native.close()

@@ -29,6 +29,7 @@ for n, m, h in PLANS:
                         ("gru 2x256", dict(cell_type="gru", hidden_sizes=[256, 256])),
                         ("rnn 3x256", dict(cell_type="rnn", hidden_sizes=[256, 256, 256])),
                         ("gru 512", dict(cell_type="gru", hidden_sizes=[512])),
+                        ("lstm 3x256", dict(cell_type="lstm", hidden_sizes=[256, 256, 256])),
                         # (the tuned kernels' own shape: l2a_lstm.h / l2a_lstm_micro_k - or, with L2A_FORCE_GENERIC=1, the generic ones)
                         ("lstm 256" + (" (generic kernels)" if os.environ.get("L2A_FORCE_GENERIC") else ""), dict(cell_type="lstm", hidden_sizes=[256]))):
         case = dict(base, n=n, h=h, m=m, **over)
