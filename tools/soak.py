@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Soak: a minute of randomly mixed launches (split / unsplit / tail-split MLP plans, blocking launches, recurrent plans
-with and without the unit-tile split, adaptation steps) - the status word must stay clean and every plan must return the
+with and without the unit-tile split, the micro-tile kernels of all three families) - the status word must stay clean and every plan must return the
 bits of its first run.  Developer aid, needs a GPU:  python tools/soak.py [seconds]"""
 import os
 import sys
@@ -45,7 +45,11 @@ for name, over in [("c2_hc_rs_n2000_h30_e5", {}), ("c3_ant_rs_n2000_h20_pb5", di
     plans.append(dict(run=run, run_sync=run_sync, key=k.clone(), rets=r.clone(), keep=(model, env)))
 for over in (dict(n=2000, h=30, m=1), dict(), dict(n=4096, h=6, m=1),
              dict(cell_type="gru", hidden_sizes=[96, 40], units=136, n=300, h=5, m=3),          # generic matrix-core kernel
-             dict(cell_type="lstm", hidden_sizes=[128, 64], units=192, n=700, h=4, m=2)):
+             dict(cell_type="lstm", hidden_sizes=[128, 64], units=192, n=700, h=4, m=2),
+             # the generic micro-tile kernel (csrc/l2a_rnn_micro.h): three-tile workgroups, a GRU stack, several rounds of four-tile ones
+             dict(cell_type="gru", hidden_sizes=[256], units=256, n=500, h=10, m=5),
+             dict(cell_type="lstm", hidden_sizes=[256, 256], units=512, n=333, h=4, m=3),
+             dict(cell_type="rnn", hidden_sizes=[256], units=256, n=5000, h=3, m=1)):
     case = dict(C["c6_hc_rnn_rs_n500_h10_m5"], **over)
     env, model = cases.product_rnn_model(case)
     nat = model.planner_model()
