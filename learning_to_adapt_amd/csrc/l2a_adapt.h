@@ -68,7 +68,8 @@ __device__ __forceinline__ float l2a_act_grad_from_output(float o, int kind) {
 }
 
 #define L2A_AW 8        // waves per forward / backward workgroup (each takes 1 / 8 of the reduction)
-#define L2A_SB 8        // MFMA k-steps (of 4) whose operands are fetched before the first MFMA of a batch
+#define L2A_SB 16       // MFMA k-steps (of 4) whose operands are fetched before the first MFMA of a batch: a wave's whole share of
+                        // K = 512 (round 4; 8 until then - two exposed round trips per forward launch, 13.5 -> 10.2 us)
 #define L2A_XS_MAX 128  // widest input layer whose batch is staged through LDS in the first forward launch
 
 // Reduce the 8 waves' accumulators (4 unit tiles x f32x4 per lane) through LDS in a fixed order; wave 0 gets the sums.
@@ -264,28 +265,59 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwd_k(const L2AAdaptPar
         kok[t] = k < k_in;
         wrow[t] = p.w[l] + (long long)(kok[t] ? k : 0) * n_out;
     }
-    const int steps = (n_out + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
-    const int s0 = us * per < steps ? us * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s = s0; s < s1; s += L2A_SB) {
-        float a[L2A_SB][4], b[L2A_SB];
+    if ((n_out & 15) == 0 && (reinterpret_cast<unsigned long long>(p.w[l]) & 15ull) == 0) {
+        // Hidden layers (n_out a multiple of 16, rows 16-byte aligned): the weight rows are read 16 BYTES per lane - lane (i, q) takes W[k_i][16 G + 4 q + 0..3]
+        // for a group G of sixteen u, and MFMA j of the group contracts u = 16 G + 4 q' + j over the quarters q' (dZ read to match) -
+        // a quarter of the load instructions and of the cache lines each touches (round 4: a 512 x 512 layer 20.8 -> 12 us; until
+        // then one dword per lane and u-step, sixteen 16-byte segments of sixteen different rows per instruction).
+        constexpr int GB = 4;                           // groups (of sixteen u) in flight: one batch covers a wave's share of 512
+        const int groups = n_out >> 4, perg = (groups + L2A_AW - 1) / L2A_AW;
+        const int g0 = us * perg < groups ? us * perg : groups, g1 = (g0 + perg < groups) ? g0 + perg : groups;
+        for (int g = g0; g < g1; g += GB) {
+            f32x4 a4[GB][4];
+            float b[GB][4];
 #pragma unroll
-        for (int j = 0; j < L2A_SB; ++j) {
-            const int u = 4 * (s + j) + q;
-            const bool ok = (s + j < s1) && (u < n_out);
-            const int uu = ok ? u : 0;
-            b[j] = Z[uu * L2A_AR + i16];
+            for (int jg = 0; jg < GB; ++jg) {
+                const bool ok = g + jg < g1;
+                const int u4 = 16 * (ok ? g + jg : g0) + 4 * q;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a[j][t] = wrow[t][uu];
-            if (!ok) b[j] = 0.0f;
+                for (int t = 0; t < 4; ++t) a4[jg][t] = *reinterpret_cast<const f32x4*>(wrow[t] + u4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[jg][j] = ok ? Z[(u4 + j) * L2A_AR + i16] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);          // every load of the batch in flight before the first MFMA
+#pragma unroll
+            for (int jg = 0; jg < GB; ++jg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a4[jg][t][j] : 0.0f, b[jg][j], acc[t]);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        const int steps = (n_out + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
+        const int s0 = us * per < steps ? us * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
+        constexpr int SBB = 8;                          // (narrow output layer: eight u-steps a batch measured faster than sixteen)
+        for (int s = s0; s < s1; s += SBB) {
+            float a[SBB][4], b[SBB];
 #pragma unroll
-        for (int j = 0; j < L2A_SB; ++j)
+            for (int j = 0; j < SBB; ++j) {
+                const int u = 4 * (s + j) + q;
+                const bool ok = (s + j < s1) && (u < n_out);
+                const int uu = ok ? u : 0;
+                b[j] = Z[uu * L2A_AR + i16];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
+                for (int t = 0; t < 4; ++t) a[j][t] = wrow[t][uu];
+                if (!ok) b[j] = 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < SBB; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
+        }
     }
     l2a_adapt_reduce(acc, red, us, lane);
     if (us != 0) return;
@@ -336,8 +368,7 @@ __global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p
     const int KG = (k_in + 15) / 16;
     const int k0 = kc * L2A_UK, k1 = (k0 + L2A_UK < k_in) ? k0 + L2A_UK : k_in;
     const float* wsrc = p.w[l] + u;
-#pragma unroll 4
-    for (int k = k0; k < k1; ++k) {
+    auto grad = [&](int k) {
         const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[l] + k * L2A_AR);
         const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
         float g = 0.0f;
@@ -345,13 +376,48 @@ __global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p
         g = fmaf(a1.x, z1.x, g); g = fmaf(a1.y, z1.y, g); g = fmaf(a1.z, z1.z, g); g = fmaf(a1.w, z1.w, g);
         g = fmaf(a2.x, z2.x, g); g = fmaf(a2.y, z2.y, g); g = fmaf(a2.z, z2.z, g); g = fmaf(a2.w, z2.w, g);
         g = fmaf(a3.x, z3.x, g); g = fmaf(a3.y, z3.y, g); g = fmaf(a3.z, z3.z, g); g = fmaf(a3.w, z3.w, g);
-        const float wn = wsrc[(long long)k * n_out] - d.lr * g;
-        dst[d.raw_w[l] + (long long)k * n_out + u] = wn;
+        return g;
+    };
+    // where the micro-tile copy keeps four rows of a 16-row block side by side: rows 16 a + c + 4 j, j = 0 .. 3 (chain order), unless
+    // the O4 output slots scatter them over lanes
+    const bool mk_vec = d.has_mk && !(l == p.n_layers - 1 && d.mk_o4 && u >= 16);
+    if (k1 - k0 == L2A_UK) {
+        // a whole block of sixteen rows: the new weights in registers, then 16-byte stores into the two packed copies (the MFMA
+        // fragment order keeps rows 4 a .. 4 a + 3 of a unit side by side) - until round 4 one dword store per row and copy, each
+        // filling a quarter of a 16-byte slot: 35 MB of partial-line writes were most of the launch's 21 us
+        float wn[L2A_UK];
+#pragma unroll
+        for (int kk = 0; kk < L2A_UK; ++kk) wn[kk] = wsrc[(long long)(k0 + kk) * n_out] - d.lr * grad(k0 + kk);
+#pragma unroll
+        for (int kk = 0; kk < L2A_UK; ++kk) dst[d.raw_w[l] + (long long)(k0 + kk) * n_out + u] = wn[kk];
         if (d.has_pk) {
-            const long long pidx = ((((long long)(u >> 4) * KG + (k >> 4)) * 64 + ((u & 15) + 16 * ((k & 15) >> 2))) << 2) + (k & 3);
-            dst[d.pk[l] + pidx] = wn;
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const long long pidx = (((long long)(u >> 4) * KG + (k0 >> 4)) * 64 + ((u & 15) + 16 * a4)) << 2;
+                *reinterpret_cast<f32x4*>(dst + d.pk[l] + pidx) = (f32x4){wn[4 * a4], wn[4 * a4 + 1], wn[4 * a4 + 2], wn[4 * a4 + 3]};
+            }
         }
-        if (d.has_mk) dst[d.mk + l2a_mlp_micro_index(d.mk_H, d.mk_KG0, p.n_layers - 1, d.mk_o4, l, k, u)] = wn;
+        if (mk_vec) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<f32x4*>(dst + d.mk + l2a_mlp_micro_index(d.mk_H, d.mk_KG0, p.n_layers - 1, d.mk_o4, l, k0 + c, u)) =
+                    (f32x4){wn[c], wn[c + 4], wn[c + 8], wn[c + 12]};
+        } else if (d.has_mk) {
+#pragma unroll
+            for (int kk = 0; kk < L2A_UK; ++kk)
+                dst[d.mk + l2a_mlp_micro_index(d.mk_H, d.mk_KG0, p.n_layers - 1, d.mk_o4, l, k0 + kk, u)] = wn[kk];
+        }
+    } else {
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const float wn = wsrc[(long long)k * n_out] - d.lr * grad(k);
+            dst[d.raw_w[l] + (long long)k * n_out + u] = wn;
+            if (d.has_pk) {
+                const long long pidx = ((((long long)(u >> 4) * KG + (k >> 4)) * 64 + ((u & 15) + 16 * ((k & 15) >> 2))) << 2) + (k & 3);
+                dst[d.pk[l] + pidx] = wn;
+            }
+            if (d.has_mk) dst[d.mk + l2a_mlp_micro_index(d.mk_H, d.mk_KG0, p.n_layers - 1, d.mk_o4, l, k, u)] = wn;
+        }
     }
     if (kc == 0) {
         float gb = 0.0f;
