@@ -135,18 +135,28 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
     float acc[L2A_AR];
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) acc[r] = 0.0f;
-    for (int k = k0; k < k1; ++k) {
-        const float w = W[(long long)k * n_out];
+    if (staged) {
+        // (a wave's weights - at most 16 rows of a staged width - requested together, not one exposed round trip per row)
+        constexpr int CH = (L2A_XS_MAX + L2A_AW - 1) / L2A_AW;
+        float wv[CH];
 #pragma unroll
-        for (int r = 0; r < L2A_AR; ++r) {
-            float a;
-            if (staged) {
-                a = xs[k * L2A_AR + r];
-            } else {
-                a = (r < p.rows) ? x[r * k_in + k] : 0.0f;
-                if (blockIdx.x == 0 && lane == r) sc[p.a_off[0] + k * L2A_AR + r] = a;
+        for (int j = 0; j < CH; ++j) wv[j] = (k0 + j < k1) ? W[(long long)(k0 + j) * n_out] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (k0 + j < k1) {
+#pragma unroll
+                for (int r = 0; r < L2A_AR; ++r) acc[r] = fmaf(wv[j], xs[(k0 + j) * L2A_AR + r], acc[r]);
             }
-            acc[r] = fmaf(w, a, acc[r]);
+        }
+    } else {
+        for (int k = k0; k < k1; ++k) {
+            const float w = W[(long long)k * n_out];
+#pragma unroll
+            for (int r = 0; r < L2A_AR; ++r) {
+                const float a = (r < p.rows) ? x[r * k_in + k] : 0.0f;
+                if (blockIdx.x == 0 && lane == r) sc[p.a_off[0] + k * L2A_AR + r] = a;
+                acc[r] = fmaf(w, a, acc[r]);
+            }
         }
     }
     if (ks > 0) {
