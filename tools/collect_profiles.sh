@@ -28,6 +28,7 @@ for f in $SRC/timeline_micro_*.txt; do [ -f "$f" ] && grep -v amdgpu.ids $f > $D
 [ -f $SRC/ab_micro.jsonl ] && cp $SRC/ab_micro.jsonl $DST/${TAG}_ab_micro.jsonl
 [ -f $SRC/ab_nt.jsonl ] && cp $SRC/ab_nt.jsonl $DST/${TAG}_ab_nt.jsonl
 [ -f $SRC/pmc_rnn_micro.txt ] && cp $SRC/pmc_rnn_micro.txt $DST/${TAG}_pmc_rnn_micro.txt
+[ -f $SRC/pmc_micro.txt ] && cp $SRC/pmc_micro.txt $DST/${TAG}_pmc_micro.txt
 [ -f $SRC/ab_rnn_micro.jsonl ] && grep -v amdgpu.ids $SRC/ab_rnn_micro.jsonl > $DST/${TAG}_ab_rnn_micro.jsonl
 [ -f $SRC/defaults_kernel_stats.csv ] && cp $SRC/defaults_kernel_stats.csv $DST/${TAG}_defaults_kernel_stats.csv
 python tools/pmc_traffic.py $SRC > /dev/null 2>&1 || true

@@ -53,16 +53,17 @@ for shape in c1 c3b c6 gru lstm2; do for mic in 1 0; do
   [ -n "$f" ] && (echo "# $shape, L2A_MICRO=$mic"; head -1 "$f"; grep -E '^"(void )?l2a_(rollout|lstm|mlp|rnn)' "$f") >> $OUT/defaults_kernel_stats.csv
   rm -rf $OUT/prof_def
 done; done; echo "defaults rocprof done"; cat $OUT/defaults_kernel_stats.csv | cut -c1-150
-echo "== PMC passes for the generic micro-tile kernel (GRU 256, LSTM 2 x 256 at the ReBAL plan size; counters only, own runs)"
-for shape in gru lstm2; do
+echo "== PMC passes for the micro-tile kernels (GRU 256, LSTM 2 x 256, c3b, c6, c1 at their default plan sizes; counters only, own runs)"
+for shape in gru lstm2 c3b c6 c1; do
   for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
              "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
              "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     name=$(echo $set | cut -d" " -f1)
     (cd /tmp && timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmcr_${shape}_$name -o pmc -- python $GRAFT_REPO_ROOT/tools/prof_defaults.py $shape 20 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmcr_${shape}_$name.err); echo "pmc $shape $name rc=$?"
   done
-  (echo "# $shape (tools/prof_defaults.py $shape 20): l2a_rnn_micro_k"; python tools/pmc_summary.py $OUT l2a_rnn_micro_k pmcr_${shape}_) >> $OUT/pmc_rnn_micro.txt 2>&1
-done; cat $OUT/pmc_rnn_micro.txt
+  case $shape in gru|lstm2) kn=l2a_rnn_micro_k; of=pmc_rnn_micro.txt;; c6) kn=l2a_lstm_micro_k; of=pmc_micro.txt;; *) kn=l2a_mlp_micro_k; of=pmc_micro.txt;; esac
+  (echo "# $shape (tools/prof_defaults.py $shape 20): $kn"; python tools/pmc_summary.py $OUT $kn pmcr_${shape}_) >> $OUT/$of 2>&1
+done; cat $OUT/pmc_rnn_micro.txt $OUT/pmc_micro.txt
 echo "== GrBAL adaptation step"
 timeout 120 python tools/probe_adapt.py 2> /dev/null > $OUT/probe_adapt.json; echo "probe_adapt rc=$?"
 bash tools/adapt_trace.sh > $OUT/adapt_trace.txt 2>&1; echo "adapt_trace rc=$?"; cd $GRAFT_REPO_ROOT
