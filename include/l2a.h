@@ -24,6 +24,7 @@ extern "C" {
 typedef struct l2a_ctx l2a_ctx;
 typedef struct l2a_model l2a_model;
 typedef struct l2a_lstm l2a_lstm;
+typedef struct l2a_controller l2a_controller;
 
 /* ---- error codes --------------------------------------------------------------------- */
 #define L2A_OK 0
@@ -406,6 +407,54 @@ int l2a_lstm_predict(l2a_lstm* model, const float* obs, const float* act, const 
 
 /* 1 when (obs_dim, act_dim, units) is eligible for the MFMA LSTM kernel, else 0.                 */
 int l2a_lstm_mfma_eligible(int obs_dim, int act_dim, int units);
+
+/* ---- the controller step as one call ----------------------------------------------------------
+ * `MPCController.get_actions(observations)` in random-shooting mode (policies/mpc_controller.py:59-69,108-129) and
+ * `RNNMPCController.get_actions` (policies/rnn_mpc_controller.py:57-65,112-134), as their caller sees them: float64
+ * observations in, the float64 first action of every env's best candidate out, NumPy's legacy global generator left
+ * exactly where the reference's `np.random.uniform(low, high, (h*n*m, act_dim))` (:67-69,114) leaves it.  One GPU.
+ *
+ * A controller owns two page-locked / HBM buffer pairs for the candidate tensor [h, m*n, act_dim] and a producer
+ * thread (csrc/l2a_rng.c, `l2a_ahead_*`) that draws the NEXT step's candidates from a private copy of the generator
+ * state and uploads them while the GPU runs the current plan.
+ *   np_state_addr  address of the global generator's `mt19937_state` { uint32 key[624]; int pos; } - in Python
+ *                  `np.random.mtrand._rand._bit_generator.ctypes.state_address`; the caller holds the generator's
+ *                  lock (`_bit_generator.lock`) around l2a_controller_step / _rearm when other threads may draw
+ *   low / high     the action bounds (`env.action_space.low / high`, float64 [act_dim], act_dim <= 16)
+ *   rng_threads    threads of one draw (the stream is cut into disjoint slices, same numbers for every count)
+ * l2a_controller_step:
+ *   obs          HOST float64 [m, obs_dim]        (cast to fp32 like the host would, staged in host-mapped memory)
+ *   action_out   HOST float64 [m, act_dim]        cand_a[i, argmax_i] (:118,129) - the float64 values NumPy drew
+ *   index_out    HOST int64 [m] or NULL           the winning candidate of each env
+ *   return_out   HOST fp32 [m] or NULL            its (fp32) return
+ *   returns      L2A_OK; L2A_STEP_UNSPLIT (= OK, but a tile-split launch lost its partner and the plan was repeated
+ *                unsplit - same bits - with the context switched to l2a_set_split(ctx, 0)); L2A_STEP_MISS when no
+ *                valid block of candidates was waiting - first call, somebody else drew from np.random since the last
+ *                step, a forked child - in which case NOTHING was consumed or launched: the caller draws and plans the
+ *                ordinary way (l2a_plan_rs_sync) and calls l2a_controller_rearm afterwards; a negative L2A_E* on failure.
+ * l2a_lstm_controller_step additionally takes the controller's recurrent state c0 / h0 (device fp32 [m, state width])
+ * and, with c_next / h_next, advances it with the winning first actions behind the plan (l2a_lstm_plan_rs_sync).
+ * l2a_controller_rearm: restart the chain at the CURRENT global generator state (after a synchronous draw).
+ * l2a_controller_actions: the device tensor [h, m*n, act_dim] the latest successful step planned on (diagnostics).
+ * l2a_controller_stats: out[0..6] host microseconds of the latest step - take | stage obs | launch | kick | wait |
+ * decode + gather | whole call; [7] steps, [8] unsplit relaunches; [9..14] chain: hits, misses, blocks produced,
+ * producer us per block, consumer wait us per take, armed.                                                      */
+#define L2A_STEP_MISS 1
+#define L2A_STEP_UNSPLIT 2
+int l2a_controller_create(l2a_model* model, int m, int n, int h, const double* low, const double* high, double discount,
+                          const l2a_reward* reward, void* np_state_addr, int rng_threads, l2a_controller** out);
+int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const double* low, const double* high,
+                               double discount, const l2a_reward* reward, void* np_state_addr, int rng_threads,
+                               l2a_controller** out);
+void l2a_controller_destroy(l2a_controller* controller);
+int l2a_controller_step(l2a_controller* controller, const double* obs, double* action_out, long long* index_out,
+                        float* return_out, void* stream);
+int l2a_lstm_controller_step(l2a_controller* controller, const double* obs, const float* c0, const float* h0,
+                             float* c_next, float* h_next, double* action_out, long long* index_out, float* return_out,
+                             void* stream);
+int l2a_controller_rearm(l2a_controller* controller);
+const float* l2a_controller_actions(const l2a_controller* controller);
+int l2a_controller_stats(l2a_controller* controller, double* out, int cap);
 
 /* ---- introspection used by tests (no GPU needed) ------------------------------------------ */
 /* 1 when (obs_dim, act_dim, hidden[]) is eligible for the MFMA kernel, else 0.               */

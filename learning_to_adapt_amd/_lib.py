@@ -18,6 +18,8 @@ LIB_PATH = os.environ.get("L2A_LIB_PATH") or os.path.join(_HERE, "libl2a_hip.so"
 # include/l2a.h
 L2A_OK = 0
 L2A_ESPLIT = -5
+L2A_STEP_MISS = 1
+L2A_STEP_UNSPLIT = 2
 ACT_CODES = {None: 0, "identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4}
 MODE_CODES = {"single": 0, "per_block": 1, "mean": 2}
 KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
@@ -34,6 +36,8 @@ EXPORTED_SYMBOLS = (
     "l2a_cem_sample", "l2a_cem_refit", "l2a_cem_pick",
     "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_sync", "l2a_lstm_plan_rs_chunk",
     "l2a_lstm_predict", "l2a_lstm_mfma_eligible",
+    "l2a_controller_create", "l2a_lstm_controller_create", "l2a_controller_destroy", "l2a_controller_step",
+    "l2a_lstm_controller_step", "l2a_controller_rearm", "l2a_controller_actions", "l2a_controller_stats",
 )
 
 
@@ -174,6 +178,25 @@ def load():
         lib.l2a_plan_payload.restype = i32
     lib.l2a_lstm_mfma_eligible.argtypes = [i32, i32, i32]
     lib.l2a_lstm_mfma_eligible.restype = i32
+    if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_controller_step"):
+        pass                                               # developer A/B against a library of an earlier round
+    else:
+        lib.l2a_controller_create.argtypes = [vp, i32, i32, i32, vp, vp, c.c_double, c.POINTER(RewardSpec), vp, i32, c.POINTER(vp)]
+        lib.l2a_controller_create.restype = i32
+        lib.l2a_lstm_controller_create.argtypes = lib.l2a_controller_create.argtypes
+        lib.l2a_lstm_controller_create.restype = i32
+        lib.l2a_controller_destroy.argtypes = [vp]
+        lib.l2a_controller_destroy.restype = None
+        lib.l2a_controller_step.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.l2a_controller_step.restype = i32
+        lib.l2a_lstm_controller_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.l2a_lstm_controller_step.restype = i32
+        lib.l2a_controller_rearm.argtypes = [vp]
+        lib.l2a_controller_rearm.restype = i32
+        lib.l2a_controller_actions.argtypes = [vp]
+        lib.l2a_controller_actions.restype = vp
+        lib.l2a_controller_stats.argtypes = [vp, dp, i32]
+        lib.l2a_controller_stats.restype = i32
     _lib = lib
     return lib
 

@@ -18,8 +18,8 @@ OUT = os.path.join(PKG, "libl2a_hip.so")
 RNG_OUT = os.path.join(PKG, "libl2a_rng.so")        # host-only helper (gcc), see l2a_rng.c
 OBJ_DIR = os.path.join(HERE, "_obj")
 HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_adapt.h", "l2a_mfma.h", "l2a_mfma_launch.h", "l2a_lstm.h",
-           "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_rnn_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", os.path.join("..", "..", "include", "l2a.h")]
-SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_rnn_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_rng.c"]
+           "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_rnn_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", "l2a_rng.h", os.path.join("..", "..", "include", "l2a.h")]
+SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_rnn_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_step.hip", "l2a_rng.c"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -42,10 +42,10 @@ def _hipcc():
 
 def build_rng(verbose=True):
     """The host RNG helper: plain C, built with gcc.  Optional - without it parity mode uses NumPy's own loop."""
-    gcc = shutil.which("gcc")
+    gcc = shutil.which("gcc") or shutil.which("clang") or ("/opt/rocm/lib/llvm/bin/clang" if os.path.exists("/opt/rocm/lib/llvm/bin/clang") else None)
     if gcc is None:
         if verbose:
-            print("[l2a] gcc not found: skipping libl2a_rng.so (parity mode falls back to np.random.random_sample)")
+            print("[l2a] no C compiler found: libl2a_rng.so cannot be built")
         return None
     # -ffp-contract=off: NumPy's baseline build has no FMA; a contracted x1*x1 + x2*x2 would change bits
     subprocess.check_call([gcc, "-O3", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
@@ -95,6 +95,7 @@ def unit_table():
          "l2a_lstm_api.o": ("l2a_lstm_api.hip", KERNEL_FLAGS),
          "l2a_comm.o": ("l2a_comm.hip", []),
          "l2a_cem.o": ("l2a_cem.hip", []),
+         "l2a_step.o": ("l2a_step.hip", []),
          "l2a_micro.o": ("l2a_micro_inst.hip", MICRO_FLAGS),
          "l2a_rnn_micro.o": ("l2a_rnn_micro_inst.hip", MICRO_FLAGS)}
     for utw in LSTM_INSTANCES:
@@ -106,7 +107,13 @@ def unit_table():
 
 
 def link(objs, out):
-    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], cwd=HERE)
+    """libl2a_hip.so needs libl2a_rng.so (the controller step's draw-ahead chain, l2a_step.hip): found next to it at load time."""
+    if not os.path.exists(RNG_OUT) or os.path.getmtime(RNG_OUT) < os.path.getmtime(os.path.join(HERE, "l2a_rng.c")):
+        build_rng(verbose=False)
+    if not os.path.exists(RNG_OUT):
+        raise RuntimeError("libl2a_rng.so could not be built (no gcc / clang): libl2a_hip.so links against it")
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs +
+                          ["-L" + PKG, "-ll2a_rng", "-Wl,-rpath,$ORIGIN", "-ldl"], cwd=HERE)
     return out
 
 
@@ -161,8 +168,8 @@ def build(force=False, verbose=True, only=None):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(_compile, jobs))
-    link([os.path.join(OBJ_DIR, o) for o in table], OUT)
     build_rng(verbose)
+    link([os.path.join(OBJ_DIR, o) for o in table], OUT)
     return OUT
 
 

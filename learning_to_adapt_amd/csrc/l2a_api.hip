@@ -1062,8 +1062,20 @@ int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tk, int m, bool published,
 int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions, int m, int n, int h,
                      double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
                      unsigned long long* keys_host_out, void* stream_v) {
+    return l2a_plan_rs_sync_hook(md, obs_host, actions, m, n, h, discount, reward, cand_offset, returns_out, keys_host_out,
+                                 stream_v, nullptr, nullptr);
+}
+
+void l2a_model_facts(const l2a_model* md, l2a_ctx** ctx, int* obs_dim, int* act_dim) {
+    *ctx = md->ctx; *obs_dim = md->obs_dim; *act_dim = md->act_dim;
+}
+
+int l2a_plan_rs_sync_hook(l2a_model* md, const float* obs_host, const float* actions, int m, int n, int h,
+                          double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                          unsigned long long* keys_host_out, void* stream_v, l2a_after_launch_fn hook, void* hook_arg) {
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
+    ctx->stamps_us[0] = l2a_now_us();
     if (!obs_host || !actions || !reward || !keys_host_out)
         return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: null obs / actions / reward / keys_host_out");
     if (m < 1 || n < 1 || h < 1) return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: m, n and h must be >= 1");
@@ -1097,8 +1109,14 @@ int l2a_plan_rs_sync(l2a_model* md, const float* obs_host, const float* actions,
         p.mail_seq = tk.seq;
         p.next_keys = tk.next_keys;
     }
+    ctx->stamps_us[1] = l2a_now_us();
     rc = launch_rollout(md, p, stream_v);
-    return l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_plan_rs_sync");
+    ctx->stamps_us[2] = l2a_now_us();
+    if (rc == L2A_OK && hook) hook(hook_arg);
+    ctx->stamps_us[3] = l2a_now_us();
+    rc = l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_plan_rs_sync");
+    ctx->stamps_us[4] = l2a_now_us();
+    return rc;
 }
 
 int l2a_plan_rs_chunk(l2a_model* md, const float* state, int state_per_row, const float* actions, int m, int n,

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <ctime>
 #include <string>
 
 #include "../../include/l2a.h"
@@ -36,6 +37,7 @@ struct l2a_ctx {
     int ring_dirty[2] = {L2A_MAIL_KEYS, L2A_MAIL_KEYS};   // leading entries of each slot that may be non-zero
     unsigned long long mail_seq = 0;
     double sync_ema_us = 0.0;             // expected duration of the next blocking plan (sleep-then-spin)
+    double stamps_us[6] = {0, 0, 0, 0, 0, 0};   // latest blocking plan, host clock: entry | staged | launched | hook done | keys seen | (free)
     unsigned long long sync_shape = 0;    // plan shape the estimate belongs to (l2a_mail_ticket::shape)
     // RCCL communicator of sharded plans (l2a_comm.hip); null = single GPU
     void* comm = nullptr;
@@ -85,12 +87,33 @@ struct l2a_mail_ticket {
 // Stage `obs_floats` observation floats, pick and clear the key slot.  Kernel parameters of a publishing launch:
 // best_key = keys_dev, done_ctr = ctx->done_ctr, mail_keys = ctx->mail_dev->keys, mail_seq_ptr = &ctx->mail_dev->seq,
 // mail_seq = seq, next_keys.
-extern "C" int l2a_mail_begin(l2a_ctx* ctx, int m, const float* obs_host, long long obs_floats, hipStream_t stream,
-                              l2a_mail_ticket* ticket);
+#define L2A_HIDDEN __attribute__((visibility("hidden")))        // internal to libl2a_hip.so: not part of the C ABI, not exported
+extern "C" L2A_HIDDEN int l2a_mail_begin(l2a_ctx* ctx, int m, const float* obs_host, long long obs_floats, hipStream_t stream,
+                                         l2a_mail_ticket* ticket);
 // After the launch (`launch_rc` = its return code): wait for the keys - mailbox word when the kernel publishes, copy +
 // stream synchronisation otherwise - and check the status word (L2A_ESPLIT).
-extern "C" int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& ticket, int m, bool published, int launch_rc,
-                            hipStream_t stream, unsigned long long* keys_host_out, const char* who);
+extern "C" L2A_HIDDEN int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& ticket, int m, bool published, int launch_rc,
+                                       hipStream_t stream, unsigned long long* keys_host_out, const char* who);
+
+// ---- the blocking plans with a hook between launch and wait (l2a_step.hip: the controller step kicks the producer of the NEXT
+//      step's candidates there - after the launch is on its way, before the host starts waiting) ----
+typedef void (*l2a_after_launch_fn)(void* arg);
+extern "C" L2A_HIDDEN int l2a_plan_rs_sync_hook(l2a_model* md, const float* obs_host, const float* actions, int m, int n, int h,
+                                                double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
+                                                unsigned long long* keys_host_out, void* stream, l2a_after_launch_fn hook,
+                                                void* hook_arg);
+extern "C" L2A_HIDDEN int l2a_lstm_plan_rs_sync_hook(l2a_lstm* md, const float* obs_host, const float* c0, const float* h0,
+                                                     const float* actions, int m, int n, int h, double discount,
+                                                     const l2a_reward* reward, int cand_offset, unsigned long long* keys_host_out,
+                                                     float* c_next, float* h_next, void* stream, l2a_after_launch_fn hook,
+                                                     void* hook_arg);
+extern "C" L2A_HIDDEN void l2a_model_facts(const l2a_model* md, l2a_ctx** ctx, int* obs_dim, int* act_dim);
+extern "C" L2A_HIDDEN void l2a_lstm_facts(const l2a_lstm* md, l2a_ctx** ctx, int* obs_dim, int* act_dim, int* units);
+inline double l2a_now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
 
 // Makes the context's device current for the duration of an entry point and restores the caller's (a process
 // driving several GPUs, or a torch thread whose current device differs from the model's).

@@ -123,8 +123,15 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
             // with LDS rows for sixteen candidates: 256-unit layers, where the stack still fits)
             int mtm = 3;
             if (hi > 3 && md->gmicro4_ok) { hi = 4; mtm = 4; }
-            if (hi >= 1 && hi <= 4) W = l2a_ceil_div(quads, hi);
-            const bool eligible = !p.obs_per_row && !p.state_out && !p.c_out && !p.h_out && hi <= mtm && (p.returns_out || p.best_key);
+            if (hi >= 1 && hi <= 4) {
+                W = l2a_ceil_div(quads, hi);
+                // `hi` forced down to four is not the natural ceil(quads / W) of the W it yields (quads = 5: W = 2 would leave
+                // 5 - 2 * 3 = -1 workgroups of four): take the natural one, so that 1 <= mc_r <= W always holds
+                hi = l2a_ceil_div(quads, W);
+            }
+            const int mc_r = quads - W * (hi - 1);
+            const bool eligible = !p.obs_per_row && !p.state_out && !p.c_out && !p.h_out && hi <= mtm && (p.returns_out || p.best_key) &&
+                                  W >= 1 && mc_r >= 1 && mc_r <= W;
             if (eligible && ctx->micro_policy != 0) {
                 p.mc_w = W;
                 p.mc_hi = hi;
@@ -559,8 +566,21 @@ int l2a_lstm_plan_rs(l2a_lstm* md, const float* obs0, const float* c0, const flo
 int l2a_lstm_plan_rs_sync(l2a_lstm* md, const float* obs_host, const float* c0, const float* h0, const float* actions,
                           int m, int n, int h, double discount, const l2a_reward* reward, int cand_offset,
                           unsigned long long* keys_host_out, float* c_next, float* h_next, void* stream_v) {
+    return l2a_lstm_plan_rs_sync_hook(md, obs_host, c0, h0, actions, m, n, h, discount, reward, cand_offset, keys_host_out, c_next,
+                                      h_next, stream_v, nullptr, nullptr);
+}
+
+void l2a_lstm_facts(const l2a_lstm* md, l2a_ctx** ctx, int* obs_dim, int* act_dim, int* units) {
+    *ctx = md->ctx; *obs_dim = md->obs_dim; *act_dim = md->act_dim; *units = md->units;
+}
+
+int l2a_lstm_plan_rs_sync_hook(l2a_lstm* md, const float* obs_host, const float* c0, const float* h0, const float* actions,
+                               int m, int n, int h, double discount, const l2a_reward* reward, int cand_offset,
+                               unsigned long long* keys_host_out, float* c_next, float* h_next, void* stream_v,
+                               l2a_after_launch_fn hook, void* hook_arg) {
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
+    ctx->stamps_us[0] = l2a_now_us();
     if (!obs_host || !c0 || !h0 || !actions || !reward || !keys_host_out)
         return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: null obs / c0 / h0 / actions / reward / keys_host_out");
     if ((!c_next) != (!h_next)) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: pass c_next and h_next together");
@@ -597,6 +617,7 @@ int l2a_lstm_plan_rs_sync(l2a_lstm* md, const float* obs_host, const float* c0, 
         p.mail_seq = tk.seq;
         p.next_keys = tk.next_keys;
     }
+    ctx->stamps_us[1] = l2a_now_us();
     rc = launch(md, p, stream_v);
     if (rc == L2A_OK && c_next) {
         // the controller's own state moves on with the chosen action (rnn_mpc_controller.py:63) - in stream order
@@ -615,7 +636,12 @@ int l2a_lstm_plan_rs_sync(l2a_lstm* md, const float* obs_host, const float* c0, 
         // still run - an exchange timeout in it would be noticed one call late and the state it wrote adopted
         rc = launch(md, q, stream_v, false);
     }
-    return l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_lstm_plan_rs_sync");
+    ctx->stamps_us[2] = l2a_now_us();
+    if (rc == L2A_OK && hook) hook(hook_arg);
+    ctx->stamps_us[3] = l2a_now_us();
+    rc = l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_lstm_plan_rs_sync");
+    ctx->stamps_us[4] = l2a_now_us();
+    return rc;
 }
 
 int l2a_lstm_plan_rs_chunk(l2a_lstm* md, const float* state, const float* c, const float* h, int per_row,

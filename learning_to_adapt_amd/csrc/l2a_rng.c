@@ -33,6 +33,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #define MT_N 624
@@ -820,4 +821,223 @@ int l2a_mt19937_skip_mode(uint32_t* key, int* pos, long long words, int use_jump
     return 0;
 }
 
-int l2a_rng_version(void) { return 6; }
+/* ---- draw-ahead chain: the NEXT controller step's candidates, drawn while the GPU runs the current plan ----------
+ * The reference draws `get_random_action(h*n*m)` at the top of every controller step (policies/mpc_controller.py:
+ * 67-69,114) from the global generator; the stream is a pure function of the generator state, so the block of step
+ * k + 1 is known as soon as step k has consumed its numbers.  A chain owns ONE producer thread that fills the block
+ * (l2a_mt19937_uniform_rows' job, on the pool of the non-main threads) from a PRIVATE copy of the state, then calls
+ * `post(arg, slot)` (libl2a_hip.so: the upload of the block on a side stream) and marks the block ready.  The consumer
+ *   l2a_ahead_take : waits for the block in flight; adopts it only if the global generator's words are still EXACTLY
+ *                    the state the block started from (nobody else drew from np.random in between) - the global state
+ *                    is then set to the block's end state, i.e. where the reference's own draw would have left it -
+ *                    and returns the slot (0 / 1); anything else drops the chain and returns -1 (the caller draws
+ *                    synchronously, as before)
+ *   l2a_ahead_next : after a successful take (and after the caller's launch): the block after the one just taken is
+ *                    produced into the other slot
+ *   l2a_ahead_arm  : (re)start the chain at the CURRENT global state (after a synchronous draw)
+ * Until round 5 this lived in Python (policies/draw_ahead.py: a threading.Condition shared with a worker thread
+ * under the GIL, 55 us per controller step); numbers, order and the state left behind are the reference's either way.
+ * Two slots suffice: the consumer is done with slot s (its plan has completed) before block k + 2 is requested.
+ * One consumer thread per chain; a forked child starts with an idle chain and a fresh producer thread. */
+typedef int (*l2a_ahead_post_fn)(void* arg, int slot);
+typedef struct l2a_ahead {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_done;
+    pthread_t th;
+    int have_thread, quit;
+    pid_t pid;
+    /* the request (fixed at creation) */
+    long long rows, period, sel_lo, sel_hi, rows64;
+    int act_dim, nthreads;
+    double low[16], high[16];
+    float* out_f32[2];
+    double* out_f64[2];
+    l2a_ahead_post_fn post;
+    void* post_arg;
+    /* the chain */
+    int armed;              /* a block has been requested and not been taken / dropped */
+    int want;               /* request posted, not yet picked up by the producer */
+    int busy;               /* producer at work */
+    int ready;              /* the requested block is complete (and `end` valid) */
+    int error;
+    int slot;               /* slot of the requested block */
+    unsigned gen;           /* bumped by every drop: results of older generations are discarded */
+    mt_t base, end;
+    /* diagnostics */
+    unsigned long long hits, misses, produced;
+    double produce_us, wait_us;
+} l2a_ahead;
+
+static double ahead_now_us(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
+static void* ahead_worker(void* argp) {
+    l2a_ahead* a = (l2a_ahead*)argp;
+    pthread_mutex_lock(&a->mu);
+    for (;;) {
+        while (!a->want && !a->quit) pthread_cond_wait(&a->cv_work, &a->mu);
+        if (a->quit) break;
+        a->want = 0;
+        a->busy = 1;
+        const unsigned gen = a->gen;
+        const int slot = a->slot;
+        mt_t s0 = a->base;
+        pthread_mutex_unlock(&a->mu);
+        const double t0 = ahead_now_us();
+        double range[16];
+        for (int k = 0; k < a->act_dim; ++k) range[k] = a->high[k] - a->low[k];
+        uni_job j = {&s0, s0, a->rows, a->act_dim, a->low, range, a->period, a->sel_lo, a->sel_hi,
+                     (a->sel_hi > a->sel_lo) ? a->out_f32[slot] : NULL, a->rows64, a->out_f64[slot]};
+        int nt = a->nthreads;
+        if (a->rows * a->act_dim < 65536) nt = 1;
+        if (a->rows > 0) run_parallel(uniform_slice, &j, nt);
+        const int rc = a->post ? a->post(a->post_arg, slot) : 0;
+        const double t1 = ahead_now_us();
+        pthread_mutex_lock(&a->mu);
+        a->busy = 0;
+        a->produced += 1;
+        a->produce_us += t1 - t0;
+        if (gen == a->gen) {
+            a->end = j.end;
+            a->error = rc;
+            a->ready = 1;
+        }
+        pthread_cond_broadcast(&a->cv_done);
+    }
+    pthread_mutex_unlock(&a->mu);
+    return NULL;
+}
+
+/* Takes a->mu; a forked child first rebuilds the locks (they may have been held at fork time) and forgets the parent's
+ * producer thread and block.  Then makes sure the producer exists.  Returns 0 with the lock held, -1 without. */
+static int ahead_lock(l2a_ahead* a) {
+    if (a->pid != getpid()) {
+        pthread_mutex_init(&a->mu, NULL);
+        pthread_cond_init(&a->cv_work, NULL);
+        pthread_cond_init(&a->cv_done, NULL);
+        a->armed = a->want = a->busy = a->ready = 0;
+        a->gen += 1;
+        a->have_thread = 0;
+        a->pid = getpid();
+    }
+    pthread_mutex_lock(&a->mu);
+    if (!a->have_thread) {
+        if (pthread_create(&a->th, NULL, ahead_worker, a) != 0) { pthread_mutex_unlock(&a->mu); return -1; }
+        a->have_thread = 1;
+    }
+    return 0;
+}
+
+l2a_ahead* l2a_ahead_create(long long rows, int act_dim, const double* low, const double* high, long long period,
+                            long long sel_lo, long long sel_hi, long long rows64, float* out_f32_slot0,
+                            float* out_f32_slot1, double* out_f64_slot0, double* out_f64_slot1, int nthreads,
+                            l2a_ahead_post_fn post, void* post_arg) {
+    if (!low || !high || rows < 0 || act_dim < 1 || act_dim > 16) return NULL;
+    if (period < 1 || sel_lo < 0 || sel_hi < sel_lo || sel_hi > period || rows64 < 0 || rows64 > rows) return NULL;
+    if (sel_hi > sel_lo && (!out_f32_slot0 || !out_f32_slot1)) return NULL;
+    if (rows64 > 0 && (!out_f64_slot0 || !out_f64_slot1)) return NULL;
+    l2a_ahead* a = (l2a_ahead*)calloc(1, sizeof(l2a_ahead));
+    if (!a) return NULL;
+    pthread_mutex_init(&a->mu, NULL);
+    pthread_cond_init(&a->cv_work, NULL);
+    pthread_cond_init(&a->cv_done, NULL);
+    a->pid = getpid();
+    a->rows = rows; a->act_dim = act_dim; a->period = period; a->sel_lo = sel_lo; a->sel_hi = sel_hi; a->rows64 = rows64;
+    for (int k = 0; k < act_dim; ++k) { a->low[k] = low[k]; a->high[k] = high[k]; }
+    a->out_f32[0] = out_f32_slot0; a->out_f32[1] = out_f32_slot1;
+    a->out_f64[0] = rows64 > 0 ? out_f64_slot0 : NULL; a->out_f64[1] = rows64 > 0 ? out_f64_slot1 : NULL;
+    a->nthreads = nthreads < 1 ? 1 : nthreads;
+    a->post = post; a->post_arg = post_arg;
+    a->slot = 1;
+    return a;
+}
+
+/* Stops the producer (waits for a block in flight: its post callback may be using the caller's buffers). */
+void l2a_ahead_destroy(l2a_ahead* a) {
+    if (!a) return;
+    if (a->pid == getpid() && a->have_thread) {
+        pthread_mutex_lock(&a->mu);
+        a->quit = 1;
+        pthread_cond_broadcast(&a->cv_work);
+        pthread_mutex_unlock(&a->mu);
+        pthread_join(a->th, NULL);
+    }
+    free(a);
+}
+
+static void ahead_request(l2a_ahead* a, const mt_t* base) {      /* under a->mu */
+    a->base = *base;
+    a->slot ^= 1;
+    a->armed = 1; a->ready = 0; a->error = 0; a->want = 1;
+    pthread_cond_signal(&a->cv_work);
+}
+
+/* Drop whatever the chain holds and produce the block that starts at the global generator's current state. */
+int l2a_ahead_arm(l2a_ahead* a, const void* np_state_addr) {
+    if (!a || !np_state_addr) return -1;
+    if (ahead_lock(a) != 0) return -1;
+    const np_mt19937_state* g = (const np_mt19937_state*)np_state_addr;
+    mt_t base;
+    memcpy(base.key, g->key, sizeof(base.key));
+    base.pos = g->pos;
+    a->gen += 1;            /* a block of an older generation still in production is discarded when it completes */
+    ahead_request(a, &base);
+    pthread_mutex_unlock(&a->mu);
+    return 0;
+}
+
+/* >= 0: the slot of the adopted block (global state advanced to its end); -1: no valid block (chain dropped). */
+int l2a_ahead_take(l2a_ahead* a, void* np_state_addr) {
+    if (!a || !np_state_addr || a->pid != getpid()) return -1;
+    pthread_mutex_lock(&a->mu);
+    if (!a->armed) { pthread_mutex_unlock(&a->mu); return -1; }
+    if (!a->ready) {
+        const double t0 = ahead_now_us();
+        while (!a->ready) pthread_cond_wait(&a->cv_done, &a->mu);
+        a->wait_us += ahead_now_us() - t0;
+    }
+    np_mt19937_state* g = (np_mt19937_state*)np_state_addr;
+    const int same = a->error == 0 && g->pos == a->base.pos && memcmp(g->key, a->base.key, sizeof(g->key)) == 0;
+    a->armed = 0;
+    if (!same) {
+        a->gen += 1;
+        a->ready = 0;
+        a->misses += 1;
+        pthread_mutex_unlock(&a->mu);
+        return -1;
+    }
+    memcpy(g->key, a->end.key, sizeof(g->key));
+    g->pos = a->end.pos;
+    a->hits += 1;
+    const int slot = a->slot;
+    pthread_mutex_unlock(&a->mu);
+    return slot;
+}
+
+/* After a successful take: request the block that follows it (into the other slot). */
+int l2a_ahead_next(l2a_ahead* a) {
+    if (!a || a->pid != getpid()) return -1;
+    pthread_mutex_lock(&a->mu);
+    if (a->armed || !a->ready) { pthread_mutex_unlock(&a->mu); return -1; }      /* nothing was taken */
+    const mt_t base = a->end;
+    ahead_request(a, &base);
+    pthread_mutex_unlock(&a->mu);
+    return 0;
+}
+
+/* out[0..5] = hits, misses, blocks produced, producer us per block, consumer wait us per take, armed */
+void l2a_ahead_stats(l2a_ahead* a, double* out) {
+    if (!a || !out) return;
+    if (a->pid != getpid()) { for (int i = 0; i < 6; ++i) out[i] = 0.0; return; }
+    pthread_mutex_lock(&a->mu);
+    out[0] = (double)a->hits; out[1] = (double)a->misses; out[2] = (double)a->produced;
+    out[3] = a->produced ? a->produce_us / (double)a->produced : 0.0;
+    out[4] = (a->hits + a->misses) ? a->wait_us / (double)(a->hits + a->misses) : 0.0;
+    out[5] = (double)a->armed;
+    pthread_mutex_unlock(&a->mu);
+}
+
+int l2a_rng_version(void) { return 7; }

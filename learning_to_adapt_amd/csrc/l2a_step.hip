@@ -1,0 +1,238 @@
+// l2a_step.hip - the controller step as ONE C-ABI call (include/l2a.h: l2a_controller_*).
+//
+// What `MPCController.get_actions` (policies/mpc_controller.py:59-69,108-129) and `RNNMPCController.get_actions`
+// (policies/rnn_mpc_controller.py:57-65,112-134) are to their caller in parity mode: float64 observations in, the float64 first
+// action of the best candidate out, NumPy's global generator left exactly where the reference's own draw leaves it.  Until
+// round 5 the pieces of a step were glued together in Python (a Condition shared with a worker thread under the GIL for the
+// candidates drawn ahead, ~10 ctypes / torch calls around the launch): ~0.1 ms per call beside a 0.18 - 1.4 ms kernel.  Here:
+//   take   the block of candidates the chain of csrc/l2a_rng.c drew (and this file's callback uploaded) while the previous plan
+//          ran - adopted only if the global generator's words are still the state the block started from
+//   launch the fused rollout from host-mapped observations (l2a_plan_rs_sync's path; recurrent: + the state advance)
+//   kick   the producer of the next block (between launch and wait)
+//   wait   for the mailbox word, decode the keys, gather the winners' float64 first actions from the block's `cand_a`
+// A block that is not valid (first call, a foreign consumer of np.random between two steps, a forked child) makes the step
+// return L2A_STEP_MISS without having touched anything: the caller draws synchronously as before and re-arms the chain.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "l2a_host.h"
+#include "l2a_rng.h"
+
+struct l2a_controller {
+    l2a_ctx* ctx = nullptr;
+    l2a_model* mlp = nullptr;
+    l2a_lstm* rnn = nullptr;
+    int m = 0, n = 0, h = 0, obs_dim = 0, act_dim = 0, units = 0;
+    double discount = 1.0;
+    l2a_reward rw;
+    void* np_addr = nullptr;
+    size_t act_floats = 0;
+    float* pin[2] = {nullptr, nullptr};         // page-locked staging of the fp32 candidate tensor [h, m * n, act_dim]
+    float* dev[2] = {nullptr, nullptr};         // its copy in HBM (what the rollout reads)
+    double* c64[2] = {nullptr, nullptr};        // float64 `cand_a` = the first horizon step's rows [m * n, act_dim]
+    hipStream_t side = nullptr;                 // the producer's upload stream
+    l2a_ahead* chain = nullptr;
+    int slot = -1;                              // block of the latest successful step
+    bool producer_bound = false;                // the producer thread has made ctx->device current
+    std::string upload_err;
+    double stage_us[8] = {0};
+    unsigned long long steps = 0, relaunches = 0;
+};
+
+namespace {
+
+int fail(l2a_ctx* ctx, int code, const std::string& msg) { return l2a_fail(ctx, code, msg); }
+
+// Producer thread, after the block's draw: one H2D copy on the side stream, completed before the block is marked ready - the
+// consumer neither waits on an event nor launches behind an unfinished copy.
+int upload_block(void* arg, int slot) {
+    l2a_controller* c = static_cast<l2a_controller*>(arg);
+    if (!c->producer_bound) {
+        if (hipSetDevice(c->ctx->device) != hipSuccess) { c->upload_err = "hipSetDevice on the producer thread failed"; return -1; }
+        c->producer_bound = true;
+    }
+    hipError_t e = hipMemcpyAsync(c->dev[slot], c->pin[slot], c->act_floats * sizeof(float), hipMemcpyHostToDevice, c->side);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->side);
+    if (e != hipSuccess) { c->upload_err = std::string("uploading a candidate block: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
+
+void kick_next(void* arg) { (void)l2a_ahead_next(static_cast<l2a_controller*>(arg)->chain); }
+
+int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim, int units, int m, int n, int h,
+           const double* low, const double* high, double discount, const l2a_reward* reward, void* np_state_addr,
+           int rng_threads, l2a_controller** out) {
+    if (!out) return fail(ctx, L2A_EINVAL, "l2a_controller_create: out is null");
+    *out = nullptr;
+    if (!low || !high || !reward || !np_state_addr)
+        return fail(ctx, L2A_EINVAL, "l2a_controller_create: null low / high / reward / generator state address");
+    if (m < 1 || m > L2A_MAIL_KEYS || (long long)m * obs_dim > L2A_MAIL_OBS || n < 1 || h < 1)
+        return fail(ctx, L2A_EINVAL, "l2a_controller_create: needs 1 <= m <= 64 envs (at most 4096 observation floats), n >= 1, h >= 1");
+    if (act_dim < 1 || act_dim > 16) return fail(ctx, L2A_EINVAL, "l2a_controller_create: the host draw takes 1 <= act_dim <= 16");
+    if ((long long)m * n > 0x3fffffffLL) return fail(ctx, L2A_EINVAL, "l2a_controller_create: too many candidates");
+    if (l2a_rng_version() < 7) return fail(ctx, L2A_ESTATE, "l2a_controller_create: libl2a_rng.so is older than this library");
+    l2a_controller* c = new (std::nothrow) l2a_controller();
+    if (!c) return fail(ctx, L2A_EHIP, "l2a_controller_create: out of memory");
+    c->ctx = ctx; c->mlp = mlp; c->rnn = rnn;
+    c->m = m; c->n = n; c->h = h; c->obs_dim = obs_dim; c->act_dim = act_dim; c->units = units;
+    c->discount = discount; c->rw = *reward; c->np_addr = np_state_addr;
+    c->act_floats = (size_t)h * m * n * act_dim;
+    l2a_device_guard guard(ctx->device);
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&c->pin[s]), c->act_floats * sizeof(float), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev[s]), c->act_floats * sizeof(float));
+        if (e == hipSuccess) {
+            c->c64[s] = static_cast<double*>(std::malloc(sizeof(double) * (size_t)m * n * act_dim));
+            if (!c->c64[s]) e = hipErrorOutOfMemory;
+        }
+    }
+    if (e == hipSuccess) {
+        // rows of the reference's draw: h * n * m (mpc_controller.py:114), row r <-> candidate r % n; the whole env-major tensor
+        // goes up (one GPU: every candidate is local); the first n * m rows are kept in float64 (`cand_a`, :118)
+        c->chain = l2a_ahead_create((long long)h * n * m, act_dim, low, high, n, 0, n, (long long)n * m, c->pin[0], c->pin[1],
+                                    c->c64[0], c->c64[1], rng_threads, upload_block, c);
+        if (!c->chain) e = hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) {
+        const std::string msg = std::string("l2a_controller_create: ") + hipGetErrorString(e);
+        l2a_controller_destroy(c);
+        return fail(ctx, L2A_EHIP, msg);
+    }
+    *out = c;
+    return L2A_OK;
+}
+
+int step(l2a_controller* c, const double* obs, const float* c0, const float* h0, float* c1, float* h1, double* action_out,
+         long long* index_out, float* return_out, void* stream) {
+    l2a_ctx* ctx = c->ctx;
+    if (!obs || !action_out) return fail(ctx, L2A_EINVAL, "l2a_controller_step: null obs / action_out");
+    const double t0 = l2a_now_us();
+    const int slot = l2a_ahead_take(c->chain, c->np_addr);
+    if (slot < 0) {
+        if (!c->upload_err.empty()) { const std::string msg = c->upload_err; c->upload_err.clear(); return fail(ctx, L2A_EHIP, msg); }
+        return L2A_STEP_MISS;
+    }
+    c->slot = slot;
+    const double t1 = l2a_now_us();
+    float obs32[L2A_MAIL_OBS];
+    const int no = c->m * c->obs_dim;
+    for (int i = 0; i < no; ++i) obs32[i] = (float)obs[i];          // np.float64 -> np.float32 (round to nearest even), as the host cast
+    unsigned long long keys[L2A_MAIL_KEYS];
+    int rc = L2A_OK, result = L2A_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        l2a_after_launch_fn hook = attempt == 0 ? kick_next : nullptr;
+        if (c->mlp)
+            rc = l2a_plan_rs_sync_hook(c->mlp, obs32, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, nullptr, keys, stream,
+                                       hook, c);
+        else
+            rc = l2a_lstm_plan_rs_sync_hook(c->rnn, obs32, c0, h0, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, keys,
+                                            c1, h1, stream, hook, c);
+        if (rc != L2A_ESPLIT) break;
+        // a tile-split partner was not co-resident: the unsplit geometry gives the same bits (the caller is told: L2A_STEP_UNSPLIT)
+        if (attempt == 1) return fail(ctx, L2A_ESPLIT, "l2a_controller_step: the rollout was flagged invalid with the tile split disabled");
+        (void)l2a_set_split(ctx, 0);
+        c->relaunches += 1;
+        result = L2A_STEP_UNSPLIT;
+    }
+    if (rc != L2A_OK) return rc;
+    const double t2 = l2a_now_us();
+    for (int i = 0; i < c->m; ++i) {
+        float ret = 0.0f;
+        int idx = 0;
+        l2a_key_decode(keys[i], &ret, &idx);
+        if (idx < 0 || idx >= c->n) return fail(ctx, L2A_EHIP, "l2a_controller_step: the arg-max key holds no candidate index");
+        if (index_out) index_out[i] = idx;
+        if (return_out) return_out[i] = ret;
+        std::memcpy(action_out + (size_t)i * c->act_dim, c->c64[slot] + ((size_t)i * c->n + idx) * c->act_dim,
+                    sizeof(double) * (size_t)c->act_dim);                    // cand_a[i, idx] (:118,129)
+    }
+    const double t3 = l2a_now_us();
+    c->steps += 1;
+    const double* st = ctx->stamps_us;
+    c->stage_us[0] = t1 - t0;               // take (compare + adopt the block; waits only if the producer is late)
+    c->stage_us[1] = st[1] - t1;            // observation cast + staging
+    c->stage_us[2] = st[2] - st[1];         // launch call(s)
+    c->stage_us[3] = st[3] - st[2];         // producer kick
+    c->stage_us[4] = st[4] - st[3];         // wait for the keys
+    c->stage_us[5] = t3 - t2;               // decode + gather
+    c->stage_us[6] = t3 - t0;               // whole call
+    return result;
+}
+
+}  // namespace
+
+extern "C" {
+
+int l2a_controller_create(l2a_model* model, int m, int n, int h, const double* low, const double* high, double discount,
+                          const l2a_reward* reward, void* np_state_addr, int rng_threads, l2a_controller** out) {
+    if (!model) return L2A_EINVAL;
+    l2a_ctx* ctx = nullptr;
+    int obs_dim = 0, act_dim = 0;
+    l2a_model_facts(model, &ctx, &obs_dim, &act_dim);
+    return create(ctx, model, nullptr, obs_dim, act_dim, 0, m, n, h, low, high, discount, reward, np_state_addr, rng_threads, out);
+}
+
+int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const double* low, const double* high, double discount,
+                               const l2a_reward* reward, void* np_state_addr, int rng_threads, l2a_controller** out) {
+    if (!model) return L2A_EINVAL;
+    l2a_ctx* ctx = nullptr;
+    int obs_dim = 0, act_dim = 0, units = 0;
+    l2a_lstm_facts(model, &ctx, &obs_dim, &act_dim, &units);
+    return create(ctx, nullptr, model, obs_dim, act_dim, units, m, n, h, low, high, discount, reward, np_state_addr, rng_threads, out);
+}
+
+void l2a_controller_destroy(l2a_controller* c) {
+    if (!c) return;
+    l2a_ahead_destroy(c->chain);                // joins the producer: no upload is in flight afterwards
+    l2a_device_guard guard(c->ctx->device);
+    for (int s = 0; s < 2; ++s) {
+        if (c->pin[s]) (void)hipHostFree(c->pin[s]);
+        if (c->dev[s]) (void)hipFree(c->dev[s]);
+        std::free(c->c64[s]);
+    }
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+int l2a_controller_step(l2a_controller* c, const double* obs, double* action_out, long long* index_out, float* return_out,
+                        void* stream) {
+    if (!c) return L2A_EINVAL;
+    if (!c->mlp) return fail(c->ctx, L2A_EINVAL, "l2a_controller_step: this controller plans with a recurrent model (l2a_lstm_controller_step)");
+    return step(c, obs, nullptr, nullptr, nullptr, nullptr, action_out, index_out, return_out, stream);
+}
+
+int l2a_lstm_controller_step(l2a_controller* c, const double* obs, const float* c0, const float* h0, float* c_next, float* h_next,
+                             double* action_out, long long* index_out, float* return_out, void* stream) {
+    if (!c) return L2A_EINVAL;
+    if (!c->rnn) return fail(c->ctx, L2A_EINVAL, "l2a_lstm_controller_step: this controller plans with an MLP model (l2a_controller_step)");
+    if (!c0 || !h0) return fail(c->ctx, L2A_EINVAL, "l2a_lstm_controller_step: null c0 / h0");
+    return step(c, obs, c0, h0, c_next, h_next, action_out, index_out, return_out, stream);
+}
+
+int l2a_controller_rearm(l2a_controller* c) {
+    if (!c) return L2A_EINVAL;
+    if (l2a_ahead_arm(c->chain, c->np_addr) != 0) return fail(c->ctx, L2A_ESTATE, "l2a_controller_rearm: the producer thread could not be started");
+    return L2A_OK;
+}
+
+const float* l2a_controller_actions(const l2a_controller* c) {
+    return (c && c->slot >= 0) ? c->dev[c->slot] : nullptr;
+}
+
+int l2a_controller_stats(l2a_controller* c, double* out, int cap) {
+    if (!c || !out || cap < 1) return L2A_EINVAL;
+    double v[16] = {0};
+    for (int i = 0; i < 7; ++i) v[i] = c->stage_us[i];
+    double ch[6];
+    l2a_ahead_stats(c->chain, ch);
+    v[7] = (double)c->steps; v[8] = (double)c->relaunches;
+    for (int i = 0; i < 6; ++i) v[9 + i] = ch[i];
+    for (int i = 0; i < cap && i < 16; ++i) out[i] = v[i];
+    return L2A_OK;
+}
+
+}  // extern "C"

@@ -23,14 +23,16 @@ plan step is cut into this many horizon chunks so that the host draws / uploads 
 GPU rolls out chunk k - same RNG stream, bit-identical result; 1 = one launch), ``draw_ahead`` (parity
 mode: the NEXT controller step's candidates are drawn on a private copy of the generator state while the
 GPU runs the current plan and adopted only if the global generator is still in exactly that state -
-``policies/draw_ahead.py``; numbers, order and the state left behind are the reference's).
+``policies/draw_ahead.py``; numbers, order and the state left behind are the reference's), ``native_step`` (parity-mode
+random shooting on one GPU: the whole step - adopt the block drawn ahead by a C thread, launch, wait, decode, gather - is ONE
+C call, ``l2a_controller_step``, ``policies/native_step.py``; a step that finds no valid block falls back to the path above).
 
 A tile-split launch whose exchange partner was not co-resident (another process on the GPU) flags a status
 word instead of hanging; the controller then switches the context to the unsplit geometry (bit-identical
 results) and relaunches the plan - it never raises mid-rollout for that.
 """
 
-import zlib
+import os
 
 import numpy as np
 import torch
@@ -63,6 +65,7 @@ class MPCController(Policy, Serializable):
             shard_candidates=True,
             pipeline_chunks=5,
             draw_ahead=True,
+            native_step=True,
     ):
         self.dynamics_model = dynamics_model
         self.reward_model = reward_model
@@ -82,6 +85,7 @@ class MPCController(Policy, Serializable):
         self.shard_candidates = shard_candidates
         self.pipeline_chunks = int(pipeline_chunks)
         self.draw_ahead = bool(draw_ahead)
+        self.native_step = bool(native_step)
 
         self.unwrapped_env = innermost_env(env)
 
@@ -94,6 +98,8 @@ class MPCController(Policy, Serializable):
         self._reward_spec = None if use_reward_model else reward_spec_for_env(env)
         self._bufs = {}
         self._ahead = None          # DrawAhead chain (parity mode), created on first use
+        self._cstep = None          # NativeStep (l2a_controller): the whole parity-mode step in one C call
+        self._cstep_no = None       # request key the C controller was found ineligible for
         self._cem_first_chunk = 4   # horizon steps of the first chunk of a pipelined CEM rollout (0: equal chunks)
         self.last_plan = None       # diagnostics of the latest fused plan (returns, keys, ...)
 
@@ -424,6 +430,74 @@ class MPCController(Policy, Serializable):
             return dict(a_dev=a_dev, event=ev, cand_a=c64.reshape(m, n, act_dim))
         return produce
 
+    # ------------------------------------------------------------------ the whole step in one C call
+    def _native_step_stock(self):
+        """The launch path is the product's own (a test harness that replaces it must not be bypassed)."""
+        return (getattr(self._rollout, "__func__", None) is MPCController._rollout
+                and getattr(self._plan_keys, "__func__", None) is MPCController._plan_keys)
+
+    def _native_step_state(self, native, m):
+        """Recurrent planners: ``((c0, h0, c_next, h_next) device pointers, what to keep)``; None here."""
+        return None, None
+
+    def _native_step_done(self, keep):
+        pass
+
+    def _native_step_build(self, native, m, key):
+        from .native_step import NativeStep
+        if self._cstep is not None:
+            self._cstep.close()
+            self._cstep = None
+        if os.environ.get("L2A_NATIVE_STEP", "1") == "0" or not hasattr(native.lib, "l2a_controller_step"):
+            return None
+        if getattr(native, "sync_max_envs", 0) < m or m * native.obs_dim > 4096 or native.act_dim > 16:
+            return None
+        if not (fast_rng.available("uniform") and fast_rng.available("direct")) or fast_rng._global_addr() is None:
+            return None
+        st = NativeStep(native, hasattr(native, "units"), m, self.n_candidates, self.horizon, self.action_space.low,
+                        self.action_space.high, self.discount, self._reward_spec)
+        st.key = key
+        self._cstep = st
+        return st
+
+    def _native_rs_step(self, observations, m):
+        """Parity-mode random shooting on one GPU through ``l2a_controller_step`` (``policies/native_step.py``).  Returns the
+        actions, or None when the C controller does not apply (sharded plan, test harness, no helper library) or found no
+        valid block of candidates (first call, a foreign draw from ``np.random`` since the last step): the caller then takes
+        the ordinary path - which draws synchronously from the global generator - and the chain is re-armed behind that draw."""
+        if self.use_cem or not self._native_step_stock():
+            return None
+        world = self._dist()[1]
+        native = self.dynamics_model.planner_model()
+        key = (os.getpid(), id(native), native.handle.value, world, m, self.n_candidates, self.horizon, float(self.discount))
+        st = self._cstep
+        if st is None or st.key != key:
+            if self._cstep_no == key:
+                return None
+            st = self._native_step_build(native, m, key) if world == 1 else None
+            if st is None:
+                self._cstep_no = key
+                return None
+            self._cstep_no = None
+        self._check_blocks(m)
+        state, keep = self._native_step_state(native, m)
+        if not st.step(observations, torch.cuda.current_stream(native.device).cuda_stream, state):
+            return None
+        self._native_step_done(keep)
+        self.last_plan = dict(best_index=st.idx.copy(), best_return=st.ret.copy(), n_local=self.n_candidates,
+                              shard=(0, self.n_candidates))
+        return st.act.copy()
+
+    def draw_ahead_stats(self):
+        """``dict(hits=, misses=)`` of the candidate blocks drawn ahead of time (C controller and Python chain together)."""
+        hits = misses = 0
+        if self._cstep is not None:
+            s = self._cstep.stats()
+            hits, misses = hits + s["hits"], misses + s["misses"]
+        if self._ahead is not None:
+            hits, misses = hits + self._ahead.hits, misses + self._ahead.misses
+        return dict(hits=hits, misses=misses)
+
     # ------------------------------------------------------------------ random shooting (reference :108-129)
     def get_rs_action(self, observations):
         n = self.n_candidates
@@ -432,6 +506,11 @@ class MPCController(Policy, Serializable):
 
         if not self._fusable():
             return self._get_rs_action_unfused(observations)
+
+        if self.rng == "numpy" and self.native_step and self.draw_ahead:
+            out = self._native_rs_step(observations, m)
+            if out is not None:
+                return out
 
         rank, world = self._dist()
         lo, hi = self._shard_range(n, rank, world)
@@ -525,13 +604,16 @@ class MPCController(Policy, Serializable):
         n_local = hi - lo
         act_dim = self.action_space.shape[0]
         dev = self._device()
-        ahead = self._use_draw_ahead("uniform")
+        cstep = self._cstep if (self._cstep is not None and self._cstep_no is None) else None
+        ahead = self._use_draw_ahead("uniform") and cstep is None      # one chain at a time: the C controller's, if it applies
         sig = ("rs", n, m, h, lo, hi)
         chain = self._ahead_chain() if ahead else None
         blk = chain.take(sig) if ahead else None
 
         def kick():     # the next controller step's candidates are drawn while this plan runs on the GPU
-            if ahead and not chain.active_for(sig):
+            if cstep is not None:
+                cstep.rearm()
+            elif ahead and not chain.active_for(sig):
                 chain.start(sig, self._rs_producer(n, m, h, lo, hi), depth=1, words_only=True)
 
         if blk is not None:

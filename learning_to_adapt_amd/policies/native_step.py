@@ -1,0 +1,99 @@
+"""Python handle on an ``l2a_controller`` (``include/l2a.h``: ``l2a_controller_*``) - the whole parity-mode controller step
+of ``MPCController.get_actions`` / ``RNNMPCController.get_actions`` in ONE C call.
+
+The reference's step (``policies/mpc_controller.py:59-69,108-129``) draws ``h*n*m`` candidate rows from NumPy's global
+generator, rolls them out and returns the best candidate's first action.  The C controller keeps that contract - same numbers,
+same generator state afterwards - with the draw done ahead of time by a C thread (``csrc/l2a_rng.c``, adopted only when the
+global generator is still in the state the block started from), and the launch, the wait for the mailbox word, the key decode
+and the gather of the float64 action inside ``l2a_controller_step``.  What is left on the Python side of a step: one copy of
+the observations into a preallocated array, one ``ctypes`` call, two small array copies.
+"""
+
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from ..utils import fast_rng
+
+
+class NativeStep(object):
+    def __init__(self, native, recurrent, m, n, h, low, high, discount, reward):
+        lib = native.lib
+        self.lib, self.ctx, self.native, self.recurrent = lib, native.ctx, native, bool(recurrent)
+        self.m, self.n, self.h = int(m), int(n), int(h)
+        low = np.ascontiguousarray(low, dtype=np.float64)
+        high = np.ascontiguousarray(high, dtype=np.float64)
+        self.addr = fast_rng._global_addr()
+        if self.addr is None:
+            raise _lib.L2AError("np.random's global generator is not the legacy MT19937")
+        self.lock = fast_rng._global_lock()
+        handle = ctypes.c_void_p()
+        create = lib.l2a_lstm_controller_create if self.recurrent else lib.l2a_controller_create
+        rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
+                    ctypes.byref(reward), self.addr, fast_rng.threads(), ctypes.byref(handle))
+        self.ctx.check(rc, "l2a_controller_create")
+        self.handle = handle
+        self.obs = np.empty((self.m, native.obs_dim), dtype=np.float64)
+        self.act = np.empty((self.m, native.act_dim), dtype=np.float64)
+        self.idx = np.empty((self.m,), dtype=np.int64)
+        self.ret = np.empty((self.m,), dtype=np.float32)
+        self._p = (self.obs.ctypes.data, self.act.ctypes.data, self.idx.ctypes.data, self.ret.ctypes.data)
+        self.misses_in_row = 0
+        self.cooldown = 0
+        self._stats = (ctypes.c_double * 16)()
+
+    def step(self, observations, stream, state=None):
+        """One controller step.  Returns True (``self.act`` / ``self.idx`` / ``self.ret`` hold the result), or False when no
+        valid block of candidates was waiting - nothing has been consumed or launched then.  ``state`` (recurrent):
+        ``(c0, h0, c_next, h_next)`` device pointers."""
+        np.copyto(self.obs, observations, casting="same_kind")
+        p = self._p
+        with self.lock:         # the generator's own lock: no other thread draws between the state compare and the adoption
+            if self.recurrent:
+                rc = self.lib.l2a_lstm_controller_step(self.handle, p[0], state[0], state[1], state[2], state[3], p[1], p[2], p[3],
+                                                       stream)
+            else:
+                rc = self.lib.l2a_controller_step(self.handle, p[0], p[1], p[2], p[3], stream)
+        if rc == _lib.L2A_OK:
+            self.misses_in_row = 0
+            return True
+        if rc == _lib.L2A_STEP_MISS:
+            return False
+        if rc == _lib.L2A_STEP_UNSPLIT:        # the C side has switched the context to the unsplit geometry (same bits)
+            self.ctx.split_degraded = True
+            self.misses_in_row = 0
+            return True
+        self.ctx.check(rc, "l2a_controller_step")
+
+    def rearm(self):
+        """After a synchronous draw: the chain restarts at the current global state.  Backs off while steps keep missing
+        (a consumer of ``np.random`` runs between the controller's steps: every block drawn ahead would be thrown away)."""
+        self.misses_in_row += 1
+        if self.misses_in_row > 2:
+            self.cooldown += 1
+            if self.cooldown % 16 != 0:
+                return
+        with self.lock:
+            self.ctx.check(self.lib.l2a_controller_rearm(self.handle), "l2a_controller_rearm")
+
+    def stats(self):
+        self.ctx.check(self.lib.l2a_controller_stats(self.handle, self._stats, 16), "l2a_controller_stats")
+        v = list(self._stats)
+        return dict(stage_us=dict(take=v[0], stage_obs=v[1], launch=v[2], kick=v[3], wait=v[4], decode=v[5], call=v[6]),
+                    steps=int(v[7]), relaunches=int(v[8]), hits=int(v[9]), misses=int(v[10]), produced=int(v[11]),
+                    producer_us_per_block=v[12], consumer_wait_us_per_take=v[13], armed=bool(v[14]))
+
+    def actions_ptr(self):
+        return self.lib.l2a_controller_actions(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.l2a_controller_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -193,6 +193,27 @@ class RNNMPCController(MPCController):
                 return keys.view(np.int64)
         raise RuntimeError("recurrent rollout launch failed twice")
 
+    # ---- the whole step in one C call (l2a_lstm_controller_step): the plan AND the state advance
+    def _native_step_stock(self):
+        return (getattr(self._rollout, "__func__", None) is RNNMPCController._rollout
+                and getattr(self._plan_keys, "__func__", None) is RNNMPCController._plan_keys)
+
+    def _native_step_state(self, native, m):
+        dev = native.device
+        self._hid_next = None
+        c0, h0 = self._device_hidden(dev)
+        assert tuple(c0.shape) == (m, native.units), "hidden state holds %d rows, %d observations were passed" % (
+            c0.shape[0], m)
+        self._hid_flip ^= 1
+        c1 = self._buf("adv_c%d" % self._hid_flip, (m, native.units), torch.float32, dev)
+        h1 = self._buf("adv_h%d" % self._hid_flip, (m, native.units), torch.float32, dev)
+        if c1.data_ptr() == c0.data_ptr() or h1.data_ptr() == h0.data_ptr():        # never write over the inputs
+            c1, h1 = torch.empty_like(c0), torch.empty_like(h0)
+        return (c0.data_ptr(), h0.data_ptr(), c1.data_ptr(), h1.data_ptr()), (c1, h1)
+
+    def _native_step_done(self, keep):
+        self._hid_next = keep          # `_advance_hidden` adopts it: the C step advanced the state behind the plan
+
     def _rollout(self, observations, actions_local, n_local, cand_offset, want_returns, obs_dev=None):
         native = self.dynamics_model.planner_model()
         m = len(observations)

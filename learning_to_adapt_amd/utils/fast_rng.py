@@ -56,7 +56,7 @@ def _load():
             c = ctypes
             vp, ll, i32 = c.c_void_p, c.c_longlong, c.c_int
             ip = c.POINTER(i32)
-            if lib.l2a_rng_version() < 6:
+            if lib.l2a_rng_version() < 7:
                 return None
             lib.l2a_mt19937_fill_double_mt.argtypes = [vp, ip, vp, ll, i32]
             lib.l2a_mt19937_fill_double_mt.restype = i32
@@ -82,6 +82,18 @@ def _load():
             lib.l2a_mt19937_state_load.restype = None
             lib.l2a_mt19937_state_digest.argtypes = [vp]
             lib.l2a_mt19937_state_digest.restype = c.c_ulonglong
+            lib.l2a_ahead_create.argtypes = [ll, i32, vp, vp, ll, ll, ll, ll, vp, vp, vp, vp, i32, vp, vp]
+            lib.l2a_ahead_create.restype = vp
+            lib.l2a_ahead_destroy.argtypes = [vp]
+            lib.l2a_ahead_destroy.restype = None
+            lib.l2a_ahead_arm.argtypes = [vp, vp]
+            lib.l2a_ahead_arm.restype = i32
+            lib.l2a_ahead_take.argtypes = [vp, vp]
+            lib.l2a_ahead_take.restype = i32
+            lib.l2a_ahead_next.argtypes = [vp]
+            lib.l2a_ahead_next.restype = i32
+            lib.l2a_ahead_stats.argtypes = [vp, _dp]
+            lib.l2a_ahead_stats.restype = None
             _state["lib"] = lib
         except (OSError, AttributeError):
             _state["lib"] = None
@@ -368,3 +380,58 @@ def cem_samples(z, row_base, h, act_dim, mean, std, low, high, a_out, clip_out, 
     if rc != 0:
         raise RuntimeError("l2a_cem_samples_steps failed (%d)" % rc)
     return True
+
+
+class AheadChain(object):
+    """The C draw-ahead chain of ``csrc/l2a_rng.c`` (``l2a_ahead_*``) on host buffers - the random-shooting draw of the NEXT
+    controller step produced by a C thread while the caller is busy, adopted only when the global generator is still in the
+    state the block started from.  ``libl2a_hip.so``'s controller step (``l2a_controller_step``) drives the same chain with
+    page-locked buffers and an upload callback; this wrapper serves the tests and hosts without a GPU."""
+
+    def __init__(self, rows, low, high, period, sel_lo, sel_hi, rows64, nthreads=None):
+        lib = _load()
+        if lib is None or not available("uniform") or not available("direct"):
+            raise RuntimeError("libl2a_rng.so is not available / not trusted on this machine")
+        self.lib = lib
+        low = np.ascontiguousarray(low, dtype=np.float64)
+        high = np.ascontiguousarray(high, dtype=np.float64)
+        act_dim = int(low.shape[0])
+        nsel = int(sel_hi) - int(sel_lo)
+        blocks = (int(rows) + int(period) - 1) // int(period)
+        self.f32 = [np.zeros((blocks * max(nsel, 1), act_dim), dtype=np.float32) for _ in (0, 1)]
+        self.f64 = [np.zeros((max(int(rows64), 1), act_dim), dtype=np.float64) for _ in (0, 1)]
+        self.addr = _global_addr()
+        self.handle = lib.l2a_ahead_create(int(rows), act_dim, low.ctypes.data, high.ctypes.data, int(period), int(sel_lo),
+                                           int(sel_hi), int(rows64), self.f32[0].ctypes.data, self.f32[1].ctypes.data,
+                                           self.f64[0].ctypes.data, self.f64[1].ctypes.data,
+                                           threads() if nthreads is None else int(nthreads), None, None)
+        if not self.handle:
+            raise RuntimeError("l2a_ahead_create refused the request")
+
+    def arm(self):
+        with _global_lock():
+            return self.lib.l2a_ahead_arm(self.handle, self.addr)
+
+    def take(self):
+        with _global_lock():
+            return self.lib.l2a_ahead_take(self.handle, self.addr)
+
+    def next(self):
+        return self.lib.l2a_ahead_next(self.handle)
+
+    def stats(self):
+        out = (ctypes.c_double * 6)()
+        self.lib.l2a_ahead_stats(self.handle, out)
+        return dict(hits=int(out[0]), misses=int(out[1]), produced=int(out[2]), produce_us=out[3], wait_us=out[4],
+                    armed=bool(out[5]))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.l2a_ahead_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -239,3 +239,46 @@ def test_random_recurrent_micro_tile_shapes_match_valu(seed):
     if "valu" in got:
         _check(got["micro"][0], got["valu"][0], got["micro"][1], n, 3)
     native.close()
+
+
+@pytest.mark.parametrize("m,n", [(129, 17), (200, 20), (160, 19), (256, 18)])
+def test_recurrent_micro_tiles_with_more_envs_than_half_the_cus(m, n):
+    """with more envs than CUs / 2 and five micro tiles per env, forcing workgroups of FOUR micro tiles left a
+    NEGATIVE count of full workgroups (quads = 5: W = 2, 5 - 2 * 3 = -1) - workgroup 0 started at candidate -4, wrote in front
+    of its env's returns and offered negative indices to the arg-max.  The dispatch now takes the natural ceil(quads / W);
+    sentinels in front of and behind the returns prove nothing is written out of bounds."""
+    rs = np.random.RandomState(7 * m + n)
+    obs_dim, act_dim, h = 20, 6, 2
+    low, high = -np.ones(act_dim), np.ones(act_dim)
+    params = synthetic.make_rnn_stack_set(obs_dim, act_dim, [256], "gru", 99)
+    norm = _norm(rs, obs_dim, act_dim, low, high)
+    spec = _reward(rs, obs_dim, act_dim)
+    native = NativeLSTM(obs_dim, act_dim, [256], "tanh", None, cell_type="gru")
+    native.set_weights(params)
+    native.set_norm(norm)
+    dev = native.device
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    obs0, acts = up(rs.randn(m, obs_dim)), up(rs.uniform(low, high, (h, m * n, act_dim)))
+    c0, h0 = up(np.zeros((m, 256))), up(np.tanh(rs.randn(m, 256)))
+    ctx = _lib.Context.get(0)
+    got = {}
+    guard = 64
+    try:
+        for name, kernel, micro in (("micro", "auto", 2), ("tiles16", "auto", 0), ("valu", "valu", 0)):
+            ctx.set_kernel(kernel)
+            ctx.set_micro(micro)
+            flat = torch.full((m * n + 2 * guard,), 12345.0, dtype=torch.float32, device=dev)
+            rets = flat[guard:guard + m * n].view(m, n)
+            best = torch.zeros((m,), dtype=torch.int64, device=dev)
+            native.plan_rs(obs0, c0, h0, acts, m, n, h, 0.95, spec, cand_offset=3, returns_out=rets, best_key=best)
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            host = flat.cpu().numpy()
+            assert np.all(host[:guard] == 12345.0) and np.all(host[guard + m * n:] == 12345.0), name
+            got[name] = (host[guard:guard + m * n].reshape(m, n).copy(), best.cpu().numpy())
+    finally:
+        ctx.set_kernel("auto")
+        ctx.set_micro(1)
+    _check(got["micro"][0], got["tiles16"][0], got["micro"][1], n, 3)
+    _check(got["micro"][0], got["valu"][0], got["micro"][1], n, 3)
+    native.close()

@@ -288,3 +288,94 @@ def test_draw_ahead_take_never_waits_for_a_worker_that_is_not_there():
     after = np.random.random_sample(3)                    # the global generator continues right behind the block
     np.random.seed(2)
     assert np.array_equal(after, np.random.random_sample(7)[4:])
+
+
+# ---- the C chain (csrc/l2a_rng.c: l2a_ahead_*) that l2a_controller_step drives ------------------------------------------
+def _c_chain(rows, low, high, period, lo, hi, rows64):
+    if not (fast_rng.available("uniform") and fast_rng.available("direct")):
+        pytest.skip("libl2a_rng.so not available / not trusted here")
+    return fast_rng.AheadChain(rows, low, high, period, lo, hi, rows64)
+
+
+def test_c_chain_reproduces_numpy_and_leaves_its_state():
+    low, high = np.array([-1.0, -0.5, -150.0]), np.array([1.0, 2.5, 150.0])
+    n, m, h = 50, 2, 7
+    rows = h * n * m
+    np.random.seed(3)
+    ch = _c_chain(rows, low, high, n, 10, 30, n * m)
+    assert ch.take() == -1                      # nothing armed
+    assert ch.arm() == 0
+    slots = []
+    for _ in range(5):
+        st = np.random.get_state()
+        want = np.random.uniform(low, high, (rows, 3))
+        after = np.random.get_state()
+        np.random.set_state(st)
+        slot = ch.take()
+        assert slot in (0, 1)
+        slots.append(slot)
+        now = np.random.get_state()
+        assert now[2] == after[2] and np.array_equal(now[1], after[1])
+        assert np.array_equal(ch.f64[slot], want[:n * m])
+        sel = want.reshape(h * m, n, 3)[:, 10:30].reshape(-1, 3).astype(np.float32)
+        assert np.array_equal(ch.f32[slot][:len(sel)], sel)
+        assert ch.take() == -1                  # a block is adopted once
+        assert ch.next() == 0
+    assert slots == [slots[0], slots[0] ^ 1] * 2 + [slots[0]]
+    s = ch.stats()
+    assert s["hits"] == 5 and s["misses"] == 0
+    ch.close()
+
+
+def test_c_chain_drops_its_block_after_a_foreign_draw_and_rearms():
+    low, high = -np.ones(6), np.ones(6)
+    n, m, h = 40, 1, 3
+    rows = h * n * m
+    np.random.seed(8)
+    ch = _c_chain(rows, low, high, n, 0, n, n)
+    ch.arm()
+    np.random.random_sample(3)                  # somebody else draws
+    st = np.random.get_state()
+    assert ch.take() == -1 and ch.stats()["misses"] == 1
+    now = np.random.get_state()
+    assert now[2] == st[2] and np.array_equal(now[1], st[1])        # a miss touches nothing
+    assert ch.next() == -1                      # nothing was taken
+    ch.arm()
+    want = np.random.uniform(low, high, (rows, 6))
+    np.random.set_state(st)
+    slot = ch.take()
+    assert slot >= 0 and np.array_equal(ch.f64[slot], want[:n])
+    # re-arming while a block is in production discards that block
+    ch.next()
+    np.random.seed(77)
+    ch.arm()
+    want = np.random.uniform(low, high, (rows, 6))
+    np.random.seed(77)
+    slot = ch.take()
+    assert slot >= 0 and np.array_equal(ch.f64[slot], want[:n])
+    ch.close()
+
+
+def test_c_chain_in_a_forked_child_starts_idle():
+    import os
+    low, high = -np.ones(2), np.ones(2)
+    np.random.seed(5)
+    ch = _c_chain(4000, low, high, 100, 0, 100, 100)
+    ch.arm()
+    pid = os.fork()
+    if pid == 0:
+        ok = False
+        try:
+            ok = ch.take() == -1                # the producer thread did not come along
+            ch.arm()                            # ... and a fresh one serves the child
+            st = np.random.get_state()
+            want = np.random.uniform(low, high, (4000, 2))
+            np.random.set_state(st)
+            slot = ch.take()
+            ok = ok and slot >= 0 and np.array_equal(ch.f64[slot], want[:100])
+        finally:
+            os._exit(0 if ok else 1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WEXITSTATUS(status) == 0
+    assert ch.take() >= 0                       # the parent's chain is untouched
+    ch.close()
