@@ -5,7 +5,8 @@
 // `adapt_batch_size` (16, run_scripts/run_grbal.py) normalised transitions, pulls the m adapted parameter
 // sets to the host and feeds them back on every later `sess.run`.  Here the step reads the base parameters once and
 // writes the adapted sets straight into the per-block model the planner launches on - raw layout AND MFMA fragment
-// order - so nothing is re-uploaded or re-packed.  2 L launches for L layers:
+// order - so nothing is re-uploaded or re-packed.  2 L - 1 launches for L layers (round 5; 2 L with the update as a launch of
+// its own until then):
 //
 //   l2a_adapt_fwd0_k, l2a_adapt_fwd_k (L - 1), l2a_adapt_bwd_k (L - 1) : the forward and backward pass, one launch per
 //                        layer, every launch spread over (64-unit slice, task) workgroups of 8 waves that each take an
@@ -19,10 +20,11 @@
 //                        tools/adapt_trace.sh): unbatched lane-per-unit loops, one exposed round trip per k: 58 us per
 //                        512 x 512 layer; batched loads + scalar loads for the activation rows: 19 us (the SGPR budget
 //                        keeps 5 of 8 row loads in flight); matrix core: see DESIGN.md 4.3
-//   l2a_adapt_update_k (1) : all layers at once, one workgroup per (layer, 256 output units, 16 input rows, task): each
-//                        thread keeps its unit's dZ row in registers and walks the input rows,
-//                        g = sum_r A_l[k][r] dZ_{l+1}[u][r], theta' = theta - lr g -> raw kernel, packed kernel;
-//                        biases alike
+//   the update             : blocks of (256 output units, 16 input rows, task): each thread keeps its unit's dZ row in
+//                        registers and walks the input rows, g = sum_r A_l[k][r] dZ_{l+1}[u][r], theta' = theta - lr g ->
+//                        raw kernel, packed kernels; biases alike.  Layer l's blocks ride in the launch that computes dZ_l
+//                        (l2a_adapt_bwdu_k: both operands were complete before it started); layer 0's columns are updated
+//                        by the last backward launch's own workgroups
 //
 // Rows beyond `rows` (padding up to 16) carry dZ = 0 and therefore no gradient.
 #pragma once
@@ -47,6 +49,7 @@ struct L2AAdaptParams {
     long long scratch_stride;           // floats per task
     long long a_off[L2A_MAX_LAYERS];    // offset of A_l in a task's scratch
     long long z_off[L2A_MAX_LAYERS + 1];// offset of dZ_l (l = 1 .. L)
+    long long y_off;                    // raw mode: the normalised target deltas [obs_dim][16] (written by the first launch)
     int hmax;
     // raw mode (l2a_model_adapt_sgd_raw): the batches arrive un-normalised as float64 and are normalised here exactly as
     // the reference does on the host - (v - mean) / (std + 1e-10) in float64, then the cast to fp32 (mlp_dynamics.py:265-266,
@@ -56,7 +59,30 @@ struct L2AAdaptParams {
     const double* raw_next;             // [m, rows, obs_dim]
     const double* raw_norm;             // mean_obs[od] std_obs[od] mean_act[ad] std_act[ad] mean_delta[od] std_delta[od]
     int obs_dim, act_dim;
+    unsigned long long* dbg;            // timeline builds (tools/timeline_adapt.py): [phase 8][wave 8][slot 8] shader clocks of workgroup (0, 0)
 };
+
+// Phase timeline (builds with -DL2A_TIMELINE only): the waves of workgroup (0, 0) stamp the shader clock (slot 7: the 100 MHz
+// constant clock, s_memrealtime, at the same instant as slot 0 / the last slot - converts clocks to microseconds).
+#ifndef L2A_TIMELINE
+#define L2A_ATS(phase, slot)
+#define L2A_ATS_REAL(phase, slot)
+#else
+#define L2A_ATS(phase, slot)                                                                            \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0) {                                                  \
+        unsigned long long ts_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((threadIdx.x & 63) == 0) p.dbg[(((phase) * 8) + (threadIdx.x >> 6)) * 8 + (slot)] = ts_;    \
+    }
+#define L2A_ATS_REAL(phase, slot)                                                                       \
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0) {                                                  \
+        unsigned long long ts_;                                                                         \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");              \
+        if ((threadIdx.x & 63) == 0) p.dbg[(((phase) * 8) + (threadIdx.x >> 6)) * 8 + (slot)] = ts_;    \
+    }
+#endif
 
 __device__ __forceinline__ float l2a_act_grad_from_output(float o, int kind) {
     switch (kind) {
@@ -72,44 +98,58 @@ __device__ __forceinline__ float l2a_act_grad_from_output(float o, int kind) {
                         // K = 512 (round 4; 8 until then - two exposed round trips per forward launch, 13.5 -> 10.2 us)
 #define L2A_XS_MAX 128  // widest input layer whose batch is staged through LDS in the first forward launch
 
-// Reduce the 8 waves' accumulators (4 unit tiles x f32x4 per lane) through LDS in a fixed order; wave 0 gets the sums.
-__device__ __forceinline__ void l2a_adapt_reduce(f32x4 (&acc)[4], float (&red)[L2A_AW - 1][64][L2A_AR + 1], int ks, int lane) {
-    if (ks > 0) {
+// The 8 waves' accumulator tiles (4 tiles x f32x4 per lane: D[unit or k][row]) meet in LDS; then EVERY thread sums two
+// outputs - local unit / k index ul = tid >> 3, rows 2 (tid & 7) + {0, 1} - over the waves in the fixed order 0 .. 7 (what
+// wave 0 alone did until round 5: 112 dependent LDS reads and the whole epilogue on one wave, 4 - 6k of a launch's ~20k
+// clocks).  VEC: a tile's M index m holds local unit 4 m + t (weight rows read 16 bytes per lane), else 16 t + m.
+template <bool VEC>
+__device__ __forceinline__ void l2a_adapt_reduce2(const f32x4 (&acc)[4], float* red, int w, int lane, float (&out)[2]) {
+    const int i16 = lane & 15, q = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) red[ks - 1][lane][4 * t + i] = acc[t][i];
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int ul = VEC ? 4 * (4 * q + i) + t : 16 * t + 4 * q + i;
+            red[(w * 64 + ul) * (L2A_AR + 1) + i16] = acc[t][i];
+        }
     __syncthreads();
-    if (ks == 0) {
+    const int ul = threadIdx.x >> 3, r0 = (threadIdx.x & 7) * 2;
+    float v0 = red[ul * (L2A_AR + 1) + r0], v1 = red[ul * (L2A_AR + 1) + r0 + 1];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int w = 0; w < L2A_AW - 1; ++w) acc[t][i] += red[w][lane][4 * t + i];
+    for (int ww = 1; ww < L2A_AW; ++ww) {
+        v0 += red[(ww * 64 + ul) * (L2A_AR + 1) + r0];
+        v1 += red[(ww * 64 + ul) * (L2A_AR + 1) + r0 + 1];
     }
+    out[0] = v0; out[1] = v1;
 }
 
 // First forward launch (layer 0, K = obs_dim + act_dim): 64 output units of one task per workgroup, lane = unit,
 // wave w sums its eighth of the k range.  A_0[k][r] = x[task][r][k] (zero beyond `rows`); x may live in host-mapped
 // memory (l2a_model_adapt_sgd_host): one coalesced pass brings it into LDS - a single bus round trip instead of one
-// per element - and workgroup 0 of the task publishes A_0 for the update pass.  grid (ceil(n_out / 64), m).
+// per element - and workgroup 0 of the task publishes A_0 for the update pass and, in raw mode, the normalised target
+// deltas (so that the last forward launch does not cross the bus again).  grid (ceil(n_out / 64), m).
 __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptParams p) {
     __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
     __shared__ float xs[L2A_XS_MAX * L2A_AR];
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    L2A_ATS(0, 0) L2A_ATS_REAL(0, 6)
     const int task = blockIdx.y;
     const int k_in = p.dims[0], n_out = p.dims[1];
     const int u = blockIdx.x * 64 + lane;
     const bool live = u < n_out;
     float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float* W = p.w[0] + (live ? u : 0);           // dead lanes read unit 0's column and never store
+    const float bias = (ks == 0 && live) ? p.b[0][u] : 0.0f;       // requested now, used after the reduction
     const int chunk = (k_in + L2A_AW - 1) / L2A_AW;
     const int k0 = ks * chunk, k1 = (k0 + chunk < k_in) ? k0 + chunk : k_in;
     const float* x = p.x + (long long)task * p.rows * k_in;
     const bool staged = k_in <= L2A_XS_MAX;             // (raw mode is only launched for staged widths)
+    constexpr int CH = (L2A_XS_MAX + L2A_AW - 1) / L2A_AW;
+    float wv[CH];
     if (staged) {
+        // (a wave's weights - at most 16 rows of a staged width - requested together and BEFORE the batch crosses the bus)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) wv[j] = (k0 + j < k1) ? W[(long long)(k0 + j) * n_out] : 0.0f;
         const int od = p.obs_dim, ad = p.act_dim;
         for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) {      // x in its own order: coalesced
             const int r = i / k_in, kk = i - r * k_in;
@@ -128,7 +168,22 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
             }
             xs[kk * L2A_AR + r] = v;
         }
+        if (blockIdx.x == 0 && p.raw_obs) {
+            // normalised target deltas, float64 like the host would compute them, [u][r] in the task's scratch
+            const int n_y = p.dims[p.n_layers];
+            for (int i = threadIdx.x; i < n_y * L2A_AR; i += blockDim.x) {
+                const int r = i / n_y, uu = i - r * n_y;
+                float y = 0.0f;
+                if (r < p.rows) {
+                    const long long e = ((long long)task * p.rows + r) * n_y + uu;
+                    const double delta = p.raw_next[e] - p.raw_obs[e];
+                    y = (float)((delta - p.raw_norm[2 * od + 2 * ad + uu]) / (p.raw_norm[3 * od + 2 * ad + uu] + 1e-10));
+                }
+                sc[p.y_off + uu * L2A_AR + r] = y;
+            }
+        }
         __syncthreads();
+        L2A_ATS(0, 1)
         if (blockIdx.x == 0)
             for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) sc[p.a_off[0] + i] = xs[i];
     }
@@ -136,11 +191,6 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) acc[r] = 0.0f;
     if (staged) {
-        // (a wave's weights - at most 16 rows of a staged width - requested together, not one exposed round trip per row)
-        constexpr int CH = (L2A_XS_MAX + L2A_AW - 1) / L2A_AW;
-        float wv[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) wv[j] = (k0 + j < k1) ? W[(long long)(k0 + j) * n_out] : 0.0f;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (k0 + j < k1) {
@@ -159,13 +209,14 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
             }
         }
     }
+    L2A_ATS(0, 2)
     if (ks > 0) {
 #pragma unroll
         for (int r = 0; r < L2A_AR; ++r) red[ks - 1][lane][r] = acc[r];
     }
     __syncthreads();
+    L2A_ATS(0, 3)
     if (ks != 0 || !live) return;
-    const float bias = p.b[0][u];
     float* dst = sc + p.a_off[1] + u * L2A_AR;
 #pragma unroll
     for (int r = 0; r < L2A_AR; ++r) {
@@ -174,28 +225,47 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
         for (int w = 0; w < L2A_AW - 1; ++w) v += red[w][lane][r];
         dst[r] = l2a_act1(v + bias, p.hidden_act);
     }
+    L2A_ATS(0, 4) L2A_ATS_REAL(0, 7)
 }
 
 // Forward through layer l >= 1 for 64 output units of one task on the matrix core: D[unit][row] += W^T[unit][k] A_l[k][row]
-// as v_mfma_f32_16x16x4_f32 (4 unit tiles per wave; lane (i, q) supplies W[k + q][u0 + 16 t + i] and A_l[k + q][i] - the
-// activation rows are one coalesced 256-byte load per k-step).  The 8 waves split the k-steps; operands of 8 k-steps are
-// fetched before the first MFMA; partial tiles meet in LDS in a fixed order.  The last layer writes
-// dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.  grid (ceil(n_out / 64), m).
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
-    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
+// as v_mfma_f32_16x16x4_f32 (4 unit tiles per wave; the activation rows are one coalesced 256-byte load per k-step).  The 8
+// waves split the k-steps; a wave's whole share of K is requested before its first MFMA; partial tiles meet in LDS in a fixed
+// order.  VEC (layer widths that are multiples of four, 16-byte aligned kernels: every hidden layer): lane (i, q) reads
+// W[k + q][u0 + 4 i .. 4 i + 3] with ONE 16-byte load and tile t takes element t - unit u0 + 4 i + t sits at M index i of
+// tile t (round 5; until then four dword loads per k-step, 640 load instructions per workgroup: 4.3 - 4.8k clocks before the
+// first MFMA could issue); otherwise (the 41-wide output layer) lane (i, q) reads W[k + q][u0 + 16 t + i] per tile.
+// The last layer writes dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.  grid (ceil(n_out / 64), m).
+template <bool VEC>
+__device__ __forceinline__ void l2a_adapt_fwd_body(const L2AAdaptParams& p, const int l, float* red) {
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
+    L2A_ATS(l, 0) L2A_ATS_REAL(l, 6)
     const int task = blockIdx.y;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
     const int u0 = blockIdx.x * 64;
     float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float* A = sc + p.a_off[l];
     const float* W = p.w[l];
+    const bool last = (l == p.n_layers - 1);
+    // what the epilogue of this thread needs - requested first, consumed last
+    const int ul = threadIdx.x >> 3, r0 = (threadIdx.x & 7) * 2;
+    const int ue = u0 + ul;
+    const bool ue_ok = ue < n_out;
+    const float bias_e = ue_ok ? p.b[l][ue] : 0.0f;
+    float y_e[2] = {0.0f, 0.0f};
+    if (last && ue_ok) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int r = r0 + c;
+            if (r < p.rows) y_e[c] = p.raw_obs ? sc[p.y_off + ue * L2A_AR + r] : p.y[((long long)task * p.rows + r) * n_out + ue];
+        }
+    }
     int ucol[4];
     bool uok[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int u = u0 + 16 * t + i16;
+        const int u = VEC ? u0 + 4 * i16 + t : u0 + 16 * t + i16;
         uok[t] = u < n_out;
         ucol[t] = uok[t] ? u : 0;
     }
@@ -205,146 +275,57 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptPar
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int s = s0; s < s1; s += L2A_SB) {
-        float a[L2A_SB][4], b[L2A_SB];
+        f32x4 a[L2A_SB];
+        float b[L2A_SB];
 #pragma unroll
         for (int j = 0; j < L2A_SB; ++j) {
             const int k = 4 * (s + j) + q;
             const bool ok = (s + j < s1) && (k < k_in);
             const int kk = ok ? k : 0;
             b[j] = A[kk * L2A_AR + i16];
+            if (VEC) {
+                a[j] = *reinterpret_cast<const f32x4*>(W + (long long)kk * n_out + ucol[0]);
+            } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a[j][t] = W[(long long)kk * n_out + ucol[t]];
+                for (int t = 0; t < 4; ++t) a[j][t] = W[(long long)kk * n_out + ucol[t]];
+            }
             if (!ok) b[j] = 0.0f;           // a zero row annihilates whatever the clamped weight loads returned
         }
-        __builtin_amdgcn_sched_barrier(0);  // all 40 loads of the batch in flight before the first MFMA
+        __builtin_amdgcn_sched_barrier(0);  // every load of the batch in flight before the first MFMA
+        L2A_ATS(l, 1)
 #pragma unroll
         for (int j = 0; j < L2A_SB; ++j)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(uok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
     }
-    l2a_adapt_reduce(acc, red, ks, lane);
-    if (ks != 0) return;
-    const bool last = (l == p.n_layers - 1);
-    const float scale = 2.0f / (float)(p.rows * n_out);
-    float* dst = sc + (last ? p.z_off[l + 1] : p.a_off[l + 1]);
-    const int r = i16;                      // D fragment: lane (row r, q) holds units u0 + 16 t + 4 q + 0..3
+    L2A_ATS(l, 2)
+    float v[2];
+    l2a_adapt_reduce2<VEC>(acc, red, ks, lane, v);
+    L2A_ATS(l, 3)
+    if (ue_ok) {
+        const float scale = 2.0f / (float)(p.rows * n_out);
+        float o[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int u = u0 + 16 * t + 4 * q + i;
-            if (u >= n_out) continue;
-            float v = acc[t][i] + p.b[l][u];
-            if (last) {
-                float y = 0.0f;
-                if (r < p.rows) {
-                    const long long e = ((long long)task * p.rows + r) * n_out + u;
-                    if (p.raw_obs) {        // normalised target delta, float64 like the host would compute it
-                        const int od = p.obs_dim, ad = p.act_dim;
-                        const double delta = p.raw_next[e] - p.raw_obs[e];
-                        y = (float)((delta - p.raw_norm[2 * od + 2 * ad + u]) / (p.raw_norm[3 * od + 2 * ad + u] + 1e-10));
-                    } else {
-                        y = p.y[e];
-                    }
-                }
-                v = (r < p.rows) ? scale * (v - y) : 0.0f;
-            } else {
-                v = l2a_act1(v, p.hidden_act);
-            }
-            dst[u * L2A_AR + r] = v;
+        for (int c = 0; c < 2; ++c) {
+            const float z = v[c] + bias_e;
+            o[c] = last ? ((r0 + c < p.rows) ? scale * (z - y_e[c]) : 0.0f) : l2a_act1(z, p.hidden_act);
         }
+        float* dst = sc + (last ? p.z_off[l + 1] : p.a_off[l + 1]) + ue * L2A_AR + r0;
+        *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+    }
+    L2A_ATS(l, 4) L2A_ATS_REAL(l, 7)
 }
 
-// dZ_l = (W_l dZ_{l+1}) * act'(A_l) for 64 input units k of layer l (1 <= l < L), same scheme: D[k][row] += W[k][u] dZ[u][row],
-// lane (i, q) supplies W[k0 + 16 t + i][u + q] (16 weight rows x 16 bytes per load; a row's line is reused by the next 7
-// u-steps) and dZ_{l+1}[u + q][i]; the waves split the u-steps.  grid (ceil(k_in / 64), m).
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwd_k(const L2AAdaptParams p, int l) {
-    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
-    const int lane = threadIdx.x & 63, us = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i16 = lane & 15, q = lane >> 4;
-    const int task = blockIdx.y;
-    const int k_in = p.dims[l], n_out = p.dims[l + 1];
-    const int k0 = blockIdx.x * 64;
-    float* sc = p.scratch + (long long)task * p.scratch_stride;
-    const float* Z = sc + p.z_off[l + 1];
-    const float* wrow[4];
-    bool kok[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int k = k0 + 16 * t + i16;
-        kok[t] = k < k_in;
-        wrow[t] = p.w[l] + (long long)(kok[t] ? k : 0) * n_out;
-    }
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if ((n_out & 15) == 0 && (reinterpret_cast<unsigned long long>(p.w[l]) & 15ull) == 0) {
-        // Hidden layers (n_out a multiple of 16, rows 16-byte aligned): the weight rows are read 16 BYTES per lane - lane (i, q) takes W[k_i][16 G + 4 q + 0..3]
-        // for a group G of sixteen u, and MFMA j of the group contracts u = 16 G + 4 q' + j over the quarters q' (dZ read to match) -
-        // a quarter of the load instructions and of the cache lines each touches (round 4: a 512 x 512 layer 20.8 -> 12 us; until
-        // then one dword per lane and u-step, sixteen 16-byte segments of sixteen different rows per instruction).
-        constexpr int GB = 4;                           // groups (of sixteen u) in flight: one batch covers a wave's share of 512
-        const int groups = n_out >> 4, perg = (groups + L2A_AW - 1) / L2A_AW;
-        const int g0 = us * perg < groups ? us * perg : groups, g1 = (g0 + perg < groups) ? g0 + perg : groups;
-        for (int g = g0; g < g1; g += GB) {
-            f32x4 a4[GB][4];
-            float b[GB][4];
-#pragma unroll
-            for (int jg = 0; jg < GB; ++jg) {
-                const bool ok = g + jg < g1;
-                const int u4 = 16 * (ok ? g + jg : g0) + 4 * q;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) a4[jg][t] = *reinterpret_cast<const f32x4*>(wrow[t] + u4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[jg][j] = ok ? Z[(u4 + j) * L2A_AR + i16] : 0.0f;
-            }
-            __builtin_amdgcn_sched_barrier(0);          // every load of the batch in flight before the first MFMA
-#pragma unroll
-            for (int jg = 0; jg < GB; ++jg)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a4[jg][t][j] : 0.0f, b[jg][j], acc[t]);
-        }
-    } else {
-        const int steps = (n_out + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
-        const int s0 = us * per < steps ? us * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
-        constexpr int SBB = 8;                          // (narrow output layer: eight u-steps a batch measured faster than sixteen)
-        for (int s = s0; s < s1; s += SBB) {
-            float a[SBB][4], b[SBB];
-#pragma unroll
-            for (int j = 0; j < SBB; ++j) {
-                const int u = 4 * (s + j) + q;
-                const bool ok = (s + j < s1) && (u < n_out);
-                const int uu = ok ? u : 0;
-                b[j] = Z[uu * L2A_AR + i16];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) a[j][t] = wrow[t][uu];
-                if (!ok) b[j] = 0.0f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < SBB; ++j)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
-        }
-    }
-    l2a_adapt_reduce(acc, red, us, lane);
-    if (us != 0) return;
-    const int r = i16;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + 16 * t + 4 * q + i;
-            if (k >= k_in) continue;
-            sc[p.z_off[l] + k * L2A_AR + r] = acc[t][i] * l2a_act_grad_from_output(sc[p.a_off[l] + k * L2A_AR + r], p.hidden_act);
-        }
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
+    __shared__ float red[L2A_AW * 64 * (L2A_AR + 1)];
+    const int n_out = p.dims[l + 1];
+    if ((n_out & 3) == 0 && (reinterpret_cast<unsigned long long>(p.w[l]) & 15ull) == 0) l2a_adapt_fwd_body<true>(p, l, red);
+    else l2a_adapt_fwd_body<false>(p, l, red);
 }
 
 // Where the adapted sets go: the per-block model's weight block (raw reference layout + MFMA fragment order), and
-// how the update launch's blockIdx.x maps to (layer, 256-unit block, 16-row chunk).
-#define L2A_UK 16       // input rows per update workgroup
+// how an update block index maps to (256-unit block, 16-row chunk) of its layer.
+#define L2A_UK 16       // input rows per update block
 struct L2AAdaptDst {
     float* blk;
     long long set_stride;
@@ -354,23 +335,54 @@ struct L2AAdaptDst {
     int has_mk, mk_H, mk_KG0, mk_o4;        // the micro-tile kernel's copy (l2a_micro_pack.h), at offset mk
     long long mk;
     float lr;
-    int first_block[L2A_MAX_LAYERS + 1];    // prefix sums of the layers' workgroup counts
 };
 
-// theta' = theta - lr * A_l^T dZ_{l+1} for every layer: grid (sum of the layers' blocks, m).  A thread owns one output
-// unit u (its dZ row stays in registers) and walks 16 input rows k; the row-0 workgroups also do the biases.  Writes
-// the raw layout and (has_pk) the MFMA fragment order (inverse of l2a_pack_decode); the last layer's bias also goes
+__device__ __forceinline__ int l2a_adapt_update_blocks(const L2AAdaptParams& p, int l) {
+    return ((p.dims[l + 1] + 255) / 256) * ((p.dims[l] + L2A_UK - 1) / L2A_UK);
+}
+
+// g = sum_r A[k][r] dZ[u][r] as ONE sequential fp32 FMA chain over the rows (every form of the update uses this order)
+__device__ __forceinline__ float l2a_adapt_grad(const float4 a0, const float4 a1, const float4 a2, const float4 a3, const float4 z0,
+                                                const float4 z1, const float4 z2, const float4 z3) {
+    float g = 0.0f;
+    g = fmaf(a0.x, z0.x, g); g = fmaf(a0.y, z0.y, g); g = fmaf(a0.z, z0.z, g); g = fmaf(a0.w, z0.w, g);
+    g = fmaf(a1.x, z1.x, g); g = fmaf(a1.y, z1.y, g); g = fmaf(a1.z, z1.z, g); g = fmaf(a1.w, z1.w, g);
+    g = fmaf(a2.x, z2.x, g); g = fmaf(a2.y, z2.y, g); g = fmaf(a2.z, z2.z, g); g = fmaf(a2.w, z2.w, g);
+    g = fmaf(a3.x, z3.x, g); g = fmaf(a3.y, z3.y, g); g = fmaf(a3.z, z3.z, g); g = fmaf(a3.w, z3.w, g);
+    return g;
+}
+__device__ __forceinline__ float l2a_adapt_bias_grad(const float4 z0, const float4 z1, const float4 z2, const float4 z3) {
+    float gb = 0.0f;
+    gb += (z0.x + z0.y) + (z0.z + z0.w);
+    gb += (z1.x + z1.y) + (z1.z + z1.w);
+    gb += (z2.x + z2.y) + (z2.z + z2.w);
+    gb += (z3.x + z3.y) + (z3.z + z3.w);
+    return gb;
+}
+
+// One new weight into the adapted set's three copies (raw layout, MFMA fragment order, micro-tile order), element by element
+__device__ __forceinline__ void l2a_adapt_put(const L2AAdaptParams& p, const L2AAdaptDst& d, float* dst, int l, int k, int u, float wn) {
+    const int k_in = p.dims[l], n_out = p.dims[l + 1];
+    const int KG = (k_in + 15) / 16;
+    dst[d.raw_w[l] + (long long)k * n_out + u] = wn;
+    if (d.has_pk) {
+        const long long pidx = ((((long long)(u >> 4) * KG + (k >> 4)) * 64 + ((u & 15) + 16 * ((k & 15) >> 2))) << 2) + (k & 3);
+        dst[d.pk[l] + pidx] = wn;
+    }
+    if (d.has_mk) dst[d.mk + l2a_mlp_micro_index(d.mk_H, d.mk_KG0, p.n_layers - 1, d.mk_o4, l, k, u)] = wn;
+}
+
+// theta' = theta - lr * A_l^T dZ_{l+1} for update block `b` of layer l (256 threads: `tid`).  A thread owns one output unit u
+// (its dZ row stays in registers) and walks 16 input rows k; the row-0 blocks also do the biases.  Writes the raw layout, the
+// MFMA fragment order (has_pk; inverse of l2a_pack_decode) and the micro-tile order (has_mk); the last layer's bias also goes
 // to the padded output-bias copy.
-__global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p, const L2AAdaptDst d) {
-    int l = 0;
-    while (l + 1 < p.n_layers && (int)blockIdx.x >= d.first_block[l + 1]) ++l;
+__device__ __forceinline__ void l2a_adapt_update_block(const L2AAdaptParams& p, const L2AAdaptDst& d, const int l, const int b,
+                                                       const int task, const int tid) {
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
     const int ublocks = (n_out + 255) / 256;
-    const int b = blockIdx.x - d.first_block[l];
     const int kc = b / ublocks, ub = b - kc * ublocks;
-    const int u = ub * 256 + threadIdx.x;
+    const int u = ub * 256 + tid;
     if (u >= n_out) return;
-    const int task = blockIdx.y;
     const float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float4* zp = reinterpret_cast<const float4*>(sc + p.z_off[l + 1] + u * L2A_AR);
     const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
@@ -380,21 +392,14 @@ __global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p
     const float* wsrc = p.w[l] + u;
     auto grad = [&](int k) {
         const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[l] + k * L2A_AR);
-        const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-        float g = 0.0f;
-        g = fmaf(a0.x, z0.x, g); g = fmaf(a0.y, z0.y, g); g = fmaf(a0.z, z0.z, g); g = fmaf(a0.w, z0.w, g);
-        g = fmaf(a1.x, z1.x, g); g = fmaf(a1.y, z1.y, g); g = fmaf(a1.z, z1.z, g); g = fmaf(a1.w, z1.w, g);
-        g = fmaf(a2.x, z2.x, g); g = fmaf(a2.y, z2.y, g); g = fmaf(a2.z, z2.z, g); g = fmaf(a2.w, z2.w, g);
-        g = fmaf(a3.x, z3.x, g); g = fmaf(a3.y, z3.y, g); g = fmaf(a3.z, z3.z, g); g = fmaf(a3.w, z3.w, g);
-        return g;
+        return l2a_adapt_grad(a[0], a[1], a[2], a[3], z0, z1, z2, z3);
     };
     // where the micro-tile copy keeps four rows of a 16-row block side by side: rows 16 a + c + 4 j, j = 0 .. 3 (chain order), unless
     // the O4 output slots scatter them over lanes
     const bool mk_vec = d.has_mk && !(l == p.n_layers - 1 && d.mk_o4 && u >= 16);
     if (k1 - k0 == L2A_UK) {
         // a whole block of sixteen rows: the new weights in registers, then 16-byte stores into the two packed copies (the MFMA
-        // fragment order keeps rows 4 a .. 4 a + 3 of a unit side by side) - until round 4 one dword store per row and copy, each
-        // filling a quarter of a 16-byte slot: 35 MB of partial-line writes were most of the launch's 21 us
+        // fragment order keeps rows 4 a .. 4 a + 3 of a unit side by side)
         float wn[L2A_UK];
 #pragma unroll
         for (int kk = 0; kk < L2A_UK; ++kk) wn[kk] = wsrc[(long long)(k0 + kk) * n_out] - d.lr * grad(k0 + kk);
@@ -419,24 +424,139 @@ __global__ void __launch_bounds__(256) l2a_adapt_update_k(const L2AAdaptParams p
         }
     } else {
 #pragma unroll 4
-        for (int k = k0; k < k1; ++k) {
-            const float wn = wsrc[(long long)k * n_out] - d.lr * grad(k);
-            dst[d.raw_w[l] + (long long)k * n_out + u] = wn;
-            if (d.has_pk) {
-                const long long pidx = ((((long long)(u >> 4) * KG + (k >> 4)) * 64 + ((u & 15) + 16 * ((k & 15) >> 2))) << 2) + (k & 3);
-                dst[d.pk[l] + pidx] = wn;
-            }
-            if (d.has_mk) dst[d.mk + l2a_mlp_micro_index(d.mk_H, d.mk_KG0, p.n_layers - 1, d.mk_o4, l, k, u)] = wn;
-        }
+        for (int k = k0; k < k1; ++k) l2a_adapt_put(p, d, dst, l, k, u, wsrc[(long long)k * n_out] - d.lr * grad(k));
     }
     if (kc == 0) {
-        float gb = 0.0f;
-        gb += (z0.x + z0.y) + (z0.z + z0.w);
-        gb += (z1.x + z1.y) + (z1.z + z1.w);
-        gb += (z2.x + z2.y) + (z2.z + z2.w);
-        gb += (z3.x + z3.y) + (z3.z + z3.w);
-        const float bn = p.b[l][u] - d.lr * gb;
+        const float bn = p.b[l][u] - d.lr * l2a_adapt_bias_grad(z0, z1, z2, z3);
         dst[d.raw_b[l] + u] = bn;
         if (d.has_pk && l == p.n_layers - 1) dst[d.pk_bout + u] = bn;
     }
+}
+
+// Backward through layer l (1 <= l < L) and, beside it, the update of that layer - one launch, grid (S + ceil(B / 2), m):
+//   workgroups x < S = ceil(dims[l] / 64):  dZ_l = (W_l dZ_{l+1}) * act'(A_l) for 64 input units k of layer l on the matrix core,
+//       D[k][row] += W[k][u] dZ[u][row]: lane (i, q) supplies W[k0 + 16 t + i][u + q] (16 weight rows x 16 bytes per load; a
+//       row's line is reused by the next 7 u-steps) and dZ_{l+1}[u + q][i]; the waves split the u-steps.  The workgroups of the
+//       LAST backward launch (l = 1) go on to update their 64 columns of W_0 and b_0 from the dZ_1 they have just computed (a
+//       49 x 64 block each) - no launch is left behind the backward pass.
+//   workgroups x >= S:  two update blocks of layer l each (theta' = theta - lr A_l^T dZ_{l+1}: both operands were complete
+//       before this launch started), on the CUs the 8 x m backward workgroups leave idle.
+// Until round 5 the update of all layers was a launch of its own behind the backward pass (15 of 85 us).
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwdu_k(const L2AAdaptParams p, const L2AAdaptDst d, int l) {
+    __shared__ float red[L2A_AW * 64 * (L2A_AR + 1)];
+    const int k_in = p.dims[l], n_out = p.dims[l + 1];
+    const int S = (k_in + 63) / 64;
+    const int task = blockIdx.y;
+    if ((int)blockIdx.x >= S) {
+        const int b = 2 * ((int)blockIdx.x - S) + (int)(threadIdx.x >> 8);
+        if (b < l2a_adapt_update_blocks(p, l)) l2a_adapt_update_block(p, d, l, b, task, (int)(threadIdx.x & 255));
+        return;
+    }
+    const int lane = threadIdx.x & 63, us = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int ph = 2 * p.n_layers - 1 - l;      // (timeline slot of this launch)
+    (void)ph;
+    L2A_ATS(ph, 0) L2A_ATS_REAL(ph, 6)
+    const int k0 = blockIdx.x * 64;
+    float* sc = p.scratch + (long long)task * p.scratch_stride;
+    const float* Z = sc + p.z_off[l + 1];
+    // what this thread's epilogue needs (the activations whose derivative scales its two outputs) - requested first
+    const int kl = threadIdx.x >> 3, r0 = (threadIdx.x & 7) * 2;
+    const int ke = k0 + kl;
+    const bool ke_ok = ke < k_in;
+    const float2 a_e = ke_ok ? *reinterpret_cast<const float2*>(sc + p.a_off[l] + ke * L2A_AR + r0) : make_float2(0.f, 0.f);
+    const float* wrow[4];
+    bool kok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = k0 + 16 * t + i16;
+        kok[t] = k < k_in;
+        wrow[t] = p.w[l] + (long long)(kok[t] ? k : 0) * n_out;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if ((n_out & 15) == 0 && (reinterpret_cast<unsigned long long>(p.w[l]) & 15ull) == 0) {
+        // Hidden layers (n_out a multiple of 16, rows 16-byte aligned): the weight rows are read 16 BYTES per lane - lane (i, q) takes W[k_i][16 G + 4 q + 0..3]
+        // for a group G of sixteen u, and MFMA j of the group contracts u = 16 G + 4 q' + j over the quarters q' (dZ read to match) -
+        // a quarter of the load instructions and of the cache lines each touches
+        constexpr int GB = 4;                           // groups (of sixteen u) in flight: one batch covers a wave's share of 512
+        const int groups = n_out >> 4, perg = (groups + L2A_AW - 1) / L2A_AW;
+        const int g0 = us * perg < groups ? us * perg : groups, g1 = (g0 + perg < groups) ? g0 + perg : groups;
+        for (int g = g0; g < g1; g += GB) {
+            f32x4 a4[GB][4];
+            float b[GB][4];
+#pragma unroll
+            for (int jg = 0; jg < GB; ++jg) {
+                const bool ok = g + jg < g1;
+                const int u4 = 16 * (ok ? g + jg : g0) + 4 * q;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a4[jg][t] = *reinterpret_cast<const f32x4*>(wrow[t] + u4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[jg][j] = ok ? Z[(u4 + j) * L2A_AR + i16] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);          // every load of the batch in flight before the first MFMA
+            L2A_ATS(ph, 1)
+#pragma unroll
+            for (int jg = 0; jg < GB; ++jg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a4[jg][t][j] : 0.0f, b[jg][j], acc[t]);
+        }
+    } else {
+        const int steps = (n_out + 3) / 4, per = (steps + L2A_AW - 1) / L2A_AW;
+        const int s0 = us * per < steps ? us * per : steps, s1 = (s0 + per < steps) ? s0 + per : steps;
+        constexpr int SBB = 8;                          // (narrow output layer: eight u-steps a batch measured faster than sixteen)
+        for (int s = s0; s < s1; s += SBB) {
+            float a[SBB][4], b[SBB];
+#pragma unroll
+            for (int j = 0; j < SBB; ++j) {
+                const int u = 4 * (s + j) + q;
+                const bool ok = (s + j < s1) && (u < n_out);
+                const int uu = ok ? u : 0;
+                b[j] = Z[uu * L2A_AR + i16];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[j][t] = wrow[t][uu];
+                if (!ok) b[j] = 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            L2A_ATS(ph, 1)
+#pragma unroll
+            for (int j = 0; j < SBB; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = L2A_MFMA(kok[t] ? a[j][t] : 0.0f, b[j], acc[t]);
+        }
+    }
+    L2A_ATS(ph, 2)
+    float v[2];
+    l2a_adapt_reduce2<false>(acc, red, us, lane, v);
+    L2A_ATS(ph, 3)
+    const float z_e0 = v[0] * l2a_act_grad_from_output(a_e.x, p.hidden_act);
+    const float z_e1 = v[1] * l2a_act_grad_from_output(a_e.y, p.hidden_act);
+    if (ke_ok) *reinterpret_cast<float2*>(sc + p.z_off[l] + ke * L2A_AR + r0) = make_float2(z_e0, z_e1);
+    L2A_ATS(ph, 4)
+    if (l == 1) {
+        // ---- layer 0's update, columns k0 .. k0 + 63, by the workgroup that owns their dZ_1 rows: through LDS (the partials are
+        //      done with), then thread (unit ul = tid & 63, part = tid >> 6) walks the input rows part, part + 8, ...
+        __syncthreads();                        // every thread has read its partial sums
+        float* zs = red;                        // [64][16]
+        if (ke_ok) { zs[kl * L2A_AR + r0] = z_e0; zs[kl * L2A_AR + r0 + 1] = z_e1; }
+        __syncthreads();
+        const int ul = threadIdx.x & 63, part = threadIdx.x >> 6;
+        const int u = k0 + ul;
+        if (u < k_in) {
+            const float4* zp = reinterpret_cast<const float4*>(zs + ul * L2A_AR);
+            const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
+            float* dst = d.blk + (long long)task * d.set_stride;
+            const int k_in0 = p.dims[0];
+            for (int k = part; k < k_in0; k += L2A_AW) {
+                const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[0] + k * L2A_AR);
+                const float g = l2a_adapt_grad(a[0], a[1], a[2], a[3], z0, z1, z2, z3);
+                l2a_adapt_put(p, d, dst, 0, k, u, p.w[0][(long long)k * k_in + u] - d.lr * g);
+            }
+            if (part == 0) dst[d.raw_b[0] + u] = p.b[0][u] - d.lr * l2a_adapt_bias_grad(z0, z1, z2, z3);
+        }
+    }
+    L2A_ATS_REAL(ph, 7)
 }

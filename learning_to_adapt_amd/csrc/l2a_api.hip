@@ -701,6 +701,7 @@ int adapt_prepare(l2a_model* md, const void* const* base_ptrs, const float* x, c
     for (int l = 0; l <= L; ++l) hmax = ap.dims[l] > hmax ? ap.dims[l] : hmax;
     for (int l = 0; l < L; ++l) { ap.a_off[l] = off; off += (long long)ap.dims[l] * L2A_AR; }
     for (int l = 1; l <= L; ++l) { ap.z_off[l] = off; off += (long long)ap.dims[l] * L2A_AR; }
+    ap.y_off = off; off += (long long)ap.dims[L] * L2A_AR;
     ap.scratch_stride = off;
     ap.hmax = hmax;
     for (int l = 0; l < L; ++l) {
@@ -718,6 +719,7 @@ int adapt_prepare(l2a_model* md, const void* const* base_ptrs, const float* x, c
         md->adapt_scratch_floats = need;
     }
     ap.scratch = md->adapt_scratch;
+    ap.dbg = ctx->dbg;
     return L2A_OK;
 }
 
@@ -747,14 +749,12 @@ int adapt_enqueue(l2a_model* md, const L2AAdaptParams& ap, int m, float lr, hipS
     for (int l = 1; l < L; ++l)
         hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3((unsigned)((ap.dims[l + 1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
                            stream, ap, l);
-    for (int l = L - 1; l >= 1; --l)
-        hipLaunchKernelGGL(l2a_adapt_bwd_k, dim3((unsigned)((ap.dims[l] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
-                           stream, ap, l);
-    L2A_HIP(ctx, hipGetLastError());
-    d.first_block[0] = 0;
-    for (int l = 0; l < L; ++l)
-        d.first_block[l + 1] = d.first_block[l] + ((ap.dims[l + 1] + 255) / 256) * ((ap.dims[l] + L2A_UK - 1) / L2A_UK);
-    hipLaunchKernelGGL(l2a_adapt_update_k, dim3((unsigned)d.first_block[L], (unsigned)m), dim3(256), 0, stream, ap, d);
+    // backward through layer l beside the update of layer l; the last of them (l = 1) also updates layer 0
+    for (int l = L - 1; l >= 1; --l) {
+        const int ub = ((ap.dims[l + 1] + 255) / 256) * ((ap.dims[l] + L2A_UK - 1) / L2A_UK);
+        hipLaunchKernelGGL(l2a_adapt_bwdu_k, dim3((unsigned)((ap.dims[l] + 63) / 64 + (ub + 1) / 2), (unsigned)m), dim3(64 * L2A_AW), 0,
+                           stream, ap, d, l);
+    }
     L2A_HIP(ctx, hipGetLastError());
     return L2A_OK;
 }

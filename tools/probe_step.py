@@ -106,6 +106,16 @@ def run(which, calls):
         row["python_outside_c_call_us_median"] = round(float(np.median(tot - np.array(pre_us) - S[:, names.index("call")])), 1)
         s = st.stats()
         row["chain"] = {k: s[k] for k in ("hits", "misses", "produced", "producer_us_per_block", "consumer_wait_us_per_take")}
+        # every call slower than 1.15 x the median, attributed to the stage with the largest excess over its own median
+        med = np.median(S, axis=0)
+        blame = {}
+        for i in np.nonzero(tot > 1.15 * np.median(tot))[0]:
+            ex = S[i, :6] - med[:6]
+            j = int(np.argmax(ex))
+            outside = tot[i] - pre_us[i] - S[i, names.index("call")]
+            k = names[j] if ex[j] >= outside else "python_outside_c_call"
+            blame[k] = blame.get(k, 0) + 1
+        row["slow_calls_by_stage"] = blame
         slow = np.argsort(tot)[-5:]
         row["slowest_calls"] = [dict(call_us=round(float(tot[i]), 1), **{k: round(float(S[i, j]), 1) for j, k in enumerate(names)})
                                 for i in slow]
