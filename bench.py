@@ -153,7 +153,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    rccl_ranks = None
+    collective_ranks = None
     backend = None
     if world > 1:
         import torch.distributed as dist
@@ -167,8 +167,8 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         ones = torch.ones((1,), dtype=torch.int64, device=torch.device("cuda", local_rank))
         dist.all_reduce(ones)                               # a real collective: how many ranks answered
-        rccl_ranks = int(ones.cpu()[0])
-        assert rccl_ranks == world
+        collective_ranks = int(ones.cpu()[0])
+        assert collective_ranks == world
 
     from learning_to_adapt_amd import _lib
     from learning_to_adapt_amd.dynamics.native_model import NativeModel
@@ -252,19 +252,46 @@ def main():
     resident_s = max_over_ranks(_timed_calls(resident_step, args.steps, args.warmup, sync))
     native.ctx.launch_status()          # raises if any launch flagged a problem
 
-    # ---- kernel duration: HIP events around each launch on the launch stream -----------------------------------
-    kern_ms = None
-    if rank == 0:
-        k2 = min(args.steps, 100)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k2)]
-        clock_warm()
-        for i in range(k2):
-            evs[i][0].record()
-            native.plan_rs(obs0, bufs[i % len(bufs)], 1, N_CAND, HORIZON, 1.0, spec, cand_offset=lo, best_key=best)
-            evs[i][1].record()
-        torch.cuda.synchronize()
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # ---- kernel duration: HIP events around each launch on the launch stream (every rank: min / max over ranks at N > 1) -----
+    k2 = min(args.steps, 100)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k2)]
+    clock_warm()
+    for i in range(k2):
+        evs[i][0].record()
+        native.plan_rs(obs0, bufs[i % len(bufs)], 1, N_CAND, HORIZON, 1.0, spec, cand_offset=lo, best_key=best)
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms_ranks = None
+    collective = None
     if world > 1:
+        t = torch.zeros((world,), dtype=torch.float64, device=dev)
+        t[rank] = kern_ms
+        dist.all_reduce(t)
+        kern_ms_ranks = [float(v) for v in t.cpu()]
+        # the collective on its own: the step's one int64 MAX all-reduce of the keys, HIP events on the launch stream around each
+        # call (the blocking form torch.distributed gives the controller: the launch stream waits for the collective), the ranks
+        # aligned by a barrier in front of every call so that the number is the collective, not the ranks' skew
+        k3 = min(args.steps, 50)
+        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k3)]
+        wall = []
+        for _ in range(5):
+            dist.all_reduce(best, op=dist.ReduceOp.MAX)
+        for i in range(k3):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cev[i][0].record()
+            dist.all_reduce(best, op=dist.ReduceOp.MAX)
+            cev[i][1].record()
+            torch.cuda.synchronize()
+            wall.append(1e6 * (time.perf_counter() - t0))
+        dev_us = [1e3 * a.elapsed_time(b) for a, b in cev]
+        c = torch.tensor([float(np.median(dev_us)), float(np.median(wall))], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.MAX)
+        collective = {"collective_us": round(float(c.cpu()[0]), 2), "collective_host_wall_us": round(float(c.cpu()[1]), 2),
+                      "what": "median over %d isolated int64 MAX all-reduces of the step's key word (max over ranks): HIP events "
+                              "on the launch stream | host wall clock incl. the stream synchronisation" % k3}
         dist.barrier()
 
     # ---- completed controller steps through the drop-in MPCController ------------------------------------------
@@ -287,8 +314,11 @@ def main():
                 e2e_index_match = bool(first_index == int(gold_glob["best"][0]))
                 assert e2e_index_match, "get_actions picked %d, reference picked %d" % (first_index, int(gold_glob["best"][0]))
             e2e[mode] = max_over_ranks(_timed_calls(lambda: ctrl.get_actions(obs_np), args.steps, args.warmup, sync))
-            if mode == "numpy" and ctrl._ahead is not None:
-                e2e["draw_ahead_hits"] = int(ctrl._ahead.hits)
+            if mode == "numpy":
+                e2e["draw_ahead_hits"] = int(ctrl.draw_ahead_stats()["hits"])
+                e2e["native_step"] = ctrl._cstep is not None
+                if ctrl._cstep is not None:
+                    e2e["native_step_stage_us"] = {k: round(v, 1) for k, v in ctrl._cstep.stats()["stage_us"].items()}
             if mode == "numpy":
                 # the mode an in-process env sees (n_parallel = 1: samplers/vectorized_env_executor.py:45 ->
                 # envs/mujoco_env.py:85-87 reset noise; samplers/utils.py rollout()): somebody else consumes the global
@@ -298,12 +328,15 @@ def main():
                 def foreign_step():
                     np.random.uniform()
                     ctrl.get_actions(obs_np)
-                hits0 = int(ctrl._ahead.hits) if ctrl._ahead is not None else 0
+                hits0 = int(ctrl.draw_ahead_stats()["hits"])
                 clock_warm()
                 e2e["foreign"] = max_over_ranks(_timed_calls(foreign_step, args.steps, min(args.warmup, 5), sync))
-                e2e["foreign_hits"] = (int(ctrl._ahead.hits) if ctrl._ahead is not None else 0) - hits0
+                e2e["foreign_hits"] = int(ctrl.draw_ahead_stats()["hits"]) - hits0
             if ctrl._ahead is not None:
                 ctrl._ahead.stop()
+            if ctrl._cstep is not None:
+                ctrl._cstep.close()
+                ctrl._cstep = None
 
     # ---- strong scaling of THIS plan (n_glob candidates): rank 0 alone runs the whole plan on its one GPU ------------
     strong = None
@@ -391,6 +424,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
+            "value_strong": round(plan_steps, 3),
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -401,33 +435,45 @@ def main():
                          "reference, upload, fused rollout, arg-max%s, read-back)"
                          % (", int64 MAX all-reduce" if world > 1 else "")) if "numpy" in e2e else
                         "kernel-only: memset + fused rollout over candidates resident in HBM (--no-e2e)",
-                "value_definition": "n_gpus x plan_steps_per_s: 2000-candidate controller steps per second",
+                "value_definition": "value = n_gpus x plan_steps_per_s: 2000-candidate controller steps per second (weak scaling: per-GPU "
+                                    "work fixed); value_strong = plan_steps_per_s = completed plans of n_gpus x 2000 candidates per second - "
+                                    "read both (at N = 1 they coincide)",
                 "candidates_per_plan": n_glob,
                 "plan_steps_per_s": round(plan_steps, 3),
                 "kernel_only_plan_steps_per_s": round(args.steps / resident_s, 3),
                 "kernel_only_ms_per_step": round(1e3 * resident_s / args.steps, 4),
                 "mlp_steps_per_ms": round(world * N_CAND * HORIZON * ENSEMBLE / ms_per_step, 1),
                 "collective": "int64 MAX all-reduce of 1 key per plan step" if world > 1 else "none",
-                "backend": backend, "rccl_ranks": rccl_ranks,
+                "backend": backend, "collective_ranks": collective_ranks,
                 "action_index_match_vs_reference": index_match if e2e_index_match is None else
                                                    bool(index_match and e2e_index_match),
                 "best_index": idx0, "best_return": round(ret0, 4),
                 "host_rng_threads": fast_rng.threads(),
-                "clock_warm": "0.15 s of untimed kernel launches in front of every timed leg (the board's clock ramp)",
+                "clock_warm": "0.15 s of untimed kernel launches in front of every timed leg (the board's clock ramp; since round 4 - "
+                              "BENCH_r01..r03 were measured without it and read 2 - 3 % lower on short runs)",
             },
         }
         if "numpy" in e2e:
             out["config"]["get_actions_parity_plan_steps_per_s"] = round(args.steps / e2e["numpy"], 3)
             out["config"]["draw_ahead_hits"] = e2e.get("draw_ahead_hits")
+            out["config"]["native_step"] = e2e.get("native_step")
+            if e2e.get("native_step_stage_us"):
+                out["config"]["native_step_stage_us"] = e2e["native_step_stage_us"]
+            out["config"]["host_path_us_per_step"] = round(1e3 * (ms_per_step - 1e3 * resident_s / args.steps), 1)
         if "foreign" in e2e:
             out["config"]["get_actions_parity_foreign_draw_plan_steps_per_s"] = round(args.steps / e2e["foreign"], 3)
             out["config"]["foreign_draw_note"] = ("one np.random.uniform() consumed between calls (an in-process env reset): "
                                                   "draw-ahead hits in that loop: %d of %d" % (e2e["foreign_hits"], args.steps))
         if strong is not None:
             out["config"]["strong_scaling"] = strong
+        if collective is not None:
+            out["config"].update(collective)
+        if kern_ms_ranks is not None:
+            out["config"]["kernel_ms_per_rank"] = {"min": round(min(kern_ms_ranks), 4), "max": round(max(kern_ms_ranks), 4),
+                                                   "ranks": [round(v, 4) for v in kern_ms_ranks]}
         if "device" in e2e:
             out["config"]["get_actions_device_rng_plan_steps_per_s"] = round(args.steps / e2e["device"], 3)
-        if kern_ms is not None:
+        if kern_ms is not None and rank == 0:
             # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x 2 correction +
             # WRITE_SIZE, MI355X_MICROARCH.md section HBM); counters cannot be read live.
             traffic, traffic_src = None, None
@@ -454,8 +500,10 @@ def main():
                 "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                 "kernel_ms": round(kern_ms, 4),
-                "kernel_ms_rocprof": None if rocprof_ms is None else round(rocprof_ms, 4),
-                "kernel_ms_rocprof_source": rocprof_src,
+                "kernel_ms_rocprof_committed": None if rocprof_ms is None else round(rocprof_ms, 4),
+                "kernel_ms_rocprof_committed_source": rocprof_src,
+                "kernel_ms_rocprof_committed_note": "NOT from this run: the same kernel's average in the rocprofv3 --kernel-trace --stats "
+                                                    "summary committed under profiles/ (same command, another box and run); kernel_ms is this run's",
                 "flop_per_launch": FLOP_PER_LAUNCH,
                 "hbm_algorithmic_bytes_per_launch": HBM_BYTES_PER_LAUNCH,
                 "hbm_achieved_GBps": round(HBM_BYTES_PER_LAUNCH / (kern_ms * 1e-3) / 1e9, 3),

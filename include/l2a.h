@@ -113,7 +113,10 @@ int l2a_set_xcd_align(l2a_ctx* ctx, int on);
  * plans, run_grbal.py:84-85 / run_rebal.py:77-78: 5 x 500 candidates = 160 tiles on 256 CUs - can run in candidate tiles of
  * FOUR on v_mfma_f32_4x4x1_16b_f32 instead: workgroups of 4, 8 or 12 candidates, every CU busy, no exchange between
  * workgroups.  0 = never; 1 (default) = where it shortens the launch; 2 = whenever the plan is eligible (testing).  The
- * arithmetic is ordered like the 16-candidate kernels': results are bit-identical under all three policies.   */
+ * arithmetic is ordered like the 16-candidate MATRIX-CORE kernels': results are bit-identical under all three policies wherever
+ * policy 0 runs such a kernel.  The one exception: a generic recurrent stack whose 16-candidate matrix-core kernel does not fit
+ * the LDS runs the VALU kernel under policy 0 (and for one-step / predict launches) - a different rounding, so there the
+ * policies, and ranks of a sharded plan whose shard widths select different kernels, agree to the fp32 tolerance only.   */
 int l2a_set_micro(l2a_ctx* ctx, int policy);
 /* Status word of the launches issued since the last call (caller must have synchronised the
  * stream): 0 = fine, bit 0 = a member-split exchange timed out (results are invalid; relaunch
@@ -288,7 +291,8 @@ int l2a_cem_refit(l2a_ctx* ctx, const float* returns, const float* a_clip, int n
 /* l2a_cem_pick: what the plan returns (:106), in one buffer for one read-back: per env the arg-max of the LAST iteration's
  * `returns` [m, n] (first maximum), the first action of that candidate in `cand` - the unclipped samples read as [m, n, D]
  * (reference = 1, :92-96) or the clipped samples [n, m, D] (0) - and its return; behind them the final mean / std.
- * out: m x (act_dim + 2) floats (action | return | index as the bits of an int32), then mean [m, D], std [m, D].       */
+ * out: m x (act_dim + 2) floats (action | return | index as the bits of an int32), then mean [m, D], std [m, D].  NaN
+ * returns are ordered as np.argmax orders them (a NaN is the maximum, the first one wins): a diverged plan reports NaN.  */
 int l2a_cem_pick(l2a_ctx* ctx, const float* returns, const float* cand, const float* mean, const float* std, int n, int m,
                  int D, int act_dim, int reference, float* out, void* stream);
 

@@ -259,7 +259,9 @@ class Context(object):
         self.check(self.lib.l2a_set_batch(self.handle, int(sets)), "l2a_set_batch")
 
     def set_micro(self, policy):
-        """Micro-tile kernels: 0 = never, 1 = where they fill the chip better (default), 2 = whenever eligible (bit-identical)."""
+        """Micro-tile kernels: 0 = never, 1 = where they fill the chip better (default), 2 = whenever eligible.  Bit-identical to
+        the 16-candidate matrix-core kernels; a generic recurrent stack too large for those (policy 0: VALU kernel) agrees to the
+        fp32 tolerance only (include/l2a.h)."""
         self.check(self.lib.l2a_set_micro(self.handle, int(policy)), "l2a_set_micro")
 
     def set_xcd_align(self, on):

@@ -129,7 +129,7 @@ __device__ __forceinline__ void l2a_adapt_reduce2(const f32x4 (&acc)[4], float* 
 // per element - and workgroup 0 of the task publishes A_0 for the update pass and, in raw mode, the normalised target
 // deltas (so that the last forward launch does not cross the bus again).  grid (ceil(n_out / 64), m).
 __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptParams p) {
-    __shared__ float red[L2A_AW - 1][64][L2A_AR + 1];
+    __shared__ float red[L2A_AW * 64 * (L2A_AR + 1)];
     __shared__ float xs[L2A_XS_MAX * L2A_AR];
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     L2A_ATS(0, 0) L2A_ATS_REAL(0, 6)
@@ -139,7 +139,10 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
     const bool live = u < n_out;
     float* sc = p.scratch + (long long)task * p.scratch_stride;
     const float* W = p.w[0] + (live ? u : 0);           // dead lanes read unit 0's column and never store
-    const float bias = (ks == 0 && live) ? p.b[0][u] : 0.0f;       // requested now, used after the reduction
+    // this thread's share of the epilogue (as in the other launches): unit blockIdx.x * 64 + (tid >> 3), rows 2 (tid & 7) + {0, 1};
+    // its bias is requested now, used after the reduction
+    const int ue = blockIdx.x * 64 + (threadIdx.x >> 3), r0 = (threadIdx.x & 7) * 2;
+    const float bias = (ue < n_out) ? p.b[0][ue] : 0.0f;
     const int chunk = (k_in + L2A_AW - 1) / L2A_AW;
     const int k0 = ks * chunk, k1 = (k0 + chunk < k_in) ? k0 + chunk : k_in;
     const float* x = p.x + (long long)task * p.rows * k_in;
@@ -210,20 +213,21 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
         }
     }
     L2A_ATS(0, 2)
-    if (ks > 0) {
+    // the waves' partial chains meet in LDS; every thread sums two outputs over the waves in the fixed order 0 .. 7
 #pragma unroll
-        for (int r = 0; r < L2A_AR; ++r) red[ks - 1][lane][r] = acc[r];
-    }
+    for (int r = 0; r < L2A_AR; ++r) red[(ks * 64 + lane) * (L2A_AR + 1) + r] = acc[r];
     __syncthreads();
     L2A_ATS(0, 3)
-    if (ks != 0 || !live) return;
-    float* dst = sc + p.a_off[1] + u * L2A_AR;
+    if (ue < n_out) {
+        const int ul = threadIdx.x >> 3;
+        float v0 = red[ul * (L2A_AR + 1) + r0], v1 = red[ul * (L2A_AR + 1) + r0 + 1];
 #pragma unroll
-    for (int r = 0; r < L2A_AR; ++r) {
-        float v = acc[r];
-#pragma unroll
-        for (int w = 0; w < L2A_AW - 1; ++w) v += red[w][lane][r];
-        dst[r] = l2a_act1(v + bias, p.hidden_act);
+        for (int w = 1; w < L2A_AW; ++w) {
+            v0 += red[(w * 64 + ul) * (L2A_AR + 1) + r0];
+            v1 += red[(w * 64 + ul) * (L2A_AR + 1) + r0 + 1];
+        }
+        *reinterpret_cast<float2*>(sc + p.a_off[1] + ue * L2A_AR + r0) =
+            make_float2(l2a_act1(v0 + bias, p.hidden_act), l2a_act1(v1 + bias, p.hidden_act));
     }
     L2A_ATS(0, 4) L2A_ATS_REAL(0, 7)
 }
@@ -236,16 +240,16 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
 // tile t (round 5; until then four dword loads per k-step, 640 load instructions per workgroup: 4.3 - 4.8k clocks before the
 // first MFMA could issue); otherwise (the 41-wide output layer) lane (i, q) reads W[k + q][u0 + 16 t + i] per tile.
 // The last layer writes dZ_L = 2 (y_hat - y) / (rows * obs_dim) instead of its output.  grid (ceil(n_out / 64), m).
+// `A`: the layer's input rows [k][16] (global scratch, or LDS when the previous layer was computed by this workgroup); `u0`:
+// first output unit; `dst`: where outputs [u][16] go (global scratch or LDS), indexed by u - dst_u0.
 template <bool VEC>
-__device__ __forceinline__ void l2a_adapt_fwd_body(const L2AAdaptParams& p, const int l, float* red) {
+__device__ __forceinline__ void l2a_adapt_fwd_body(const L2AAdaptParams& p, const int l, float* red, const float* A, const int astride,
+                                                   const int u0, float* dst_base, const int dst_u0) {
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    L2A_ATS(l, 0) L2A_ATS_REAL(l, 6)
     const int task = blockIdx.y;
     const int k_in = p.dims[l], n_out = p.dims[l + 1];
-    const int u0 = blockIdx.x * 64;
     float* sc = p.scratch + (long long)task * p.scratch_stride;
-    const float* A = sc + p.a_off[l];
     const float* W = p.w[l];
     const bool last = (l == p.n_layers - 1);
     // what the epilogue of this thread needs - requested first, consumed last
@@ -282,7 +286,7 @@ __device__ __forceinline__ void l2a_adapt_fwd_body(const L2AAdaptParams& p, cons
             const int k = 4 * (s + j) + q;
             const bool ok = (s + j < s1) && (k < k_in);
             const int kk = ok ? k : 0;
-            b[j] = A[kk * L2A_AR + i16];
+            b[j] = A[kk * astride + i16];
             if (VEC) {
                 a[j] = *reinterpret_cast<const f32x4*>(W + (long long)kk * n_out + ucol[0]);
             } else {
@@ -310,17 +314,25 @@ __device__ __forceinline__ void l2a_adapt_fwd_body(const L2AAdaptParams& p, cons
             const float z = v[c] + bias_e;
             o[c] = last ? ((r0 + c < p.rows) ? scale * (z - y_e[c]) : 0.0f) : l2a_act1(z, p.hidden_act);
         }
-        float* dst = sc + (last ? p.z_off[l + 1] : p.a_off[l + 1]) + ue * L2A_AR + r0;
+        float* dst = dst_base + (ue - dst_u0) * L2A_AR + r0;
         *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
     }
-    L2A_ATS(l, 4) L2A_ATS_REAL(l, 7)
+    L2A_ATS(l, 4)
+}
+
+__device__ __forceinline__ bool l2a_adapt_vec_ok(const L2AAdaptParams& p, int l) {
+    return (p.dims[l + 1] & 3) == 0 && (reinterpret_cast<unsigned long long>(p.w[l]) & 15ull) == 0;
 }
 
 __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd_k(const L2AAdaptParams p, int l) {
     __shared__ float red[L2A_AW * 64 * (L2A_AR + 1)];
-    const int n_out = p.dims[l + 1];
-    if ((n_out & 3) == 0 && (reinterpret_cast<unsigned long long>(p.w[l]) & 15ull) == 0) l2a_adapt_fwd_body<true>(p, l, red);
-    else l2a_adapt_fwd_body<false>(p, l, red);
+    L2A_ATS(l, 0) L2A_ATS_REAL(l, 6)
+    float* sc = p.scratch + (long long)blockIdx.y * p.scratch_stride;
+    const float* A = sc + p.a_off[l];
+    float* dst = sc + ((l == p.n_layers - 1) ? p.z_off[l + 1] : p.a_off[l + 1]);
+    if (l2a_adapt_vec_ok(p, l)) l2a_adapt_fwd_body<true>(p, l, red, A, L2A_AR, blockIdx.x * 64, dst, 0);
+    else l2a_adapt_fwd_body<false>(p, l, red, A, L2A_AR, blockIdx.x * 64, dst, 0);
+    L2A_ATS_REAL(l, 7)
 }
 
 // Where the adapted sets go: the per-block model's weight block (raw reference layout + MFMA fragment order), and
@@ -433,33 +445,19 @@ __device__ __forceinline__ void l2a_adapt_update_block(const L2AAdaptParams& p, 
     }
 }
 
-// Backward through layer l (1 <= l < L) and, beside it, the update of that layer - one launch, grid (S + ceil(B / 2), m):
-//   workgroups x < S = ceil(dims[l] / 64):  dZ_l = (W_l dZ_{l+1}) * act'(A_l) for 64 input units k of layer l on the matrix core,
-//       D[k][row] += W[k][u] dZ[u][row]: lane (i, q) supplies W[k0 + 16 t + i][u + q] (16 weight rows x 16 bytes per load; a
-//       row's line is reused by the next 7 u-steps) and dZ_{l+1}[u + q][i]; the waves split the u-steps.  The workgroups of the
-//       LAST backward launch (l = 1) go on to update their 64 columns of W_0 and b_0 from the dZ_1 they have just computed (a
-//       49 x 64 block each) - no launch is left behind the backward pass.
-//   workgroups x >= S:  two update blocks of layer l each (theta' = theta - lr A_l^T dZ_{l+1}: both operands were complete
-//       before this launch started), on the CUs the 8 x m backward workgroups leave idle.
-// Until round 5 the update of all layers was a launch of its own behind the backward pass (15 of 85 us).
-__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwdu_k(const L2AAdaptParams p, const L2AAdaptDst d, int l) {
-    __shared__ float red[L2A_AW * 64 * (L2A_AR + 1)];
-    const int k_in = p.dims[l], n_out = p.dims[l + 1];
-    const int S = (k_in + 63) / 64;
-    const int task = blockIdx.y;
-    if ((int)blockIdx.x >= S) {
-        const int b = 2 * ((int)blockIdx.x - S) + (int)(threadIdx.x >> 8);
-        if (b < l2a_adapt_update_blocks(p, l)) l2a_adapt_update_block(p, d, l, b, task, (int)(threadIdx.x & 255));
-        return;
-    }
+// dZ_l = (W_l dZ_{l+1}) * act'(A_l) for the 64 input units k0 .. k0 + 63 of layer l (1 <= l < L) on the matrix core:
+// D[k][row] += W[k][u] dZ[u][row]; lane (i, q) supplies W[k0 + 16 t + i][u + q] (hidden layers: 16 weight rows x 16 bytes per
+// load, a row's line reused by the next 7 u-steps) and dZ_{l+1}[u + q][i] from `Z` (global scratch, or LDS when this workgroup
+// computed it); the waves split the u-steps.  Every thread ends up with two outputs (k0 + (tid >> 3), rows 2 (tid & 7) + {0, 1}),
+// stores them to the task's scratch and returns them.
+__device__ __forceinline__ void l2a_adapt_bwd_body(const L2AAdaptParams& p, const int l, float* red, const float* Z, const int k0,
+                                                   const int ph, float (&zout)[2]) {
+    (void)ph;
     const int lane = threadIdx.x & 63, us = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    const int ph = 2 * p.n_layers - 1 - l;      // (timeline slot of this launch)
-    (void)ph;
-    L2A_ATS(ph, 0) L2A_ATS_REAL(ph, 6)
-    const int k0 = blockIdx.x * 64;
+    const int task = blockIdx.y;
+    const int k_in = p.dims[l], n_out = p.dims[l + 1];
     float* sc = p.scratch + (long long)task * p.scratch_stride;
-    const float* Z = sc + p.z_off[l + 1];
     // what this thread's epilogue needs (the activations whose derivative scales its two outputs) - requested first
     const int kl = threadIdx.x >> 3, r0 = (threadIdx.x & 7) * 2;
     const int ke = k0 + kl;
@@ -532,31 +530,61 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwdu_k(const L2AAdaptPa
     float v[2];
     l2a_adapt_reduce2<false>(acc, red, us, lane, v);
     L2A_ATS(ph, 3)
-    const float z_e0 = v[0] * l2a_act_grad_from_output(a_e.x, p.hidden_act);
-    const float z_e1 = v[1] * l2a_act_grad_from_output(a_e.y, p.hidden_act);
-    if (ke_ok) *reinterpret_cast<float2*>(sc + p.z_off[l] + ke * L2A_AR + r0) = make_float2(z_e0, z_e1);
+    zout[0] = v[0] * l2a_act_grad_from_output(a_e.x, p.hidden_act);
+    zout[1] = v[1] * l2a_act_grad_from_output(a_e.y, p.hidden_act);
+    if (ke_ok) *reinterpret_cast<float2*>(sc + p.z_off[l] + ke * L2A_AR + r0) = make_float2(zout[0], zout[1]);
     L2A_ATS(ph, 4)
-    if (l == 1) {
-        // ---- layer 0's update, columns k0 .. k0 + 63, by the workgroup that owns their dZ_1 rows: through LDS (the partials are
-        //      done with), then thread (unit ul = tid & 63, part = tid >> 6) walks the input rows part, part + 8, ...
-        __syncthreads();                        // every thread has read its partial sums
-        float* zs = red;                        // [64][16]
-        if (ke_ok) { zs[kl * L2A_AR + r0] = z_e0; zs[kl * L2A_AR + r0 + 1] = z_e1; }
-        __syncthreads();
-        const int ul = threadIdx.x & 63, part = threadIdx.x >> 6;
-        const int u = k0 + ul;
-        if (u < k_in) {
-            const float4* zp = reinterpret_cast<const float4*>(zs + ul * L2A_AR);
-            const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
-            float* dst = d.blk + (long long)task * d.set_stride;
-            const int k_in0 = p.dims[0];
-            for (int k = part; k < k_in0; k += L2A_AW) {
-                const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[0] + k * L2A_AR);
-                const float g = l2a_adapt_grad(a[0], a[1], a[2], a[3], z0, z1, z2, z3);
-                l2a_adapt_put(p, d, dst, 0, k, u, p.w[0][(long long)k * k_in + u] - d.lr * g);
-            }
-            if (part == 0) dst[d.raw_b[0] + u] = p.b[0][u] - d.lr * l2a_adapt_bias_grad(z0, z1, z2, z3);
-        }
+}
+
+// Layer 0's update, columns k0 .. k0 + 63, by the workgroup that has just computed their dZ_1 rows (`zout`: the thread's two
+// values): through LDS (the partial sums in `red` are done with), then thread (unit = tid & 63, part = tid >> 6) walks the
+// input rows part, part + 8, ...
+__device__ __forceinline__ void l2a_adapt_update0_cols(const L2AAdaptParams& p, const L2AAdaptDst& d, float* red, const int k0,
+                                                       const float (&zout)[2]) {
+    const int task = blockIdx.y;
+    const int n1 = p.dims[1], k_in0 = p.dims[0];
+    const float* sc = p.scratch + (long long)task * p.scratch_stride;
+    const int kl = threadIdx.x >> 3, r0 = (threadIdx.x & 7) * 2;
+    __syncthreads();                        // every thread has read its partial sums
+    float* zs = red;                        // [64][16]
+    zs[kl * L2A_AR + r0] = zout[0];
+    zs[kl * L2A_AR + r0 + 1] = zout[1];
+    __syncthreads();
+    const int ul = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int u = k0 + ul;
+    if (u >= n1) return;
+    const float4* zp = reinterpret_cast<const float4*>(zs + ul * L2A_AR);
+    const float4 z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
+    float* dst = d.blk + (long long)task * d.set_stride;
+    for (int k = part; k < k_in0; k += L2A_AW) {
+        const float4* a = reinterpret_cast<const float4*>(sc + p.a_off[0] + k * L2A_AR);
+        const float g = l2a_adapt_grad(a[0], a[1], a[2], a[3], z0, z1, z2, z3);
+        l2a_adapt_put(p, d, dst, 0, k, u, p.w[0][(long long)k * n1 + u] - d.lr * g);
     }
+    if (part == 0) dst[d.raw_b[0] + u] = p.b[0][u] - d.lr * l2a_adapt_bias_grad(z0, z1, z2, z3);
+}
+
+// Backward through layer l (1 <= l < L) and, beside it, the update of that layer - one launch, grid (S + ceil(B / 2), m):
+//   workgroups x < S = ceil(dims[l] / 64):  dZ_l for 64 input units of layer l (l2a_adapt_bwd_body).  The workgroups of the LAST
+//       backward launch (l = 1) go on to update their 64 columns of W_0 and b_0 from the dZ_1 they have just computed (a 49 x 64
+//       block each) - no launch is left behind the backward pass.
+//   workgroups x >= S:  two update blocks of layer l each (theta' = theta - lr A_l^T dZ_{l+1}: both operands were complete
+//       before this launch started), on the CUs the 8 x m backward workgroups leave idle.
+// Until round 5 the update of all layers was a launch of its own behind the backward pass (15 of 85 us).
+__global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_bwdu_k(const L2AAdaptParams p, const L2AAdaptDst d, int l) {
+    __shared__ float red[L2A_AW * 64 * (L2A_AR + 1)];
+    const int S = (p.dims[l] + 63) / 64;
+    const int task = blockIdx.y;
+    if ((int)blockIdx.x >= S) {
+        const int b = 2 * ((int)blockIdx.x - S) + (int)(threadIdx.x >> 8);
+        if (b < l2a_adapt_update_blocks(p, l)) l2a_adapt_update_block(p, d, l, b, task, (int)(threadIdx.x & 255));
+        return;
+    }
+    const int ph = 2 * p.n_layers - 1 - l;      // (timeline slot of this launch)
+    L2A_ATS(ph, 0) L2A_ATS_REAL(ph, 6)
+    const float* Z = p.scratch + (long long)task * p.scratch_stride + p.z_off[l + 1];
+    float zout[2];
+    l2a_adapt_bwd_body(p, l, red, Z, blockIdx.x * 64, ph, zout);
+    if (l == 1) l2a_adapt_update0_cols(p, d, red, blockIdx.x * 64, zout);
     L2A_ATS_REAL(ph, 7)
 }

@@ -745,15 +745,15 @@ int adapt_enqueue(l2a_model* md, const L2AAdaptParams& ap, int m, float lr, hipS
             else d.pk[l] = md->pk_wout;
         }
     }
-    hipLaunchKernelGGL(l2a_adapt_fwd0_k, dim3((unsigned)((ap.dims[1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0, stream, ap);
+    const dim3 block(64 * L2A_AW);
+    auto slices = [&](int dim) { return (unsigned)((dim + 63) / 64); };
+    hipLaunchKernelGGL(l2a_adapt_fwd0_k, dim3(slices(ap.dims[1]), (unsigned)m), block, 0, stream, ap);
     for (int l = 1; l < L; ++l)
-        hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3((unsigned)((ap.dims[l + 1] + 63) / 64), (unsigned)m), dim3(64 * L2A_AW), 0,
-                           stream, ap, l);
+        hipLaunchKernelGGL(l2a_adapt_fwd_k, dim3(slices(ap.dims[l + 1]), (unsigned)m), block, 0, stream, ap, l);
     // backward through layer l beside the update of layer l; the last of them (l = 1) also updates layer 0
     for (int l = L - 1; l >= 1; --l) {
         const int ub = ((ap.dims[l + 1] + 255) / 256) * ((ap.dims[l] + L2A_UK - 1) / L2A_UK);
-        hipLaunchKernelGGL(l2a_adapt_bwdu_k, dim3((unsigned)((ap.dims[l] + 63) / 64 + (ub + 1) / 2), (unsigned)m), dim3(64 * L2A_AW), 0,
-                           stream, ap, d, l);
+        hipLaunchKernelGGL(l2a_adapt_bwdu_k, dim3(slices(ap.dims[l]) + (unsigned)((ub + 1) / 2), (unsigned)m), block, 0, stream, ap, d, l);
     }
     L2A_HIP(ctx, hipGetLastError());
     return L2A_OK;

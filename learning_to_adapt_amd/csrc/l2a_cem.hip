@@ -180,9 +180,19 @@ __global__ void __launch_bounds__(256) l2a_cem_stats_k(const float* a_clip, cons
     }
 }
 
+// np.argmax's order (the reference's `np.argmax(returns, axis=1)`, mpc_controller.py:128-129): a NaN is the maximum, the first
+// NaN wins; otherwise the largest value, ties to the lowest index.  A diverged rollout therefore surfaces as a NaN best return
+// exactly as it does in the reference, instead of a finite-looking action.
+__device__ __forceinline__ bool l2a_argmax_better(float x, int c, float best, int idx) {
+    const bool xn = x != x, bn = best != best;
+    if (xn != bn) return xn;
+    if (xn) return c < idx;
+    return x > best || (x == best && c < idx);
+}
+
 // The plan's result in ONE buffer (one read-back instead of five launches and five copies): per env the arg-max of its
-// returns (first maximum, NaN never wins - np.argmax would return a NaN's index; a plan with NaN returns has no meaning
-// either way), the first action of that candidate as the rollout saw it, its return; behind them the final mean / std.
+// returns (np.argmax's order, NaN included), the first action of that candidate as the rollout saw it, its return; behind them
+// the final mean / std.
 // out: [m][act_dim + 2] floats (action | return | index as the bit pattern of an int32), then mean [m, D], std [m, D].
 // grid (m + ceil(2 m D / 256)): block i < m is env i.
 __global__ void __launch_bounds__(256) l2a_cem_pick_k(const float* returns, const float* cand, const float* mean, const float* std,
@@ -201,14 +211,14 @@ __global__ void __launch_bounds__(256) l2a_cem_pick_k(const float* returns, cons
     int idx = 0x7fffffff;
     for (int c = threadIdx.x; c < n; c += 256) {
         const float x = returns[(long long)i * n + c];
-        if (x > best || (x == best && c < idx)) { best = x; idx = c; }
+        if (l2a_argmax_better(x, c, best, idx)) { best = x; idx = c; }
     }
     bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) {
             const float x = bv[threadIdx.x + s]; const int c = bi[threadIdx.x + s];
-            if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && c < bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = c; }
+            if (l2a_argmax_better(x, c, bv[threadIdx.x], bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = c; }
         }
         __syncthreads();
     }

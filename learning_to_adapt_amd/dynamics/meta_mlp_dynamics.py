@@ -81,6 +81,8 @@ class MetaMLPDynamicsModel(Serializable):
         self._params_dev = None          # (list identity, device, device copies) of self._params
         self._adapted_stacked = None     # adapted sets stacked along a leading axis (batched adapt)
         self.use_native_adapt = True     # False: inner step with stock PyTorch autograd even on the GPU
+        self._cuda_ok = None             # torch.cuda.is_available(), asked once (2 - 4 us a call, on every adapt otherwise)
+        self._adapt_stage = None         # float64 arrays the sampler's lists are stacked into
         self._adapted_norm_of = None     # (native model, normalization) whose vectors are already uploaded
         self._adapted_param_values = None
         self._num_adapted_models = 0
@@ -206,27 +208,33 @@ class MetaMLPDynamicsModel(Serializable):
         ``[adapt_batch_size, dim]`` (``samplers/sampler.py:81-90``)."""
         self._num_adapted_models = len(obs)
         assert len(obs) == len(act) == len(obs_next)
-        dev = core.training_device()
         xs = ys = None
-        uniform = len({np.shape(o) for o in obs}) == 1
-        if (uniform and self.normalize_input and 1 <= np.shape(obs[0])[0] <= 16 and self._native_adapt_ok(None)
+        shape0 = np.shape(obs[0])
+        uniform = all(np.shape(o) == shape0 for o in obs)
+        if (uniform and self.normalize_input and len(shape0) == 2 and 1 <= shape0[0] <= 16 and self._native_adapt_ok(None)
                 and self.obs_space_dims + self.action_space_dims <= 128):
             # the sampler's case on a GPU: raw float64 transitions straight to the library, which normalises them on
             # the device with the host's own arithmetic (l2a_model_adapt_sgd_raw) - the host only stacks and copies
-            ob = np.asarray(obs, dtype=np.float64)
-            ac = np.asarray(act, dtype=np.float64)
-            ob_next = np.asarray(obs_next, dtype=np.float64)
-            assert ob.ndim == 3 and ob.shape[2] == self.obs_space_dims
-            assert ac.ndim == 3 and ac.shape[2] == self.action_space_dims
-            assert ob_next.shape == ob.shape and ac.shape[:2] == ob.shape[:2]
-            native = self._adapted_handle(len(obs))
+            # (into arrays kept from step to step: this preamble sits in front of the step's first launch)
+            m, rows = len(obs), shape0[0]
+            st = self._adapt_stage
+            if st is None or st[0].shape[:2] != (m, rows):
+                st = self._adapt_stage = (np.empty((m, rows, self.obs_space_dims)), np.empty((m, rows, self.action_space_dims)),
+                                          np.empty((m, rows, self.obs_space_dims)))
+            ob, ac, ob_next = st
+            assert shape0[1] == self.obs_space_dims
+            np.concatenate(obs, out=ob.reshape(m * rows, -1))               # raises on any other shape / a mismatch between the lists
+            np.concatenate(act, out=ac.reshape(m * rows, -1))
+            np.concatenate(obs_next, out=ob_next.reshape(m * rows, -1))
+            native = self._adapted_handle(m)
             native.adapt_sgd_raw(self._device_params(native.device), ob, ac, ob_next, self._norm(),
                                  self.inner_learning_rate)
             self._adapted_stacked = None
             self._prev_params = self._params      # parameter tensors are never modified in place
-            self._adapted_param_values = _ResidentSets(native, len(obs))
+            self._adapted_param_values = _ResidentSets(native, m)
             self._adapted_dirty = True
             return
+        dev = core.training_device()
         if uniform:
             # equal batches (the sampler's case): all tasks normalised in one pass - the same float64 arithmetic per
             # element as the per-task loop below, a dozen NumPy calls instead of thirty (0.1 ms of a 2.7 ms step)
@@ -323,7 +331,11 @@ class MetaMLPDynamicsModel(Serializable):
     def _native_adapt_ok(self, xs):
         """The fused device path needs a GPU, equal batches of at most 16 rows (``xs`` = None: the caller has checked
         that), an identity output layer and a hidden nonlinearity whose derivative follows from its output."""
-        if not (self.use_native_adapt and torch.cuda.is_available()):
+        if not self.use_native_adapt:
+            return False
+        if self._cuda_ok is None:
+            self._cuda_ok = bool(torch.cuda.is_available())
+        if not self._cuda_ok:
             return False
         if xs is not None:
             rows = {x.shape[0] for x in xs}

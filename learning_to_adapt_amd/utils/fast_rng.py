@@ -134,18 +134,18 @@ def global_digest(with_gauss=False):
     the cached second value of the legacy polar Gaussian is folded in as well - planners that draw normals (CEM in parity
     mode) would otherwise combine returns of different samples when only that cache differs."""
     h = None
-    if available("direct"):
-        addr = _global_addr()
-        if addr is not None:
-            with _global_lock():
-                h = int(_state["lib"].l2a_mt19937_state_digest(addr))
     st = None
+    addr = _global_addr() if available("direct") else None
+    with _global_lock():            # ONE consistent view: key, position and the Gaussian cache read under the generator's own lock
+        if addr is not None:        # (every NumPy draw holds it; get_state itself does not take it)
+            h = int(_state["lib"].l2a_mt19937_state_digest(addr))
+        if h is None or with_gauss:
+            st = np.random.get_state()      # copies the 624 words: CEM in parity mode only (one call per plan step beside ~15 ms)
     if h is None:
-        st = np.random.get_state()
+        # no helper library: the same FNV-1a in Python, a sequential 625-word loop (~100 us per step - the price of planning
+        # sharded without libl2a_rng.so, which then also draws with NumPy's own loop)
         h = _fnv1a_words(_FNV_OFFSET, list(np.asarray(st[1], dtype=np.uint32)) + [int(st[2]) & 0xFFFFFFFF])
     if with_gauss:
-        if st is None:
-            st = np.random.get_state()
         g = np.float64(st[4]).view(np.uint64)
         h = _fnv1a_words(h, [int(st[3]) & 0xFFFFFFFF, int(g) & 0xFFFFFFFF, int(g) >> 32])
     return h & 0x7FFFFFFFFFFF

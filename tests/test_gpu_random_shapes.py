@@ -220,7 +220,8 @@ def test_random_recurrent_micro_tile_shapes_match_valu(seed):
     ctx = _lib.Context.get(0)
     got = {}
     try:
-        # ("auto": a stack whose 16-candidate matrix-core kernel does not fit the LDS runs the VALU kernel under every policy)
+        # ("auto" with policy 0: a stack whose 16-candidate matrix-core kernel does not fit the LDS runs the VALU kernel; the
+        #  micro-tile kernel still takes it under policies 1 / 2 - hence tolerances here, not bit identity)
         for name, kernel, micro in (("micro", "auto", 2), ("tiles16", "auto", 0), ("valu", "valu", 0)):
             if name == "valu" and m * n * h > 12000:
                 continue

@@ -379,3 +379,23 @@ def test_c_chain_in_a_forked_child_starts_idle():
     assert os.WEXITSTATUS(status) == 0
     assert ch.take() >= 0                       # the parent's chain is untouched
     ch.close()
+
+
+def test_helper_threads_are_divided_among_the_ranks_of_one_host(monkeypatch):
+    """Eight ranks of a torch.distributed.run launch on one host (`LOCAL_WORLD_SIZE`) share its cores: the helper's thread count
+    per rank is half of this process' CPUs divided by the ranks, capped at 8 - never 8 x 8 draw threads + 8 producers on 16 cores."""
+    import os
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    monkeypatch.delenv("L2A_RNG_THREADS", raising=False)
+    seen = {}
+    for local in (1, 2, 8, 64):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(local))
+        monkeypatch.setitem(fast_rng._state, "threads", None)
+        seen[local] = fast_rng.threads()
+        assert seen[local] == max(1, min(8, ncpu // (2 * local)))
+        assert seen[local] * local <= max(local, ncpu // 2) or seen[local] == 1
+    assert seen[1] >= seen[2] >= seen[8] >= seen[64] >= 1
+    monkeypatch.setenv("L2A_RNG_THREADS", "3")
+    monkeypatch.setitem(fast_rng._state, "threads", None)
+    assert fast_rng.threads() == 3
+    monkeypatch.setitem(fast_rng._state, "threads", None)

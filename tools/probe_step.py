@@ -146,5 +146,7 @@ if __name__ == "__main__":
     for a in sys.argv[1:]:
         if a.startswith("--calls="):
             calls = int(a.split("=")[1])
+        if a.startswith("--switch="):       # CPython's GIL switch interval (seconds; default 0.005) - for the Python path's tail
+            sys.setswitchinterval(float(a.split("=")[1]))
     for w in (args or ["c2", "rebal", "grbal", "mbmpc"]):
         run(w, calls)

@@ -61,7 +61,7 @@ nm.adapt_sgd(base, xd, yd, 0.01)
 torch.cuda.synchronize()
 ctx.check(ctx.lib.l2a_set_debug_buffer(ctx.handle, ctypes.c_void_p(0)), "dbg")
 d = dbg[:512].view(8, 8, 8).cpu().numpy().astype(np.int64)
-names = ["fwd0", "fwd1", "fwd2", "fwd3 (out, dZ_L)", "bwd3 | upd3", "bwd2 | upd2", "bwd1 | upd1, upd0", "-"]
+names = ["fwd0 + fwd1", "fwd1", "fwd2", "fwd3 (out, dZ_L)", "fwd3 + bwd3 + upd3", "bwd2 | upd2", "bwd1 | upd1, upd0", "-"]
 print("adaptation, 5 tasks x 16 rows, 3 x 512%s: workgroup (0, 0), wave 0; clocks (us by the 100 MHz clock)" % (", plan between adaptations" if cold else ", back to back"))
 t_first = d[0, 0, 6]
 prev_end = None
