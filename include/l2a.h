@@ -409,6 +409,15 @@ int l2a_lstm_plan_rs_chunk(l2a_lstm* model, const float* state, const float* c, 
 int l2a_lstm_predict(l2a_lstm* model, const float* obs, const float* act, const float* c, const float* h,
                      int rows, float* next_obs_out, float* c_out, float* h_out, void* stream);
 
+/* The controller's OWN state step - `_, self._hidden_state = self.dynamics_model.predict(observations, actions,
+ * self._hidden_state)` (rnn_mpc_controller.py:63), whose predicted observation the caller discards: c_out / h_out [rows, state
+ * width] from obs [rows, obs_dim], act [rows, act_dim] (the chosen actions), c / h (all device fp32; the outputs must not alias
+ * the inputs).  For one LSTM layer a dedicated small-rows kernel (the gate matrix cut over units / 16 workgroups, no output
+ * layer) - the launch l2a_lstm_plan_rs_sync enqueues behind its plan; other cells take one step of their rollout kernel
+ * (rows <= 64).  Agrees with l2a_lstm_predict's states to fp32 rounding (another summation order), not bit for bit.           */
+int l2a_lstm_advance(l2a_lstm* model, const float* obs, const float* act, const float* c, const float* h, int rows,
+                     float* c_out, float* h_out, void* stream);
+
 /* 1 when (obs_dim, act_dim, units) is eligible for the MFMA LSTM kernel, else 0.                 */
 int l2a_lstm_mfma_eligible(int obs_dim, int act_dim, int units);
 

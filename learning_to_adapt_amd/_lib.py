@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = (
     "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best", "l2a_plan_payload",
     "l2a_cem_sample", "l2a_cem_refit", "l2a_cem_pick",
     "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_sync", "l2a_lstm_plan_rs_chunk",
-    "l2a_lstm_predict", "l2a_lstm_mfma_eligible",
+    "l2a_lstm_predict", "l2a_lstm_advance", "l2a_lstm_mfma_eligible",
     "l2a_controller_create", "l2a_lstm_controller_create", "l2a_controller_destroy", "l2a_controller_step",
     "l2a_lstm_controller_step", "l2a_controller_rearm", "l2a_controller_actions", "l2a_controller_stats",
 )
@@ -171,6 +171,9 @@ def load():
     lib.l2a_lstm_plan_rs_chunk.restype = i32
     lib.l2a_lstm_predict.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.l2a_lstm_predict.restype = i32
+    if hasattr(lib, "l2a_lstm_advance"):
+        lib.l2a_lstm_advance.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
+        lib.l2a_lstm_advance.restype = i32
     if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_plan_payload"):
         pass                                               # developer A/B against a library of an earlier round
     else:

@@ -154,35 +154,47 @@ __global__ void __launch_bounds__(64 * L2A_AW) l2a_adapt_fwd0_k(const L2AAdaptPa
 #pragma unroll
         for (int j = 0; j < CH; ++j) wv[j] = (k0 + j < k1) ? W[(long long)(k0 + j) * n_out] : 0.0f;
         const int od = p.obs_dim, ad = p.act_dim;
-        for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) {      // x in its own order: coalesced
-            const int r = i / k_in, kk = i - r * k_in;
-            float v = 0.0f;
-            if (r < p.rows) {
-                if (p.raw_obs) {
+        if (p.raw_obs) {
+            // raw mode: the batch and the normalisation vectors sit in HOST-mapped staging - every load is a bus round trip
+            // (~2.5 us).  ALL of a thread's loads are issued before the first is used: one round trip per workgroup, where the
+            // loops below (one element at a time, x then y) took up to four in a row (15 us for this launch, round 5: ~9)
+            constexpr int NX = (L2A_XS_MAX * L2A_AR + 64 * L2A_AW - 1) / (64 * L2A_AW);      // 4 elements of x per thread at most
+            double xr[NX], xm[NX], xd[NX], yn[NX], yo[NX], ym[NX], yd[NX];
+            const int n_y = p.dims[p.n_layers];
+            const bool do_y = blockIdx.x == 0;
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                const int i = threadIdx.x + q * 64 * L2A_AW;
+                const int r = i / k_in, kk = i - r * k_in;
+                xr[q] = 0.0; xm[q] = 0.0; xd[q] = 1.0;
+                if (i < k_in * L2A_AR && r < p.rows) {
                     const bool is_obs = kk < od;
-                    const double raw = is_obs ? p.raw_obs[((long long)task * p.rows + r) * od + kk]
-                                              : p.raw_act[((long long)task * p.rows + r) * ad + (kk - od)];
-                    const double mu = is_obs ? p.raw_norm[kk] : p.raw_norm[2 * od + (kk - od)];
-                    const double sd = is_obs ? p.raw_norm[od + kk] : p.raw_norm[2 * od + ad + (kk - od)];
-                    v = (float)((raw - mu) / (sd + 1e-10));
-                } else {
-                    v = x[i];
+                    xr[q] = is_obs ? p.raw_obs[((long long)task * p.rows + r) * od + kk] : p.raw_act[((long long)task * p.rows + r) * ad + (kk - od)];
+                    xm[q] = is_obs ? p.raw_norm[kk] : p.raw_norm[2 * od + (kk - od)];
+                    xd[q] = is_obs ? p.raw_norm[od + kk] : p.raw_norm[2 * od + ad + (kk - od)];
+                }
+                const int ry = i / n_y, uy = i - ry * n_y;
+                yn[q] = 0.0; yo[q] = 0.0; ym[q] = 0.0; yd[q] = 1.0;
+                if (do_y && i < n_y * L2A_AR && ry < p.rows) {
+                    const long long e = ((long long)task * p.rows + ry) * n_y + uy;
+                    yn[q] = p.raw_next[e]; yo[q] = p.raw_obs[e];
+                    ym[q] = p.raw_norm[2 * od + 2 * ad + uy]; yd[q] = p.raw_norm[3 * od + 2 * ad + uy];
                 }
             }
-            xs[kk * L2A_AR + r] = v;
-        }
-        if (blockIdx.x == 0 && p.raw_obs) {
-            // normalised target deltas, float64 like the host would compute them, [u][r] in the task's scratch
-            const int n_y = p.dims[p.n_layers];
-            for (int i = threadIdx.x; i < n_y * L2A_AR; i += blockDim.x) {
-                const int r = i / n_y, uu = i - r * n_y;
-                float y = 0.0f;
-                if (r < p.rows) {
-                    const long long e = ((long long)task * p.rows + r) * n_y + uu;
-                    const double delta = p.raw_next[e] - p.raw_obs[e];
-                    y = (float)((delta - p.raw_norm[2 * od + 2 * ad + uu]) / (p.raw_norm[3 * od + 2 * ad + uu] + 1e-10));
-                }
-                sc[p.y_off + uu * L2A_AR + r] = y;
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                const int i = threadIdx.x + q * 64 * L2A_AW;
+                const int r = i / k_in, kk = i - r * k_in;
+                // (v - mean) / (std + 1e-10) in float64, then the cast: the host's arithmetic (mlp_dynamics.py:265-266)
+                if (i < k_in * L2A_AR) xs[kk * L2A_AR + r] = (r < p.rows) ? (float)((xr[q] - xm[q]) / (xd[q] + 1e-10)) : 0.0f;
+                const int ry = i / n_y, uy = i - ry * n_y;
+                if (do_y && i < n_y * L2A_AR)
+                    sc[p.y_off + uy * L2A_AR + ry] = (ry < p.rows) ? (float)(((yn[q] - yo[q]) - ym[q]) / (yd[q] + 1e-10)) : 0.0f;
+            }
+        } else {
+            for (int i = threadIdx.x; i < k_in * L2A_AR; i += blockDim.x) {      // x in its own order: coalesced
+                const int r = i / k_in, kk = i - r * k_in;
+                xs[kk * L2A_AR + r] = (r < p.rows) ? x[i] : 0.0f;
             }
         }
         __syncthreads();

@@ -119,7 +119,7 @@ int choose_nt(const l2a_model* md, int m, int n, int e_loop, int sa_bytes_nt2, i
     // n = 8000: 2.51 against 2.13 ms, config 4's 16 000 candidates: 3.53 against 3.50 ms per 10 steps (profiles/r04_ab_nt.jsonl)
     // - and so do the 49 - 64-dimensional observations at width 256.  Those shapes run NT = 1 (whole rounds + a shared tail);
     // the (2, 8) instances are no longer built.
-    if (md->TPW >= 8 || md->OT >= 4) return 1;
+    if (md->TPW >= 8 || md->OT >= 4) return 1;      // (no NT = 2 instance exists for OT >= 4: l2a_mfma_inst.hip)
     static const int force_nt = [] { const char* e = std::getenv("L2A_FORCE_NT"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
     if (force_nt) return force_nt;      // developer A/B (tools/ab_nt.py)
     const long long wg1 = (long long)m * ceil_div(n, 16);

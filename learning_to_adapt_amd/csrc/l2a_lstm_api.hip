@@ -254,6 +254,30 @@ int launch(l2a_lstm* md, L2ALstmParams& p, void* stream_v, bool allow_split = tr
     return L2A_OK;
 }
 
+// The controller's own state step on the small-rows kernel (single LSTM layer, units a multiple of 16): see l2a_lstm_advance_k.
+bool advance_kernel_ok(const l2a_lstm* md) {
+    return !md->generic && (md->units % 16) == 0 && md->units >= 16 && md->ctx->kernel_kind != L2A_KERNEL_VALU &&
+           (md->in_dim + md->units) * L2A_ADV_ROWS * 4 + 4 * 64 * L2A_ADV_ROWS * 4 <= 64 * 1024;
+}
+
+int launch_advance(l2a_lstm* md, const float* obs, const float* act, const unsigned long long* best_key, const float* actions, int n,
+                   int cand_offset, const float* c0, const float* h0, float* c1, float* h1, int m, hipStream_t stream) {
+    l2a_ctx* ctx = md->ctx;
+    if (!md->weights_set) return l2a_fail(ctx, L2A_ESTATE, "LSTM weights were never set");
+    if (!md->norm_set) return l2a_fail(ctx, L2A_ESTATE, "LSTM normalisation was never set");
+    L2ALstmAdvParams a;
+    std::memset(&a, 0, sizeof(a));
+    a.wblk = md->wblk; a.raw_wk = md->raw_wk; a.raw_bk = md->raw_bk; a.nm_off = md->nm_off;
+    a.obs_dim = md->obs_dim; a.act_dim = md->act_dim; a.in_dim = md->in_dim; a.units = md->units; a.KG0 = md->KG0;
+    a.cell_act = md->cell_act;
+    a.obs = obs; a.act = act; a.best_key = best_key; a.actions = actions; a.n = n; a.cand_offset = cand_offset;
+    a.c0 = c0; a.h0 = h0; a.c1 = c1; a.h1 = h1; a.m = m;
+    const int smem = (md->in_dim + md->units) * L2A_ADV_ROWS * 4 + 4 * 64 * L2A_ADV_ROWS * 4;
+    hipLaunchKernelGGL(l2a_lstm_advance_k, dim3((unsigned)(md->units / 16)), dim3(256), smem, stream, a);
+    L2A_HIP(ctx, hipGetLastError());
+    return L2A_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -619,9 +643,13 @@ int l2a_lstm_plan_rs_sync_hook(l2a_lstm* md, const float* obs_host, const float*
     }
     ctx->stamps_us[1] = l2a_now_us();
     rc = launch(md, p, stream_v);
-    if (rc == L2A_OK && c_next) {
-        // the controller's own state moves on with the chosen action (rnn_mpc_controller.py:63) - in stream order
-        // behind the plan, without waiting for the host to learn the arg-max
+    if (rc == L2A_OK && c_next && advance_kernel_ok(md)) {
+        // the controller's own state moves on with the chosen action (rnn_mpc_controller.py:63) - in stream order behind the
+        // plan, without waiting for the host to learn the arg-max: ONE small launch that gathers the winners' first actions
+        // through the keys and spreads the gate matrix over units / 16 workgroups (l2a_lstm_advance_k)
+        rc = launch_advance(md, tk.obs_dev, nullptr, tk.keys_dev, actions, n, cand_offset, c0, h0, c_next, h_next, m, stream);
+    } else if (rc == L2A_OK && c_next) {
+        // generic cells / stacks: a gather launch and a one-step launch of the rollout kernel
         float* act_sel = md->adv_buf;
         float* obs_next = md->adv_buf + (size_t)L2A_MAIL_KEYS * md->act_dim;
         hipLaunchKernelGGL(l2a_gather_best_k, dim3((unsigned)m), dim3(64), 0, stream, tk.keys_dev, actions, m, n, cand_offset,
@@ -680,6 +708,29 @@ int l2a_lstm_plan_rs_chunk(l2a_lstm* md, const float* state, const float* c, con
     p.disc0 = d0;
     p.m = m; p.n = n; p.h = h_chunk; p.cand_offset = cand_offset; p.discount = discount; p.rw = *reward;
     return launch(md, p, stream_v);
+}
+
+int l2a_lstm_advance(l2a_lstm* md, const float* obs, const float* act, const float* c, const float* h, int rows,
+                     float* c_out, float* h_out, void* stream_v) {
+    if (!md) return L2A_EINVAL;
+    l2a_ctx* ctx = md->ctx;
+    if (!obs || !act || !c || !h || !c_out || !h_out) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_advance: null pointer");
+    if (rows < 1) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_advance: rows must be >= 1");
+    if (c_out == c || h_out == h) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_advance: the next state must not alias the current one");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    l2a_device_guard guard(ctx->device);
+    if (advance_kernel_ok(md)) return launch_advance(md, obs, act, nullptr, nullptr, 0, 0, c, h, c_out, h_out, rows, stream);
+    // generic cells / stacks (and the VALU kernel when asked for): one step of the rollout kernel, the predicted observation dropped
+    if ((long long)rows > L2A_MAIL_KEYS) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_advance: at most 64 rows (use l2a_lstm_predict)");
+    if (!md->adv_buf)
+        L2A_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&md->adv_buf), sizeof(float) * L2A_MAIL_KEYS * (md->act_dim + md->obs_dim)));
+    L2ALstmParams p;
+    fill(md, p);
+    p.obs0 = obs; p.c0 = c; p.h0 = h; p.actions = act;
+    p.state_out = md->adv_buf + (size_t)L2A_MAIL_KEYS * md->act_dim; p.c_out = c_out; p.h_out = h_out;
+    p.obs_per_row = 1; p.hid_per_row = 1;
+    p.m = 1; p.n = rows; p.h = 1; p.discount = 1.0;
+    return launch(md, p, stream_v, false);
 }
 
 int l2a_lstm_predict(l2a_lstm* md, const float* obs, const float* act, const float* c, const float* h, int rows,

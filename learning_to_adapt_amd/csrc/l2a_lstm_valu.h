@@ -149,3 +149,119 @@ __global__ void __launch_bounds__(256) l2a_lstm_valu_k(const L2ALstmParams p) {
         if (tid == 0 && key != 0ull) atomicMax(p.best_key + env, key);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// The controller's own state step (policies/rnn_mpc_controller.py:63: `_, self._hidden_state = dynamics_model.predict(obs,
+// chosen actions, hidden)`) for the few rows a controller has (one per env): c', h' only - the predicted observation is thrown
+// away by the caller - and the kernel's 4 U columns cut over U / 16 workgroups, each streaming its 64 columns of all K = in + U
+// rows (72 KB at U = 256).  Until round 5 this was a one-tile launch of the 16-candidate rollout kernel (ONE workgroup streaming
+// the whole 1.1 MB gate matrix and the output layer: 24 us) behind a gather launch (5 us) - 29 us of a 210 us ReBAL step.
+// The first actions come either as [m, act_dim] rows (`act`) or are gathered here from the plan's candidate tensor through the
+// arg-max keys (`best_key`; l2a_gather_best_k's clamped index).  Thread (column c = tid & 63 -> gate c >> 4, unit u0 + (c & 15);
+// k quarter tid >> 6); rows in chunks of eight; the quarters' partial sums meet in LDS in the order 0 .. 3.
+// ------------------------------------------------------------------------------------------
+struct L2ALstmAdvParams {
+    const float* wblk;
+    long long raw_wk, raw_bk, nm_off;
+    int obs_dim, act_dim, in_dim, units, KG0, cell_act;
+    const float* obs;                       // [m, obs_dim] (device or host-mapped)
+    const float* act;                       // [m, act_dim] or null
+    const unsigned long long* best_key;     // gather form: keys [m], candidate tensor `actions` (step 0: [m * n, act_dim])
+    const float* actions;
+    int n, cand_offset;
+    const float* c0;
+    const float* h0;
+    float* c1;
+    float* h1;
+    int m;
+};
+
+#define L2A_ADV_ROWS 8
+__global__ void __launch_bounds__(256) l2a_lstm_advance_k(const L2ALstmAdvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char l2a_smem[];
+    const int U = p.units, K = p.in_dim + U;
+    float* xs = reinterpret_cast<float*>(l2a_smem);             // [K][8]
+    float* ps = xs + K * L2A_ADV_ROWS;                          // [4][64][8]
+    const int tid = threadIdx.x;
+    const int col = tid & 63, kp = tid >> 6;
+    const int g = col >> 4, j = col & 15;
+    const int u0 = blockIdx.x * 16;
+    const float* wk = p.wblk + p.raw_wk + (long long)g * U + u0 + j;
+    const float* bk = p.wblk + p.raw_bk;
+    const float* in_mu = p.wblk + p.nm_off;
+    const float* in_iv = in_mu + 16 * p.KG0;
+    const int Kq = (K + 3) / 4;
+    const int k0 = kp * Kq, k1 = (k0 + Kq < K) ? k0 + Kq : K;
+    for (int r0 = 0; r0 < p.m; r0 += L2A_ADV_ROWS) {
+        for (int i = tid; i < K * L2A_ADV_ROWS; i += 256) {
+            const int k = i >> 3, r = i & 7;
+            const int row = r0 + r;
+            float v = 0.0f;
+            if (row < p.m) {
+                if (k < p.obs_dim) {
+                    v = (p.obs[(long long)row * p.obs_dim + k] - in_mu[k]) * in_iv[k];
+                } else if (k < p.in_dim) {
+                    float a;
+                    if (p.act) {
+                        a = p.act[(long long)row * p.act_dim + (k - p.obs_dim)];
+                    } else {
+                        const unsigned int low = (unsigned int)(p.best_key[row] & 0x7fffffffull);
+                        int idx = (int)(0x7fffffffu - low) - p.cand_offset;
+                        idx = idx < 0 ? 0 : (idx >= p.n ? p.n - 1 : idx);
+                        a = p.actions[((long long)row * p.n + idx) * p.act_dim + (k - p.obs_dim)];
+                    }
+                    v = (a - in_mu[k]) * in_iv[k];
+                } else {
+                    v = p.h0[(long long)row * U + (k - p.in_dim)];
+                }
+            }
+            xs[i] = v;
+        }
+        __syncthreads();
+        float acc[L2A_ADV_ROWS];
+#pragma unroll
+        for (int r = 0; r < L2A_ADV_ROWS; ++r) acc[r] = 0.0f;
+        for (int k = k0; k < k1; k += 8) {
+            float w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = (k + q < k1) ? wk[(long long)(k + q) * 4 * U] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (k + q < k1) {
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + (k + q) * L2A_ADV_ROWS);
+                    const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + (k + q) * L2A_ADV_ROWS + 4);
+                    acc[0] = fmaf(xa[0], w[q], acc[0]); acc[1] = fmaf(xa[1], w[q], acc[1]);
+                    acc[2] = fmaf(xa[2], w[q], acc[2]); acc[3] = fmaf(xa[3], w[q], acc[3]);
+                    acc[4] = fmaf(xb[0], w[q], acc[4]); acc[5] = fmaf(xb[1], w[q], acc[5]);
+                    acc[6] = fmaf(xb[2], w[q], acc[6]); acc[7] = fmaf(xb[3], w[q], acc[7]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < L2A_ADV_ROWS; ++r) ps[(kp * 64 + col) * L2A_ADV_ROWS + r] = acc[r];
+        __syncthreads();
+        if (tid < 16 * L2A_ADV_ROWS) {
+            const int r = tid >> 4, jj = tid & 15;
+            const int row = r0 + r, u = u0 + jj;
+            if (row < p.m) {
+                float z[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    float s = ps[(0 * 64 + gg * 16 + jj) * L2A_ADV_ROWS + r];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) s += ps[(q * 64 + gg * 16 + jj) * L2A_ADV_ROWS + r];
+                    z[gg] = s;
+                }
+                // tensorflow==1.13.1 LSTMCell, gate order i, j, f, o, forget bias 1 (l2a_lstm_valu_k above; dynamics/core/utils.py:192-213)
+                const float ig = l2a_sigmoid(z[0] + bk[u]);
+                const float jg = l2a_act1(z[1] + bk[U + u], p.cell_act);
+                const float fg = l2a_sigmoid(z[2] + bk[2 * U + u] + 1.0f);
+                const float og = l2a_sigmoid(z[3] + bk[3 * U + u]);
+                const float cn = fg * p.c0[(long long)row * U + u] + ig * jg;
+                p.c1[(long long)row * U + u] = cn;
+                p.h1[(long long)row * U + u] = og * l2a_act1(cn, p.cell_act);
+            }
+        }
+        __syncthreads();
+    }
+}

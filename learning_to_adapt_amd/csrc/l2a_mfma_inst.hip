@@ -42,8 +42,12 @@ int launch_shape(int ot, int kg0, const L2AKParams* p, unsigned grid, int smem, 
         case 3 * 8 + 4:     // Ant: 41 + 8 = 49 inputs end one feature into the last k-group (its own instance; relu / identity)
             if (!GACT && p->in_dim == 49) return launch_one<3, 4, GACT, 1>(p, grid, smem, stream);
             return launch_one<3, 4, GACT>(p, grid, smem, stream);
+#if L2A_INST_NT == 1
+        // 49 - 64 observation dims: NT = 1 only (choose_nt, l2a_api.hip: the NT = 2 instances spilled 43 - 58 VGPRs and lost every
+        // plan measured; they are no longer built)
         case 4 * 8 + 4: return launch_one<4, 4, GACT>(p, grid, smem, stream);
         case 4 * 8 + 5: return launch_one<4, 5, GACT>(p, grid, smem, stream);
+#endif
         default: return -100;
     }
 }

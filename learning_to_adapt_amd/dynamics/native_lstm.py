@@ -165,3 +165,19 @@ class NativeLSTM(object):
                                        _ptr(c_out), _ptr(h_out), _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_lstm_predict")
         return nxt, c_out, h_out
+
+    def advance(self, obs, act, c, h, c_out=None, h_out=None):
+        """The controller's own state step (``l2a_lstm_advance``): ``(c_out, h_out)`` CUDA tensors from the chosen actions - no
+        predicted observation.  The kernel the blocking plan launch enqueues behind its plan, so every controller path moves the
+        state with the same arithmetic."""
+        for t in (obs, act, c, h):
+            assert t.is_cuda and t.dtype == torch.float32
+        rows = obs.shape[0]
+        assert c.shape == (rows, self.units) and h.shape == (rows, self.units)
+        if c_out is None:
+            c_out = torch.empty((rows, self.units), dtype=torch.float32, device=self.device)
+            h_out = torch.empty((rows, self.units), dtype=torch.float32, device=self.device)
+        rc = self.lib.l2a_lstm_advance(self.handle, _ptr(obs.contiguous()), _ptr(act.contiguous()), _ptr(c.contiguous()),
+                                       _ptr(h.contiguous()), int(rows), _ptr(c_out), _ptr(h_out), _stream_ptr(self.device))
+        self.ctx.check(rc, "l2a_lstm_advance")
+        return c_out, h_out

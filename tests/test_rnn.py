@@ -682,7 +682,7 @@ def test_gpu_rnn_micro_tiles_are_bit_identical(units, m, n, h, env_name):
                                               ("lstm", (64, 32), 2, 50, 3)])
 def test_gpu_blocking_recurrent_plan_matches_the_plain_launches(cell, units, m, n, h):
     """`l2a_lstm_plan_rs_sync` (observations from host-mapped staging, keys through the mailbox, the controller's state
-    advanced in stream order with the winning first actions) against `l2a_lstm_plan_rs` + `l2a_lstm_predict` with the
+    advanced in stream order with the winning first actions) against `l2a_lstm_plan_rs` + `l2a_lstm_advance` with the
     action picked on the host: keys and next state bit for bit - MFMA kernel (mailbox, split and unsplit plans) and the
     generic kernels (copy + synchronise), repeated calls, changing m."""
     from learning_to_adapt_amd import _lib
@@ -704,12 +704,17 @@ def test_gpu_blocking_recurrent_plan_matches_the_plain_launches(cell, units, m, 
         want = best.cpu().numpy()
         idx = np.array([_lib.key_decode(k)[1] for k in want]) - 11 * it
         chosen = acts[0].reshape(m, n, 6)[torch.arange(m), torch.from_numpy(idx).to(dev)]
-        _, c_want, h_want = native.predict(up(obs), chosen.contiguous(), c0, h0)
+        # the state step: `l2a_lstm_advance` with the action picked on the host - bit for bit (one LSTM layer: the small-rows
+        # kernel, which the blocking launch feeds through the keys instead; other cells: one step of the rollout kernel) - and
+        # `l2a_lstm_predict`'s states to fp32 rounding (the small-rows kernel sums its 4 x (in + U) / 4 products in another order)
+        c_want, h_want = native.advance(up(obs), chosen.contiguous(), c0, h0)
+        _, c_pred, h_pred = native.predict(up(obs), chosen.contiguous(), c0, h0)
         c1 = torch.full((m, U), float("nan"), device=dev)
         h1 = torch.full((m, U), float("nan"), device=dev)
         got = native.plan_rs_sync(obs, c0, h0, acts, m, n, h, 0.97, env.reward_spec, cand_offset=11 * it, c_next=c1, h_next=h1)
         assert got is not None and np.array_equal(got.view(np.int64), want), (it, got, want)
         assert torch.equal(c1, c_want) and torch.equal(h1, h_want), it
+        assert float((c1 - c_pred).abs().max()) < 2e-6 and float((h1 - h_pred).abs().max()) < 2e-6, it
         keys_only = native.plan_rs_sync(obs, c0, h0, acts, m, n, h, 0.97, env.reward_spec, cand_offset=11 * it)
         assert np.array_equal(keys_only, got)
         c0, h0 = c1, h1
