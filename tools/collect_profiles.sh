@@ -19,7 +19,10 @@ cp $SRC/parity_report.txt $DST/${TAG}_parity_report.txt
 cp $SRC/probe_adapt.json $DST/${TAG}_probe_adapt.json
 grep -v amdgpu.ids $SRC/adapt_trace.txt > $DST/${TAG}_adapt_trace.txt
 grep -v amdgpu.ids $SRC/cem_trace.txt | cut -c1-140 > $DST/${TAG}_cem_trace.txt
-cp $SRC/probe_jitter.json $DST/${TAG}_probe_jitter.json
+[ -f $SRC/probe_jitter.json ] && cp $SRC/probe_jitter.json $DST/${TAG}_probe_jitter.json
+for f in probe_steps.jsonl probe_jitter.jsonl probe_steps_python_path.jsonl two_planners.jsonl; do [ -f $SRC/$f ] && cp $SRC/$f $DST/${TAG}_$f; done
+for f in $SRC/step_trace_*.txt; do [ -f "$f" ] && grep -v amdgpu.ids $f | cut -c1-150 > $DST/${TAG}_$(basename $f); done
+[ -f $SRC/timeline_adapt.txt ] && grep -v amdgpu.ids $SRC/timeline_adapt.txt > $DST/${TAG}_timeline_adapt.txt
 tail -12 $SRC/pytest_gpu.log | grep -v amdgpu.ids > $DST/${TAG}_pytest_gpu_tail.txt
 # rocprofv3 --stats: the rollout kernels only (torch's elementwise kernels have kilobyte-long names)
 f=$(find $SRC/prof -name "*kernel_stats.csv" | head -1)

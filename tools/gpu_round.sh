@@ -68,7 +68,13 @@ echo "== GrBAL adaptation step"
 timeout 120 python tools/probe_adapt.py 2> /dev/null > $OUT/probe_adapt.json; echo "probe_adapt rc=$?"
 bash tools/adapt_trace.sh > $OUT/adapt_trace.txt 2>&1; echo "adapt_trace rc=$?"; cd $GRAFT_REPO_ROOT
 bash tools/cem_trace.sh > $OUT/cem_trace.txt 2>&1; echo "cem_trace rc=$?"; cd $GRAFT_REPO_ROOT
-timeout 120 python tools/probe_jitter.py > $OUT/probe_jitter.json 2> /dev/null; echo "probe_jitter rc=$?"
+echo "== round 5: the controller step as one C call - stage tables of the four default workloads, the 5000-call distribution, dispatch traces"
+timeout 900 python tools/probe_step.py c2 rebal grbal mbmpc --calls=1000 > $OUT/probe_steps.jsonl 2> $OUT/probe_steps.err; echo "probe_steps rc=$?"
+timeout 600 python tools/probe_step.py c2 --calls=5000 > $OUT/probe_jitter.jsonl 2>> $OUT/probe_steps.err; echo "probe_jitter rc=$?"
+L2A_NATIVE_STEP=0 timeout 600 python tools/probe_step.py c2 rebal grbal mbmpc --calls=500 > $OUT/probe_steps_python_path.jsonl 2>> $OUT/probe_steps.err; echo "probe_steps (python path) rc=$?"
+for w in c2 rebal grbal mbmpc; do bash tools/step_trace.sh $w > $OUT/step_trace_$w.txt 2>&1; cd $GRAFT_REPO_ROOT; done; echo "step traces done"
+timeout 120 python tools/timeline_adapt.py cold > $OUT/timeline_adapt.txt 2>&1; echo "timeline_adapt rc=$?"
+timeout 300 python tools/two_planners.py > $OUT/two_planners.jsonl 2> $OUT/two_planners.err; echo "two_planners rc=$?"
 echo "== host RNG helper / end-to-end stage probes"
 timeout 300 python tools/bench_rng.py > $OUT/rng.jsonl 2>&1; echo "rng rc=$?"
 timeout 300 python tools/probe_e2e.py > $OUT/probe_c2.jsonl 2> $OUT/probe.err; echo "probe c2 rc=$?"
