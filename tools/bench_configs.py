@@ -83,6 +83,9 @@ def _retire(ctrl):
     parity-mode steps tens of microseconds each (measured: ReBAL 0.36 ms after the GrBAL section, 0.29 ms alone)."""
     if getattr(ctrl, "_ahead", None) is not None:
         ctrl._ahead.stop()
+    if getattr(ctrl, "_cstep", None) is not None:
+        ctrl._cstep.close()
+        ctrl._cstep = None
 
 
 def report(tag, case, env, ms, **extra):
@@ -127,14 +130,17 @@ def main():
         ctrl = cases.product_controller(case, model=model, env=env, rng=mode)
         obs_np = np.random.RandomState(3).randn(10, 20)
         np.random.seed(0)
-        for _ in range(5):
+        # 30 calls of warm-up: the first draws of a new plan size compute the generator's jump polynomials for their slice
+        # offsets (~100 ms once per process and size, csrc/l2a_rng.c) - inside 50 timed calls that was +0.4 ms per call
+        # (r05: 2.288 here against tools/probe_step.py's 1.899 for the same loop)
+        for _ in range(30):
             ctrl.get_actions(obs_np)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(50):
+        for _ in range(200):
             ctrl.get_actions(obs_np)
         torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / 50
+        ms = 1e3 * (time.perf_counter() - t0) / 200
         print(json.dumps(dict(config="run_mb_mpc.py default end to end through MPCController.get_actions (10 envs), rng=" + mode,
                               ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1), env_steps_per_s=round(1e4 / ms, 1))), flush=True)
         _retire(ctrl)
