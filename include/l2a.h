@@ -440,20 +440,23 @@ int l2a_lstm_mfma_eligible(int obs_dim, int act_dim, int units);
  *   action_out   HOST float64 [m, act_dim]        cand_a[i, argmax_i] (:118,129) - the float64 values NumPy drew
  *   index_out    HOST int64 [m] or NULL           the winning candidate of each env
  *   return_out   HOST fp32 [m] or NULL            its (fp32) return
- *   returns      L2A_OK; L2A_STEP_UNSPLIT (= OK, but a tile-split launch lost its partner and the plan was repeated
- *                unsplit - same bits - with the context switched to l2a_set_split(ctx, 0)); L2A_STEP_MISS when no
- *                valid block of candidates was waiting - first call, somebody else drew from np.random since the last
- *                step, a forked child - in which case NOTHING was consumed or launched: the caller draws and plans the
- *                ordinary way (l2a_plan_rs_sync) and calls l2a_controller_rearm afterwards; a negative L2A_E* on failure.
+ *   returns      L2A_OK; L2A_STEP_DREW (= OK: no valid block was waiting - first call, somebody else drew from np.random
+ *                since the last step - so the step drew the candidates itself, the reference's own draw from the global
+ *                generator on the helper's threads, and re-armed the chain behind it); L2A_STEP_UNSPLIT (= OK, but a
+ *                tile-split launch lost its partner and the plan was repeated unsplit - same bits - with the context
+ *                switched to l2a_set_split(ctx, 0)); L2A_STEP_MISS when this controller cannot serve the call (a forked
+ *                child): NOTHING was consumed or launched, the caller plans the ordinary way (l2a_plan_rs_sync) and may
+ *                call l2a_controller_rearm afterwards; a negative L2A_E* on failure.
  * l2a_lstm_controller_step additionally takes the controller's recurrent state c0 / h0 (device fp32 [m, state width])
  * and, with c_next / h_next, advances it with the winning first actions behind the plan (l2a_lstm_plan_rs_sync).
  * l2a_controller_rearm: restart the chain at the CURRENT global generator state (after a synchronous draw).
  * l2a_controller_actions: the device tensor [h, m*n, act_dim] the latest successful step planned on (diagnostics).
  * l2a_controller_stats: out[0..6] host microseconds of the latest step - take | stage obs | launch | kick | wait |
  * decode + gather | whole call; [7] steps, [8] unsplit relaunches; [9..14] chain: hits, misses, blocks produced,
- * producer us per block, consumer wait us per take, armed.                                                      */
+ * producer us per block, consumer wait us per take, armed; [15] steps that drew synchronously.                  */
 #define L2A_STEP_MISS 1
 #define L2A_STEP_UNSPLIT 2
+#define L2A_STEP_DREW 3
 int l2a_controller_create(l2a_model* model, int m, int n, int h, const double* low, const double* high, double discount,
                           const l2a_reward* reward, void* np_state_addr, int rng_threads, l2a_controller** out);
 int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const double* low, const double* high,

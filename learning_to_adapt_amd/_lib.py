@@ -20,6 +20,7 @@ L2A_OK = 0
 L2A_ESPLIT = -5
 L2A_STEP_MISS = 1
 L2A_STEP_UNSPLIT = 2
+L2A_STEP_DREW = 3
 ACT_CODES = {None: 0, "identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4}
 MODE_CODES = {"single": 0, "per_block": 1, "mean": 2}
 KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}

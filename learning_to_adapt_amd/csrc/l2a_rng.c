@@ -1028,6 +1028,16 @@ int l2a_ahead_next(l2a_ahead* a) {
     return 0;
 }
 
+/* The slot a synchronous draw of the caller may use while the chain is idle (nothing requested, nothing in production): the one
+ * the chain wrote last, so that the next arm / next - which toggles - takes the other.  -1 while a block is requested. */
+int l2a_ahead_idle_slot(l2a_ahead* a) {
+    if (!a || a->pid != getpid()) return -1;
+    pthread_mutex_lock(&a->mu);
+    const int slot = (a->armed || a->want || a->busy) ? -1 : a->slot;
+    pthread_mutex_unlock(&a->mu);
+    return slot;
+}
+
 /* out[0..5] = hits, misses, blocks produced, producer us per block, consumer wait us per take, armed */
 void l2a_ahead_stats(l2a_ahead* a, double* out) {
     if (!a || !out) return;

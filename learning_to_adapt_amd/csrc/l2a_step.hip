@@ -10,8 +10,11 @@
 //   launch the fused rollout from host-mapped observations (l2a_plan_rs_sync's path; recurrent: + the state advance)
 //   kick   the producer of the next block (between launch and wait)
 //   wait   for the mailbox word, decode the keys, gather the winners' float64 first actions from the block's `cand_a`
-// A block that is not valid (first call, a foreign consumer of np.random between two steps, a forked child) makes the step
-// return L2A_STEP_MISS without having touched anything: the caller draws synchronously as before and re-arms the chain.
+// When no valid block is waiting (first call, a foreign consumer of np.random between two steps) the step draws the candidates
+// itself - the reference's draw from the GLOBAL generator, on the helper's threads, into the idle slot, uploaded on the launch
+// stream in front of the kernel - and re-arms the chain behind that draw (L2A_STEP_DREW); while steps keep missing it re-arms only
+// every 16th step (every block drawn ahead would be thrown away).  L2A_STEP_MISS is left for a controller that cannot serve the
+// call at all (a forked child: its producer thread and its HIP state did not come along).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -39,7 +42,11 @@ struct l2a_controller {
     bool producer_bound = false;                // the producer thread has made ctx->device current
     std::string upload_err;
     double stage_us[8] = {0};
-    unsigned long long steps = 0, relaunches = 0;
+    unsigned long long steps = 0, relaunches = 0, sync_draws = 0;
+    double low[16], high[16];
+    int rng_threads = 1;
+    int misses_in_row = 0;
+    unsigned long long cooldown = 0;
 };
 
 namespace {
@@ -62,6 +69,15 @@ int upload_block(void* arg, int slot) {
 
 void kick_next(void* arg) { (void)l2a_ahead_next(static_cast<l2a_controller*>(arg)->chain); }
 
+// After a synchronous draw: the chain restarts at the generator's new state - unless steps keep missing (a consumer of np.random
+// runs between the controller's steps): then only every 16th step tries again.
+void kick_arm(void* arg) {
+    l2a_controller* c = static_cast<l2a_controller*>(arg);
+    c->misses_in_row += 1;
+    if (c->misses_in_row > 2 && (++c->cooldown % 16) != 0) return;
+    (void)l2a_ahead_arm(c->chain, c->np_addr);
+}
+
 int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim, int units, int m, int n, int h,
            const double* low, const double* high, double discount, const l2a_reward* reward, void* np_state_addr,
            int rng_threads, l2a_controller** out) {
@@ -79,6 +95,8 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
     c->ctx = ctx; c->mlp = mlp; c->rnn = rnn;
     c->m = m; c->n = n; c->h = h; c->obs_dim = obs_dim; c->act_dim = act_dim; c->units = units;
     c->discount = discount; c->rw = *reward; c->np_addr = np_state_addr;
+    for (int k = 0; k < act_dim; ++k) { c->low[k] = low[k]; c->high[k] = high[k]; }
+    c->rng_threads = rng_threads < 1 ? 1 : rng_threads;
     c->act_floats = (size_t)h * m * n * act_dim;
     l2a_device_guard guard(ctx->device);
     hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
@@ -111,10 +129,25 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
     l2a_ctx* ctx = c->ctx;
     if (!obs || !action_out) return fail(ctx, L2A_EINVAL, "l2a_controller_step: null obs / action_out");
     const double t0 = l2a_now_us();
-    const int slot = l2a_ahead_take(c->chain, c->np_addr);
+    int slot = l2a_ahead_take(c->chain, c->np_addr);
+    bool drew = false;
     if (slot < 0) {
         if (!c->upload_err.empty()) { const std::string msg = c->upload_err; c->upload_err.clear(); return fail(ctx, L2A_EHIP, msg); }
-        return L2A_STEP_MISS;
+        slot = l2a_ahead_idle_slot(c->chain);
+        if (slot < 0) return L2A_STEP_MISS;                     // (a forked child, or a chain somebody else is driving)
+        // the reference's own draw (mpc_controller.py:67-69,114) from the global generator, advanced in place
+        struct np_state { unsigned int key[624]; int pos; };
+        np_state* g = static_cast<np_state*>(c->np_addr);
+        if (l2a_mt19937_uniform_rows(g->key, &g->pos, (long long)c->h * c->n * c->m, c->act_dim, c->low, c->high, c->n, 0, c->n,
+                                     c->pin[slot], (long long)c->n * c->m, c->c64[slot], c->rng_threads) != 0)
+            return fail(ctx, L2A_EINVAL, "l2a_controller_step: the generator state at np_state_addr is not a legacy MT19937 state");
+        l2a_device_guard guard(ctx->device);
+        L2A_HIP(ctx, hipMemcpyAsync(c->dev[slot], c->pin[slot], c->act_floats * sizeof(float), hipMemcpyHostToDevice,
+                                    reinterpret_cast<hipStream_t>(stream)));
+        drew = true;
+        c->sync_draws += 1;
+    } else {
+        c->misses_in_row = 0;
     }
     c->slot = slot;
     const double t1 = l2a_now_us();
@@ -122,9 +155,9 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
     const int no = c->m * c->obs_dim;
     for (int i = 0; i < no; ++i) obs32[i] = (float)obs[i];          // np.float64 -> np.float32 (round to nearest even), as the host cast
     unsigned long long keys[L2A_MAIL_KEYS];
-    int rc = L2A_OK, result = L2A_OK;
+    int rc = L2A_OK, result = drew ? L2A_STEP_DREW : L2A_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        l2a_after_launch_fn hook = attempt == 0 ? kick_next : nullptr;
+        l2a_after_launch_fn hook = attempt == 0 ? (drew ? kick_arm : kick_next) : nullptr;
         if (c->mlp)
             rc = l2a_plan_rs_sync_hook(c->mlp, obs32, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, nullptr, keys, stream,
                                        hook, c);
@@ -133,7 +166,8 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
                                             c1, h1, stream, hook, c);
         if (rc != L2A_ESPLIT) break;
         // a tile-split partner was not co-resident: the unsplit geometry gives the same bits (the caller is told: L2A_STEP_UNSPLIT)
-        if (attempt == 1) return fail(ctx, L2A_ESPLIT, "l2a_controller_step: the rollout was flagged invalid with the tile split disabled");
+        if (attempt == 1 || ctx->split_policy == 0)
+            return fail(ctx, L2A_ESPLIT, "l2a_controller_step: the rollout was flagged invalid with the tile split disabled");
         (void)l2a_set_split(ctx, 0);
         c->relaunches += 1;
         result = L2A_STEP_UNSPLIT;
@@ -231,6 +265,7 @@ int l2a_controller_stats(l2a_controller* c, double* out, int cap) {
     l2a_ahead_stats(c->chain, ch);
     v[7] = (double)c->steps; v[8] = (double)c->relaunches;
     for (int i = 0; i < 6; ++i) v[9 + i] = ch[i];
+    v[15] = (double)c->sync_draws;
     for (int i = 0; i < cap && i < 16; ++i) out[i] = v[i];
     return L2A_OK;
 }

@@ -462,9 +462,10 @@ class MPCController(Policy, Serializable):
 
     def _native_rs_step(self, observations, m):
         """Parity-mode random shooting on one GPU through ``l2a_controller_step`` (``policies/native_step.py``).  Returns the
-        actions, or None when the C controller does not apply (sharded plan, test harness, no helper library) or found no
-        valid block of candidates (first call, a foreign draw from ``np.random`` since the last step): the caller then takes
-        the ordinary path - which draws synchronously from the global generator - and the chain is re-armed behind that draw."""
+        actions, or None when the C controller does not apply (sharded plan, test harness, no helper library, a forked child):
+        the caller then takes the ordinary path.  A step that finds no valid block of candidates (first call, a foreign draw
+        from ``np.random`` since the last step) draws them itself inside the C call - the reference's draw from the global
+        generator - and re-arms the chain behind it."""
         if self.use_cem or not self._native_step_stock():
             return None
         world = self._dist()[1]

@@ -44,9 +44,10 @@ class NativeStep(object):
         self._stats = (ctypes.c_double * 16)()
 
     def step(self, observations, stream, state=None):
-        """One controller step.  Returns True (``self.act`` / ``self.idx`` / ``self.ret`` hold the result), or False when no
-        valid block of candidates was waiting - nothing has been consumed or launched then.  ``state`` (recurrent):
-        ``(c0, h0, c_next, h_next)`` device pointers."""
+        """One controller step.  Returns True (``self.act`` / ``self.idx`` / ``self.ret`` hold the result; when no valid block of
+        candidates was waiting the C step drew them itself from the global generator), or False when the controller cannot serve
+        the call (a forked child) - nothing has been consumed or launched then.  ``state`` (recurrent): ``(c0, h0, c_next,
+        h_next)`` device pointers."""
         np.copyto(self.obs, observations, casting="same_kind")
         p = self._p
         with self.lock:         # the generator's own lock: no other thread draws between the state compare and the adoption
@@ -55,7 +56,7 @@ class NativeStep(object):
                                                        stream)
             else:
                 rc = self.lib.l2a_controller_step(self.handle, p[0], p[1], p[2], p[3], stream)
-        if rc == _lib.L2A_OK:
+        if rc == _lib.L2A_OK or rc == _lib.L2A_STEP_DREW:   # (DREW: no valid block was waiting, the step drew synchronously itself)
             self.misses_in_row = 0
             return True
         if rc == _lib.L2A_STEP_MISS:
@@ -81,7 +82,7 @@ class NativeStep(object):
         self.ctx.check(self.lib.l2a_controller_stats(self.handle, self._stats, 16), "l2a_controller_stats")
         v = list(self._stats)
         return dict(stage_us=dict(take=v[0], stage_obs=v[1], launch=v[2], kick=v[3], wait=v[4], decode=v[5], call=v[6]),
-                    steps=int(v[7]), relaunches=int(v[8]), hits=int(v[9]), misses=int(v[10]), produced=int(v[11]),
+                    steps=int(v[7]), relaunches=int(v[8]), sync_draws=int(v[15]), hits=int(v[9]), misses=int(v[10]), produced=int(v[11]),
                     producer_us_per_block=v[12], consumer_wait_us_per_take=v[13], armed=bool(v[14]))
 
     def actions_ptr(self):

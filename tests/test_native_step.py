@@ -23,7 +23,7 @@ def test_native_step_reproduces_the_reference_golden(cid):
     gold = cases.load_golden(cid)
     ctrl = cases.product_controller(case)
     np.random.seed(12345)
-    ctrl.get_actions(gold["obs0"])                     # miss: builds the controller, draws synchronously, arms the chain
+    ctrl.get_actions(gold["obs0"])                     # builds the controller; no block yet: the C step draws synchronously, arms the chain
     assert ctrl._cstep is not None, "the C controller does not apply to this case"
     np.random.seed(seed)
     ctrl._cstep.misses_in_row = 0
@@ -63,7 +63,8 @@ def test_native_step_equals_the_python_path(name):
         assert np.array_equal(a0, a1) and np.array_equal(i0, i1) and np.array_equal(r0, r1)
     assert c0._cstep is None and c1._cstep is not None
     st = c1._cstep.stats()
-    assert st["hits"] == 5 and st["misses"] == 1 and st["steps"] == 5       # steps 0 (nothing armed) and 3 (foreign draw) fell back
+    # steps 0 (nothing armed yet) and 3 (foreign draw: the block drawn ahead was stale) drew synchronously INSIDE the C step
+    assert st["hits"] == 5 and st["misses"] == 1 and st["steps"] == 7 and st["sync_draws"] == 2
     assert c1.draw_ahead_stats()["hits"] == 5
     c1._cstep.close()
     c1._cstep = None
@@ -102,7 +103,7 @@ def test_native_recurrent_step_equals_the_python_path(name):
     for (a0, i0, cc0, hh0), (a1, i1, cc1, hh1) in zip(s0, s1):
         assert np.array_equal(a0, a1) and np.array_equal(i0, i1)
         assert np.array_equal(cc0, cc1) and np.array_equal(hh0, hh1)
-    assert c1._cstep is not None and c1._cstep.stats()["hits"] == 5
+    assert c1._cstep is not None and c1._cstep.stats()["hits"] == 5 and c1._cstep.stats()["sync_draws"] == 1
     c1._cstep.close()
     c1._cstep = None
     if c0._ahead is not None:
@@ -154,5 +155,42 @@ def test_native_step_stage_table_adds_up():
     s = ctrl._cstep.stats()["stage_us"]
     parts = s["take"] + s["stage_obs"] + s["launch"] + s["kick"] + s["wait"] + s["decode"]
     assert 0 < parts <= s["call"] + 1.0 and s["call"] - parts < 20.0
+    ctrl._cstep.close()
+    ctrl._cstep = None
+
+
+@pytest.mark.parametrize("cid", [c for c in RS_IDS if c.endswith("_s0")])
+def test_the_synchronous_draw_inside_the_c_step_reproduces_the_reference_golden(cid):
+    """No block waiting (the first call of a controller): the C step draws the candidates itself - the reference's draw from the
+    GLOBAL generator on the helper's threads - and must leave the generator where the reference leaves it."""
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    ctrl = cases.product_controller(case)
+    np.random.seed(seed)
+    actions, _ = ctrl.get_actions(gold["obs0"])
+    assert ctrl._cstep is not None and ctrl._cstep.stats()["sync_draws"] == 1 and ctrl._cstep.stats()["hits"] == 0
+    assert np.random.uniform() == float(gold["rng_next"])
+    assert np.array_equal(ctrl.last_plan["best_index"], gold["best"])
+    np.testing.assert_array_equal(actions, gold["chosen"])
+    ctrl._cstep.close()
+    ctrl._cstep = None
+
+
+def test_steps_that_keep_missing_back_off():
+    """A consumer of np.random between every two steps: every step draws synchronously (bit-identical results: the golden tests),
+    and after the third miss in a row the chain is re-armed only every 16th step - no block is drawn ahead just to be thrown away."""
+    case = cases.CASES["c1_hc_rs_n500_h10_e1"]
+    ctrl = cases.product_controller(case)
+    obs = np.random.RandomState(0).randn(1, 20)
+    np.random.seed(0)
+    for _ in range(40):
+        ctrl.get_actions(obs)
+        np.random.uniform()
+    st = ctrl._cstep.stats()
+    assert st["sync_draws"] == 40 and st["hits"] == 0
+    assert st["produced"] <= 6              # 2 early re-arms + every 16th step
+    for _ in range(40):                     # the foreign consumer stops: the chain comes back within 16 steps and then hits
+        ctrl.get_actions(obs)
+    assert ctrl._cstep.stats()["hits"] >= 20
     ctrl._cstep.close()
     ctrl._cstep = None
