@@ -462,6 +462,15 @@ int l2a_controller_create(l2a_model* model, int m, int n, int h, const double* l
 int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const double* low, const double* high,
                                double discount, const l2a_reward* reward, void* np_state_addr, int rng_threads,
                                l2a_controller** out);
+/* The same step with the candidates drawn ON THE DEVICE (`MPCController(rng="device")`: statistically equivalent to the reference's
+ * draw, not its numbers; NumPy's generator is not touched): every step a Philox4x32-10 kernel fills the candidate tensor from the
+ * counter-based stream (seed, steps so far) in front of the plan, and the winners' first actions are recomputed on the host from
+ * the same stream (csrc/l2a_philox.h: identical integer rounds and fp32 map on both sides) - no upload, no gather, no copy back.
+ * Steps through l2a_controller_step / l2a_lstm_controller_step as above (they never return L2A_STEP_DREW / _MISS here). */
+int l2a_controller_create_device(l2a_model* model, int m, int n, int h, const double* low, const double* high, double discount,
+                                 const l2a_reward* reward, unsigned long long seed, l2a_controller** out);
+int l2a_lstm_controller_create_device(l2a_lstm* model, int m, int n, int h, const double* low, const double* high,
+                                      double discount, const l2a_reward* reward, unsigned long long seed, l2a_controller** out);
 void l2a_controller_destroy(l2a_controller* controller);
 int l2a_controller_step(l2a_controller* controller, const double* obs, double* action_out, long long* index_out,
                         float* return_out, void* stream);

@@ -4,6 +4,7 @@
 // holding raw + MFMA-packed weights and the padded normalisation vectors) and the launch logic
 // of the fused rollout kernels in l2a_kernels.h.  Everything is enqueued on the caller's stream.
 
+#define L2A_PACK_KERNELS 1      // this unit launches the weight re-packing kernels of l2a_micro_pack.h
 #include "l2a_host.h"
 #include "l2a_kernels.h"
 #include "l2a_valu.h"

@@ -3,6 +3,7 @@
 // re-packing and the launch logic of the kernels in l2a_lstm.h.  Everything is enqueued on the
 // caller's stream.
 
+#define L2A_PACK_KERNELS 1      // this unit launches the weight re-packing kernels of l2a_micro_pack.h
 #include "l2a_host.h"
 #include "l2a_lstm.h"
 #include "l2a_lstm_valu.h"

@@ -22,6 +22,7 @@ __host__ __device__ constexpr int l2a_micro_row(int U) { return U + 16 * L2A_MIC
 __host__ __device__ inline long long l2a_lstm_micro_gate_floats(int U, int KG0) {
     return (long long)(U / 64) * 4 * (U / 4 + 4 * KG0) * 256 + 1024;
 }
+#ifdef L2A_PACK_KERNELS     // compiled once per library: defined by the API units that launch them (l2a_api.hip, l2a_lstm_api.hip)
 static __global__ void l2a_lstm_micro_pack_k(const float* __restrict__ wk, int in_dim, int U, int KG0, long long total, float* dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -40,7 +41,9 @@ static __global__ void l2a_lstm_micro_pack_k(const float* __restrict__ wk, int i
     else { const int k = l2a_chain_k(4 * (gi - 2 * HG) + e); k_tf = (k < in_dim) ? k : -1; }
     dst[idx] = (k_tf >= 0) ? wk[(long long)k_tf * 4 * U + q * U + unit] : 0.0f;
 }
+#endif
 // Packed output layer: [k-group of 4 chain positions over all U][lane = obs dim][4]
+#ifdef L2A_PACK_KERNELS     // compiled once per library: defined by the API units that launch them (l2a_api.hip, l2a_lstm_api.hip)
 static __global__ void l2a_lstm_micro_pack_out_k(const float* __restrict__ wo, int U, int obs_dim, long long total, float* dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -48,6 +51,7 @@ static __global__ void l2a_lstm_micro_pack_out_k(const float* __restrict__ wo, i
     const int gi = (int)(idx >> 8);
     dst[idx] = (lane < obs_dim) ? wo[(long long)l2a_chain_k(4 * gi + e) * obs_dim + lane] : 0.0f;
 }
+#endif
 
 
 // Generic recurrent cells (l2a_rnn_micro.h): one product of a layer, TF kernel w [kin + U, G U] (input rows, then recurrent rows;
@@ -59,6 +63,7 @@ __host__ __device__ inline int l2a_rnn_micro_kgx(int kin) { return (((kin + 15) 
 __host__ __device__ inline long long l2a_rnn_micro_floats(int kin, int U, int G) {
     return (long long)(U / 64) * G * (4 * l2a_rnn_micro_kgx(kin) + U / 4) * 256 + 256;
 }
+#ifdef L2A_PACK_KERNELS     // compiled once per library: defined by the API units that launch them (l2a_api.hip, l2a_lstm_api.hip)
 static __global__ void l2a_rnn_micro_pack_k(const float* __restrict__ w, int kin, int U, int G, long long total, float* dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -75,6 +80,7 @@ static __global__ void l2a_rnn_micro_pack_k(const float* __restrict__ w, int kin
     else row = kin + l2a_chain_k(4 * (gi - NX) + e);
     dst[idx] = (row >= 0) ? w[(long long)row * G * U + q * U + unit] : 0.0f;
 }
+#endif
 
 
 // LDS row of a layer's h / c / r * h: U + 24 = 24 mod 32 floats - the four rows of a micro tile start 24 banks apart
@@ -141,6 +147,7 @@ __host__ __device__ inline long long l2a_mlp_micro_index(int H, int KG0, int n_h
     return ((((long long)T * nrec + rec) * 64 + lane) << 2) + (p & 3);
 }
 // one layer of `count` sets: grid (ceil(k_in n_out / 256), count); w = the layer's [k_in, n_out] kernel of the first set
+#ifdef L2A_PACK_KERNELS     // compiled once per library: defined by the API units that launch them (l2a_api.hip, l2a_lstm_api.hip)
 static __global__ void l2a_mlp_micro_pack_k(const float* __restrict__ w, long long w_stride, int k_in, int n_out, int l, int H, int KG0,
                                             int n_hidden, int o4, float* dst, long long dst_stride) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,6 +155,7 @@ static __global__ void l2a_mlp_micro_pack_k(const float* __restrict__ w, long lo
     const int k = (int)(idx / n_out), u = (int)(idx - (long long)k * n_out);
     dst[(long long)blockIdx.y * dst_stride + l2a_mlp_micro_index(H, KG0, n_hidden, o4, l, k, u)] = w[(long long)blockIdx.y * w_stride + idx];
 }
+#endif
 // LDS bytes: activation rows [2][12][H + 88] | output partials [2][4 waves][3][64] f32x4 | inputs [sets][12][104] | constants per set
 __host__ __device__ inline int l2a_mlp_micro_cst(int H, int KG0, int n_hidden) { return 32 * KG0 + 192 + n_hidden * H; }
 __host__ __device__ inline int l2a_mlp_micro_smem(int H, int KG0, int n_hidden, int sets) {

@@ -22,6 +22,7 @@
 #include <string>
 
 #include "l2a_host.h"
+#include "l2a_philox.h"
 #include "l2a_rng.h"
 
 struct l2a_controller {
@@ -47,7 +48,29 @@ struct l2a_controller {
     int rng_threads = 1;
     int misses_in_row = 0;
     unsigned long long cooldown = 0;
+    // device-RNG mode (`rng="device"`): no chain - the candidates are drawn by a Philox kernel in front of the plan
+    bool device_rng = false;
+    unsigned long long seed = 0, calls = 0;
+    float* lowr_dev = nullptr;                  // [2][16]: low | high - low, fp32
 };
+
+// Device-RNG mode: the candidate tensor [h, m * n, act_dim] from the counter-based stream (seed, offset + element): four elements
+// per thread (one Philox block), the action dimension of an element = its index modulo act_dim.
+__global__ void __launch_bounds__(256) l2a_uniform_fill_k(unsigned long long seed, unsigned long long offset, long long total,
+                                                          int act_dim, const float* __restrict__ lowr, float* __restrict__ out) {
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;      // block of four elements
+    if (4 * b >= total) return;
+    unsigned int c[4];
+    l2a_philox4x32_10(seed, (offset >> 2) + (unsigned long long)b, L2A_PHILOX_UNIFORM, c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long e = 4 * b + i;
+        if (e < total) {
+            const int k = (int)(e % act_dim);
+            out[e] = l2a_uniform_from_word(c[i], lowr[k], lowr[16 + k]);
+        }
+    }
+}
 
 namespace {
 
@@ -80,10 +103,10 @@ void kick_arm(void* arg) {
 
 int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim, int units, int m, int n, int h,
            const double* low, const double* high, double discount, const l2a_reward* reward, void* np_state_addr,
-           int rng_threads, l2a_controller** out) {
+           int rng_threads, l2a_controller** out, bool device_rng = false, unsigned long long seed = 0) {
     if (!out) return fail(ctx, L2A_EINVAL, "l2a_controller_create: out is null");
     *out = nullptr;
-    if (!low || !high || !reward || !np_state_addr)
+    if (!low || !high || !reward || (!np_state_addr && !device_rng))
         return fail(ctx, L2A_EINVAL, "l2a_controller_create: null low / high / reward / generator state address");
     if (m < 1 || m > L2A_MAIL_KEYS || (long long)m * obs_dim > L2A_MAIL_OBS || n < 1 || h < 1)
         return fail(ctx, L2A_EINVAL, "l2a_controller_create: needs 1 <= m <= 64 envs (at most 4096 observation floats), n >= 1, h >= 1");
@@ -99,7 +122,26 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
     c->rng_threads = rng_threads < 1 ? 1 : rng_threads;
     c->act_floats = (size_t)h * m * n * act_dim;
     l2a_device_guard guard(ctx->device);
-    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    c->device_rng = device_rng; c->seed = seed;
+    hipError_t e = hipSuccess;
+    if (device_rng) {
+        // the stream's elements are addressed in blocks of four: a step's tensor starts on a block boundary
+        e = hipMalloc(reinterpret_cast<void**>(&c->dev[0]), ((c->act_floats + 3) / 4 * 4) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->lowr_dev), 32 * sizeof(float));
+        if (e == hipSuccess) {
+            float lr[32] = {0};
+            for (int k = 0; k < act_dim; ++k) { lr[k] = (float)low[k]; lr[16 + k] = (float)high[k] - (float)low[k]; }
+            e = hipMemcpy(c->lowr_dev, lr, sizeof(lr), hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            const std::string msg = std::string("l2a_controller_create_device: ") + hipGetErrorString(e);
+            l2a_controller_destroy(c);
+            return fail(ctx, L2A_EHIP, msg);
+        }
+        *out = c;
+        return L2A_OK;
+    }
+    e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     for (int s = 0; s < 2 && e == hipSuccess; ++s) {
         e = hipHostMalloc(reinterpret_cast<void**>(&c->pin[s]), c->act_floats * sizeof(float), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev[s]), c->act_floats * sizeof(float));
@@ -129,9 +171,19 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
     l2a_ctx* ctx = c->ctx;
     if (!obs || !action_out) return fail(ctx, L2A_EINVAL, "l2a_controller_step: null obs / action_out");
     const double t0 = l2a_now_us();
-    int slot = l2a_ahead_take(c->chain, c->np_addr);
+    int slot = 0;
     bool drew = false;
-    if (slot < 0) {
+    unsigned long long offset = 0;
+    if (c->device_rng) {
+        // candidates of this step: elements [offset, offset + h m n act_dim) of the stream (seed) - drawn on the launch stream
+        const unsigned long long per_step = (unsigned long long)((c->act_floats + 3) / 4 * 4);
+        offset = c->calls * per_step;
+        l2a_device_guard guard(ctx->device);
+        const long long total = (long long)c->act_floats;
+        hipLaunchKernelGGL(l2a_uniform_fill_k, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           c->seed, offset, total, c->act_dim, c->lowr_dev, c->dev[0]);
+        L2A_HIP(ctx, hipGetLastError());
+    } else if ((slot = l2a_ahead_take(c->chain, c->np_addr)) < 0) {
         if (!c->upload_err.empty()) { const std::string msg = c->upload_err; c->upload_err.clear(); return fail(ctx, L2A_EHIP, msg); }
         slot = l2a_ahead_idle_slot(c->chain);
         if (slot < 0) return L2A_STEP_MISS;                     // (a forked child, or a chain somebody else is driving)
@@ -157,7 +209,7 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
     unsigned long long keys[L2A_MAIL_KEYS];
     int rc = L2A_OK, result = drew ? L2A_STEP_DREW : L2A_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        l2a_after_launch_fn hook = attempt == 0 ? (drew ? kick_arm : kick_next) : nullptr;
+        l2a_after_launch_fn hook = (attempt == 0 && !c->device_rng) ? (drew ? kick_arm : kick_next) : nullptr;
         if (c->mlp)
             rc = l2a_plan_rs_sync_hook(c->mlp, obs32, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, nullptr, keys, stream,
                                        hook, c);
@@ -181,11 +233,22 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
         if (idx < 0 || idx >= c->n) return fail(ctx, L2A_EHIP, "l2a_controller_step: the arg-max key holds no candidate index");
         if (index_out) index_out[i] = idx;
         if (return_out) return_out[i] = ret;
-        std::memcpy(action_out + (size_t)i * c->act_dim, c->c64[slot] + ((size_t)i * c->n + idx) * c->act_dim,
-                    sizeof(double) * (size_t)c->act_dim);                    // cand_a[i, idx] (:118,129)
+        if (c->device_rng) {
+            // the winner's first action, recomputed from the counter-based stream: element (row i n + idx of step 0, dim k) -
+            // the fp32 value the kernel planned on, as float64 (no gather launch, no copy back)
+            for (int k = 0; k < c->act_dim; ++k) {
+                const unsigned long long e = offset + ((unsigned long long)i * c->n + idx) * c->act_dim + k;
+                action_out[(size_t)i * c->act_dim + k] =
+                    (double)l2a_philox_uniform(c->seed, e, (float)c->low[k], (float)c->high[k] - (float)c->low[k]);
+            }
+        } else {
+            std::memcpy(action_out + (size_t)i * c->act_dim, c->c64[slot] + ((size_t)i * c->n + idx) * c->act_dim,
+                        sizeof(double) * (size_t)c->act_dim);                // cand_a[i, idx] (:118,129)
+        }
     }
     const double t3 = l2a_now_us();
     c->steps += 1;
+    c->calls += 1;
     const double* st = ctx->stamps_us;
     c->stage_us[0] = t1 - t0;               // take (compare + adopt the block; waits only if the producer is late)
     c->stage_us[1] = st[1] - t1;            // observation cast + staging
@@ -219,15 +282,34 @@ int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const doubl
     return create(ctx, nullptr, model, obs_dim, act_dim, units, m, n, h, low, high, discount, reward, np_state_addr, rng_threads, out);
 }
 
+int l2a_controller_create_device(l2a_model* model, int m, int n, int h, const double* low, const double* high, double discount,
+                                 const l2a_reward* reward, unsigned long long seed, l2a_controller** out) {
+    if (!model) return L2A_EINVAL;
+    l2a_ctx* ctx = nullptr;
+    int obs_dim = 0, act_dim = 0;
+    l2a_model_facts(model, &ctx, &obs_dim, &act_dim);
+    return create(ctx, model, nullptr, obs_dim, act_dim, 0, m, n, h, low, high, discount, reward, nullptr, 1, out, true, seed);
+}
+
+int l2a_lstm_controller_create_device(l2a_lstm* model, int m, int n, int h, const double* low, const double* high, double discount,
+                                      const l2a_reward* reward, unsigned long long seed, l2a_controller** out) {
+    if (!model) return L2A_EINVAL;
+    l2a_ctx* ctx = nullptr;
+    int obs_dim = 0, act_dim = 0, units = 0;
+    l2a_lstm_facts(model, &ctx, &obs_dim, &act_dim, &units);
+    return create(ctx, nullptr, model, obs_dim, act_dim, units, m, n, h, low, high, discount, reward, nullptr, 1, out, true, seed);
+}
+
 void l2a_controller_destroy(l2a_controller* c) {
     if (!c) return;
-    l2a_ahead_destroy(c->chain);                // joins the producer: no upload is in flight afterwards
+    if (c->chain) l2a_ahead_destroy(c->chain);                // joins the producer: no upload is in flight afterwards
     l2a_device_guard guard(c->ctx->device);
     for (int s = 0; s < 2; ++s) {
         if (c->pin[s]) (void)hipHostFree(c->pin[s]);
         if (c->dev[s]) (void)hipFree(c->dev[s]);
         std::free(c->c64[s]);
     }
+    if (c->lowr_dev) (void)hipFree(c->lowr_dev);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
@@ -249,6 +331,7 @@ int l2a_lstm_controller_step(l2a_controller* c, const double* obs, const float* 
 
 int l2a_controller_rearm(l2a_controller* c) {
     if (!c) return L2A_EINVAL;
+    if (c->device_rng) return L2A_OK;
     if (l2a_ahead_arm(c->chain, c->np_addr) != 0) return fail(c->ctx, L2A_ESTATE, "l2a_controller_rearm: the producer thread could not be started");
     return L2A_OK;
 }
@@ -261,8 +344,8 @@ int l2a_controller_stats(l2a_controller* c, double* out, int cap) {
     if (!c || !out || cap < 1) return L2A_EINVAL;
     double v[16] = {0};
     for (int i = 0; i < 7; ++i) v[i] = c->stage_us[i];
-    double ch[6];
-    l2a_ahead_stats(c->chain, ch);
+    double ch[6] = {0, 0, 0, 0, 0, 0};
+    if (c->chain) l2a_ahead_stats(c->chain, ch);
     v[7] = (double)c->steps; v[8] = (double)c->relaunches;
     for (int i = 0; i < 6; ++i) v[9 + i] = ch[i];
     v[15] = (double)c->sync_draws;

@@ -137,12 +137,22 @@ class NativeModel(object):
     def adapt_sgd_raw(self, base_params, obs, act, obs_next, normalization, lr):
         """``adapt_sgd`` from the un-normalised float64 transitions ``[m, rows, dim]`` and ``normalization`` (the
         model's dict of (mean, std) pairs): the device normalises exactly as the host would
-        (``l2a_model_adapt_sgd_raw``)."""
-        obs = np.ascontiguousarray(obs, dtype=np.float64)
-        act = np.ascontiguousarray(act, dtype=np.float64)
-        obs_next = np.ascontiguousarray(obs_next, dtype=np.float64)
-        m, rows = int(obs.shape[0]), int(obs.shape[1])
-        assert obs.shape == (m, rows, self.obs_dim) and act.shape == (m, rows, self.act_dim) and obs_next.shape == obs.shape
+        (``l2a_model_adapt_sgd_raw``).  This wrapper sits in front of the GrBAL step's first launch: arrays and
+        pointers it has seen before (the caller's stacking buffers, the normalisation vectors) are not converted again."""
+        raw = self._keep.get("adapt_raw")
+        if raw is None or raw[0] is not obs or raw[1] is not act or raw[2] is not obs_next:
+            obs_c = np.ascontiguousarray(obs, dtype=np.float64)
+            act_c = np.ascontiguousarray(act, dtype=np.float64)
+            next_c = np.ascontiguousarray(obs_next, dtype=np.float64)
+            m, rows = int(obs_c.shape[0]), int(obs_c.shape[1])
+            assert obs_c.shape == (m, rows, self.obs_dim) and act_c.shape == (m, rows, self.act_dim) and next_c.shape == obs_c.shape
+            # (identity of the CALLER's arrays is only remembered when they needed no conversion: the library copies out of
+            #  them during the call, so the same buffers with new contents are fine)
+            same = obs_c is obs and act_c is act and next_c is obs_next
+            raw = (obs if same else None, act, obs_next, obs_c, act_c, next_c, m, rows,
+                   ctypes.c_void_p(obs_c.ctypes.data), ctypes.c_void_p(act_c.ctypes.data), ctypes.c_void_p(next_c.ctypes.data))
+            self._keep["adapt_raw"] = raw
+        m, rows = raw[6], raw[7]
         base = self._keep.get("adapt_base")
         if base is None or base[0] is not base_params:
             dev = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in base_params]
@@ -152,11 +162,10 @@ class NativeModel(object):
         if nv is None or nv[0] is not normalization:
             vecs = [np.ascontiguousarray(normalization[k][j], dtype=np.float64) for k in ("obs", "act", "delta") for j in (0, 1)]
             assert vecs[0].shape == (self.obs_dim,) and vecs[2].shape == (self.act_dim,) and vecs[4].shape == (self.obs_dim,)
-            nv = (normalization, vecs)
+            nv = (normalization, vecs, [ctypes.c_void_p(v.ctypes.data) for v in vecs])
             self._keep["adapt_norm"] = nv
-        p = [ctypes.c_void_p(v.ctypes.data) for v in nv[1]]
-        rc = self.lib.l2a_model_adapt_sgd_raw(self.handle, base[2], ctypes.c_void_p(obs.ctypes.data),
-                                              ctypes.c_void_p(act.ctypes.data), ctypes.c_void_p(obs_next.ctypes.data),
+        p = nv[2]
+        rc = self.lib.l2a_model_adapt_sgd_raw(self.handle, base[2], raw[8], raw[9], raw[10],
                                               p[0], p[1], p[2], p[3], p[4], p[5], m, rows, float(lr),
                                               _stream_ptr(self.device))
         self.ctx.check(rc, "l2a_model_adapt_sgd_raw")

@@ -15,7 +15,8 @@ because its elite rule (``:101``) needs every candidate's rank.
 
 Extra keyword arguments (all optional, defaults reproduce the reference):
 ``rng`` (``'numpy'`` = parity mode, host MT19937 as in the reference; ``'device'`` = candidates
-drawn on the GPU with torch's Philox generator - statistically equivalent, not bit-identical),
+drawn on the GPU - the library's counter-based Philox stream under ``torch.initial_seed()`` on one GPU, torch's generator
+when sharded - statistically equivalent, not bit-identical),
 ``cem_mode`` (``'reference'`` keeps the reference's three CEM quirks, SURVEY.md section 3.3;
 ``'fixed'`` = clipped rollouts, true top-k elites, env-consistent row order),
 ``shard_candidates`` (use torch.distributed when initialised), ``pipeline_chunks`` (parity mode: the
@@ -452,10 +453,12 @@ class MPCController(Policy, Serializable):
             return None
         if getattr(native, "sync_max_envs", 0) < m or m * native.obs_dim > 4096 or native.act_dim > 16:
             return None
-        if not (fast_rng.available("uniform") and fast_rng.available("direct")) or fast_rng._global_addr() is None:
+        device = self.rng == "device"
+        if not device and (not (fast_rng.available("uniform") and fast_rng.available("direct")) or fast_rng._global_addr() is None):
             return None
         st = NativeStep(native, hasattr(native, "units"), m, self.n_candidates, self.horizon, self.action_space.low,
-                        self.action_space.high, self.discount, self._reward_spec)
+                        self.action_space.high, self.discount, self._reward_spec,
+                        device_seed=(int(torch.initial_seed()) if device else None))
         st.key = key
         self._cstep = st
         return st
@@ -470,7 +473,10 @@ class MPCController(Policy, Serializable):
             return None
         world = self._dist()[1]
         native = self.dynamics_model.planner_model()
-        key = (os.getpid(), id(native), native.handle.value, world, m, self.n_candidates, self.horizon, float(self.discount))
+        # (device mode: the library's counter-based stream restarts whenever torch's seed changes - reproducible under
+        #  torch.manual_seed like the device CEM)
+        key = (os.getpid(), id(native), native.handle.value, world, m, self.n_candidates, self.horizon, float(self.discount),
+               int(torch.initial_seed()) if self.rng == "device" else None)
         st = self._cstep
         if st is None or st.key != key:
             if self._cstep_no == key:
@@ -508,7 +514,7 @@ class MPCController(Policy, Serializable):
         if not self._fusable():
             return self._get_rs_action_unfused(observations)
 
-        if self.rng == "numpy" and self.native_step and self.draw_ahead:
+        if self.native_step and (self.draw_ahead or self.rng == "device"):
             out = self._native_rs_step(observations, m)
             if out is not None:
                 return out

@@ -18,20 +18,29 @@ from ..utils import fast_rng
 
 
 class NativeStep(object):
-    def __init__(self, native, recurrent, m, n, h, low, high, discount, reward):
+    def __init__(self, native, recurrent, m, n, h, low, high, discount, reward, device_seed=None):
+        """``device_seed``: None = parity mode (NumPy's global generator, candidates drawn ahead by a C thread); an integer =
+        ``rng="device"``: the candidates come from the library's counter-based Philox stream under that seed, drawn on the GPU."""
         lib = native.lib
         self.lib, self.ctx, self.native, self.recurrent = lib, native.ctx, native, bool(recurrent)
         self.m, self.n, self.h = int(m), int(n), int(h)
         low = np.ascontiguousarray(low, dtype=np.float64)
         high = np.ascontiguousarray(high, dtype=np.float64)
-        self.addr = fast_rng._global_addr()
-        if self.addr is None:
-            raise _lib.L2AError("np.random's global generator is not the legacy MT19937")
-        self.lock = fast_rng._global_lock()
         handle = ctypes.c_void_p()
-        create = lib.l2a_lstm_controller_create if self.recurrent else lib.l2a_controller_create
-        rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
-                    ctypes.byref(reward), self.addr, fast_rng.threads(), ctypes.byref(handle))
+        self.device_rng = device_seed is not None
+        if self.device_rng:
+            self.addr, self.lock = None, None
+            create = lib.l2a_lstm_controller_create_device if self.recurrent else lib.l2a_controller_create_device
+            rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
+                        ctypes.byref(reward), ctypes.c_ulonglong(int(device_seed) & 0xFFFFFFFFFFFFFFFF), ctypes.byref(handle))
+        else:
+            self.addr = fast_rng._global_addr()
+            if self.addr is None:
+                raise _lib.L2AError("np.random's global generator is not the legacy MT19937")
+            self.lock = fast_rng._global_lock()
+            create = lib.l2a_lstm_controller_create if self.recurrent else lib.l2a_controller_create
+            rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
+                        ctypes.byref(reward), self.addr, fast_rng.threads(), ctypes.byref(handle))
         self.ctx.check(rc, "l2a_controller_create")
         self.handle = handle
         self.obs = np.empty((self.m, native.obs_dim), dtype=np.float64)
@@ -50,12 +59,11 @@ class NativeStep(object):
         h_next)`` device pointers."""
         np.copyto(self.obs, observations, casting="same_kind")
         p = self._p
-        with self.lock:         # the generator's own lock: no other thread draws between the state compare and the adoption
-            if self.recurrent:
-                rc = self.lib.l2a_lstm_controller_step(self.handle, p[0], state[0], state[1], state[2], state[3], p[1], p[2], p[3],
-                                                       stream)
-            else:
-                rc = self.lib.l2a_controller_step(self.handle, p[0], p[1], p[2], p[3], stream)
+        if self.device_rng:
+            rc = self._call(p, state, stream)
+        else:
+            with self.lock:     # the generator's own lock: no other thread draws between the state compare and the adoption
+                rc = self._call(p, state, stream)
         if rc == _lib.L2A_OK or rc == _lib.L2A_STEP_DREW:   # (DREW: no valid block was waiting, the step drew synchronously itself)
             self.misses_in_row = 0
             return True
@@ -67,9 +75,16 @@ class NativeStep(object):
             return True
         self.ctx.check(rc, "l2a_controller_step")
 
+    def _call(self, p, state, stream):
+        if self.recurrent:
+            return self.lib.l2a_lstm_controller_step(self.handle, p[0], state[0], state[1], state[2], state[3], p[1], p[2], p[3], stream)
+        return self.lib.l2a_controller_step(self.handle, p[0], p[1], p[2], p[3], stream)
+
     def rearm(self):
         """After a synchronous draw: the chain restarts at the current global state.  Backs off while steps keep missing
         (a consumer of ``np.random`` runs between the controller's steps: every block drawn ahead would be thrown away)."""
+        if self.device_rng:
+            return
         self.misses_in_row += 1
         if self.misses_in_row > 2:
             self.cooldown += 1

@@ -194,3 +194,83 @@ def test_steps_that_keep_missing_back_off():
     assert ctrl._cstep.stats()["hits"] >= 20
     ctrl._cstep.close()
     ctrl._cstep = None
+
+
+# ---- rng="device" through the C controller: candidates from the library's counter-based Philox stream ---------------------------
+def _philox_uniform_ref(seed, e0, count, act_dim, low, high):
+    """NumPy restatement of csrc/l2a_philox.h: elements e0 .. e0 + count - 1 of the uniform stream (four per Philox4x32-10 block,
+    counter (e >> 2), domain word 'unif'), value = fma(high - low, (word >> 8) / 2^24, low) in fp32, dimension = local index % act_dim."""
+    M = np.uint64(0xFFFFFFFF)
+    e = np.arange(e0, e0 + count, dtype=np.uint64)
+    ctr = e >> np.uint64(2)
+    c = [ctr & M, (ctr >> np.uint64(32)) & M, np.full(count, 0x756E6966, dtype=np.uint64), np.zeros(count, dtype=np.uint64)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M, p0 & M]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    words = np.stack(c, axis=1)[np.arange(count), (e & np.uint64(3)).astype(np.int64)]
+    u = ((words >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float64)
+    k = (np.arange(count) % act_dim)
+    lo32 = np.asarray(low, dtype=np.float32)
+    rng32 = np.asarray(high, dtype=np.float32) - lo32
+    # one rounding (the product of two 24-bit significands and the sum with a 24-bit addend are exact in float64 here)
+    return (rng32[k].astype(np.float64) * u + lo32[k].astype(np.float64)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["hc_rs_m3_n64_h5", "c1_hc_rs_n500_h10_e1"])
+def test_device_rng_step_plans_on_the_librarys_philox_stream(name):
+    """`MPCController(rng="device")` on one GPU is one C call too: a Philox kernel fills the candidate tensor in front of the plan
+    and the HOST recomputes the winner's first action from the same counter-based stream.  Against a NumPy restatement of the
+    stream + the oracle: the chosen index, its return, and the returned action = exactly the fp32 candidate the kernel planned on;
+    step k uses block k of the stream; same torch seed -> same plan; NumPy's generator is not touched."""
+    from oracle import make_reward
+    from oracle.planner import rollout_returns
+    case = cases.CASES[name]
+    env, model = cases.product_model(case)
+    dyn, reward = cases.oracle_dynamics(case), make_reward(case["env"], env.dt)
+    m, n, h, ad = case["m"], case["n"], case["h"], env.action_space.shape[0]
+    obs = np.random.RandomState(4).randn(m, env.observation_space.shape[0])
+    per_step = (h * m * n * ad + 3) // 4 * 4
+    runs = []
+    for rep in range(2):
+        ctrl = cases.product_controller(case, model=model, env=env, rng="device")
+        torch.manual_seed(77)
+        state = np.random.get_state()[1].copy()
+        seq = []
+        for k in range(3):
+            a, _ = ctrl.get_actions(obs)
+            seq.append((a.copy(), np.array(ctrl.last_plan["best_index"]), np.array(ctrl.last_plan["best_return"])))
+        assert ctrl._cstep is not None and ctrl._cstep.device_rng and ctrl._cstep.stats()["steps"] == 3
+        assert np.array_equal(np.random.get_state()[1], state)
+        runs.append(seq)
+        ctrl._cstep.close()
+        ctrl._cstep = None
+    for (a0, i0, r0), (a1, i1, r1) in zip(*runs):
+        assert np.array_equal(a0, a1) and np.array_equal(i0, i1) and np.array_equal(r0, r1)
+    for k, (a, idx, ret) in enumerate(runs[0]):
+        cand = _philox_uniform_ref(77, k * per_step, h * m * n * ad, ad, env.action_space.low, env.action_space.high)
+        cand = cand.reshape(h, m * n, ad).astype(np.float64)
+        rets = rollout_returns(dyn, reward, obs, cand, n, case.get("discount", 1.0)).reshape(m, n)
+        want = np.argmax(rets, axis=1)
+        top2 = np.sort(rets, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * np.maximum(1.0, np.abs(top2[:, 1]))
+        assert np.array_equal(idx[clear], want[clear])
+        assert np.all(np.abs(ret - rets[np.arange(m), idx]) <= 1e-4 * np.maximum(1.0, np.abs(ret)))
+        np.testing.assert_array_equal(a, cand[0].reshape(m, n, ad)[np.arange(m), idx])
+
+
+def test_device_rng_recurrent_step_runs_through_the_c_controller():
+    case = dict(cases.CASES["c6_hc_rnn_rs_n500_h10_m5"])
+    ctrl = cases.product_rnn_controller(case, rng="device")
+    obs = np.random.RandomState(0).randn(5, 20)
+    ctrl.reset(dones=[True] * 5)
+    torch.manual_seed(5)
+    outs = [ctrl.get_actions(obs)[0].copy() for _ in range(3)]
+    assert ctrl._cstep is not None and ctrl._cstep.device_rng and ctrl._cstep.stats()["steps"] == 3
+    assert all(o.shape == (5, 6) and np.all(np.abs(o) <= 1.0) for o in outs)
+    assert not np.array_equal(outs[0], outs[1])                 # another block of the stream every step
+    c, h = ctrl._pack(ctrl._hidden_state)
+    assert np.isfinite(c).all() and np.abs(h).max() <= 1.0 and np.abs(h).max() > 0.0       # the state was advanced
+    ctrl._cstep.close()
+    ctrl._cstep = None
