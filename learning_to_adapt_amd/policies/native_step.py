@@ -10,6 +10,7 @@ the observations into a preallocated array, one ``ctypes`` call, two small array
 """
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -43,6 +44,7 @@ class NativeStep(object):
                         ctypes.byref(reward), self.addr, fast_rng.threads(), ctypes.byref(handle))
         self.ctx.check(rc, "l2a_controller_create")
         self.handle = handle
+        self.pid = os.getpid()      # a forked child must not tear down the parent's HIP objects (it drops the handle instead)
         self.obs = np.empty((self.m, native.obs_dim), dtype=np.float64)
         self.act = np.empty((self.m, native.act_dim), dtype=np.float64)
         self.idx = np.empty((self.m,), dtype=np.int64)
@@ -105,7 +107,8 @@ class NativeStep(object):
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.l2a_controller_destroy(self.handle)
+            if getattr(self, "pid", None) == os.getpid():
+                self.lib.l2a_controller_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
