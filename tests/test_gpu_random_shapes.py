@@ -283,3 +283,74 @@ def test_recurrent_micro_tiles_with_more_envs_than_half_the_cus(m, n):
     _check(got["micro"][0], got["tiles16"][0], got["micro"][1], n, 3)
     _check(got["micro"][0], got["valu"][0], got["micro"][1], n, 3)
     native.close()
+
+
+@pytest.mark.parametrize("seed", range(max(10, _EXTRA)))
+def test_random_adaptation_shapes_match_autograd_and_their_packed_copies_match_the_packer(seed):
+    """The GrBAL adaptation launches (csrc/l2a_adapt.h; round 5: every layer's update rides in the backward launch that follows its
+    dZ, layer 0's columns are updated by the last backward workgroups) on random shapes - observation / action widths anywhere
+    in a tile, 1 - 3 hidden layers of widths on and off the tile sizes, 1 - 16 rows, 1 - 5 tasks, every nonlinearity - against
+    a float64 autograd step; and the three copies the update writes (reference layout, MFMA fragment order, micro-tile order)
+    against the library's own packer: a second model loaded with the adapted raw weights through `set_weights` must plan
+    bit for bit like the adapted one, on the 16-candidate and on the micro-tile kernel."""
+    rs = np.random.RandomState(4200 + seed)
+    od = int(rs.choice([3, 11, 16, 17, 20, 33, 41, 48, 64]))
+    ad = int(rs.choice([1, 2, 6, 8, 13, 16]))
+    depth = int(rs.choice([1, 2, 3]))
+    same = rs.rand() < 0.6          # equal widths of 128 / 256 / 512: the matrix-core (and micro-tile) planner kernels take the model
+    hidden = [int(rs.choice([128, 256, 512]))] * depth if same else [int(rs.choice([64, 72, 128, 200, 256])) for _ in range(depth)]
+    act = str(rs.choice(["relu", "tanh", "sigmoid"]))
+    m, rows = int(rs.choice([1, 2, 3, 5])), int(rs.choice([1, 3, 7, 16]))
+    lr = float(rs.choice([0.01, 0.1]))
+    dev = torch.device("cuda:0")
+    low, high = -np.ones(ad), np.ones(ad)
+    base_np = synthetic.make_weight_set(od, ad, hidden, int(rs.randint(1 << 30)))
+    base = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(dev) for w in base_np]
+    x = rs.randn(m, rows, od + ad).astype(np.float32)
+    y = rs.randn(m, rows, od).astype(np.float32)
+    adapted = NativeModel(od, ad, hidden, act, None, m, "per_block")
+    adapted.adapt_sgd(base, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), lr)
+    got = [[w.cpu().numpy() for w in adapted.get_weights(e)] for e in range(m)]
+    # float64 autograd step per task (meta_mlp_dynamics.py:409-421, loss :118)
+    fn = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    for e in range(m):
+        params = [torch.tensor(np.asarray(w, dtype=np.float64), requires_grad=True) for w in base_np]
+        t = torch.from_numpy(x[e].astype(np.float64))
+        for li in range(depth + 1):
+            t = t @ params[2 * li] + params[2 * li + 1]
+            if li < depth:
+                t = fn(t)
+        loss = torch.mean((torch.from_numpy(y[e].astype(np.float64)) - t) ** 2)
+        grads = torch.autograd.grad(loss, params)
+        for w0, g, w1 in zip(params, grads, got[e]):
+            want = (w0 - lr * g).detach().numpy()
+            step = float(np.abs(lr * g.numpy()).max())
+            assert np.abs(w1 - want).max() <= 3e-5 * max(step, 1e-3) + 2e-7, (seed, e, w1.shape)
+    # the packed copies: adapted model vs a model PACKED from the adapted raw weights
+    packed = NativeModel(od, ad, hidden, act, None, m, "per_block")
+    norm = _norm(rs, od, ad, low, high)
+    for e in range(m):
+        packed.set_weights(e, adapted.get_weights(e))
+        adapted.set_norm(e, norm)
+        packed.set_norm(e, norm)
+    spec = _reward(rs, od, ad)
+    n, h = int(rs.choice([5, 37, 130])), 3
+    obs0 = torch.from_numpy(rs.randn(m, od).astype(np.float32)).to(dev)
+    acts = torch.from_numpy(rs.uniform(low, high, (h, m * n, ad)).astype(np.float32)).to(dev)
+    ctx = _lib.Context.get(0)
+    try:
+        for micro in (0, 2):
+            ctx.set_micro(micro)
+            outs = []
+            for nm in (adapted, packed):
+                rets = torch.empty((m, n), dtype=torch.float32, device=dev)
+                best = torch.zeros((m,), dtype=torch.int64, device=dev)
+                nm.plan_rs(obs0, acts, m, n, h, 0.97, spec, returns_out=rets, best_key=best)
+                torch.cuda.synchronize()
+                ctx.launch_status()
+                outs.append((rets.cpu().numpy(), best.cpu().numpy()))
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (seed, micro)
+    finally:
+        ctx.set_micro(1)
+    adapted.close()
+    packed.close()

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""Where a parity-mode controller step spends its host time (config 2): wraps the controller's stages with timers."""
+"""Where a parity-mode controller step of the PYTHON path spends its host time (config 2; CEM: config 5): wraps the controller's
+stages with timers.  Since round 5 random shooting on one GPU is one C call (tools/probe_step.py has its stage table); this probe
+forces the Python path (L2A_NATIVE_STEP=0), which CEM, sharded plans and the fallback still take."""
 import json
 import os
+os.environ.setdefault("L2A_NATIVE_STEP", "0")
 import sys
 import time
 
