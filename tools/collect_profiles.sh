@@ -22,6 +22,8 @@ grep -v amdgpu.ids $SRC/cem_trace.txt | cut -c1-140 > $DST/${TAG}_cem_trace.txt
 [ -f $SRC/probe_jitter.json ] && cp $SRC/probe_jitter.json $DST/${TAG}_probe_jitter.json
 for f in probe_steps.jsonl probe_jitter.jsonl probe_steps_python_path.jsonl two_planners.jsonl; do [ -f $SRC/$f ] && cp $SRC/$f $DST/${TAG}_$f; done
 for f in $SRC/step_trace_*.txt; do [ -f "$f" ] && grep -v amdgpu.ids $f | cut -c1-150 > $DST/${TAG}_$(basename $f); done
+[ -f $SRC/soak_step.txt ] && grep -v amdgpu.ids $SRC/soak_step.txt > $DST/${TAG}_soak_step.txt
+[ -f $SRC/soak.txt ] && grep -v amdgpu.ids $SRC/soak.txt | tail -30 > $DST/${TAG}_soak.txt
 [ -f $SRC/timeline_adapt.txt ] && grep -v amdgpu.ids $SRC/timeline_adapt.txt > $DST/${TAG}_timeline_adapt.txt
 tail -12 $SRC/pytest_gpu.log | grep -v amdgpu.ids > $DST/${TAG}_pytest_gpu_tail.txt
 # rocprofv3 --stats: the rollout kernels only (torch's elementwise kernels have kilobyte-long names)

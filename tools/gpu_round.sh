@@ -75,6 +75,8 @@ L2A_NATIVE_STEP=0 timeout 600 python tools/probe_step.py c2 rebal grbal mbmpc --
 for w in c2 rebal grbal mbmpc; do bash tools/step_trace.sh $w > $OUT/step_trace_$w.txt 2>&1; cd $GRAFT_REPO_ROOT; done; echo "step traces done"
 timeout 120 python tools/timeline_adapt.py cold > $OUT/timeline_adapt.txt 2>&1; echo "timeline_adapt rc=$?"
 timeout 300 python tools/two_planners.py > $OUT/two_planners.jsonl 2> $OUT/two_planners.err; echo "two_planners rc=$?"
+timeout 300 python tools/soak_step.py 6000 > $OUT/soak_step.txt 2>&1; echo "soak_step rc=$?"
+timeout 600 python tools/soak.py > $OUT/soak.txt 2>&1; echo "soak rc=$?"
 echo "== host RNG helper / end-to-end stage probes"
 timeout 300 python tools/bench_rng.py > $OUT/rng.jsonl 2>&1; echo "rng rc=$?"
 timeout 300 python tools/probe_e2e.py > $OUT/probe_c2.jsonl 2> $OUT/probe.err; echo "probe c2 rc=$?"
