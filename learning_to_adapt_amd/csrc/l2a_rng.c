@@ -821,6 +821,40 @@ int l2a_mt19937_skip_mode(uint32_t* key, int* pos, long long words, int use_jump
     return 0;
 }
 
+/* ---- CEM elite statistics --------------------------------------------------------------------------------------------
+ * `elites = a_stacked[elites_idx]; np.mean(elites, axis=0); np.std(elites, axis=0)` (policies/mpc_controller.py:101-104) in two
+ * passes over the masked rows instead of a gather and five temporaries.  Same bits as NumPy: its reduction over the leading axis
+ * of a C-ordered array adds row after row (pairwise summation applies along the contiguous axis only), so per dimension d
+ *   mean = (((x_0 + x_1) + x_2) + ...) / N ;  std = sqrt((((x_0 - mean)^2 + (x_1 - mean)^2) + ...) / N)
+ * with the rows in index order - float64, no contraction (-ffp-contract=off).  The Python side checks that against np.mean /
+ * np.std on the running machine before it trusts it.  a [rows, D] row-major, mask [rows] (non-zero = elite).  Returns the elite
+ * count, or -1 on a bad argument. */
+long long l2a_cem_elite_stats(const double* a, const unsigned char* mask, long long rows, int D, double* mean_out, double* std_out) {
+    if (!a || !mask || !mean_out || !std_out || rows < 0 || D < 1) return -1;
+    long long cnt = 0;
+    for (int d = 0; d < D; ++d) { mean_out[d] = 0.0; std_out[d] = 0.0; }
+    for (long long r = 0; r < rows; ++r) {
+        if (!mask[r]) continue;
+        const double* x = a + r * D;
+        if (cnt == 0) { for (int d = 0; d < D; ++d) mean_out[d] = x[d]; }       /* (NumPy starts from the first row, not from 0.0 + x) */
+        else { for (int d = 0; d < D; ++d) mean_out[d] = mean_out[d] + x[d]; }
+        ++cnt;
+    }
+    if (cnt == 0) return 0;
+    const double N = (double)cnt;
+    for (int d = 0; d < D; ++d) mean_out[d] = mean_out[d] / N;
+    long long seen = 0;
+    for (long long r = 0; r < rows; ++r) {
+        if (!mask[r]) continue;
+        const double* x = a + r * D;
+        if (seen == 0) { for (int d = 0; d < D; ++d) { const double t = x[d] - mean_out[d]; std_out[d] = t * t; } }
+        else { for (int d = 0; d < D; ++d) { const double t = x[d] - mean_out[d]; std_out[d] = std_out[d] + t * t; } }
+        ++seen;
+    }
+    for (int d = 0; d < D; ++d) std_out[d] = sqrt(std_out[d] / N);
+    return cnt;
+}
+
 /* ---- draw-ahead chain: the NEXT controller step's candidates, drawn while the GPU runs the current plan ----------
  * The reference draws `get_random_action(h*n*m)` at the top of every controller step (policies/mpc_controller.py:
  * 67-69,114) from the global generator; the stream is a pure function of the generator state, so the block of step
@@ -1050,4 +1084,4 @@ void l2a_ahead_stats(l2a_ahead* a, double* out) {
     pthread_mutex_unlock(&a->mu);
 }
 
-int l2a_rng_version(void) { return 7; }
+int l2a_rng_version(void) { return 8; }

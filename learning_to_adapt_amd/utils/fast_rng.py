@@ -56,7 +56,7 @@ def _load():
             c = ctypes
             vp, ll, i32 = c.c_void_p, c.c_longlong, c.c_int
             ip = c.POINTER(i32)
-            if lib.l2a_rng_version() < 7:
+            if lib.l2a_rng_version() < 8:
                 return None
             lib.l2a_mt19937_fill_double_mt.argtypes = [vp, ip, vp, ll, i32]
             lib.l2a_mt19937_fill_double_mt.restype = i32
@@ -82,6 +82,8 @@ def _load():
             lib.l2a_mt19937_state_load.restype = None
             lib.l2a_mt19937_state_digest.argtypes = [vp]
             lib.l2a_mt19937_state_digest.restype = c.c_ulonglong
+            lib.l2a_cem_elite_stats.argtypes = [vp, vp, ll, i32, vp, vp]
+            lib.l2a_cem_elite_stats.restype = ll
             lib.l2a_ahead_create.argtypes = [ll, i32, vp, vp, ll, ll, ll, ll, vp, vp, vp, vp, i32, vp, vp]
             lib.l2a_ahead_create.restype = vp
             lib.l2a_ahead_destroy.argtypes = [vp]
@@ -299,6 +301,16 @@ def _verify(kind):
                     nxt = np.random.random_sample(5)
                     np.random.set_state(after)
                     ok = np.array_equal(nxt, np.random.random_sample(5))
+        elif kind == "elite":
+            rs = np.random.RandomState(12345)
+            ok = True
+            for rows, D, frac in ((4000, 180, 0.1), (333, 7, 0.5), (64, 2, 1.0), (50, 33, 0.02), (1000, 60, 0.05)):
+                a = rs.randn(rows, D) * 10.0 ** rs.randint(-3, 4, size=(1, D))
+                mask = rs.rand(rows) < frac
+                mask[rs.randint(rows)] = True
+                mu, sd = elite_stats(a, mask, _trusted=True)
+                el = a[mask]
+                ok = ok and np.array_equal(mu, np.mean(el, axis=0)) and np.array_equal(sd, np.std(el, axis=0))
         elif kind == "normal":
             np.random.normal()                                   # leave a cached Gaussian behind
             start = np.random.get_state()
@@ -354,6 +366,25 @@ def standard_normal(shape):
             st.to_global()
             return out.reshape(shape)
     return np.random.normal(size=shape)
+
+
+def elite_stats(a, mask, _trusted=False):
+    """``(np.mean(a[mask], axis=0), np.std(a[mask], axis=0))`` for ``a [rows, D]`` float64 and a boolean ``mask [rows]`` - bit for
+    bit (NumPy reduces the leading axis row after row; ``l2a_cem_elite_stats`` does the same in two passes without the gather and
+    the temporaries), or ``None`` when the helper is missing / has not reproduced NumPy on this machine."""
+    if not _trusted and not available("elite"):
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    mask = np.ascontiguousarray(mask, dtype=np.bool_)
+    rows, D = a.shape
+    assert mask.shape == (rows,)
+    if D < 2:       # one column: the reduced axis is the contiguous one and NumPy sums it PAIRWISE - leave that to NumPy
+        return None
+    mu, sd = np.empty(D), np.empty(D)
+    cnt = _state["lib"].l2a_cem_elite_stats(a.ctypes.data, mask.ctypes.data, rows, D, mu.ctypes.data, sd.ctypes.data)
+    if cnt <= 0:
+        return None
+    return mu, sd
 
 
 def cem_samples(z, row_base, h, act_dim, mean, std, low, high, a_out, clip_out, seq_f32, n, sel_lo, sel_hi,

@@ -399,3 +399,32 @@ def test_helper_threads_are_divided_among_the_ranks_of_one_host(monkeypatch):
     monkeypatch.setitem(fast_rng._state, "threads", None)
     assert fast_rng.threads() == 3
     monkeypatch.setitem(fast_rng._state, "threads", None)
+
+
+def test_elite_statistics_are_numpys_bits():
+    """`l2a_cem_elite_stats` (the refit of a CEM iteration, policies/mpc_controller.py:101-104, without the gather and the
+    temporaries) against `np.mean` / `np.std` of the gathered rows: bit for bit - NumPy reduces the leading axis row after row -
+    over sizes, scales, one elite, all elites; a single column is left to NumPy (its reduced axis is the contiguous one: pairwise)."""
+    assert fast_rng.available("elite")
+    rs = np.random.RandomState(77)
+    for rows, D, k in ((4000, 180, 400), (4000, 180, 1), (500, 60, 25), (17, 2, 17), (1000, 6, 100), (64, 33, 3)):
+        a = rs.randn(rows, D) * 10.0 ** rs.randint(-4, 5, size=(1, D)) + rs.randn(1, D)
+        mask = np.zeros(rows, dtype=bool)
+        mask[rs.choice(rows, k, replace=False)] = True
+        mu, sd = fast_rng.elite_stats(a, mask)
+        el = a[mask]
+        assert np.array_equal(mu, np.mean(el, axis=0)) and np.array_equal(sd, np.std(el, axis=0)), (rows, D, k)
+    assert fast_rng.elite_stats(rs.randn(10, 1), np.ones(10, dtype=bool)) is None
+    # through the controller's refit: the reference reading (rank mask pooled over the envs)
+    case = cases.CASES["hc_cem_m2_n100_h4"]
+    ctrl = cases.product_controller(case)
+    n, m, D = case["n"], case["m"], case["h"] * 6
+    a_st = rs.randn(n, m, D)
+    returns = rs.randn(m, n)
+    mean0 = rs.randn(m, D)
+    k = 10
+    got = ctrl._cem_refit(mean0, a_st, returns, k, True)
+    idx = ((-returns).argsort(axis=-1) < k).T
+    el = a_st[idx]
+    want = (mean0 * ctrl.alpha + (1 - ctrl.alpha) * np.mean(el, axis=0), np.std(el, axis=0))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

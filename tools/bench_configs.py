@@ -78,6 +78,15 @@ def time_launches(launch, reps=30, warm_ms=80.0):
     return float(np.median([s.elapsed_time(e) for s, e in evs]))
 
 
+def _step_stats(ctrl):
+    """hits / synchronous draws of the C controller behind a drop-in controller (None: the Python path ran)."""
+    st = getattr(ctrl, "_cstep", None)
+    if st is None:
+        return None
+    s = st.stats()
+    return {"steps": s["steps"], "hits": s["hits"], "sync_draws": s["sync_draws"], "stale_blocks": s["misses"]}
+
+
 def _retire(ctrl):
     """Stop a finished section's draw-ahead worker: an idle chain of an earlier section still costs the later sections'
     parity-mode steps tens of microseconds each (measured: ReBAL 0.36 ms after the GrBAL section, 0.29 ms alone)."""
@@ -256,7 +265,7 @@ def main():
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / 200
         print(json.dumps(dict(config="c6 ReBAL controller step end to end (plan + hidden-state advance), rng=" + mode,
-                              ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1))), flush=True)
+                              ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1), native_step=_step_stats(ctrl))), flush=True)
         _retire(ctrl)
     # config 5: one CEM plan step (5 iterations x 4000 candidates) through the drop-in controller
     case = C["c5_hc_cem_n4000_h30_e5"]
@@ -302,7 +311,7 @@ def main():
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / 200
         print(json.dumps(dict(config="config 2 end to end through MPCController.get_actions, rng=" + mode,
-                              ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1))), flush=True)
+                              ms_per_call=round(ms, 3), calls_per_s=round(1e3 / ms, 1), native_step=_step_stats(ctrl))), flush=True)
         _retire(ctrl)
 
 
