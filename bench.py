@@ -25,7 +25,8 @@ path, timed on this box's host cores, N = 1 only).
 
 `config.get_actions_parity_foreign_draw_plan_steps_per_s` is the parity loop with one foreign `np.random.uniform()`
 between calls (what an in-process env reset does): the draw-ahead block is stale every step and the draw is pipelined
-under the rollout instead.  At N > 1 `config.strong_scaling` compares the sharded plan with the SAME plan on one GPU.
+under the rollout instead.  `config.c5_cem` is BASELINE config 5 at this N: one CEM plan step (5 x 4000 candidates, the plan's
+candidates sharded over the ranks - strong scaling).  At N > 1 `config.strong_scaling` compares the sharded plan with the SAME plan on one GPU.
 
 `python bench.py --gpus N` without a torch.distributed.run environment launches the N ranks itself.
 """
@@ -338,6 +339,27 @@ def main():
                 ctrl._cstep.close()
                 ctrl._cstep = None
 
+    # ---- BASELINE config 5: one CEM plan step (5 iterations x n = 4000, h = 30, E = 5), candidates sharded over the ranks ----
+    # Device-RNG controller (sample / rollout of this rank's shard / all-gather of the returns / refit, five times, + pick:
+    # policies/mpc_controller.py get_cem_action_device).  n = 4000 is the WHOLE plan at every N (strong scaling: 4000 / N per
+    # rank - at N = 8 the 500-candidate shard the member fan of csrc/l2a_mfma.h exists for).  Bounded: <= ~0.5 s.
+    c5 = None
+    if not args.no_e2e:
+        case5 = cases.CASES["c5_hc_cem_n4000_h30_e5"]
+        ctrl5 = cases.product_controller(case5, model=model, env=env, rng="device")
+        torch.manual_seed(0)                    # every rank alike: the ranks sample the same normals and keep their slice
+        for _ in range(3):
+            ctrl5.get_actions(obs_np)
+        clock_warm()
+        k5 = max(5, min(20, args.steps))
+        c5_s = max_over_ranks(_timed_calls(lambda: ctrl5.get_actions(obs_np), k5, 2, sync))
+        lo5, hi5 = ctrl5._shard_range(case5["n"], rank, world)
+        c5 = {"workload": "BASELINE config 5: HalfCheetah CEM, %d iterations x n=%d, h=%d, ens=%d; candidates sharded over %d rank(s) "
+                          "(%d per rank), rng=device" % (case5["num_cem_iters"], case5["n"], case5["h"], case5["E"], world, hi5 - lo5),
+              "plan_step_ms": round(1e3 * c5_s / k5, 4), "plan_steps_per_s": round(k5 / c5_s, 3), "timed_plan_steps": k5,
+              "candidates_per_rank": hi5 - lo5, "scaling": "strong (the plan is 4000 candidates at every N)",
+              "best_index": int(ctrl5.last_plan["best_index"][0])}
+
     # ---- strong scaling of THIS plan (n_glob candidates): rank 0 alone runs the whole plan on its one GPU ------------
     strong = None
     if world > 1:
@@ -464,6 +486,8 @@ def main():
             out["config"]["get_actions_parity_foreign_draw_plan_steps_per_s"] = round(args.steps / e2e["foreign"], 3)
             out["config"]["foreign_draw_note"] = ("one np.random.uniform() consumed between calls (an in-process env reset): "
                                                   "draw-ahead hits in that loop: %d of %d" % (e2e["foreign_hits"], args.steps))
+        if c5 is not None:
+            out["config"]["c5_cem"] = c5
         if strong is not None:
             out["config"]["strong_scaling"] = strong
         if collective is not None:

@@ -109,6 +109,14 @@ int l2a_set_batch(l2a_ctx* ctx, int sets);
  * launch late (config 2, 125 tiles: 1.431 -> 1.417 ms).  0: the contiguous remap of 2 x tiles workgroups.  Placement
  * only: results are bit-identical.                                                                          */
 int l2a_set_xcd_align(l2a_ctx* ctx, int on);
+/* Member fan of the MFMA kernel (mean ensembles of 3 .. 8 sets).  A small plan - E x candidate tiles <= CUs, e.g. one
+ * rank's 500-candidate shard of BASELINE config 5: 32 tiles - runs ONE workgroup per (candidate tile, ensemble member):
+ * every workgroup streams one weight set, and once per horizon step the E workgroups of a tile swap their members' terms
+ * (the tagged granules of the tile split, E - 1 partners instead of one) and add them in the unsplit launch's order.  The
+ * tile split runs such a plan on 2 x tiles workgroups of 2.5 sets each; the fan on E x tiles of one set each.  1 (default)
+ * = wherever it fits (and l2a_set_split is not 0: a flagged launch degrades to the unsplit geometry as before), 0 = never.
+ * Geometry only: results are bit-identical.                                                                     */
+int l2a_set_fan(l2a_ctx* ctx, int on);
 /* Micro tiles (csrc/l2a_micro.h).  A plan whose 16-candidate tiles would leave CUs idle - e.g. the reference's own default
  * plans, run_grbal.py:84-85 / run_rebal.py:77-78: 5 x 500 candidates = 160 tiles on 256 CUs - can run in candidate tiles of
  * FOUR on v_mfma_f32_4x4x1_16b_f32 instead: workgroups of 4, 8 or 12 candidates, every CU busy, no exchange between
@@ -431,8 +439,8 @@ int l2a_lstm_mfma_eligible(int obs_dim, int act_dim, int units);
  * thread (csrc/l2a_rng.c, `l2a_ahead_*`) that draws the NEXT step's candidates from a private copy of the generator
  * state and uploads them while the GPU runs the current plan.
  *   np_state_addr  address of the global generator's `mt19937_state` { uint32 key[624]; int pos; } - in Python
- *                  `np.random.mtrand._rand._bit_generator.ctypes.state_address`; the caller holds the generator's
- *                  lock (`_bit_generator.lock`) around l2a_controller_step / _rearm when other threads may draw
+ *                  `np.random.mtrand._rand._bit_generator.ctypes.state_address` (who may touch it when: the threading
+ *                  contract at l2a_controller_begin below)
  *   low / high     the action bounds (`env.action_space.low / high`, float64 [act_dim], act_dim <= 16)
  *   rng_threads    threads of one draw (the stream is cut into disjoint slices, same numbers for every count)
  * l2a_controller_step:
@@ -477,6 +485,21 @@ int l2a_controller_step(l2a_controller* controller, const double* obs, double* a
 int l2a_lstm_controller_step(l2a_controller* controller, const double* obs, const float* c0, const float* h0,
                              float* c_next, float* h_next, double* action_out, long long* index_out, float* return_out,
                              void* stream);
+/* The step in two halves.  l2a_controller_begin / l2a_lstm_controller_begin: take (or draw) the candidates, stage the
+ * observations, launch, kick the producer - and return while the GPU plans (L2A_OK; L2A_STEP_MISS / negative codes as above,
+ * nothing in flight then).  l2a_controller_finish: wait for the keys, decode, gather - returns what l2a_controller_step
+ * returns (L2A_OK / L2A_STEP_DREW / L2A_STEP_UNSPLIT); between the two the host is free (the next env step's bookkeeping).
+ * One step in flight per controller; the recurrent state pointers must stay valid until the step is finished.
+ * THREADING CONTRACT of `np_state_addr`: the generator's words are read and written ONLY inside l2a_controller_begin (and
+ * therefore the first half of l2a_controller_step) and l2a_controller_rearm, on the calling thread; the producer thread
+ * works on a private copy of the state and never touches the caller's; l2a_controller_finish / _stats / _actions / _destroy
+ * do not access it.  A caller whose OTHER threads may draw from the same generator holds that generator's lock (NumPy:
+ * `_bit_generator.lock`) around _begin / _rearm - not around the wait for the GPU; a single-threaded caller (the
+ * reference's run scripts) needs no lock.                                                                            */
+int l2a_controller_begin(l2a_controller* controller, const double* obs, void* stream);
+int l2a_lstm_controller_begin(l2a_controller* controller, const double* obs, const float* c0, const float* h0,
+                              float* c_next, float* h_next, void* stream);
+int l2a_controller_finish(l2a_controller* controller, double* action_out, long long* index_out, float* return_out);
 int l2a_controller_rearm(l2a_controller* controller);
 const float* l2a_controller_actions(const l2a_controller* controller);
 int l2a_controller_stats(l2a_controller* controller, double* out, int cap);

@@ -27,7 +27,7 @@ KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
 CELL_CODES = {"lstm": 0, "gru": 1, "rnn": 2}
 
 EXPORTED_SYMBOLS = (
-    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split", "l2a_set_batch", "l2a_set_xcd_align", "l2a_set_micro",
+    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split", "l2a_set_batch", "l2a_set_xcd_align", "l2a_set_fan", "l2a_set_micro",
     "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_adapt_sgd_raw", "l2a_model_get_weights",
@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = (
     "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_sync", "l2a_lstm_plan_rs_chunk",
     "l2a_lstm_predict", "l2a_lstm_advance", "l2a_lstm_mfma_eligible",
     "l2a_controller_create", "l2a_lstm_controller_create", "l2a_controller_create_device", "l2a_lstm_controller_create_device",
-    "l2a_controller_destroy", "l2a_controller_step",
+    "l2a_controller_destroy", "l2a_controller_step", "l2a_controller_begin", "l2a_lstm_controller_begin", "l2a_controller_finish",
     "l2a_lstm_controller_step", "l2a_controller_rearm", "l2a_controller_actions", "l2a_controller_stats",
 )
 
@@ -84,6 +84,11 @@ def load():
     else:
         lib.l2a_set_micro.argtypes = [vp, i32]
         lib.l2a_set_micro.restype = i32
+    if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_set_fan"):
+        lib.l2a_set_fan = lambda handle, on: 0
+    else:
+        lib.l2a_set_fan.argtypes = [vp, i32]
+        lib.l2a_set_fan.restype = i32
     if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_set_xcd_align"):
         lib.l2a_set_xcd_align = lambda handle, on: 0
     else:
@@ -202,6 +207,12 @@ def load():
         lib.l2a_lstm_controller_step.restype = i32
         lib.l2a_controller_rearm.argtypes = [vp]
         lib.l2a_controller_rearm.restype = i32
+        lib.l2a_controller_begin.argtypes = [vp, vp, vp]
+        lib.l2a_controller_begin.restype = i32
+        lib.l2a_lstm_controller_begin.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        lib.l2a_lstm_controller_begin.restype = i32
+        lib.l2a_controller_finish.argtypes = [vp, vp, vp, vp]
+        lib.l2a_controller_finish.restype = i32
         lib.l2a_controller_actions.argtypes = [vp]
         lib.l2a_controller_actions.restype = vp
         lib.l2a_controller_stats.argtypes = [vp, dp, i32]
@@ -276,6 +287,10 @@ class Context(object):
     def set_xcd_align(self, on):
         """Split launches: ensemble group A on XCDs 0-3, B on 4-7 exactly (padded grid; default on; bit-identical)."""
         self.check(self.lib.l2a_set_xcd_align(self.handle, int(bool(on))), "l2a_set_xcd_align")
+
+    def set_fan(self, on):
+        """Member fan: small mean-ensemble plans on one workgroup per (candidate tile, member) - default on; bit-identical."""
+        self.check(self.lib.l2a_set_fan(self.handle, int(bool(on))), "l2a_set_fan")
 
     def launch_status_value(self):
         """Status word of the launches since the last call (stream must be synchronised); reading clears it."""

@@ -2,8 +2,8 @@
 
     python learning_to_adapt_amd/csrc/build.py [--force]
 
-The MFMA kernel template is instantiated in five translation units (one per (NT, TPW) pair), the
-LSTM kernel in three (one per units / 64); all are compiled in parallel and linked with the two API units.
+The MFMA kernel template is instantiated in eight translation units (one per (NT, TPW) pair, plus the three
+member-fan units), the LSTM kernel in three (one per units / 64); all are compiled in parallel and linked with the two API units.
 """
 
 import os
@@ -21,6 +21,7 @@ HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_adapt.h", "l2a_mfma
            "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_rnn_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", "l2a_rng.h", os.path.join("..", "..", "include", "l2a.h")]
 SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_rnn_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_step.hip", "l2a_rng.c"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4)]
+FAN_INSTANCES = [(1, 2), (1, 4), (1, 8)]    # member-fan instances of the same template (-DL2A_INST_FAN=1), NT = 1 only
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Rollout kernels: MFMA accumulators in architectural VGPRs where the allocator can afford it - every epilogue reads its
@@ -41,7 +42,9 @@ def _hipcc():
 
 
 def build_rng(verbose=True):
-    """The host RNG helper: plain C, built with gcc.  Optional - without it parity mode uses NumPy's own loop."""
+    """The host RNG helper: plain C, built with gcc.  REQUIRED since round 5: libl2a_hip.so links against it (the controller
+    step's draw-ahead chain, l2a_step.hip; found next to the library at load time through rpath $ORIGIN - an L2A_LIB_PATH
+    library placed elsewhere needs its libl2a_rng.so beside it).  Both sides require l2a_rng_version() >= 8."""
     gcc = shutil.which("gcc") or shutil.which("clang") or ("/opt/rocm/lib/llvm/bin/clang" if os.path.exists("/opt/rocm/lib/llvm/bin/clang") else None)
     if gcc is None:
         if verbose:
@@ -103,6 +106,9 @@ def unit_table():
     for nt, tpw in INSTANCES:
         t["l2a_mfma_%d_%d.o" % (nt, tpw)] = ("l2a_mfma_inst.hip", ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw] +
                                                (KERNEL_FLAGS if nt == 1 else []))
+    for nt, tpw in FAN_INSTANCES:
+        t["l2a_mfma_fan_%d_%d.o" % (nt, tpw)] = ("l2a_mfma_inst.hip", ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw,
+                                                                        "-DL2A_INST_FAN=1"] + KERNEL_FLAGS)
     return t
 
 
@@ -157,7 +163,7 @@ def build(force=False, verbose=True, only=None):
     for o, (src, flags) in table.items():
         obj = os.path.join(OBJ_DIR, o)
         if only is not None and o.startswith("l2a_mfma_") and os.path.exists(obj) and \
-                tuple(int(x) for x in o[len("l2a_mfma_"):-2].split("_")) not in only:
+                tuple(int(x) for x in o[len("l2a_mfma_"):-2].replace("fan_", "").split("_")) not in only:
             continue
         if not force and only is None and _obj_fresh(obj):
             continue

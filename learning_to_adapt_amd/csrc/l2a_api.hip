@@ -221,7 +221,14 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         p.split_from = -1;
         long long split_pairs = 0;          // tiles shared by two workgroups
         auto split_mode = [&]() { return split_mode_for(md, e_loop); };
-        if (ctx->split_policy != 0 && nt == 1 && p.h < 4096) {
+        // Member fan: E workgroups per tile, one set each (l2a_mfma.h) - small mean-ensemble plans, e.g. one rank's
+        // shard of config 5 (n = 500: 32 tiles -> 160 workgroups of one set instead of 64 of 2.5 sets).
+        const bool fan = ctx->split_policy != 0 && ctx->fan_policy != 0 && nt == 1 && p.h < 4096 &&
+                         p.mode == L2A_MODE_MEAN && e_loop >= 3 && e_loop <= 8 && pairs * e_loop <= cus;
+        if (fan) {
+            p.split = 3;
+            split_pairs = pairs;
+        } else if (ctx->split_policy != 0 && nt == 1 && p.h < 4096) {
             if (2 * pairs <= cus) {
                 p.split = split_mode();
                 split_pairs = p.split ? pairs : 0;
@@ -234,7 +241,8 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             }
         }
         if (p.split) {
-            const long long need = split_pairs * 2 * 2 * 2 * (long long)(nt * md->OT * 2 * 64 * 16) / 8;   // in 8-byte units
+            // in 8-byte units: per shared tile 2 workgroups x 2 step parities x 2 regions (fan: E workgroups x 2 parities)
+            const long long need = split_pairs * (fan ? e_loop : 4) * 2 * (long long)(nt * md->OT * 2 * 64 * 16) / 8;
             if (need > md->xbuf_granules) {
                 if (md->xbuf) { L2A_HIP(ctx, hipStreamSynchronize(stream)); L2A_HIP(ctx, hipFree(md->xbuf)); md->xbuf = nullptr; }
                 L2A_HIP(ctx, l2a_xbuf_alloc(reinterpret_cast<void**>(&md->xbuf), (size_t)need * 8));
@@ -259,9 +267,9 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         // (<= 4, <= the longest set sequence of a workgroup) that fits the CU's LDS; 1 = one set at a time.
         const bool uniform_split = p.split && p.split_from < 0;
         const int e_half = (e_loop + 1) / 2;
-        const int nseq = uniform_split ? e_half : e_loop;            // sets the busiest workgroup runs in sequence
+        const int nseq = fan ? 1 : uniform_split ? e_half : e_loop;  // sets the busiest workgroup runs in sequence
         const int ps_bytes = L2A_NW * nt * md->OT * 64 * 16;         // the waves' output-layer partials of one set
-        const int x_bytes = 2 * nt * md->OT * 64 * 16;
+        const int x_bytes = (fan ? e_loop : 2) * nt * md->OT * 64 * 16;   // exchange staging: the partner's two regions / every member's term
         const int cst_bytes_all = nseq * p.cst_set * 4;
         p.n_cst = nseq;
         p.lb = 1;
@@ -281,7 +289,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         const int smem = p.cst_off * 16 + cst_bytes_all + x_bytes;
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
-        long long n_wg = pairs + (p.split ? split_pairs : 0);
+        long long n_wg = fan ? pairs * e_loop : pairs + (p.split ? split_pairs : 0);
         p.pl_units = 0;
         if (ctx->xcd_align && p.split_from < 0 && n_wg <= cus) {
             // one unit of weight-sharing workgroups per XCD (see the kernel's geometry): the two groups of a split
@@ -289,6 +297,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             int units = 0;
             long long w = 0;
             if (p.mode == L2A_MODE_PER_BLOCK) { units = p.m; w = (long long)p.tiles_per_env * (p.split ? 2 : 1); }
+            else if (fan) { units = e_loop; w = pairs; }      // every member's workgroups on their own XCD(s)
             else if (p.split && e_loop > 1) { units = 2; w = pairs; }
             if (units >= 2 && units <= 8) {
                 const int f = 8 / units;
@@ -301,7 +310,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         }
         const dim3 grid((unsigned)n_wg), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
-        int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, &p, grid.x, smem, stream);
+        int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, fan ? 1 : 0, &p, grid.x, smem, stream);
         if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");
         if (rc != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch: ") + hipGetErrorString((hipError_t)rc));
         rc = L2A_OK;
@@ -387,6 +396,8 @@ int l2a_init(int device, l2a_ctx** out) {
     if (sp && sp[0] >= '0' && sp[0] <= '2') ctx->split_policy = sp[0] - '0';
     const char* xa = std::getenv("L2A_XCD_ALIGN");
     if (xa && (xa[0] == '0' || xa[0] == '1')) ctx->xcd_align = xa[0] - '0';
+    const char* fn = std::getenv("L2A_FAN");
+    if (fn && (fn[0] == '0' || fn[0] == '1')) ctx->fan_policy = fn[0] - '0';
     const char* bs = std::getenv("L2A_BATCH");
     if (bs && bs[0] >= '0' && bs[0] <= '4') ctx->batch_sets = bs[0] - '0';
     const char* mc = std::getenv("L2A_MICRO");
@@ -409,6 +420,13 @@ int l2a_set_split(l2a_ctx* ctx, int policy) {
     if (!ctx) return L2A_EINVAL;
     if (policy < 0 || policy > 2) return fail(ctx, L2A_EINVAL, "split policy must be 0, 1 or 2");
     ctx->split_policy = policy;
+    return L2A_OK;
+}
+
+int l2a_set_fan(l2a_ctx* ctx, int on) {
+    if (!ctx) return L2A_EINVAL;
+    if (on != 0 && on != 1) return fail(ctx, L2A_EINVAL, "member fan must be 0 or 1");
+    ctx->fan_policy = on;
     return L2A_OK;
 }
 
@@ -1021,9 +1039,16 @@ int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tk, int m, bool published,
         if (ctx->sync_shape != tk.shape) { ctx->sync_shape = tk.shape; ctx->sync_ema_us = 0.0; }
         const volatile unsigned long long* seqp = &mh->seq;
         bool overslept = false;
+        // (a plan that had already published when the host came to wait - l2a_controller_finish after other host work - says
+        // nothing about its duration: the estimate is left alone)
+        const bool ready_at_entry = (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == tk.seq);
         if (sleep_mode && ctx->sync_ema_us > 400.0) {
-            usleep((useconds_t)(ctx->sync_ema_us * 0.8 - 100.0));
-            overslept = (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == tk.seq);
+            // (what is left of the expected duration: l2a_controller_finish may be called long after the launch)
+            const double left = ctx->sync_ema_us * 0.8 - 100.0 - (now_us() - tk.t0_us);
+            if (left > 20.0 && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != tk.seq) {
+                usleep((useconds_t)left);
+                overslept = (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == tk.seq);
+            }
         }
         unsigned long long spins = 0;
         while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != tk.seq) {
@@ -1046,7 +1071,8 @@ int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tk, int m, bool published,
             }
         }
         const double us = now_us() - tk.t0_us;
-        ctx->sync_ema_us = overslept ? 0.0 : (ctx->sync_ema_us == 0.0) ? us : 0.75 * ctx->sync_ema_us + 0.25 * us;
+        if (!ready_at_entry)
+            ctx->sync_ema_us = overslept ? 0.0 : (ctx->sync_ema_us == 0.0) ? us : 0.75 * ctx->sync_ema_us + 0.25 * us;
         for (int i = 0; i < m; ++i) keys_host_out[i] = mh->keys[i];
     } else {
         L2A_HIP(ctx, hipMemcpyAsync(mh->keys, tk.keys_dev, sizeof(unsigned long long) * (size_t)m, hipMemcpyDeviceToHost, stream));
@@ -1073,11 +1099,12 @@ void l2a_model_facts(const l2a_model* md, l2a_ctx** ctx, int* obs_dim, int* act_
 
 int l2a_plan_rs_sync_hook(l2a_model* md, const float* obs_host, const float* actions, int m, int n, int h,
                           double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
-                          unsigned long long* keys_host_out, void* stream_v, l2a_after_launch_fn hook, void* hook_arg) {
+                          unsigned long long* keys_host_out, void* stream_v, l2a_after_launch_fn hook, void* hook_arg,
+                          l2a_mail_pending* pending) {
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
     ctx->stamps_us[0] = l2a_now_us();
-    if (!obs_host || !actions || !reward || !keys_host_out)
+    if (!obs_host || !actions || !reward || (!keys_host_out && !pending))
         return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: null obs / actions / reward / keys_host_out");
     if (m < 1 || n < 1 || h < 1) return fail(ctx, L2A_EINVAL, "l2a_plan_rs_sync: m, n and h must be >= 1");
     if (m > L2A_MAIL_KEYS || (long long)m * md->obs_dim > L2A_MAIL_OBS)
@@ -1115,7 +1142,21 @@ int l2a_plan_rs_sync_hook(l2a_model* md, const float* obs_host, const float* act
     ctx->stamps_us[2] = l2a_now_us();
     if (rc == L2A_OK && hook) hook(hook_arg);
     ctx->stamps_us[3] = l2a_now_us();
+    if (pending && rc == L2A_OK) {
+        pending->tk = tk; pending->publish = publish; pending->m = m; pending->stream = stream;
+        pending->who = "l2a_plan_rs_sync"; pending->live = true;
+        return L2A_OK;
+    }
     rc = l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_plan_rs_sync");
+    ctx->stamps_us[4] = l2a_now_us();
+    return rc;
+}
+
+int l2a_plan_finish(l2a_ctx* ctx, l2a_mail_pending* pending, unsigned long long* keys_host_out) {
+    if (!pending || !pending->live) return fail(ctx, L2A_ESTATE, "no plan is in flight");
+    pending->live = false;
+    l2a_device_guard guard(ctx->device);
+    const int rc = l2a_mail_end(ctx, pending->tk, pending->m, pending->publish, L2A_OK, pending->stream, keys_host_out, pending->who);
     ctx->stamps_us[4] = l2a_now_us();
     return rc;
 }

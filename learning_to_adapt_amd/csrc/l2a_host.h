@@ -23,6 +23,7 @@ struct l2a_ctx {
     int kernel_kind = L2A_KERNEL_AUTO;
     int split_policy = 1;                 // 1 = split members over two workgroups when it fills the chip
     int xcd_align = 1;                    // uniform tile split: pad the grid so that each ensemble group owns four XCDs (L2A_XCD_ALIGN=0: off)
+    int fan_policy = 1;                   // member fan (one workgroup per candidate tile and ensemble member): 0 = never, 1 = where E x tiles fit the chip (L2A_FAN=0: off)
     int batch_sets = 0;                   // MFMA rollout: sets per batch; 0 = as many as fit the LDS, 1 = one at a time
     int micro_policy = 1;                 // micro-tile kernels (l2a_micro.h): 0 = never, 1 = where they fill the chip better, 2 = whenever a plan is eligible
     unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
@@ -98,15 +99,26 @@ extern "C" L2A_HIDDEN int l2a_mail_end(l2a_ctx* ctx, const l2a_mail_ticket& tick
 // ---- the blocking plans with a hook between launch and wait (l2a_step.hip: the controller step kicks the producer of the NEXT
 //      step's candidates there - after the launch is on its way, before the host starts waiting) ----
 typedef void (*l2a_after_launch_fn)(void* arg);
+// With `pending` the hook variants return right after the hook - launch on its way, nothing waited for - and the caller ends
+// the plan later with l2a_plan_finish (l2a_controller_begin / _finish).
+struct l2a_mail_pending {
+    l2a_mail_ticket tk;
+    bool publish = false;
+    int m = 0;
+    hipStream_t stream = nullptr;
+    const char* who = "";
+    bool live = false;
+};
+extern "C" L2A_HIDDEN int l2a_plan_finish(l2a_ctx* ctx, l2a_mail_pending* pending, unsigned long long* keys_host_out);
 extern "C" L2A_HIDDEN int l2a_plan_rs_sync_hook(l2a_model* md, const float* obs_host, const float* actions, int m, int n, int h,
                                                 double discount, const l2a_reward* reward, int cand_offset, float* returns_out,
                                                 unsigned long long* keys_host_out, void* stream, l2a_after_launch_fn hook,
-                                                void* hook_arg);
+                                                void* hook_arg, l2a_mail_pending* pending = nullptr);
 extern "C" L2A_HIDDEN int l2a_lstm_plan_rs_sync_hook(l2a_lstm* md, const float* obs_host, const float* c0, const float* h0,
                                                      const float* actions, int m, int n, int h, double discount,
                                                      const l2a_reward* reward, int cand_offset, unsigned long long* keys_host_out,
                                                      float* c_next, float* h_next, void* stream, l2a_after_launch_fn hook,
-                                                     void* hook_arg);
+                                                     void* hook_arg, l2a_mail_pending* pending = nullptr);
 extern "C" L2A_HIDDEN void l2a_model_facts(const l2a_model* md, l2a_ctx** ctx, int* obs_dim, int* act_dim);
 extern "C" L2A_HIDDEN void l2a_lstm_facts(const l2a_lstm* md, l2a_ctx** ctx, int* obs_dim, int* act_dim, int* units);
 inline double l2a_now_us() {

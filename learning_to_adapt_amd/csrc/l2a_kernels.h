@@ -77,7 +77,8 @@ struct L2AKParams {
     double discount;            // float64 like the reference's `self.discount ** t` (:126)
     l2a_reward rw;
     // ---- member split (MFMA kernel, mean mode): two workgroups share one candidate tile ----
-    int split;                  // 0: one workgroup runs all members; 1: group A | group B; 2: + shared set
+    int split;                  // 0: one workgroup runs all members; 1: group A | group B; 2: + shared set;
+                                // 3: member fan - n_sets workgroups per tile, one set each (FAN instances only)
     // XCD placement of a single-round launch (0 units = the contiguous remap of l2a_logical_wg).  A "unit" is a set of
     // workgroups that stream the same weights: the two ensemble groups of a split mean-mode launch, the environments of a
     // per-block launch.  The first pl_r units own pl_f + 1 XCDs each, the others pl_f; the grid is 8 ceil(pl_w / pl_f)
@@ -86,7 +87,7 @@ struct L2AKParams {
     int split_from;             // -1: `split` applies to every tile; >= 0: tail split - hardware workgroups
                                 // [0, split_from) run whole tiles, the rest are pairs sharing tiles split_from ..
     unsigned int xtag;          // per-launch tag base (launch nonce << 12); tag = xtag + t + 1
-    unsigned long long* xbuf;   // exchange granules [pair][group][slot][NT*OT*4][64]
+    unsigned long long* xbuf;   // exchange granules [pair][group][slot][region][NT*OT*2][64] (fan: [pair][member][slot][NT*OT*2][64])
     unsigned int* status;       // host-visible word; bit 0 set = exchange timed out
     unsigned int spin_limit;    // polls one workgroup may spend waiting for its partner, per launch
     unsigned long long* dbg;    // optional phase timeline (tools/timeline.py); null in production

@@ -602,11 +602,11 @@ void l2a_lstm_facts(const l2a_lstm* md, l2a_ctx** ctx, int* obs_dim, int* act_di
 int l2a_lstm_plan_rs_sync_hook(l2a_lstm* md, const float* obs_host, const float* c0, const float* h0, const float* actions,
                                int m, int n, int h, double discount, const l2a_reward* reward, int cand_offset,
                                unsigned long long* keys_host_out, float* c_next, float* h_next, void* stream_v,
-                               l2a_after_launch_fn hook, void* hook_arg) {
+                               l2a_after_launch_fn hook, void* hook_arg, l2a_mail_pending* pending) {
     if (!md) return L2A_EINVAL;
     l2a_ctx* ctx = md->ctx;
     ctx->stamps_us[0] = l2a_now_us();
-    if (!obs_host || !c0 || !h0 || !actions || !reward || !keys_host_out)
+    if (!obs_host || !c0 || !h0 || !actions || !reward || (!keys_host_out && !pending))
         return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: null obs / c0 / h0 / actions / reward / keys_host_out");
     if ((!c_next) != (!h_next)) return l2a_fail(ctx, L2A_EINVAL, "l2a_lstm_plan_rs_sync: pass c_next and h_next together");
     if (c_next && (c_next == c0 || h_next == h0))
@@ -668,6 +668,11 @@ int l2a_lstm_plan_rs_sync_hook(l2a_lstm* md, const float* obs_host, const float*
     ctx->stamps_us[2] = l2a_now_us();
     if (rc == L2A_OK && hook) hook(hook_arg);
     ctx->stamps_us[3] = l2a_now_us();
+    if (pending && rc == L2A_OK) {
+        pending->tk = tk; pending->publish = publish; pending->m = m; pending->stream = stream;
+        pending->who = "l2a_lstm_plan_rs_sync"; pending->live = true;
+        return L2A_OK;
+    }
     rc = l2a_mail_end(ctx, tk, m, publish, rc, stream, keys_host_out, "l2a_lstm_plan_rs_sync");
     ctx->stamps_us[4] = l2a_now_us();
     return rc;

@@ -44,6 +44,14 @@
 // the unit whose single-copy atomicity the recipe rests on - a {tag, v0, v1, v2} granule would need 16-byte atomicity,
 // which nothing documents).  While the records travel the waves take over the next step's actions.  Spins are bounded
 // (status word, never a hang).
+// Member fan (FAN instances, p.split == 3; l2a_set_fan): a mean ensemble of E = 3 .. 8 sets whose plan has so few tiles that
+// E x tiles <= CUs (one rank's 500-candidate shard of BASELINE config 5: 32 tiles) runs E workgroups per tile, workgroup g
+// = member g as a full member and nothing else.  Per horizon step every workgroup publishes its member's term
+// (denormalised delta, the same {tag, v, tag, v} granules, one region per (tile, member, step parity)), wave w collects
+// partners w, w + 4, .. and every wave adds all E terms from LDS in the unsplit launch's order, (0 + t_0 + .. + t_eh-1) +
+// (0 + t_eh + .. + t_E-1): same bits.  The half-member code is compiled out of these instances (330 instead of 442 VGPRs
+// on the HalfCheetah shape).  Config-5 shard, n = 500, h = 30, E = 5: 160 workgroups of one set, 0.597 ms, against the
+// tile split's 64 workgroups of 2.5 sets, 1.399 ms (rocprofv3, profiles/r06_c5shard_kernel_stats.csv).
 // Tail split (p.split_from >= 0): in a multi-round plan whose last round would fill under half of the
 // chip only the left-over tiles are shared; their workgroup pairs are dispatched last, back to back.
 //
@@ -129,7 +137,7 @@ __device__ __forceinline__ float l2a_sum_xor32(float x) {
 #define L2A_TS(slot)
 #else
 #define L2A_TS(slot)                                                                        \
-    if (p.dbg && pairid == 0 && e < 8) {                                                    \
+    if (p.dbg && pairid == 0 && e < 8 && grp < 2) {                                         \
         unsigned long long ts_;                                                             \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");       \
         if (lane == 0) p.dbg[(((long long)(grp * p.h + t) * 8 + e) * 8 + wave) * 16 + (slot)] = ts_; \
@@ -332,7 +340,7 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
             pbuf[((chunk0 * NT + nt) * OT + c) * 64 + lane] = (NCH == 2) ? acc[0][nt][c] + acc[NCH - 1][nt][c] : acc[0][nt][c];
 }
 
-template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = false>
+template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = false, bool FAN = false>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
     constexpr int HT = L2A_NW * TPW;
     constexpr int TH = TPW / 2;         // tiles per wave of a half member
@@ -373,7 +381,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     // plan (e.g. 625 tiles on 256 CUs: 512 whole + 113 shared instead of a third, 44 %-filled round).
     const int tail = p.split_from >= 0;
     const int in_tail = tail && (int)blockIdx.x >= p.split_from;
-    const int split = tail ? (in_tail ? p.split : 0) : p.split;        // this workgroup's split mode
+    const int split = FAN ? 3 : (tail ? (in_tail ? p.split : 0) : p.split);   // this workgroup's split mode (3 = member fan)
     const int n_tiles = p.m * p.tiles_per_env;
     const int n_pairs = tail ? n_tiles - p.split_from : n_tiles;       // tiles that are shared by two workgroups
     int bid, grp, lpair, pairid;
@@ -444,10 +452,11 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const bool per_block = (p.mode == L2A_MODE_PER_BLOCK);
     const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
     const int e_half = (e_loop + 1) >> 1;                   // group A = [0, e_half), B = [e_half, e_loop)
-    const int e_shared = (split == 2) ? e_half - 1 : -1;
-    const int n_full = !split ? e_loop : (grp == 0 ? e_half - (split == 2 ? 1 : 0) : e_loop - e_half);
-    const int n_seq = n_full + (split == 2 ? 1 : 0);
-    const int full0 = (split && grp == 1) ? e_half : 0;       // first full set of this workgroup
+    // Member fan (FAN instances, split == 3): workgroup `grp` of a tile runs set `grp` alone, as a full member.
+    const int e_shared = (!FAN && split == 2) ? e_half - 1 : -1;
+    const int n_full = FAN ? 1 : (!split ? e_loop : (grp == 0 ? e_half - (split == 2 ? 1 : 0) : e_loop - e_half));
+    const int n_seq = FAN ? 1 : n_full + (split == 2 ? 1 : 0);
+    const int full0 = FAN ? grp : ((split && grp == 1) ? e_half : 0);       // first full set of this workgroup
     auto seq = [&](int i) { return (i < n_full) ? full0 + i : e_shared; };
     auto set_base = [&](int e) { return p.wblk + (long long)(per_block ? env : e) * p.set_stride; };
 
@@ -545,7 +554,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     double disc_pow = p.disc0;  // discount ** t, carried in float64 like the reference (:126)
     unsigned int spin_left = p.spin_limit;      // exchange polls this workgroup may still spend (whole launch)
     const unsigned int xtag0 = p.xtag;
-    const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
+    const __amdgpu_buffer_rsrc_t xrs = l2a_rsrc(p.xbuf, FAN ? (long long)n_pairs * e_loop * 2 * (NT * OT * 2 * 64 * 16)
+                                                        : split ? (long long)n_pairs * 8 * (NT * OT * 2 * 64 * 16) : 16);
 
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
     // barrier that separates them, so a phase never starts with an exposed L2 round trip).
@@ -750,7 +760,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     // the first hidden GEMM of the batch follows (set seq(b0))
                     const int e0 = seq(b0);
                     const __amdgpu_buffer_rsrc_t rs1 = l2a_rsrc(set_base(e0) + p.pk_wmid, wm_bytes);
-                    const bool next_half = (e0 == e_shared) && n_hidden == 2;
+                    const bool next_half = !FAN && (e0 == e_shared) && n_hidden == 2;
                     if (next_half) {
 #pragma unroll
                         for (int tt = 0; tt < TH; ++tt) {
@@ -793,7 +803,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 constexpr bool last_set = decltype(last_tag)::value;
                 const int i = b0 + j;
                 const int e = seq(i);
-                const bool is_half = last_set && (e == e_shared);
+                const bool is_half = !FAN && last_set && (e == e_shared);
                 const float* wb = set_base(e);
                 const float* nr = nrm + i * NRM_SET;
                 const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
@@ -859,7 +869,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 } else {
                     const int en = seq(i + 1);
                     const __amdgpu_buffer_rsrc_t rsn = l2a_rsrc(set_base(en) + p.pk_wmid, wm_bytes);   // nb > 1: two hidden layers
-                    if (en == e_shared) {
+                    if (!FAN && en == e_shared) {
                         l2a_out_phase<NT, TPW, TPW, OT, 2 * TH, O4>(hreg, pfO, rs_out, c0, [&]() {
 #pragma unroll
                             for (int tt = 0; tt < TH; ++tt) {
@@ -892,7 +902,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             for (int j = 0; j < nb; ++j) {
                 const int i = b0 + j;
                 const int e = seq(i);
-                const bool is_half = (e == e_shared);
+                const bool is_half = !FAN && (e == e_shared);
                 const float* nr = nrm + i * NRM_SET;
                 const f32x4* pb = (LB > 1) ? pbase + j * PS : hoth;
                 L2A_TS(5)
@@ -939,7 +949,8 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                                 for (int ii = 0; ii < 4; ++ii) s[ii] = l2a_sum_xor32(l2a_sum_xor16(s[ii]));
                             }
                             s = l2a_actv<GACT>(s + bias, p.output_act, p.out_floor);
-                            dgrp[nt][c] += s * osd + omu;
+                            if (FAN) dgrp[nt][c] = s * osd + omu;      // this member's term as it stands: summed with the others' below
+                            else dgrp[nt][c] += s * osd + omu;
                         }
                     }
                 }
@@ -962,7 +973,97 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         float asq_t[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) asq_t[nt] = asq[nt];
-        if (split) {
+        if (FAN) {
+            // ---- member fan: the E workgroups of a tile each hold ONE member's term; everybody publishes its own, collects
+            // the E - 1 others (wave w polls partners w, w + 4, ..: with five members one partner per wave, all sweeps in
+            // flight together) and adds all E in the canonical order - the unsplit launch's (0 + t_0 + .. ) + (0 + t_eh + ..).
+            // One region per (tile, member, step parity): a member can be one step ahead of a partner at most (it needs the
+            // partner's record of step t + 1 to get to step t + 2, and the partner publishes that after reading step t).
+            constexpr int XREGF = NT * OT * 2 * 64 * 16;
+            auto fbase = [&](int g) { return ((lpair * e_loop + g) * 2 + (t & 1)) * XREGF + lane * 16; };
+            if (wave == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) {
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            u32x4 g;
+                            g.x = xtag; g.y = __float_as_uint(dgrp[nt][c][2 * hh]);
+                            g.z = xtag; g.w = __float_as_uint(dgrp[nt][c][2 * hh + 1]);
+                            __builtin_amdgcn_raw_buffer_store_b128(g, xrs, fbase(grp) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_SC1);
+                        }
+                        xlds[((grp * NT + nt) * OT + c) * 64 + lane] = dgrp[nt][c];
+                    }
+            }
+            { const int e = 7; L2A_TS(11) }
+            take_actions(t + 2);
+            for (int k = wave; k < e_loop - 1; k += L2A_NW) {
+                int g2 = grp + 1 + k;
+                if (g2 >= e_loop) g2 -= e_loop;
+                f32x4 oth[NT][OT];
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c)
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(
+                                    xrs, fbase(g2) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_SC1);
+                                oth[nt][c][2 * hh] = __uint_as_float(g.y);
+                                oth[nt][c][2 * hh + 1] = __uint_as_float(g.w);
+                                ok = ok && (g.x == xtag) && (g.z == xtag);
+                            }
+                    if (__all(ok)) break;
+                    if (spin_left == 0) {               // partner never arrived: flag the launch, do not hang
+                        if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    --spin_left;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int c = 0; c < OT; ++c) xlds[((g2 * NT + nt) * OT + c) * 64 + lane] = oth[nt][c];
+            }
+            { const int e = 7; L2A_TS(12) }
+            __syncthreads();
+            { const int e = 7; L2A_TS(13) }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < OT; ++c) {
+                    dsum[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    dgrp[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            {   // every term's LDS read first (slots past the ensemble re-read the last one and are not added), then the
+                // adds in member order: one exposed LDS round trip instead of E (timeline r06: 3.4k -> 1.9k clocks)
+                constexpr int EMAX = 8;
+                f32x4 v[EMAX][NT][OT];
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) {
+                    const int es = e < e_loop ? e : e_loop - 1;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c) v[e][nt][c] = xlds[((es * NT + nt) * OT + c) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c) {
+                            if (e < e_half) dsum[nt][c] += v[e][nt][c];
+                            else if (e < e_loop) dgrp[nt][c] += v[e][nt][c];
+                        }
+            }
+            // (the staging slots are rewritten after the next step's barriers, which every wave reaches after these reads)
+        } else if (split) {
             if (wave == 0) {
                 if (split == 2) xput(1, qsh);
                 else xput(0, dgrp);
@@ -1140,7 +1241,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
         }
     }
 #if defined(L2A_TIMELINE) || defined(L2A_WGREC)
-    if (p.dbg && wave == 0 && lane == 0) {      // per-workgroup record behind the phase stamps: lifetime and placement
+    if (p.dbg && wave == 0 && lane == 0 && grp < 2) {      // per-workgroup record behind the phase stamps: lifetime and placement
         unsigned long long wg_t1_, wg_r1_;
         unsigned int xcc_;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1_), "=s"(wg_r1_) : : "memory");

@@ -52,6 +52,16 @@ struct l2a_controller {
     bool device_rng = false;
     unsigned long long seed = 0, calls = 0;
     float* lowr_dev = nullptr;                  // [2][16]: low | high - low, fp32
+    // a step between l2a_controller_begin and l2a_controller_finish
+    l2a_mail_pending pending;
+    bool in_flight = false;
+    int result = L2A_OK;                        // what the finished step reports (L2A_OK / L2A_STEP_DREW / L2A_STEP_UNSPLIT)
+    unsigned long long offset = 0;              // device-RNG mode: the step's first stream element
+    float obs32[L2A_MAIL_OBS];                  // the observations as staged (a relaunch in `finish` stages them again)
+    const float *c0 = nullptr, *h0 = nullptr;   // recurrent: the caller's state pointers of the step in flight
+    float *c1 = nullptr, *h1 = nullptr;
+    void* stream = nullptr;
+    double t_begin = 0.0, t_taken = 0.0;
 };
 
 // Device-RNG mode: the candidate tensor [h, m * n, act_dim] from the counter-based stream (seed, offset + element): four elements
@@ -112,7 +122,7 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
         return fail(ctx, L2A_EINVAL, "l2a_controller_create: needs 1 <= m <= 64 envs (at most 4096 observation floats), n >= 1, h >= 1");
     if (act_dim < 1 || act_dim > 16) return fail(ctx, L2A_EINVAL, "l2a_controller_create: the host draw takes 1 <= act_dim <= 16");
     if ((long long)m * n > 0x3fffffffLL) return fail(ctx, L2A_EINVAL, "l2a_controller_create: too many candidates");
-    if (l2a_rng_version() < 7) return fail(ctx, L2A_ESTATE, "l2a_controller_create: libl2a_rng.so is older than this library");
+    if (l2a_rng_version() < 8) return fail(ctx, L2A_ESTATE, "l2a_controller_create: libl2a_rng.so is older than this library");
     l2a_controller* c = new (std::nothrow) l2a_controller();
     if (!c) return fail(ctx, L2A_EHIP, "l2a_controller_create: out of memory");
     c->ctx = ctx; c->mlp = mlp; c->rnn = rnn;
@@ -166,22 +176,23 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
     return L2A_OK;
 }
 
-int step(l2a_controller* c, const double* obs, const float* c0, const float* h0, float* c1, float* h1, double* action_out,
-         long long* index_out, float* return_out, void* stream) {
+// First half of a step: everything that touches the generator (take / draw, re-arm), the staging and the launch.  Returns
+// L2A_OK (plan in flight), L2A_STEP_MISS (nothing consumed or launched) or a negative code.
+int begin(l2a_controller* c, const double* obs, const float* c0, const float* h0, float* c1, float* h1, void* stream) {
     l2a_ctx* ctx = c->ctx;
-    if (!obs || !action_out) return fail(ctx, L2A_EINVAL, "l2a_controller_step: null obs / action_out");
+    if (!obs) return fail(ctx, L2A_EINVAL, "l2a_controller_begin: null obs");
+    if (c->in_flight) return fail(ctx, L2A_ESTATE, "l2a_controller_begin: the previous step was not finished (l2a_controller_finish)");
     const double t0 = l2a_now_us();
     int slot = 0;
     bool drew = false;
-    unsigned long long offset = 0;
     if (c->device_rng) {
         // candidates of this step: elements [offset, offset + h m n act_dim) of the stream (seed) - drawn on the launch stream
         const unsigned long long per_step = (unsigned long long)((c->act_floats + 3) / 4 * 4);
-        offset = c->calls * per_step;
+        c->offset = c->calls * per_step;
         l2a_device_guard guard(ctx->device);
         const long long total = (long long)c->act_floats;
         hipLaunchKernelGGL(l2a_uniform_fill_k, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           c->seed, offset, total, c->act_dim, c->lowr_dev, c->dev[0]);
+                           c->seed, c->offset, total, c->act_dim, c->lowr_dev, c->dev[0]);
         L2A_HIP(ctx, hipGetLastError());
     } else if ((slot = l2a_ahead_take(c->chain, c->np_addr)) < 0) {
         if (!c->upload_err.empty()) { const std::string msg = c->upload_err; c->upload_err.clear(); return fail(ctx, L2A_EHIP, msg); }
@@ -202,27 +213,51 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
         c->misses_in_row = 0;
     }
     c->slot = slot;
-    const double t1 = l2a_now_us();
-    float obs32[L2A_MAIL_OBS];
+    c->t_begin = t0;
+    c->t_taken = l2a_now_us();
     const int no = c->m * c->obs_dim;
-    for (int i = 0; i < no; ++i) obs32[i] = (float)obs[i];          // np.float64 -> np.float32 (round to nearest even), as the host cast
+    for (int i = 0; i < no; ++i) c->obs32[i] = (float)obs[i];       // np.float64 -> np.float32 (round to nearest even), as the host cast
+    c->c0 = c0; c->h0 = h0; c->c1 = c1; c->h1 = h1; c->stream = stream;
+    c->result = drew ? L2A_STEP_DREW : L2A_OK;
+    l2a_after_launch_fn hook = c->device_rng ? nullptr : (drew ? kick_arm : kick_next);
+    int rc;
+    if (c->mlp)
+        rc = l2a_plan_rs_sync_hook(c->mlp, c->obs32, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, nullptr, nullptr, stream,
+                                   hook, c, &c->pending);
+    else
+        rc = l2a_lstm_plan_rs_sync_hook(c->rnn, c->obs32, c0, h0, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, nullptr,
+                                        c1, h1, stream, hook, c, &c->pending);
+    if (rc != L2A_OK) return rc;
+    c->in_flight = true;
+    return L2A_OK;
+}
+
+// Second half: wait for the keys (a launch that lost its tile-split partner is repeated unsplit - same bits; the generator is not
+// touched again), decode, gather the winners' float64 first actions.
+int finish(l2a_controller* c, double* action_out, long long* index_out, float* return_out) {
+    l2a_ctx* ctx = c->ctx;
+    if (!action_out) return fail(ctx, L2A_EINVAL, "l2a_controller_finish: null action_out");
+    if (!c->in_flight) return fail(ctx, L2A_ESTATE, "l2a_controller_finish: no step is in flight (l2a_controller_begin)");
+    c->in_flight = false;
+    const int slot = c->slot;
     unsigned long long keys[L2A_MAIL_KEYS];
-    int rc = L2A_OK, result = drew ? L2A_STEP_DREW : L2A_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        l2a_after_launch_fn hook = (attempt == 0 && !c->device_rng) ? (drew ? kick_arm : kick_next) : nullptr;
-        if (c->mlp)
-            rc = l2a_plan_rs_sync_hook(c->mlp, obs32, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, nullptr, keys, stream,
-                                       hook, c);
-        else
-            rc = l2a_lstm_plan_rs_sync_hook(c->rnn, obs32, c0, h0, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, keys,
-                                            c1, h1, stream, hook, c);
-        if (rc != L2A_ESPLIT) break;
+    int result = c->result;
+    int rc = l2a_plan_finish(ctx, &c->pending, keys);
+    if (rc == L2A_ESPLIT) {
         // a tile-split partner was not co-resident: the unsplit geometry gives the same bits (the caller is told: L2A_STEP_UNSPLIT)
-        if (attempt == 1 || ctx->split_policy == 0)
+        if (ctx->split_policy == 0)
             return fail(ctx, L2A_ESPLIT, "l2a_controller_step: the rollout was flagged invalid with the tile split disabled");
         (void)l2a_set_split(ctx, 0);
         c->relaunches += 1;
         result = L2A_STEP_UNSPLIT;
+        if (c->mlp)
+            rc = l2a_plan_rs_sync_hook(c->mlp, c->obs32, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, nullptr, keys, c->stream,
+                                       nullptr, nullptr);
+        else
+            rc = l2a_lstm_plan_rs_sync_hook(c->rnn, c->obs32, c->c0, c->h0, c->dev[slot], c->m, c->n, c->h, c->discount, &c->rw, 0, keys,
+                                            c->c1, c->h1, c->stream, nullptr, nullptr);
+        if (rc == L2A_ESPLIT)
+            return fail(ctx, L2A_ESPLIT, "l2a_controller_step: the rollout was flagged invalid with the tile split disabled");
     }
     if (rc != L2A_OK) return rc;
     const double t2 = l2a_now_us();
@@ -237,7 +272,7 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
             // the winner's first action, recomputed from the counter-based stream: element (row i n + idx of step 0, dim k) -
             // the fp32 value the kernel planned on, as float64 (no gather launch, no copy back)
             for (int k = 0; k < c->act_dim; ++k) {
-                const unsigned long long e = offset + ((unsigned long long)i * c->n + idx) * c->act_dim + k;
+                const unsigned long long e = c->offset + ((unsigned long long)i * c->n + idx) * c->act_dim + k;
                 action_out[(size_t)i * c->act_dim + k] =
                     (double)l2a_philox_uniform(c->seed, e, (float)c->low[k], (float)c->high[k] - (float)c->low[k]);
             }
@@ -250,14 +285,22 @@ int step(l2a_controller* c, const double* obs, const float* c0, const float* h0,
     c->steps += 1;
     c->calls += 1;
     const double* st = ctx->stamps_us;
-    c->stage_us[0] = t1 - t0;               // take (compare + adopt the block; waits only if the producer is late)
-    c->stage_us[1] = st[1] - t1;            // observation cast + staging
-    c->stage_us[2] = st[2] - st[1];         // launch call(s)
-    c->stage_us[3] = st[3] - st[2];         // producer kick
-    c->stage_us[4] = st[4] - st[3];         // wait for the keys
-    c->stage_us[5] = t3 - t2;               // decode + gather
-    c->stage_us[6] = t3 - t0;               // whole call
+    c->stage_us[0] = c->t_taken - c->t_begin;   // take (compare + adopt the block; waits only if the producer is late)
+    c->stage_us[1] = st[1] - c->t_taken;        // observation cast + staging
+    c->stage_us[2] = st[2] - st[1];             // launch call(s)
+    c->stage_us[3] = st[3] - st[2];             // producer kick
+    c->stage_us[4] = st[4] - st[3];             // wait for the keys (begin -> finish: whatever the host did in between is in here)
+    c->stage_us[5] = t3 - t2;                   // decode + gather
+    c->stage_us[6] = t3 - c->t_begin;           // whole step
     return result;
+}
+
+int step(l2a_controller* c, const double* obs, const float* c0, const float* h0, float* c1, float* h1, double* action_out,
+         long long* index_out, float* return_out, void* stream) {
+    if (!obs || !action_out) return fail(c->ctx, L2A_EINVAL, "l2a_controller_step: null obs / action_out");
+    const int rc = begin(c, obs, c0, h0, c1, h1, stream);
+    if (rc != L2A_OK) return rc;
+    return finish(c, action_out, index_out, return_out);
 }
 
 }  // namespace
@@ -327,6 +370,25 @@ int l2a_lstm_controller_step(l2a_controller* c, const double* obs, const float* 
     if (!c->rnn) return fail(c->ctx, L2A_EINVAL, "l2a_lstm_controller_step: this controller plans with an MLP model (l2a_controller_step)");
     if (!c0 || !h0) return fail(c->ctx, L2A_EINVAL, "l2a_lstm_controller_step: null c0 / h0");
     return step(c, obs, c0, h0, c_next, h_next, action_out, index_out, return_out, stream);
+}
+
+int l2a_controller_begin(l2a_controller* c, const double* obs, void* stream) {
+    if (!c) return L2A_EINVAL;
+    if (!c->mlp) return fail(c->ctx, L2A_EINVAL, "l2a_controller_begin: this controller plans with a recurrent model (l2a_lstm_controller_begin)");
+    return begin(c, obs, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int l2a_lstm_controller_begin(l2a_controller* c, const double* obs, const float* c0, const float* h0, float* c_next, float* h_next,
+                              void* stream) {
+    if (!c) return L2A_EINVAL;
+    if (!c->rnn) return fail(c->ctx, L2A_EINVAL, "l2a_lstm_controller_begin: this controller plans with an MLP model (l2a_controller_begin)");
+    if (!c0 || !h0) return fail(c->ctx, L2A_EINVAL, "l2a_lstm_controller_begin: null c0 / h0");
+    return begin(c, obs, c0, h0, c_next, h_next, stream);
+}
+
+int l2a_controller_finish(l2a_controller* c, double* action_out, long long* index_out, float* return_out) {
+    if (!c) return L2A_EINVAL;
+    return finish(c, action_out, index_out, return_out);
 }
 
 int l2a_controller_rearm(l2a_controller* c) {

@@ -469,14 +469,22 @@ class MPCController(Policy, Serializable):
         the caller then takes the ordinary path.  A step that finds no valid block of candidates (first call, a foreign draw
         from ``np.random`` since the last step) draws them itself inside the C call - the reference's draw from the global
         generator - and re-arms the chain behind it."""
+        self._cstep_missed = False
         if self.use_cem or not self._native_step_stock():
+            if self._cstep is not None:     # built earlier, bypassed now (a harness replaced the launch path): no idle C chain
+                self._cstep.close()
+                self._cstep = None
             return None
         world = self._dist()[1]
         native = self.dynamics_model.planner_model()
-        # (device mode: the library's counter-based stream restarts whenever torch's seed changes - reproducible under
-        #  torch.manual_seed like the device CEM)
+        # (device mode: the library's counter-based stream (seed, steps so far) restarts whenever torch's seed VALUE changes, like
+        #  the device CEM's.  Calling torch.manual_seed(s) again with the same s does NOT rewind it - build a new controller, or
+        #  seed with another value in between, to replay a run.  One GPU draws from this Philox stream, a sharded plan from
+        #  torch's generator: the two streams differ, device-mode candidates are not comparable across world sizes - ADVICE r5)
+        # (parity mode: the address of the global generator's state - the C controller caches it; a generator object that was
+        #  replaced, np.random.set_bit_generator, must not leave it reading and writing the old, possibly freed one: ADVICE r5)
         key = (os.getpid(), id(native), native.handle.value, world, m, self.n_candidates, self.horizon, float(self.discount),
-               int(torch.initial_seed()) if self.rng == "device" else None)
+               int(torch.initial_seed()) if self.rng == "device" else fast_rng._global_addr())
         st = self._cstep
         if st is None or st.key != key:
             if self._cstep_no == key:
@@ -489,6 +497,7 @@ class MPCController(Policy, Serializable):
         self._check_blocks(m)
         state, keep = self._native_step_state(native, m)
         if not st.step(observations, torch.cuda.current_stream(native.device).cuda_stream, state):
+            self._cstep_missed = True       # (a forked child): this call's fallback plan re-arms the C chain instead of a Python one
             return None
         self._native_step_done(keep)
         self.last_plan = dict(best_index=st.idx.copy(), best_return=st.ret.copy(), n_local=self.n_candidates,
@@ -611,7 +620,9 @@ class MPCController(Policy, Serializable):
         n_local = hi - lo
         act_dim = self.action_space.shape[0]
         dev = self._device()
-        cstep = self._cstep if (self._cstep is not None and self._cstep_no is None) else None
+        # the C controller's chain serves the fallback only when the native step was tried in THIS call and could not serve it;
+        # a controller that is bypassed for good keeps the Python chain (a silent loss of the draw-ahead otherwise)
+        cstep = self._cstep if (self._cstep is not None and self._cstep_no is None and getattr(self, "_cstep_missed", False)) else None
         ahead = self._use_draw_ahead("uniform") and cstep is None      # one chain at a time: the C controller's, if it applies
         sig = ("rs", n, m, h, lo, hi)
         chain = self._ahead_chain() if ahead else None
@@ -953,7 +964,8 @@ class MPCController(Policy, Serializable):
         elite_rows = self._buf("cem_rows", (m * num_elites,), torch.int32, dev)
         rets = None
         obs_dev = self._upload_obs(observations)             # once per plan step, not once per CEM iteration
-        # counter-based stream: (seed, calls so far) - identical on every rank, reproducible under torch.manual_seed
+        # counter-based stream: (seed, calls so far) - identical on every rank; restarts when torch's seed VALUE changes (seeding
+        # again with the same value does not rewind it)
         seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         if self._bufs.get("cem_seed") != seed:
             self._bufs["cem_seed"], self._bufs["cem_calls"] = seed, 0

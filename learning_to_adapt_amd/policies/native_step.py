@@ -64,8 +64,14 @@ class NativeStep(object):
         if self.device_rng:
             rc = self._call(p, state, stream)
         else:
-            with self.lock:     # the generator's own lock: no other thread draws between the state compare and the adoption
-                rc = self._call(p, state, stream)
+            # The generator's own lock - no other thread draws between the state compare and the adoption - held around the
+            # FIRST half of the step only (take / draw, launch, producer kick: everything that touches the generator,
+            # include/l2a.h "threading contract"); the wait for the GPU runs without it, so a thread that draws from
+            # np.random meanwhile (an env reset) is not stalled for the length of a plan.
+            with self.lock:
+                rc = self._begin(p, state, stream)
+            if rc == _lib.L2A_OK:
+                rc = self.lib.l2a_controller_finish(self.handle, p[1], p[2], p[3])
         if rc == _lib.L2A_OK or rc == _lib.L2A_STEP_DREW:   # (DREW: no valid block was waiting, the step drew synchronously itself)
             self.misses_in_row = 0
             return True
@@ -76,6 +82,11 @@ class NativeStep(object):
             self.misses_in_row = 0
             return True
         self.ctx.check(rc, "l2a_controller_step")
+
+    def _begin(self, p, state, stream):
+        if self.recurrent:
+            return self.lib.l2a_lstm_controller_begin(self.handle, p[0], state[0], state[1], state[2], state[3], stream)
+        return self.lib.l2a_controller_begin(self.handle, p[0], stream)
 
     def _call(self, p, state, stream):
         if self.recurrent:

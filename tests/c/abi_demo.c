@@ -14,6 +14,12 @@
  *   double norm[6][...]: mean_obs, std_obs, mean_act, std_act, mean_delta, std_delta
  *   float  obs0[m * obs_dim], actions[h * m * n * act_dim]
  * prints: one line per env "env <i> index <idx> return <ret>"
+ *
+ * usage: abi_demo <case.bin> ctrl <seed> <steps> <state.bin> - the controller step as ONE call, from plain C: the program owns
+ * an MT19937 state in NumPy's layout ({uint32 key[624]; int pos;}), seeds it the way `np.random.seed(seed)` does
+ * (init_genrand, pos = 624), and calls l2a_controller_create / _step (x steps) / _stats / _rearm / _destroy on the case's
+ * observations.  Prints per step and env "step <s> env <i> index <idx> return <ret> action <act_dim hex doubles>" and
+ * writes the generator state it is left with to <state.bin> (the test loads it into a RandomState and draws from it).
  */
 #define _DEFAULT_SOURCE   /* usleep */
 #include <hip/hip_runtime_api.h>
@@ -52,7 +58,8 @@ int main(int argc, char** argv) {
     const int obs_dim = hd[0], act_dim = hd[1], n_hidden = hd[2], width = hd[3], m = hd[4], n = hd[5], h = hd[6];
     float* rw_par = (float*)rd(f, 2 * sizeof(float));
 
-    const int sharded = (argc >= 5);
+    const int ctrl_mode = (argc >= 6 && strcmp(argv[2], "ctrl") == 0);
+    const int sharded = (argc >= 5) && !ctrl_mode;
     const int rank = sharded ? atoi(argv[2]) : 0, world = sharded ? atoi(argv[3]) : 1;
     int n_dev = 1;
     CHECK_HIP(hipGetDeviceCount(&n_dev));
@@ -116,6 +123,43 @@ int main(int argc, char** argv) {
     }
 
     l2a_reward rw = {1.0f, 1.0f / rw_par[0], 0.0f, rw_par[1], 0.0f, hd[7], 0, 0};      /* half_cheetah_env.py:58-65 */
+    if (ctrl_mode) {
+        /* the reference's call sequence from a C host: np.random.seed(seed); for s in steps: policy.get_actions(obs) */
+        struct { unsigned int key[624]; int pos; } mt;                  /* numpy/random/src/mt19937/mt19937.h: mt19937_state */
+        mt.key[0] = (unsigned int)strtoul(argv[3], NULL, 10);
+        for (int i = 1; i < 624; ++i) mt.key[i] = 1812433253u * (mt.key[i - 1] ^ (mt.key[i - 1] >> 30)) + (unsigned int)i;
+        mt.pos = 624;
+        const int steps = atoi(argv[4]);
+        double low[16], high[16];
+        for (int k = 0; k < act_dim; ++k) { low[k] = -1.0; high[k] = 1.0; }     /* half_cheetah_env.py:40 */
+        double* obs64 = (double*)malloc(sizeof(double) * (size_t)m * obs_dim);
+        for (int i = 0; i < m * obs_dim; ++i) obs64[i] = (double)obs0[i];
+        l2a_controller* c = NULL;
+        CHECK_L2A(ctx, l2a_controller_create(model, m, n, h, low, high, 1.0, &rw, &mt, 2, &c));
+        double* act = (double*)malloc(sizeof(double) * (size_t)m * act_dim);
+        long long* idx = (long long*)malloc(sizeof(long long) * (size_t)m);
+        float* ret = (float*)malloc(sizeof(float) * (size_t)m);
+        for (int s = 0; s < steps; ++s) {
+            const int rc = l2a_controller_step(c, obs64, act, idx, ret, NULL);
+            if (rc < 0 || rc == L2A_STEP_MISS) { fprintf(stderr, "l2a_controller_step -> %d: %s\n", rc, l2a_last_error(ctx)); return 3; }
+            for (int i = 0; i < m; ++i) {
+                printf("step %d env %d index %lld return %.9g action", s, i, idx[i], ret[i]);
+                for (int k = 0; k < act_dim; ++k) printf(" %a", act[i * act_dim + k]);
+                printf(" rc %d\n", rc);
+            }
+            if (s == steps / 2) CHECK_L2A(ctx, l2a_controller_rearm(c));       /* legal at any time: restart the chain here */
+        }
+        double st[16];
+        CHECK_L2A(ctx, l2a_controller_stats(c, st, 16));
+        printf("stats steps %.0f hits %.0f sync_draws %.0f\n", st[7], st[9], st[15]);
+        l2a_controller_destroy(c);
+        FILE* g = fopen(argv[5], "wb");
+        if (!g || fwrite(&mt, sizeof(mt), 1, g) != 1) { perror("state file"); return 7; }
+        fclose(g);
+        l2a_model_destroy(model);
+        l2a_destroy(ctx);
+        return 0;
+    }
     if (n_loc > 0) CHECK_L2A(ctx, l2a_plan_rs(model, d_obs0, d_acts, m, n_loc, h, 1.0, &rw, lo, NULL, d_key, NULL));
     else CHECK_HIP(hipMemset(d_key, 0, sizeof(unsigned long long) * (size_t)m));            /* neutral key */
     if (sharded) CHECK_L2A(ctx, l2a_allreduce_best(ctx, d_key, m, NULL));

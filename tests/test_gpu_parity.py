@@ -234,6 +234,7 @@ def test_tile_split_is_bit_identical_to_single_workgroup(name, over):
     ctx = _lib.Context.get(0)
     out = {}
     try:
+        ctx.set_fan(0)          # (small ensembles would take the member fan under policies 1 / 2: its own test below)
         for policy in (1, 2, 0):
             ctx.set_split(policy)
             r1, k1 = _plan_returns(native, case, env, obs0, a)
@@ -243,6 +244,7 @@ def test_tile_split_is_bit_identical_to_single_workgroup(name, over):
             out[policy] = (r1, k1)
     finally:
         ctx.set_split(1)
+        ctx.set_fan(1)
     for policy in (1, 2):
         assert np.array_equal(out[policy][0], out[0][0]), "policy %d differs from the unsplit launch" % policy
         assert np.array_equal(out[policy][1], out[0][1])
@@ -251,6 +253,73 @@ def test_tile_split_is_bit_identical_to_single_workgroup(name, over):
     want = rollout_returns(cases.oracle_dynamics(case), make_reward(case["env"], env.dt), obs0, a, case["n"],
                            case.get("discount", 1.0)).reshape(case["m"], case["n"])
     assert rel_err(out[1][0], want) < RTOL
+
+
+FAN_CASES = [
+    # name, overrides - the member fan (one workgroup per candidate tile and ensemble member, csrc/l2a_mfma.h): one rank's
+    # shard of BASELINE config 5, odd / even ensembles of 3 .. 8 sets, every hidden width, one to four hidden layers, generic
+    # activations, the Ant's 41 observations (no O4 tile, K0L = 1), a distance reward, several envs with ragged tiles, a
+    # discount, and as many workgroups as the chip has CUs (51 tiles x 5)
+    ("c5_hc_cem_n4000_h30_e5", dict(n=500, h=6)),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=816, h=3)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[256, 256, 256], E=3, n=300, h=6)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128], E=3, n=200, h=5)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[512], E=4, n=100, h=4)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[128, 128], E=4, n=150, h=4, activation="tanh")),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[512, 512, 512, 512], E=6, n=90, h=3)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[256, 256], E=8, n=333, h=3)),
+    ("c2_hc_rs_n2000_h30_e5", dict(hidden=[256, 256], E=7, n=37, h=9, discount=0.9)),
+    ("ant_rs_n300_h6_e3", {}),
+    ("ant_rs_n300_h6_e3", dict(E=5, n=500, h=3)),
+    ("arm_cem_n160_h5_e3", {}),
+    ("hc_rs_m3_n64_h5", dict(E=3, mode="mean", n=70)),
+]
+
+
+@pytest.mark.parametrize("name,over", FAN_CASES)
+def test_member_fan_is_bit_identical(name, over):
+    """E workgroups per candidate tile, one weight set each, the members' terms swapped once per horizon step and added in
+    the unsplit launch's order: every return and the arg-max keys bit for bit against the tile split and the unsplit launch,
+    deterministically, with a candidate offset, with and without a returns table; then against the oracle."""
+    case = dict(cases.CASES[name], **over)
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    a = _rs_actions(case, 4, env)
+    obs0 = np.random.RandomState(14).randn(case["m"], env.observation_space.shape[0])
+    ctx = _lib.Context.get(0)
+    dev = native.device
+    out = {}
+    try:
+        ctx.set_micro(0)
+        for fan, split in ((1, 1), (0, 1), (0, 0), (1, 2)):
+            ctx.set_fan(fan)
+            ctx.set_split(split)
+            r, k = _plan_returns(native, case, env, obs0, a, cand_offset=7)
+            r2, k2 = _plan_returns(native, case, env, obs0, a, cand_offset=7)
+            assert np.array_equal(r, r2) and np.array_equal(k, k2)
+            keys_only = torch.zeros((case["m"],), dtype=torch.int64, device=dev)
+            native.plan_rs(torch.from_numpy(np.ascontiguousarray(obs0, dtype=np.float32)).to(dev),
+                           torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev),
+                           case["m"], case["n"], case["h"], case.get("discount", 1.0), env.reward_spec,
+                           cand_offset=7, best_key=keys_only)
+            torch.cuda.synchronize()
+            ctx.launch_status()
+            out[(fan, split)] = (r, k, keys_only.cpu().numpy())
+    finally:
+        ctx.set_micro(1)
+        ctx.set_split(1)
+        ctx.set_fan(1)
+    ref = out[(0, 0)]
+    assert np.array_equal(ref[1], ref[2])
+    assert np.isfinite(ref[0]).all()
+    for key in ((1, 1), (0, 1), (1, 2)):
+        for x, y in zip(ref, out[key]):
+            assert np.array_equal(x, y), key
+    from oracle import make_reward
+    from oracle.planner import rollout_returns
+    want = rollout_returns(cases.oracle_dynamics(case), make_reward(case["env"], env.dt), obs0, a, case["n"],
+                           case.get("discount", 1.0)).reshape(case["m"], case["n"])
+    assert rel_err(out[(1, 1)][0], want) < RTOL
 
 
 MICRO_CASES = [
@@ -349,6 +418,7 @@ def test_set_batching_is_bit_identical(name, over):
     ctx = _lib.Context.get(0)
     out = {}
     try:
+        ctx.set_fan(0)          # (the member fan runs one set per workgroup: nothing to batch)
         for policy in (1, 0):
             ctx.set_split(policy)
             for sets in (1, 0, 2, 3, 4):
@@ -364,6 +434,7 @@ def test_set_batching_is_bit_identical(name, over):
         ctx.set_split(1)
         ctx.set_batch(0)
         ctx.set_xcd_align(1)
+        ctx.set_fan(1)
     ref = out[(0, 1, 1)]
     for key, (r, k) in out.items():
         assert np.array_equal(r, ref[0]) and np.array_equal(k, ref[1]), "split %d, batch %d, xcd_align %d differs" % key

@@ -286,6 +286,13 @@ def main():
     report("config 5: CEM rollout kernel, one iteration (n=4000)", one, env, k_ms,
            cem_plan_step_ms_end_to_end_host_rng=round(ms, 2), cem_iters=5,
            note="end-to-end includes 5 x np.random.normal(720k) + clip + elite statistics on the host")
+    # config 5 as one of eight ranks runs it: the 500-candidate shard of an iteration (member fan: one workgroup per candidate
+    # tile and member; round 5 ran it on the tile split: 64 workgroups), tools/probe_c5_shard.py has the rank's whole plan step
+    shard = dict(case, n=500)
+    for label, fan in (("member fan (default)", 1), ("tile split, fan off (round 5's geometry)", 0)):
+        _lib.Context.get(0).set_fan(fan)
+        report("config 5 shard (n=500, h=30, E=5 mean) = one rank of 8, " + label, shard, env, time_plan(model.planner_model(), shard, env))
+    _lib.Context.get(0).set_fan(1)
     for cem_mode in ("reference", "fixed"):
         ctrl = cases.product_controller(case, rng="device", cem_mode=cem_mode)
         ctrl.get_actions(gold["obs0"])

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
 
-WHICH = sys.argv[1] if len(sys.argv) > 1 else "all"          # c1 | c3b | c6 | gru | lstm2 | all: one shape per rocprof run keeps its row apart
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "all"          # c1 | c3b | c6 | gru | lstm2 | c5shard | all: one shape per rocprof run keeps its row apart
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 plans = []
 for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
@@ -31,6 +31,18 @@ for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
     best = torch.zeros((m,), dtype=torch.int64, device=dev)
     plans.append((model, lambda native=native, obs0=obs0, a=a, m=m, n=n, h=h, env=env, best=best:
                   native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
+if WHICH == "c5shard":
+    # one rank's shard of BASELINE config 5 (CEM iteration: n = 4000 over 8 ranks -> 500 candidates, h = 30, E = 5 mean): the
+    # member-fan launch of csrc/l2a_mfma.h (L2A_FAN=0 in the environment: round 5's tile split)
+    case = dict(cases.CASES["c5_hc_cem_n4000_h30_e5"], n=500)
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    obs0 = torch.randn((1, 20), device=dev)
+    a = torch.rand((30, 500, 6), device=dev) * 2 - 1
+    best = torch.zeros((1,), dtype=torch.int64, device=dev)
+    rets = torch.zeros((1, 500), dtype=torch.float32, device=dev)
+    plans.append((model, lambda: native.plan_rs(obs0, a, 1, 500, 30, 1.0, env.reward_spec, returns_out=rets, best_key=best)))
 if WHICH in ("all", "c6"):
     case = cases.CASES["c6_hc_rnn_rs_n500_h10_m5"]
     env, model = cases.product_rnn_model(case)

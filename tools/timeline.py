@@ -26,7 +26,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c2_hc_rs_n2000_h30_e5"          # any MLP case of tests/golden/cases.json
-case = cases.CASES[name]
+case = dict(cases.CASES[name])
+for kv in sys.argv[2:]:                 # overrides, e.g. `c5_hc_cem_n4000_h30_e5 n=500` = one rank's shard of config 5 (member fan)
+    k, v = kv.split("=")
+    case[k] = int(v)
 env, model = cases.product_model(case)
 native = model.planner_model()
 dev = native.device
@@ -56,7 +59,7 @@ d = dbg.cpu().numpy().astype(np.int64)       # [grp, t, e, wave, slot]
 # barrier | reduce(s0) reduce(s1) .. | exchange.  Slots of a set: 0 L0 start, 8 operands requested, 9 MFMAs done,
 # 10 bias / activation done, 1 written to LDS; 2 GEMM start, 3 GEMM + epilogue done, 4 output partials written;
 # 5 reduce start, 6 reduce done.
-print("case %s" % name)
+print("case %s %s" % (name, " ".join(sys.argv[2:])))
 WGREC_ONLY = "wgrec" in os.path.basename(_TL)        # built with -DL2A_WGREC: the per-workgroup record without the phase stamps
 # per-workgroup record (NT = 1 shapes): start, end (own CU's clock), XCC_ID register, hardware workgroup id
 wg = dbg_all[2 * h * 8 * 8 * 16:].cpu().numpy().astype(np.int64).reshape(2, n_tiles, 6)
