@@ -479,6 +479,9 @@ def main():
             out["config"]["get_actions_parity_plan_steps_per_s"] = round(args.steps / e2e["numpy"], 3)
             out["config"]["draw_ahead_hits"] = e2e.get("draw_ahead_hits")
             out["config"]["native_step"] = e2e.get("native_step")
+            if world > 1:
+                out["config"]["native_comm"] = ("the library's own RCCL communicator (l2a_allreduce_best)" if os.environ.get("L2A_NATIVE_COMM", "0") == "1"
+                                                else "torch.distributed behind the C step's reduce callback")
             if e2e.get("native_step_stage_us"):
                 out["config"]["native_step_stage_us"] = e2e["native_step_stage_us"]
             out["config"]["host_path_us_per_step"] = round(1e3 * (ms_per_step - 1e3 * resident_s / args.steps), 1)

@@ -470,6 +470,23 @@ int l2a_controller_create(l2a_model* model, int m, int n, int h, const double* l
 int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const double* low, const double* high,
                                double discount, const l2a_reward* reward, void* np_state_addr, int rng_threads,
                                l2a_controller** out);
+/* The SHARDED step (`MPCController._shard_range / _combine_keys`): rank r of `world` rolls out candidates
+ * [r n / world, (r + 1) n / world) of every env - every rank consumes the generator for ALL h*n*m rows, so the shards are
+ * slices of the one candidate tensor the reference draws (policies/mpc_controller.py:114) - and the step's ONE collective, an
+ * int64 MAX all-reduce of [keys (m) | launch flag | digest | L2A_DIGEST_MASK - digest] packed on the device behind the
+ * launch (l2a_plan_payload), runs in stream order; one page-locked copy of m + 3 words brings the result back.  MAX on the
+ * packed keys = max return, ties -> lowest GLOBAL index = np.argmax over all candidates (:128-129); a set flag makes every
+ * rank repeat launch + collective unsplit together (L2A_STEP_UNSPLIT); digests that differ (ranks seeded differently, a
+ * foreign consumer of the generator on one rank) fail the step on every rank (L2A_ESTATE).
+ *   reduce       NULL: RCCL over xGMI through the context's communicator (l2a_comm_init; this is l2a_allreduce_best on
+ *                m + 3 words).  Otherwise the caller's collective: all-reduce `words` uint64 at `payload_dev` in place with
+ *                MAX, ordered on `stream`; return 0 on success (torch.distributed behind a ctypes callback; tests).
+ * Steps through l2a_controller_step / _begin / _finish like an unsharded controller; action_out = the float64 first action
+ * of the GLOBAL winner (every rank holds every candidate's float64 first step).  MLP models.                          */
+typedef int (*l2a_reduce_fn)(void* arg, unsigned long long* payload_dev, int words, void* stream);
+int l2a_controller_create_sharded(l2a_model* model, int m, int n, int h, const double* low, const double* high,
+                                  double discount, const l2a_reward* reward, void* np_state_addr, int rng_threads, int rank,
+                                  int world, l2a_reduce_fn reduce, void* reduce_arg, l2a_controller** out);
 /* The same step with the candidates drawn ON THE DEVICE (`MPCController(rng="device")`: statistically equivalent to the reference's
  * draw, not its numbers; NumPy's generator is not touched): every step a Philox4x32-10 kernel fills the candidate tensor from the
  * counter-based stream (seed, steps so far) in front of the plan, and the winners' first actions are recomputed on the host from

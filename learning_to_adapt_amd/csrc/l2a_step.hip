@@ -62,7 +62,23 @@ struct l2a_controller {
     float *c1 = nullptr, *h1 = nullptr;
     void* stream = nullptr;
     double t_begin = 0.0, t_taken = 0.0;
+    // sharded plan (l2a_controller_create_sharded): this rank rolls out candidates [lo, hi) of every env and the ranks' keys meet
+    // in ONE int64 MAX all-reduce of [keys (m), launch flag, digest, MASK - digest] per step
+    bool sharded = false;                       // (also with world = 1: the same code path with a one-rank collective)
+    int rank = 0, world = 1, lo = 0, hi = 0;
+    l2a_reduce_fn reduce = nullptr;             // null: RCCL through the context's communicator (l2a_comm_init)
+    void* reduce_arg = nullptr;
+    float* obs_map_host = nullptr;              // host-mapped observation staging (read by the kernel directly)
+    float* obs_map_dev = nullptr;
+    unsigned long long* keys_dev = nullptr;     // [m]
+    unsigned long long* payload_dev = nullptr;  // [m + 3]
+    unsigned long long* payload_host = nullptr; // page-locked [m + 3]
+    hipEvent_t payload_ev = nullptr;
+    unsigned long long digest = 0;
+    double t_launched = 0.0, t_kicked = 0.0;
 };
+
+extern "C" unsigned long long l2a_mt19937_state_digest(const void* addr);      // csrc/l2a_rng.c
 
 // Device-RNG mode: the candidate tensor [h, m * n, act_dim] from the counter-based stream (seed, offset + element): four elements
 // per thread (one Philox block), the action dimension of an element = its index modulo act_dim.
@@ -94,6 +110,7 @@ int upload_block(void* arg, int slot) {
         if (hipSetDevice(c->ctx->device) != hipSuccess) { c->upload_err = "hipSetDevice on the producer thread failed"; return -1; }
         c->producer_bound = true;
     }
+    if (c->hi == c->lo) return 0;                               // more ranks than candidates: this rank rolls nothing out
     hipError_t e = hipMemcpyAsync(c->dev[slot], c->pin[slot], c->act_floats * sizeof(float), hipMemcpyHostToDevice, c->side);
     if (e == hipSuccess) e = hipStreamSynchronize(c->side);
     if (e != hipSuccess) { c->upload_err = std::string("uploading a candidate block: ") + hipGetErrorString(e); return -1; }
@@ -113,7 +130,8 @@ void kick_arm(void* arg) {
 
 int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim, int units, int m, int n, int h,
            const double* low, const double* high, double discount, const l2a_reward* reward, void* np_state_addr,
-           int rng_threads, l2a_controller** out, bool device_rng = false, unsigned long long seed = 0) {
+           int rng_threads, l2a_controller** out, bool device_rng = false, unsigned long long seed = 0, int rank = 0,
+           int world = 1, l2a_reduce_fn reduce = nullptr, void* reduce_arg = nullptr, bool sharded = false) {
     if (!out) return fail(ctx, L2A_EINVAL, "l2a_controller_create: out is null");
     *out = nullptr;
     if (!low || !high || !reward || (!np_state_addr && !device_rng))
@@ -130,7 +148,11 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
     c->discount = discount; c->rw = *reward; c->np_addr = np_state_addr;
     for (int k = 0; k < act_dim; ++k) { c->low[k] = low[k]; c->high[k] = high[k]; }
     c->rng_threads = rng_threads < 1 ? 1 : rng_threads;
-    c->act_floats = (size_t)h * m * n * act_dim;
+    c->rank = rank; c->world = world; c->reduce = reduce; c->reduce_arg = reduce_arg; c->sharded = sharded;
+    c->lo = (int)((long long)rank * n / world);                 // contiguous candidate ranges (MPCController._shard_range)
+    c->hi = (int)((long long)(rank + 1) * n / world);
+    const int n_local = c->hi - c->lo;
+    c->act_floats = (size_t)h * m * (n_local > 0 ? n_local : 1) * act_dim;
     l2a_device_guard guard(ctx->device);
     c->device_rng = device_rng; c->seed = seed;
     hipError_t e = hipSuccess;
@@ -163,9 +185,18 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
     if (e == hipSuccess) {
         // rows of the reference's draw: h * n * m (mpc_controller.py:114), row r <-> candidate r % n; the whole env-major tensor
         // goes up (one GPU: every candidate is local); the first n * m rows are kept in float64 (`cand_a`, :118)
-        c->chain = l2a_ahead_create((long long)h * n * m, act_dim, low, high, n, 0, n, (long long)n * m, c->pin[0], c->pin[1],
+        // (a sharded plan: every rank consumes the generator for ALL h * n * m rows and keeps candidates [lo, hi) of every env)
+        c->chain = l2a_ahead_create((long long)h * n * m, act_dim, low, high, n, c->lo, c->hi, (long long)n * m, c->pin[0], c->pin[1],
                                     c->c64[0], c->c64[1], rng_threads, upload_block, c);
         if (!c->chain) e = hipErrorInvalidValue;
+    }
+    if (e == hipSuccess && sharded) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&c->obs_map_host), sizeof(float) * L2A_MAIL_OBS, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->obs_map_dev), c->obs_map_host, 0);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->keys_dev), sizeof(unsigned long long) * (size_t)m);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->payload_dev), sizeof(unsigned long long) * (size_t)(m + 3));
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->payload_host), sizeof(unsigned long long) * (size_t)(m + 3), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->payload_ev, hipEventDisableTiming);
     }
     if (e != hipSuccess) {
         const std::string msg = std::string("l2a_controller_create: ") + hipGetErrorString(e);
@@ -173,6 +204,36 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
         return fail(ctx, L2A_EHIP, msg);
     }
     *out = c;
+    return L2A_OK;
+}
+
+// Sharded plan: this rank's launch, the payload packed on the device behind it, the ONE collective of the step, and the copy
+// of the reduced words to page-locked memory - all in stream order, nothing on the host waits (policies/mpc_controller.py
+// `_combine_keys` did the same from Python with torch.distributed).
+int launch_sharded(l2a_controller* c, bool first) {
+    l2a_ctx* ctx = c->ctx;
+    l2a_device_guard guard(ctx->device);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(c->stream);
+    const int n_local = c->hi - c->lo;
+    std::memcpy(c->obs_map_host, c->obs32, sizeof(float) * (size_t)c->m * c->obs_dim);
+    ctx->stamps_us[1] = l2a_now_us();
+    if (n_local > 0) {
+        const int rc = l2a_plan_rs(c->mlp, c->obs_map_dev, c->dev[c->slot], c->m, n_local, c->h, c->discount, &c->rw, c->lo, nullptr,
+                                   c->keys_dev, c->stream);
+        if (rc != L2A_OK) return rc;
+    } else {
+        L2A_HIP(ctx, hipMemsetAsync(c->keys_dev, 0, sizeof(unsigned long long) * (size_t)c->m, stream));    // the neutral key
+    }
+    int rc = l2a_plan_payload(ctx, c->keys_dev, c->m, c->digest, c->payload_dev, c->stream);
+    if (rc != L2A_OK) return rc;
+    ctx->stamps_us[2] = l2a_now_us();
+    if (first && !c->device_rng) (c->result == L2A_STEP_DREW ? kick_arm : kick_next)(c);
+    ctx->stamps_us[3] = l2a_now_us();
+    rc = c->reduce ? c->reduce(c->reduce_arg, c->payload_dev, c->m + 3, c->stream)
+                   : l2a_allreduce_best(ctx, c->payload_dev, c->m + 3, c->stream);       // RCCL: uint64 MAX over xGMI
+    if (rc != L2A_OK) return c->reduce ? fail(ctx, L2A_EHIP, "l2a_controller_step: the caller's reduce function failed") : rc;
+    L2A_HIP(ctx, hipMemcpyAsync(c->payload_host, c->payload_dev, sizeof(unsigned long long) * (size_t)(c->m + 3), hipMemcpyDeviceToHost, stream));
+    L2A_HIP(ctx, hipEventRecord(c->payload_ev, stream));
     return L2A_OK;
 }
 
@@ -201,12 +262,13 @@ int begin(l2a_controller* c, const double* obs, const float* c0, const float* h0
         // the reference's own draw (mpc_controller.py:67-69,114) from the global generator, advanced in place
         struct np_state { unsigned int key[624]; int pos; };
         np_state* g = static_cast<np_state*>(c->np_addr);
-        if (l2a_mt19937_uniform_rows(g->key, &g->pos, (long long)c->h * c->n * c->m, c->act_dim, c->low, c->high, c->n, 0, c->n,
+        if (l2a_mt19937_uniform_rows(g->key, &g->pos, (long long)c->h * c->n * c->m, c->act_dim, c->low, c->high, c->n, c->lo, c->hi,
                                      c->pin[slot], (long long)c->n * c->m, c->c64[slot], c->rng_threads) != 0)
             return fail(ctx, L2A_EINVAL, "l2a_controller_step: the generator state at np_state_addr is not a legacy MT19937 state");
         l2a_device_guard guard(ctx->device);
-        L2A_HIP(ctx, hipMemcpyAsync(c->dev[slot], c->pin[slot], c->act_floats * sizeof(float), hipMemcpyHostToDevice,
-                                    reinterpret_cast<hipStream_t>(stream)));
+        if (c->hi > c->lo)
+            L2A_HIP(ctx, hipMemcpyAsync(c->dev[slot], c->pin[slot], c->act_floats * sizeof(float), hipMemcpyHostToDevice,
+                                        reinterpret_cast<hipStream_t>(stream)));
         drew = true;
         c->sync_draws += 1;
     } else {
@@ -219,6 +281,15 @@ int begin(l2a_controller* c, const double* obs, const float* c0, const float* h0
     for (int i = 0; i < no; ++i) c->obs32[i] = (float)obs[i];       // np.float64 -> np.float32 (round to nearest even), as the host cast
     c->c0 = c0; c->h0 = h0; c->c1 = c1; c->h1 = h1; c->stream = stream;
     c->result = drew ? L2A_STEP_DREW : L2A_OK;
+    if (c->sharded) {
+        // what this rank's candidates were drawn from: the generator as this step's draw left it (every rank must agree)
+        c->digest = l2a_mt19937_state_digest(c->np_addr);
+        ctx->stamps_us[0] = t0;
+        const int rc = launch_sharded(c, true);
+        if (rc != L2A_OK) return rc;
+        c->in_flight = true;
+        return L2A_OK;
+    }
     l2a_after_launch_fn hook = c->device_rng ? nullptr : (drew ? kick_arm : kick_next);
     int rc;
     if (c->mlp)
@@ -242,7 +313,32 @@ int finish(l2a_controller* c, double* action_out, long long* index_out, float* r
     const int slot = c->slot;
     unsigned long long keys[L2A_MAIL_KEYS];
     int result = c->result;
-    int rc = l2a_plan_finish(ctx, &c->pending, keys);
+    int rc = L2A_OK;
+    if (c->sharded) {
+        l2a_device_guard guard(ctx->device);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            L2A_HIP(ctx, hipEventSynchronize(c->payload_ev));
+            ctx->stamps_us[4] = l2a_now_us();
+            const unsigned long long* v = c->payload_host;
+            if (v[c->m + 1] + v[c->m + 2] != L2A_DIGEST_MASK)
+                return fail(ctx, L2A_ESTATE, "candidate sharding needs identical np.random global state on every rank (seed all ranks alike and "
+                                             "keep other consumers of the generator off the planning process; the shards themselves are disjoint)");
+            if (v[c->m] == 0) break;
+            // SOME rank's launch lost its tile-split partner: the reduced flag is the same on every rank, so all of them switch to the
+            // unsplit geometry (bit-identical results) and repeat launch + collective together
+            // (also a rank that runs unsplit already: it must stay in step with the others' collective)
+            *ctx->status_host = 0;
+            if (attempt == 1) return fail(ctx, L2A_ESPLIT, "l2a_controller_step: some rank's rollout was flagged invalid twice");
+            (void)l2a_set_split(ctx, 0);
+            c->relaunches += 1;
+            result = L2A_STEP_UNSPLIT;
+            rc = launch_sharded(c, false);
+            if (rc != L2A_OK) return rc;
+        }
+        for (int i = 0; i < c->m; ++i) keys[i] = c->payload_host[i];
+    } else {
+        rc = l2a_plan_finish(ctx, &c->pending, keys);
+    }
     if (rc == L2A_ESPLIT) {
         // a tile-split partner was not co-resident: the unsplit geometry gives the same bits (the caller is told: L2A_STEP_UNSPLIT)
         if (ctx->split_policy == 0)
@@ -316,6 +412,20 @@ int l2a_controller_create(l2a_model* model, int m, int n, int h, const double* l
     return create(ctx, model, nullptr, obs_dim, act_dim, 0, m, n, h, low, high, discount, reward, np_state_addr, rng_threads, out);
 }
 
+int l2a_controller_create_sharded(l2a_model* model, int m, int n, int h, const double* low, const double* high, double discount,
+                                  const l2a_reward* reward, void* np_state_addr, int rng_threads, int rank, int world,
+                                  l2a_reduce_fn reduce, void* reduce_arg, l2a_controller** out) {
+    if (!model) return L2A_EINVAL;
+    l2a_ctx* ctx = nullptr;
+    int obs_dim = 0, act_dim = 0;
+    l2a_model_facts(model, &ctx, &obs_dim, &act_dim);
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, L2A_EINVAL, "l2a_controller_create_sharded: bad rank / world");
+    if (!reduce && (!ctx->comm || ctx->comm_world != world || ctx->comm_rank != rank))
+        return fail(ctx, L2A_ESTATE, "l2a_controller_create_sharded: no reduce function and no communicator of this rank / world (l2a_comm_init)");
+    return create(ctx, model, nullptr, obs_dim, act_dim, 0, m, n, h, low, high, discount, reward, np_state_addr, rng_threads, out,
+                  false, 0, rank, world, reduce, reduce_arg, true);
+}
+
 int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const double* low, const double* high, double discount,
                                const l2a_reward* reward, void* np_state_addr, int rng_threads, l2a_controller** out) {
     if (!model) return L2A_EINVAL;
@@ -353,6 +463,11 @@ void l2a_controller_destroy(l2a_controller* c) {
         std::free(c->c64[s]);
     }
     if (c->lowr_dev) (void)hipFree(c->lowr_dev);
+    if (c->obs_map_host) (void)hipHostFree(c->obs_map_host);
+    if (c->keys_dev) (void)hipFree(c->keys_dev);
+    if (c->payload_dev) (void)hipFree(c->payload_dev);
+    if (c->payload_host) (void)hipHostFree(c->payload_host);
+    if (c->payload_ev) (void)hipEventDestroy(c->payload_ev);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }

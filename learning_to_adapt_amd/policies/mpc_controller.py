@@ -444,7 +444,36 @@ class MPCController(Policy, Serializable):
     def _native_step_done(self, keep):
         pass
 
-    def _native_step_build(self, native, m, key):
+    @staticmethod
+    def _reduce_payload(payload):
+        """The sharded C step's one collective through torch.distributed: int64 MAX all-reduce of ``[keys, flag, digest pair]``
+        in place (``backend="nccl"`` is RCCL over xGMI; gloo reduces host tensors only, so the words go through the host)."""
+        if torch.distributed.get_backend() == "gloo":
+            host = payload.cpu()
+            torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.MAX)
+            payload.copy_(host)
+        else:
+            torch.distributed.all_reduce(payload, op=torch.distributed.ReduceOp.MAX)
+
+    @staticmethod
+    def _native_comm(native, rank, world):
+        """``L2A_NATIVE_COMM=1``: the library's OWN RCCL communicator (``l2a_comm_init``) carries the step's collective
+        (``l2a_allreduce_best`` on m + 3 words) instead of torch.distributed; its id travels through torch.distributed once."""
+        import ctypes
+        ctx = native.ctx
+        if getattr(ctx, "native_comm", None) == (rank, world):
+            return True
+        ids = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            ctx.check(native.lib.l2a_comm_unique_id(buf), "l2a_comm_unique_id")
+            ids[0] = buf.raw
+        torch.distributed.broadcast_object_list(ids, src=0)
+        ctx.check(native.lib.l2a_comm_init(ctx.handle, int(rank), int(world), ids[0]), "l2a_comm_init")
+        ctx.native_comm = (rank, world)
+        return True
+
+    def _native_step_build(self, native, m, key, rank=0, world=1):
         from .native_step import NativeStep
         if self._cstep is not None:
             self._cstep.close()
@@ -456,9 +485,20 @@ class MPCController(Policy, Serializable):
         device = self.rng == "device"
         if not device and (not (fast_rng.available("uniform") and fast_rng.available("direct")) or fast_rng._global_addr() is None):
             return None
+        shard = None
+        if world > 1:
+            # the sharded step in one C call (parity mode, MLP models): launch, payload, the ONE collective, read-back - the ~80 us
+            # of Python glue per step of `_rs_parity_plan` / `_combine_keys` gone.  The collective: torch.distributed behind a
+            # callback (default), or the library's own RCCL communicator (L2A_NATIVE_COMM=1).
+            if device or hasattr(native, "units") or not hasattr(native.lib, "l2a_controller_create_sharded"):
+                return None
+            own = os.environ.get("L2A_NATIVE_COMM", "0") == "1" and torch.distributed.get_backend() != "gloo"
+            if own:
+                self._native_comm(native, rank, world)
+            shard = (rank, world, None if own else self._reduce_payload)
         st = NativeStep(native, hasattr(native, "units"), m, self.n_candidates, self.horizon, self.action_space.low,
                         self.action_space.high, self.discount, self._reward_spec,
-                        device_seed=(int(torch.initial_seed()) if device else None))
+                        device_seed=(int(torch.initial_seed()) if device else None), shard=shard)
         st.key = key
         self._cstep = st
         return st
@@ -475,7 +515,7 @@ class MPCController(Policy, Serializable):
                 self._cstep.close()
                 self._cstep = None
             return None
-        world = self._dist()[1]
+        rank, world = self._dist()
         native = self.dynamics_model.planner_model()
         # (device mode: the library's counter-based stream (seed, steps so far) restarts whenever torch's seed VALUE changes, like
         #  the device CEM's.  Calling torch.manual_seed(s) again with the same s does NOT rewind it - build a new controller, or
@@ -489,7 +529,7 @@ class MPCController(Policy, Serializable):
         if st is None or st.key != key:
             if self._cstep_no == key:
                 return None
-            st = self._native_step_build(native, m, key) if world == 1 else None
+            st = self._native_step_build(native, m, key, rank, world)
             if st is None:
                 self._cstep_no = key
                 return None
@@ -500,8 +540,8 @@ class MPCController(Policy, Serializable):
             self._cstep_missed = True       # (a forked child): this call's fallback plan re-arms the C chain instead of a Python one
             return None
         self._native_step_done(keep)
-        self.last_plan = dict(best_index=st.idx.copy(), best_return=st.ret.copy(), n_local=self.n_candidates,
-                              shard=(0, self.n_candidates))
+        lo, hi = self._shard_range(self.n_candidates, rank, world)
+        self.last_plan = dict(best_index=st.idx.copy(), best_return=st.ret.copy(), n_local=hi - lo, shard=(lo, hi))
         return st.act.copy()
 
     def draw_ahead_stats(self):

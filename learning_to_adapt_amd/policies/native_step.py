@@ -18,10 +18,25 @@ from .. import _lib
 from ..utils import fast_rng
 
 
+class _DevWords(object):
+    """``__cuda_array_interface__`` view of ``words`` int64 words at a raw device address (the C controller's payload buffer)."""
+
+    def __init__(self, ptr, words):
+        self.__cuda_array_interface__ = {"shape": (int(words),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def _alias_int64(ptr, words, device):
+    import torch
+    return torch.as_tensor(_DevWords(ptr, words), device=device)
+
+
 class NativeStep(object):
-    def __init__(self, native, recurrent, m, n, h, low, high, discount, reward, device_seed=None):
+    def __init__(self, native, recurrent, m, n, h, low, high, discount, reward, device_seed=None, shard=None):
         """``device_seed``: None = parity mode (NumPy's global generator, candidates drawn ahead by a C thread); an integer =
-        ``rng="device"``: the candidates come from the library's counter-based Philox stream under that seed, drawn on the GPU."""
+        ``rng="device"``: the candidates come from the library's counter-based Philox stream under that seed, drawn on the GPU.
+        ``shard``: None, or ``(rank, world, reduce)`` - the sharded step (``l2a_controller_create_sharded``, MLP models, parity
+        mode): ``reduce`` = None runs the step's one collective over the library's own RCCL communicator (``l2a_comm_init``),
+        else a callable ``reduce(payload)`` that MAX-all-reduces the int64 CUDA tensor it is handed in place (torch.distributed)."""
         lib = native.lib
         self.lib, self.ctx, self.native, self.recurrent = lib, native.ctx, native, bool(recurrent)
         self.m, self.n, self.h = int(m), int(n), int(h)
@@ -39,9 +54,32 @@ class NativeStep(object):
             if self.addr is None:
                 raise _lib.L2AError("np.random's global generator is not the legacy MT19937")
             self.lock = fast_rng._global_lock()
-            create = lib.l2a_lstm_controller_create if self.recurrent else lib.l2a_controller_create
-            rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
-                        ctypes.byref(reward), self.addr, fast_rng.threads(), ctypes.byref(handle))
+            if shard is not None and not self.recurrent:
+                rank, world, reduce = shard
+                self._reduce_cb = None
+                if reduce is not None:
+                    self._payload = None
+
+                    def _cb(arg, ptr, words, stream, _reduce=reduce):
+                        try:
+                            if self._payload is None or self._payload[0] != (ptr, words):
+                                self._payload = ((ptr, words), _alias_int64(ptr, words, native.device))
+                            _reduce(self._payload[1])
+                            return 0
+                        except Exception as exc:          # an exception must not unwind through the C frame
+                            self.reduce_error = exc
+                            return -1
+                    self._reduce_cb = lib.REDUCE_FN(_cb)    # (kept alive with the controller)
+                self.reduce_error = None
+                rc = lib.l2a_controller_create_sharded(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data,
+                                                       float(discount), ctypes.byref(reward), self.addr, fast_rng.threads(),
+                                                       int(rank), int(world),
+                                                       ctypes.cast(self._reduce_cb, ctypes.c_void_p) if self._reduce_cb else None,
+                                                       None, ctypes.byref(handle))
+            else:
+                create = lib.l2a_lstm_controller_create if self.recurrent else lib.l2a_controller_create
+                rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
+                            ctypes.byref(reward), self.addr, fast_rng.threads(), ctypes.byref(handle))
         self.ctx.check(rc, "l2a_controller_create")
         self.handle = handle
         self.pid = os.getpid()      # a forked child must not tear down the parent's HIP objects (it drops the handle instead)
@@ -81,6 +119,9 @@ class NativeStep(object):
             self.ctx.split_degraded = True
             self.misses_in_row = 0
             return True
+        if getattr(self, "reduce_error", None) is not None:
+            exc, self.reduce_error = self.reduce_error, None
+            raise exc
         self.ctx.check(rc, "l2a_controller_step")
 
     def _begin(self, p, state, stream):

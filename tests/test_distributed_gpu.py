@@ -67,7 +67,8 @@ def test_sharded_plan_on_the_gpu_equals_the_reference_plan(cid, world, tmp_path)
     returns all-gathered every iteration, uneven shards padded), the GrBAL default plan on per-block sets (micro-tile
     kernels, uneven shards), a ragged tiny plan with 9 / 10 candidates per rank: every rank must return the golden action
     of the reference planner and leave np.random where the reference leaves it."""
-    mp.spawn(_worker_golden, args=(world, _free_port(), cid, 1, str(tmp_path)), nprocs=world, join=True)
+    steps = 3 if cid.startswith("hc_rs_ragged") else 1       # (three steps: the later ones take the blocks the C chain drew ahead, sliced per rank)
+    mp.spawn(_worker_golden, args=(world, _free_port(), cid, steps, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, HERE)
     import cases
     gold = cases.load_golden(cid)
@@ -76,7 +77,20 @@ def test_sharded_plan_on_the_gpu_equals_the_reference_plan(cid, world, tmp_path)
         assert np.array_equal(o["best_0"], gold["best"])
         np.testing.assert_array_equal(o["actions_0"], gold["chosen"])
         np.testing.assert_array_equal(o["rng_next"], outs[0]["rng_next"])
-    assert float(outs[0]["rng_next"]) == float(gold["rng_next"])          # same RNG consumption as the reference
+        for k in range(1, steps):
+            np.testing.assert_array_equal(o["best_%d" % k], outs[0]["best_%d" % k])
+            np.testing.assert_array_equal(o["actions_%d" % k], outs[0]["actions_%d" % k])
+    if steps == 1:
+        assert float(outs[0]["rng_next"]) == float(gold["rng_next"])          # same RNG consumption as the reference
+    else:
+        # later steps against ONE process planning the whole case (the single-GPU path, itself pinned to the reference's goldens)
+        case, seed = cases.split_id(cid)
+        ctrl = cases.product_controller(case)
+        np.random.seed(seed)
+        for k in range(steps):
+            want, _ = ctrl.get_actions(gold["obs0"])
+            np.testing.assert_array_equal(outs[0]["actions_%d" % k], want)
+        assert float(outs[0]["rng_next"]) == float(np.random.uniform())
     if outs[0]["shard"][0] >= 0:
         edges = [int(outs[0]["shard"][0])] + [int(o["shard"][1]) for o in outs]
         assert edges[0] == 0 and edges[-1] == cases.split_id(cid)[0]["n"]

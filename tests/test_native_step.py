@@ -274,3 +274,67 @@ def test_device_rng_recurrent_step_runs_through_the_c_controller():
     assert np.isfinite(c).all() and np.abs(h).max() <= 1.0 and np.abs(h).max() > 0.0       # the state was advanced
     ctrl._cstep.close()
     ctrl._cstep = None
+
+
+@pytest.mark.parametrize("collective", ["rccl", "callback"])
+def test_sharded_c_step_with_one_rank_reproduces_the_reference_golden(collective):
+    """`l2a_controller_create_sharded` with world = 1 runs the SAME code path as a multi-rank step - slice draw, launch into a
+    device key slot, payload packed on the device, the collective, the page-locked read-back, digest and flag checks - with a
+    one-rank collective: the library's own RCCL communicator (`l2a_comm_init` + `l2a_allreduce_best` on m + 3 words; RCCL cannot
+    run two ranks on one GPU, the multi-rank protocol is tests/test_distributed_gpu.py's with gloo behind the callback) or a
+    Python callback.  Must return the reference planner's golden plan, use the draw-ahead chain and leave np.random where the
+    reference leaves it."""
+    import ctypes
+    from learning_to_adapt_amd.policies.native_step import NativeStep
+    cid = "hc_rs_m3_n64_h5_s0"
+    case, seed = cases.split_id(cid)
+    gold = cases.load_golden(cid)
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    ctx = native.ctx
+    seen = []
+    if collective == "rccl":
+        buf = ctypes.create_string_buffer(128)
+        ctx.check(native.lib.l2a_comm_unique_id(buf), "l2a_comm_unique_id")
+        ctx.check(native.lib.l2a_comm_init(ctx.handle, 0, 1, buf.raw), "l2a_comm_init")
+        reduce = None
+    else:
+        def reduce(payload):
+            assert payload.is_cuda and payload.dtype == torch.int64 and payload.numel() == case["m"] + 3
+            seen.append(payload.cpu().numpy().copy())
+    try:
+        st = NativeStep(native, False, case["m"], case["n"], case["h"], env.action_space.low, env.action_space.high, 1.0,
+                        env.reward_spec, shard=(0, 1, reduce))
+        stream = torch.cuda.current_stream(native.device).cuda_stream
+        np.random.seed(seed)
+        assert st.step(gold["obs0"], stream)
+        assert np.array_equal(st.idx, gold["best"])
+        np.testing.assert_array_equal(st.act, gold["chosen"])
+        # steps 2 and 3 adopt blocks the chain drew ahead; they must be what an unsharded controller returns
+        ctrl = cases.product_controller(case, model=model, env=env)
+        np.random.seed(seed)
+        ctrl.get_actions(gold["obs0"])
+        state_after_1 = np.random.get_state()
+        outs = []
+        for _ in range(2):
+            a, _ = ctrl.get_actions(gold["obs0"])
+            outs.append((a.copy(), np.array(ctrl.last_plan["best_index"])))
+        want_next = np.random.uniform()
+        np.random.set_state(state_after_1)
+        st.rearm()
+        for k in range(2):
+            assert st.step(gold["obs0"], stream)
+            np.testing.assert_array_equal(st.act, outs[k][0])
+            assert np.array_equal(st.idx, outs[k][1])
+        assert np.random.uniform() == want_next
+        assert st.stats()["hits"] >= 1
+        if collective == "callback":
+            assert len(seen) == 3 and all(int(v[case["m"]]) == 0 for v in seen)       # keys | flag | digest pair
+            assert all(int(v[case["m"] + 1]) + int(v[case["m"] + 2]) == 0x7FFFFFFFFFFF for v in seen)
+        st.close()
+        if ctrl._cstep is not None:
+            ctrl._cstep.close()
+            ctrl._cstep = None
+    finally:
+        if collective == "rccl":
+            native.lib.l2a_comm_destroy(ctx.handle)
