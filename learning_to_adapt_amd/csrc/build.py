@@ -21,7 +21,9 @@ HEADERS = ["l2a_host.h", "l2a_kernels.h", "l2a_valu.h", "l2a_adapt.h", "l2a_mfma
            "l2a_lstm_valu.h", "l2a_rnn_valu.h", "l2a_rnn_mfma.h", "l2a_lstm_launch.h", "l2a_micro.h", "l2a_rnn_micro.h", "l2a_micro_pack.h", "l2a_micro_launch.h", "l2a_rng.h", os.path.join("..", "..", "include", "l2a.h")]
 SOURCES = ["l2a_api.hip", "l2a_mfma_inst.hip", "l2a_lstm_api.hip", "l2a_lstm_inst.hip", "l2a_micro_inst.hip", "l2a_rnn_micro_inst.hip", "l2a_comm.hip", "l2a_cem.hip", "l2a_step.hip", "l2a_rng.c"]
 INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4)]
-FAN_INSTANCES = [(1, 2), (1, 4), (1, 8)]    # member-fan instances of the same template (-DL2A_INST_FAN=1), NT = 1 only
+# member-fan instances of the same template (-DL2A_INST_FAN=1): NT = 1 at every width, NT = 2 at width 512 (the fan instances
+# carry no half-member code: (2, 8) keeps its registers - 456 VGPRs, no scratch - where the tile-split (2, 8) instances spilled)
+FAN_INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 8)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Rollout kernels: MFMA accumulators in architectural VGPRs where the allocator can afford it - every epilogue reads its

@@ -205,7 +205,20 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     if (kind == L2A_KERNEL_MFMA) {
         const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
         const int cst_bytes = e_loop0 * (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4;
-        const int nt = choose_nt(md, p.m, p.n, e_loop0, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16);
+        int nt = choose_nt(md, p.m, p.n, e_loop0, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16);
+        // Member fan (l2a_mfma.h): E workgroups per tile, one set each - small mean-ensemble plans, e.g. one rank's shard of
+        // config 5 (n = 500: 32 tiles -> 160 workgroups of one set instead of 64 of 2.5 sets).  With two candidate tiles per
+        // workgroup (width 512, up to 48 observation dims) it reaches twice as far: one of FOUR ranks' shard of config 5
+        // (n = 1000: 32 double tiles x 5) - each weight fragment feeds two tiles and the step's fixed costs are paid once for both.
+        const int cus0 = ctx->num_cu > 0 ? ctx->num_cu : 256;
+        int fan_nt = 0;
+        if (ctx->split_policy != 0 && ctx->fan_policy != 0 && p.h < 4096 && p.mode == L2A_MODE_MEAN && e_loop0 >= 3 && e_loop0 <= 8) {
+            if ((long long)p.m * ceil_div(p.n, 16) * e_loop0 <= cus0) fan_nt = 1;
+            else if (md->TPW == 8 && md->OT <= 3 && (long long)p.m * ceil_div(p.n, 32) * e_loop0 <= cus0 &&
+                     2 * sa_elems_for(md, 2) * 16 + (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4 + e_loop0 * 2 * md->OT * 64 * 16 <= ctx->lds_per_block)
+                fan_nt = 2;
+        }
+        if (fan_nt) nt = fan_nt;
         p.sa_elems = sa_elems_for(md, nt);
         p.tiles_per_env = ceil_div(p.n, 16 * nt);
         const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
@@ -221,10 +234,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         p.split_from = -1;
         long long split_pairs = 0;          // tiles shared by two workgroups
         auto split_mode = [&]() { return split_mode_for(md, e_loop); };
-        // Member fan: E workgroups per tile, one set each (l2a_mfma.h) - small mean-ensemble plans, e.g. one rank's
-        // shard of config 5 (n = 500: 32 tiles -> 160 workgroups of one set instead of 64 of 2.5 sets).
-        const bool fan = ctx->split_policy != 0 && ctx->fan_policy != 0 && nt == 1 && p.h < 4096 &&
-                         p.mode == L2A_MODE_MEAN && e_loop >= 3 && e_loop <= 8 && pairs * e_loop <= cus;
+        const bool fan = fan_nt != 0;
         if (fan) {
             p.split = 3;
             split_pairs = pairs;

@@ -273,6 +273,12 @@ FAN_CASES = [
     ("ant_rs_n300_h6_e3", dict(E=5, n=500, h=3)),
     ("arm_cem_n160_h5_e3", {}),
     ("hc_rs_m3_n64_h5", dict(E=3, mode="mean", n=70)),
+    # two candidate tiles per workgroup (width 512): one of FOUR ranks' shard of config 5, the largest plan that fits (51 double
+    # tiles x 5), two envs with a ragged last double tile, generic activations on the Ant's shapes
+    ("c5_hc_cem_n4000_h30_e5", dict(n=1000, h=5)),
+    ("c2_hc_rs_n2000_h30_e5", dict(n=1632, h=2)),
+    ("hc_rs_m3_n64_h5", dict(E=3, mode="mean", m=2, n=909, h=3)),
+    ("ant_rs_n300_h6_e3", dict(n=1100, m=1, h=3, activation="tanh")),
 ]
 
 

@@ -58,15 +58,17 @@ def main():
     env, model = cases.product_model(full)
     native = model.planner_model()
     rows = []
-    for n in (500, 4000):
+    who = {500: "shard of one rank of 8 (n=500)", 1000: "shard of one rank of 4 (n=1000)", 2000: "shard of one rank of 2 (n=2000)",
+           4000: "on one GPU alone (n=4000)"}
+    for n in (500, 1000, 2000, 4000):
         case = dict(full, n=n)
         for label, fan, split, micro in (("member fan", 1, 1, 0), ("tile split (r5 default)", 0, 1, 0), ("unsplit", 0, 0, 0),
                                          ("micro tiles", 0, 1, 2), ("library default", 1, 1, 1)):
-            if n == 4000 and label in ("member fan", "micro tiles"):
+            if (n >= 2000 and label == "member fan") or (n >= 1000 and label == "micro tiles"):
                 continue
             ms = time_geometry(native, case, env, fan, split, micro)
             fl = flops(case, env)
-            row = dict(what="config 5 %s: CEM rollout, one iteration" % ("shard of one rank (n=500)" if n == 500 else "on one GPU alone (n=4000)"),
+            row = dict(what="config 5 %s: CEM rollout, one iteration" % who[n],
                        geometry=label, n=n, h=case["h"], E=case["E"], kernel_ms=round(ms, 4), tflops=round(fl / ms / 1e9, 2),
                        frac_fp32_peak=round(fl / ms / 1e9 / PEAK, 4))
             rows.append(row)
