@@ -83,6 +83,18 @@ timeout 300 python tools/probe_e2e.py > $OUT/probe_c2.jsonl 2> $OUT/probe.err; e
 timeout 300 python tools/probe_e2e.py c5_hc_cem_n4000_h30_e5 > $OUT/probe_c5.jsonl 2>> $OUT/probe.err; echo "probe c5 rc=$?"
 echo "== N = 2 code path: two gloo ranks sharing this GPU (self-launch; numbers meaningless)"
 L2A_BENCH_SHARE_GPU=1 L2A_SPLIT=0 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/bench_share2.json 2> $OUT/bench_share2.err; echo "share2 rc=$?"
+echo "== round 6: member fan (config-5 shards), the stationary-cluster probe, two planners on the blocking path"
+timeout 200 python tools/timeline.py c5_hc_cem_n4000_h30_e5 n=500 > $OUT/timeline_c5shard_fan.txt 2>&1; echo "timeline fan rc=$?"
+timeout 200 python tools/timeline.py c3_ant_rs_n2000_h20_pb5 > $OUT/timeline_c3.txt 2>&1; echo "timeline c3 rc=$?"
+for fan in 1 0; do
+  (cd /tmp && L2A_FAN=$fan timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_c5 -o trace -- python $GRAFT_REPO_ROOT/tools/prof_defaults.py c5shard 400 > /dev/null 2>> $GRAFT_REPO_ROOT/$OUT/prof_c5.err)
+  f=$(find $OUT/prof_c5 -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && (echo "# config 5 shard (n=500, h=30, E=5 mean; tools/prof_defaults.py c5shard 400), L2A_FAN=$fan"; head -1 "$f"; grep -E '^"(void )?l2a_(rollout|mlp)' "$f") >> $OUT/c5shard_kernel_stats.csv
+  rm -rf $OUT/prof_c5
+done; cat $OUT/c5shard_kernel_stats.csv | cut -c1-160
+timeout 300 python tools/probe_c5_shard.py > $OUT/probe_c5_shard.jsonl 2> $OUT/probe_c5_shard.err; echo "probe_c5_shard rc=$?"
+[ -x tools/probes/stationary ] && (timeout 120 tools/probes/stationary 10 > $OUT/probe_stationary.jsonl 2>&1; echo "stationary rc=$?")
+timeout 300 python tools/two_planners.py sync > $OUT/two_planners_sync.jsonl 2> /dev/null; echo "two_planners sync rc=$?"
 # keep the merged-back payload small
 find $OUT/prof -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $OUT
