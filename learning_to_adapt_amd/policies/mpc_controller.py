@@ -495,6 +495,13 @@ class MPCController(Policy, Serializable):
             own = os.environ.get("L2A_NATIVE_COMM", "0") == "1" and torch.distributed.get_backend() != "gloo"
             if own:
                 self._native_comm(native, rank, world)
+            else:
+                # dry run of the collective the callback will issue every step (every rank builds its controller in the same
+                # step, so the call is symmetric): a backend that cannot MAX-reduce int64 words on this device keeps the Python path
+                try:
+                    self._reduce_payload(torch.zeros((m + 3,), dtype=torch.int64, device=native.device))
+                except Exception:
+                    return None
             shard = (rank, world, None if own else self._reduce_payload)
         st = NativeStep(native, hasattr(native, "units"), m, self.n_candidates, self.horizon, self.action_space.low,
                         self.action_space.high, self.discount, self._reward_spec,

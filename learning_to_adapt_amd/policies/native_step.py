@@ -61,10 +61,18 @@ class NativeStep(object):
                     self._payload = None
 
                     def _cb(arg, ptr, words, stream, _reduce=reduce):
+                        # The collective runs on a tensor torch allocated itself (what every backend is used to); the library's
+                        # words are copied in and out on the same stream (two tiny copies) - the alias of the library's buffer
+                        # never reaches the process group.
                         try:
                             if self._payload is None or self._payload[0] != (ptr, words):
-                                self._payload = ((ptr, words), _alias_int64(ptr, words, native.device))
-                            _reduce(self._payload[1])
+                                import torch
+                                alias = _alias_int64(ptr, words, native.device)
+                                self._payload = ((ptr, words), alias, torch.empty_like(alias))
+                            _, alias, own = self._payload
+                            own.copy_(alias)
+                            _reduce(own)
+                            alias.copy_(own)
                             return 0
                         except Exception as exc:          # an exception must not unwind through the C frame
                             self.reduce_error = exc
