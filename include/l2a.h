@@ -522,7 +522,16 @@ const float* l2a_controller_actions(const l2a_controller* controller);
 int l2a_controller_stats(l2a_controller* controller, double* out, int cap);
 
 /* ---- introspection used by tests (no GPU needed) ------------------------------------------ */
-/* 1 when (obs_dim, act_dim, hidden[]) is eligible for the MFMA kernel, else 0.               */
+/* 1 when (obs_dim, act_dim, hidden[]) is eligible for the MFMA kernel, else 0.
+ * Eligible shapes whose kernel instance keeps part of its working set in scratch memory (spilled VGPRs; correct, slower per
+ * MFMA than their neighbours - tools/isa_notes.sh, profiles/r05_scratch_table.txt; none is a BASELINE.json shape):
+ *   - hidden width 512 with 33 .. 64 observation dims, other than 49 inputs with relu / identity (the Ant instance is clean):
+ *     6 - 8 VGPRs at 33 .. 48 observation dims, 40 - 132 at 49 .. 64.  The spill comes from the half-member paths of the tile
+ *     split; the member-fan instances of the same shapes (l2a_set_fan) have none.  Alternative: the generic VALU kernel
+ *     (l2a_set_kernel(ctx, L2A_KERNEL_VALU)), ~35 x slower.
+ *   - l2a_lstm_mfma_eligible shapes with 512 units: 10 - 134 VGPRs (the 512-unit micro-tile instance: 14); 256 and 128 units are
+ *     clean.  Alternative: the VALU kernel, ~40 x slower.
+ * They stay selectable because every alternative is an order of magnitude slower.                                  */
 int l2a_mfma_eligible(int obs_dim, int act_dim, int n_hidden, const int* hidden);
 /* Host implementation of the weight re-packing used by the device pack kernel (same index
  * function).  Packs kernel W [k_in, n_out] (row-major) into `out`, which must hold

@@ -457,6 +457,7 @@ void l2a_controller_destroy(l2a_controller* c) {
     if (!c) return;
     if (c->chain) l2a_ahead_destroy(c->chain);                // joins the producer: no upload is in flight afterwards
     l2a_device_guard guard(c->ctx->device);
+    if (c->in_flight) (void)hipDeviceSynchronize();           // a step begun and never finished: its launch still reads these buffers
     for (int s = 0; s < 2; ++s) {
         if (c->pin[s]) (void)hipHostFree(c->pin[s]);
         if (c->dev[s]) (void)hipFree(c->dev[s]);

@@ -87,8 +87,10 @@ def test_random_mlp_shapes_match_oracle(seed):
     results = []
     ctx = _lib.Context.get(0)
     try:
-        for split in (1, 0, 2):
+        # (split 1 with the member fan - what small mean ensembles take by default - and without it: the tile split)
+        for split, fan in ((1, 1), (0, 1), (2, 1), (1, 0)):
             ctx.set_split(split)
+            ctx.set_fan(fan)
             rets = torch.empty((m, n), dtype=torch.float32, device=dev)
             best = torch.zeros((m,), dtype=torch.int64, device=dev)
             native.plan_rs(up(obs0), up(acts), m, n, h, discount, spec, cand_offset=offset, returns_out=rets,
@@ -99,7 +101,8 @@ def test_random_mlp_shapes_match_oracle(seed):
             results.append(got)
     finally:
         ctx.set_split(1)
-    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+        ctx.set_fan(1)
+    assert all(np.array_equal(results[0], r) for r in results[1:])
     native.close()
 
 
