@@ -560,8 +560,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     // Operands every phase receives preloaded from the phase before it (issued ahead of the
     // barrier that separates them, so a phase never starts with an exposed L2 round trip).
     // (every layer-0 k-group a phase ahead was measured neutral for 21 more registers: profiles/r03_ab_kernel_variants.jsonl)
-    constexpr int KG0P = 1;      // layer-0 k-groups fetched a phase ahead (all of them when the input is
-                                                    // at most 32 wide: registers; wider inputs fetch the rest at layer 0)
+    // Layer-0 k-groups fetched a phase ahead: the first one; in the fan instances (110 VGPRs below the tile-split ones) both
+    // k-groups of an input of at most 32 features - config-5 shard 0.6008 -> 0.5932 ms (round 6 A/B, tools/ab_fan.sh; the same
+    // prefetch was neutral in the tile-split instances at 442 VGPRs: profiles/r03_ab_kernel_variants.jsonl)
+    constexpr int KG0P = (FAN && KG0 <= 2) ? KG0 : 1;
     f32x4 pfL0[KG0P][TPW];      // layer-0 A fragments of the upcoming (step, set)
     f32x4 pfA[TPW], pfB[TPW];   // k-groups 0 / 1 of the upcoming hidden->hidden layer
     f32x4 pfO[TPW][OT];         // output-layer A fragments of this wave's k-groups
@@ -981,6 +983,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             // partner's record of step t + 1 to get to step t + 2, and the partner publishes that after reading step t).
             constexpr int XREGF = NT * OT * 2 * 64 * 16;
             auto fbase = [&](int g) { return ((lpair * e_loop + g) * 2 + (t & 1)) * XREGF + lane * 16; };
+            // (dealing the record's rows over the four waves instead of wave 0 measured +0.1 .. +0.6 %: round 6 A/B)
             if (wave == 0) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
