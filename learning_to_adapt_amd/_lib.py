@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_adapt_sgd_raw", "l2a_model_get_weights",
-    "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible",
+    "l2a_plan_rs", "l2a_plan_rs_sync", "l2a_plan_rs_chunk", "l2a_predict", "l2a_key_encode", "l2a_key_decode", "l2a_mfma_eligible", "l2a_plan_geometry",
     "l2a_packed_layer_floats", "l2a_pack_layer_host", "l2a_micro_layout_floats", "l2a_micro_pack_layer_host",
     "l2a_comm_unique_id", "l2a_comm_init", "l2a_comm_destroy", "l2a_allreduce_best", "l2a_plan_payload",
     "l2a_cem_sample", "l2a_cem_refit", "l2a_cem_pick",
@@ -45,6 +45,22 @@ EXPORTED_SYMBOLS = (
 
 class L2AError(RuntimeError):
     pass
+
+
+def plan_geometry(obs_dim, act_dim, hidden, n_sets, mode, m, n, h, split=-1, fan=-1, micro=-1, cus=0):
+    """The launch geometry the library would pick for this plan (``l2a_plan_geometry``: the launcher's own decision code, no
+    GPU needed).  Returns a dict: kernel ('valu' | 'mfma16' | 'micro'), nt, split (0 none, 1 whole sets, 2 shared half member,
+    3 member fan), split_from, fan, workgroups, lds_bytes, sets_per_batch, micro_tiles, placement_units."""
+    lib = load()
+    hid = (ctypes.c_int * len(hidden))(*[int(x) for x in hidden])
+    pol = (ctypes.c_int * 4)(int(split), int(fan), int(micro), int(cus))
+    out = (ctypes.c_int * 10)()
+    rc = lib.l2a_plan_geometry(int(obs_dim), int(act_dim), len(hidden), hid, int(n_sets), MODE_CODES[mode], int(m), int(n), int(h), pol, out)
+    if rc != L2A_OK:
+        raise L2AError("l2a_plan_geometry failed (%d)" % rc)
+    v = list(out)
+    return dict(kernel=("valu", "mfma16", "micro")[v[0]], nt=v[1], split=v[2], split_from=v[3], fan=bool(v[4]), workgroups=v[5],
+                lds_bytes=v[6], sets_per_batch=v[7], micro_tiles=v[8], placement_units=v[9])
 
 
 _lib = None
@@ -135,6 +151,8 @@ def load():
     lib.l2a_key_decode.restype = None
     lib.l2a_mfma_eligible.argtypes = [i32, i32, i32, c.POINTER(i32)]
     lib.l2a_mfma_eligible.restype = i32
+    lib.l2a_plan_geometry.argtypes = [i32, i32, i32, c.POINTER(i32), i32, i32, i32, i32, i32, c.POINTER(i32), c.POINTER(i32)]
+    lib.l2a_plan_geometry.restype = i32
     lib.l2a_packed_layer_floats.argtypes = [i32, i32]
     lib.l2a_packed_layer_floats.restype = c.c_longlong
     lib.l2a_pack_layer_host.argtypes = [c.POINTER(f32), i32, i32, c.POINTER(f32)]

@@ -143,7 +143,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     l2a_ctx* ctx = md->ctx;
     l2a_device_guard guard(ctx->device);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-    const int sets_needed = (p.mode == L2A_MODE_PER_BLOCK) ? (p.m < md->n_sets ? p.m : md->n_sets) : md->n_sets;
+    const int sets_needed = ctx->dry ? 0 : (p.mode == L2A_MODE_PER_BLOCK) ? (p.m < md->n_sets ? p.m : md->n_sets) : md->n_sets;
     for (int e = 0; e < sets_needed; ++e) {
         if (!md->weights_set[e]) return fail(ctx, L2A_ESTATE, "weight set " + std::to_string(e) + " was never set");
         if (!md->norm_set[e]) return fail(ctx, L2A_ESTATE, "normalisation of set " + std::to_string(e) + " was never set");
@@ -195,6 +195,11 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             int smem_m = smem_need;
             if (smem_m < 84 * 1024) smem_m = 84 * 1024;     // more than half a CU's LDS: one workgroup per CU
             const bool gact_m = !(fast_act(md->hidden_act) && fast_act(md->output_act)) || md->n_hidden == 1;
+            if (ctx->dry) {     // [kind, nt, split, split_from, fan, workgroups, lds bytes, sets per batch, micro tiles of the largest workgroup, placement units]
+                const int g[10] = {2, 0, 0, -1, 0, p.m * W, smem_m, 1, hi, 0};
+                std::memcpy(ctx->dry, g, sizeof(g));
+                return L2A_OK;
+            }
             const int rc = l2a_launch_mlp_micro(md->H, gact_m ? 1 : 0, &p, (unsigned)(p.m * W), smem_m, stream);
             if (rc != 0) return fail(ctx, L2A_EHIP, std::string("micro-tile MLP kernel launch: ") +
                                                         (rc > 0 ? hipGetErrorString((hipError_t)rc) : "no instance"));
@@ -250,7 +255,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
                 p.split_from = (int)(pairs - split_pairs);
             }
         }
-        if (p.split) {
+        if (p.split && !ctx->dry) {
             // in 8-byte units: per shared tile 2 workgroups x 2 step parities x 2 regions (fan: E workgroups x 2 parities)
             const long long need = split_pairs * (fan ? e_loop : 4) * 2 * (long long)(nt * md->OT * 2 * 64 * 16) / 8;
             if (need > md->xbuf_granules) {
@@ -320,6 +325,11 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         }
         const dim3 grid((unsigned)n_wg), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
+        if (ctx->dry) {
+            const int g[10] = {1, nt, p.split, p.split_from, fan ? 1 : 0, (int)n_wg, smem, p.lb, 0, p.pl_units};
+            std::memcpy(ctx->dry, g, sizeof(g));
+            return L2A_OK;
+        }
         int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, fan ? 1 : 0, &p, grid.x, smem, stream);
         if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");
         if (rc != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch: ") + hipGetErrorString((hipError_t)rc));
@@ -330,6 +340,11 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         const int smem = (md->in_dim + 2 * md->hmax + 3 * md->obs_dim + md->act_dim + 1) * L2A_VT * 4;
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded by the VALU kernel (" + std::to_string(smem) + " B)");
+        if (ctx->dry) {
+            const int g[10] = {0, 0, 0, -1, 0, p.m * p.tiles_per_env, smem, 1, 0, 0};
+            std::memcpy(ctx->dry, g, sizeof(g));
+            return L2A_OK;
+        }
         int rc = allow_big_lds(ctx, l2a_rollout_valu_k, smem);
         if (rc != L2A_OK) return rc;
         const dim3 grid((unsigned)(p.m * p.tiles_per_env)), block(256);
@@ -337,6 +352,28 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     }
     L2A_HIP(ctx, hipGetLastError());
     return L2A_OK;
+}
+
+// What the launch logic needs to know of a model's shape (no storage): shared by l2a_model_create and l2a_plan_geometry.
+void model_shape(l2a_model* md, int obs_dim, int act_dim, int n_hidden, const int* hidden, int hidden_act, int output_act,
+                 int n_sets, int mode) {
+    md->obs_dim = obs_dim; md->act_dim = act_dim; md->in_dim = obs_dim + act_dim;
+    md->n_hidden = n_hidden;
+    md->hmax = 0;
+    for (int i = 0; i < n_hidden; ++i) {
+        md->hidden[i] = hidden[i];
+        if (hidden[i] > md->hmax) md->hmax = hidden[i];
+    }
+    md->hidden_act = hidden_act; md->output_act = output_act;
+    md->n_sets = n_sets; md->mode = mode;
+    md->KG0 = ceil_div(md->in_dim, 16);
+    md->OT = ceil_div(obs_dim, 16);
+    md->mfma_ok = mfma_eligible(obs_dim, act_dim, n_hidden, hidden);
+    md->H = md->mfma_ok ? hidden[0] : 0;
+    md->TPW = md->mfma_ok ? hidden[0] / (16 * L2A_NW) : 0;
+    md->micro_ok = md->mfma_ok && (md->H == 256 || md->H == 512);
+    // the quarter sums of the O4 instance (l2a_mfma_inst.hip picks it for exactly these shapes)
+    md->m_o4 = (md->micro_ok && md->OT == 2 && md->KG0 == 2 && n_hidden > 1 && obs_dim - 16 <= 4) ? 1 : 0;
 }
 
 void fill_model_params(const l2a_model* md, L2AKParams& p) {
@@ -424,6 +461,36 @@ void l2a_destroy(l2a_ctx* ctx) {
     if (ctx->done_ctr) (void)hipFree(ctx->done_ctr);
     if (ctx->key_ring) (void)hipFree(ctx->key_ring);
     delete ctx;
+}
+
+int l2a_plan_geometry(int obs_dim, int act_dim, int n_hidden, const int* hidden, int n_sets, int mode, int m, int n, int h,
+                      const int* policy, int* out) {
+    if (!hidden || !out || obs_dim < 1 || act_dim < 1 || n_hidden < 1 || n_hidden > L2A_MAX_LAYERS - 1 || n_sets < 1 || m < 1 || n < 1 || h < 1)
+        return L2A_EINVAL;
+    l2a_ctx ctx;                                    // never touches a device: the launcher stops before its first HIP call
+    ctx.num_cu = 256;
+    ctx.lds_per_block = 160 * 1024;
+    if (policy) {
+        if (policy[0] >= 0) ctx.split_policy = policy[0];
+        if (policy[1] >= 0) ctx.fan_policy = policy[1];
+        if (policy[2] >= 0) ctx.micro_policy = policy[2];
+        if (policy[3] > 0) ctx.num_cu = policy[3];
+    }
+    l2a_model md;
+    md.ctx = &ctx;
+    model_shape(&md, obs_dim, act_dim, n_hidden, hidden, L2A_ACT_RELU, L2A_ACT_IDENTITY, n_sets, mode);
+    L2AKParams p;
+    fill_model_params(&md, p);
+    p.m = m; p.n = n; p.h = h; p.discount = 1.0; p.disc0 = 1.0;
+    unsigned long long dummy = 0;
+    p.best_key = &dummy;                            // "a plan": returns or keys are wanted (never dereferenced here)
+    int g[10] = {0};
+    ctx.dry = g;
+    const int rc = launch_rollout(&md, p, nullptr);
+    ctx.dry = nullptr;
+    if (rc != L2A_OK) return rc;
+    for (int i = 0; i < 10; ++i) out[i] = g[i];
+    return L2A_OK;
 }
 
 int l2a_set_split(l2a_ctx* ctx, int policy) {
@@ -574,20 +641,7 @@ int l2a_model_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_hidden, const
 
     l2a_model* md = new l2a_model();
     md->ctx = ctx;
-    md->obs_dim = obs_dim; md->act_dim = act_dim; md->in_dim = obs_dim + act_dim;
-    md->n_hidden = n_hidden;
-    md->hmax = 0;
-    for (int i = 0; i < n_hidden; ++i) {
-        md->hidden[i] = hidden[i];
-        if (hidden[i] > md->hmax) md->hmax = hidden[i];
-    }
-    md->hidden_act = hidden_act; md->output_act = output_act;
-    md->n_sets = n_sets; md->mode = mode;
-    md->KG0 = ceil_div(md->in_dim, 16);
-    md->OT = ceil_div(obs_dim, 16);
-    md->mfma_ok = mfma_eligible(obs_dim, act_dim, n_hidden, hidden);
-    md->H = md->mfma_ok ? hidden[0] : 0;
-    md->TPW = md->mfma_ok ? hidden[0] / (16 * L2A_NW) : 0;
+    model_shape(md, obs_dim, act_dim, n_hidden, hidden, hidden_act, output_act, n_sets, mode);
 
     // ---- lay out one weight-set block (offsets in floats, every region 64-B aligned) ------
     long long off = 0;
@@ -604,12 +658,7 @@ int l2a_model_create(l2a_ctx* ctx, int obs_dim, int act_dim, int n_hidden, const
         md->pk_wmid_stride = packed_floats(md->H, md->H);
         md->pk_wmid = take(md->pk_wmid_stride * (n_hidden - 1));
         md->pk_wout = take(packed_floats(md->H, obs_dim));
-        md->micro_ok = (md->H == 256 || md->H == 512);
-        if (md->micro_ok) {
-            // the quarter sums of the O4 instance (l2a_mfma_inst.hip picks it for exactly these shapes)
-            md->m_o4 = (md->OT == 2 && md->KG0 == 2 && n_hidden > 1 && obs_dim - 16 <= 4) ? 1 : 0;
-            md->pk_m = take(l2a_mlp_micro_floats(md->H, md->KG0, n_hidden));
-        }
+        if (md->micro_ok) md->pk_m = take(l2a_mlp_micro_floats(md->H, md->KG0, n_hidden));
     }
     md->pk_bout = take(16 * md->OT);
     md->nm_off = take(32 * md->KG0 + 32 * md->OT);

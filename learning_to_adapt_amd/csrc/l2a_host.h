@@ -29,6 +29,7 @@ struct l2a_ctx {
     unsigned int* status_host = nullptr;  // pinned, device-visible launch status word
     unsigned int* status_dev = nullptr;
     unsigned long long* dbg = nullptr;    // optional timeline buffer (l2a_set_debug_buffer)
+    int* dry = nullptr;                   // l2a_plan_geometry: the launcher records its decisions here and launches nothing
     unsigned int spin_limit = 1u << 18;   // exchange polls per workgroup and launch before it gives up (~0.5 s)
     // result mailbox of l2a_plan_rs_sync (allocated on first use)
     struct l2a_mail* mail_host = nullptr; // host-mapped

@@ -202,3 +202,54 @@ def test_meta_fit_splits_accumulates_and_validates_on_held_out_paths():
     m2 = MetaMLPDynamicsModel(name="dyn", env=env, hidden_sizes=(16,), meta_batch_size=2, batch_size=4, init_seed=0)
     s3 = m2.fit(o, a, n, epochs=2, valid_split_ratio=0.0)
     assert (s3["TrainPaths"], s3["ValidPaths"]) == (8, 0)
+
+
+def test_launch_geometry_routing_table():
+    """`l2a_plan_geometry` runs the launcher's own decision code without a GPU: which geometry every BASELINE config and the
+    boundaries of the round-6 member fan take on a 256-CU device.  (Results never depend on the geometry - the GPU suite pins the
+    bit-identity; this pins WHICH launch a plan gets.)"""
+    from learning_to_adapt_amd import _lib
+    hc = dict(obs_dim=20, act_dim=6, hidden=[512, 512])
+    ant = dict(obs_dim=41, act_dim=8, hidden=[512, 512])
+    g = lambda shape, E, mode, m, n, h, **kw: _lib.plan_geometry(shape["obs_dim"], shape["act_dim"], shape["hidden"], E, mode, m, n, h, **kw)  # noqa: E731
+    # config 2: 125 tiles -> tile split with the shared middle set, two XCD placement units (group A | group B), three sets side by side in LDS
+    c2 = g(hc, 5, "mean", 1, 2000, 30)
+    assert (c2["kernel"], c2["nt"], c2["split"], c2["fan"], c2["placement_units"], c2["sets_per_batch"]) == ("mfma16", 1, 2, False, 2, 3)
+    assert c2["workgroups"] == 256 and c2["lds_bytes"] <= 160 * 1024
+    # config 3: 625 tiles = 512 whole + 113 shared by pairs (tail split)
+    c3 = g(ant, 5, "per_block", 5, 2000, 20)
+    assert (c3["split"], c3["split_from"], c3["workgroups"]) == (2, 512, 512 + 2 * 113)
+    # config 4's plan on ONE GPU: 1000 tiles, no tail worth splitting; config 5's iteration: 250 whole tiles
+    assert g(hc, 5, "mean", 1, 16000, 30)["split"] == 0 and g(hc, 5, "mean", 1, 16000, 30)["workgroups"] == 1000
+    assert g(hc, 5, "mean", 1, 4000, 30)["workgroups"] == 250
+    # config 5's shards: one rank of 8 -> member fan (32 tiles x 5 members, every member on its own XCDs); one rank of 4 -> the fan
+    # with two tiles per workgroup; one rank of 2 -> config 2's tile split
+    s8 = g(hc, 5, "mean", 1, 500, 30)
+    assert (s8["split"], s8["fan"], s8["nt"], s8["placement_units"], s8["sets_per_batch"]) == (3, True, 1, 5, 1)
+    s4 = g(hc, 5, "mean", 1, 1000, 30)
+    assert (s4["split"], s4["fan"], s4["nt"]) == (3, True, 2) and s4["lds_bytes"] <= 160 * 1024
+    assert g(hc, 5, "mean", 1, 2000, 30) == c2
+    # the fan's boundaries: E x tiles <= CUs (51 tiles x 5 = 255), then E x double tiles <= CUs, then back to the tile split
+    assert g(hc, 5, "mean", 1, 816, 3)["nt"] == 1 and g(hc, 5, "mean", 1, 816, 3)["workgroups"] == 255
+    assert (g(hc, 5, "mean", 1, 817, 3)["fan"], g(hc, 5, "mean", 1, 817, 3)["nt"]) == (True, 2)
+    assert g(hc, 5, "mean", 1, 1632, 3)["fan"] and not g(hc, 5, "mean", 1, 1633, 3)["fan"]
+    assert g(hc, 5, "mean", 1, 1633, 3)["split"] == 2
+    # ... and its conditions: mean ensembles of 3 .. 8 sets only, off with l2a_set_fan(0) or l2a_set_split(0), never for per-block sets
+    assert not g(hc, 2, "mean", 1, 500, 30)["fan"] and g(hc, 2, "mean", 1, 500, 30)["split"] == 1
+    assert g(hc, 3, "mean", 2, 300, 6)["fan"] and g(hc, 8, "mean", 1, 333, 3)["fan"] and not g(hc, 9, "mean", 1, 100, 3)["fan"]
+    off = g(hc, 5, "mean", 1, 500, 30, fan=0)
+    assert (off["fan"], off["split"], off["workgroups"]) == (False, 2, 64)
+    assert g(hc, 5, "mean", 1, 500, 30, split=0)["split"] == 0
+    assert not g(ant, 5, "per_block", 5, 100, 10, micro=0)["fan"]
+    # width 256: no two-tile fan instance
+    assert not g(dict(hc, hidden=[256, 256]), 5, "mean", 1, 1000, 30)["fan"]
+    # the reference's own default plans take micro tiles (c1: 125 workgroups of one micro tile; run_grbal.py default: 5 x 42 of three)
+    c1 = g(hc, 1, "single", 1, 500, 10)
+    assert (c1["kernel"], c1["workgroups"], c1["micro_tiles"]) == ("micro", 125, 1)
+    c3b = g(dict(ant, hidden=[512, 512, 512]), 5, "per_block", 5, 500, 10)
+    assert (c3b["kernel"], c3b["workgroups"], c3b["micro_tiles"]) == ("micro", 210, 3)
+    # shapes without a matrix-core instance run the generic kernel
+    assert g(dict(hc, hidden=[200, 72]), 1, "single", 1, 80, 4)["kernel"] == "valu"
+    # a smaller device: the same plan moves to two tiles per workgroup, then stops fitting the fan
+    assert (g(hc, 5, "mean", 1, 500, 30, cus=128)["fan"], g(hc, 5, "mean", 1, 500, 30, cus=128)["nt"]) == (True, 2)
+    assert not g(hc, 5, "mean", 1, 500, 30, cus=64)["fan"]
