@@ -75,7 +75,6 @@ struct l2a_controller {
     unsigned long long* payload_host = nullptr; // page-locked [m + 3]
     hipEvent_t payload_ev = nullptr;
     unsigned long long digest = 0;
-    double t_launched = 0.0, t_kicked = 0.0;
 };
 
 extern "C" unsigned long long l2a_mt19937_state_digest(const void* addr);      // csrc/l2a_rng.c
