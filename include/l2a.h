@@ -487,6 +487,14 @@ typedef int (*l2a_reduce_fn)(void* arg, unsigned long long* payload_dev, int wor
 int l2a_controller_create_sharded(l2a_model* model, int m, int n, int h, const double* low, const double* high,
                                   double discount, const l2a_reward* reward, void* np_state_addr, int rng_threads, int rank,
                                   int world, l2a_reduce_fn reduce, void* reduce_arg, l2a_controller** out);
+/* The sharded step with the candidates drawn ON THE DEVICE (`MPCController(rng="device")` at N > 1): every rank fills its slice of
+ * the SAME counter-based Philox stream (an element's value is that of its position in the whole plan's tensor [h, m*n, act_dim]),
+ * so the candidates - and the chosen action - do not depend on the number of ranks, and every rank recomputes the winner's first
+ * action from the stream on the host: one collective per step, no gather.  Ranks must be built with the same seed at the same
+ * step (the digest pair of the collective carries seed and step count: L2A_ESTATE otherwise).                              */
+int l2a_controller_create_sharded_device(l2a_model* model, int m, int n, int h, const double* low, const double* high,
+                                         double discount, const l2a_reward* reward, unsigned long long seed, int rank, int world,
+                                         l2a_reduce_fn reduce, void* reduce_arg, l2a_controller** out);
 /* The same step with the candidates drawn ON THE DEVICE (`MPCController(rng="device")`: statistically equivalent to the reference's
  * draw, not its numbers; NumPy's generator is not touched): every step a Philox4x32-10 kernel fills the candidate tensor from the
  * counter-based stream (seed, steps so far) in front of the plan, and the winners' first actions are recomputed on the host from

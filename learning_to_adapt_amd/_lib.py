@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = (
     "l2a_cem_sample", "l2a_cem_refit", "l2a_cem_pick",
     "l2a_lstm_create", "l2a_rnn_create", "l2a_lstm_destroy", "l2a_lstm_set_weights", "l2a_lstm_set_norm", "l2a_lstm_plan_rs", "l2a_lstm_plan_rs_sync", "l2a_lstm_plan_rs_chunk",
     "l2a_lstm_predict", "l2a_lstm_advance", "l2a_lstm_mfma_eligible",
-    "l2a_controller_create", "l2a_controller_create_sharded", "l2a_lstm_controller_create", "l2a_controller_create_device", "l2a_lstm_controller_create_device",
+    "l2a_controller_create", "l2a_controller_create_sharded", "l2a_controller_create_sharded_device", "l2a_lstm_controller_create", "l2a_controller_create_device", "l2a_lstm_controller_create_device",
     "l2a_controller_destroy", "l2a_controller_step", "l2a_controller_begin", "l2a_lstm_controller_begin", "l2a_controller_finish",
     "l2a_lstm_controller_step", "l2a_controller_rearm", "l2a_controller_actions", "l2a_controller_stats",
 )
@@ -230,6 +230,9 @@ def load():
         lib.l2a_controller_create_sharded.argtypes = [vp, i32, i32, i32, vp, vp, c.c_double, c.POINTER(RewardSpec), vp, i32, i32, i32,
                                                       vp, vp, c.POINTER(vp)]
         lib.l2a_controller_create_sharded.restype = i32
+        lib.l2a_controller_create_sharded_device.argtypes = [vp, i32, i32, i32, vp, vp, c.c_double, c.POINTER(RewardSpec), c.c_ulonglong, i32, i32,
+                                                             vp, vp, c.POINTER(vp)]
+        lib.l2a_controller_create_sharded_device.restype = i32
         lib.l2a_controller_begin.argtypes = [vp, vp, vp]
         lib.l2a_controller_begin.restype = i32
         lib.l2a_lstm_controller_begin.argtypes = [vp, vp, vp, vp, vp, vp, vp]

@@ -75,6 +75,7 @@ struct l2a_controller {
     unsigned long long* payload_host = nullptr; // page-locked [m + 3]
     hipEvent_t payload_ev = nullptr;
     unsigned long long digest = 0;
+    size_t glob_floats = 0;                     // h * m * n * act_dim: the WHOLE plan's candidate tensor (the device stream's step)
 };
 
 extern "C" unsigned long long l2a_mt19937_state_digest(const void* addr);      // csrc/l2a_rng.c
@@ -97,9 +98,37 @@ __global__ void __launch_bounds__(256) l2a_uniform_fill_k(unsigned long long see
     }
 }
 
+// The same stream for ONE rank of a sharded plan: this rank's candidates [lo, lo + n_local) of every env, local tensor
+// [h, m * n_local, act_dim]; an element takes the value of its GLOBAL position ((t m + i) n + j) act_dim + k in the stream, so the
+// candidates - and with them the plan - do not depend on the number of ranks.  One element per thread (its Philox block computed
+// whole: four times the rounds of the contiguous fill, on a tensor an eighth of the size).
+__global__ void __launch_bounds__(256) l2a_uniform_fill_shard_k(unsigned long long seed, unsigned long long offset, long long total_local,
+                                                                int n, int lo, int n_local, int act_dim, const float* __restrict__ lowr,
+                                                                float* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total_local) return;
+    const int k = (int)(e % act_dim);
+    const long long r = e / act_dim;                // local row (t m + i) n_local + jl
+    const long long ti = r / n_local;
+    const int jl = (int)(r - ti * n_local);
+    const unsigned long long g = (unsigned long long)((ti * n + lo + jl) * act_dim + k);
+    out[e] = l2a_philox_uniform(seed, offset + g, lowr[k], lowr[16 + k]);
+}
+
 namespace {
 
 int fail(l2a_ctx* ctx, int code, const std::string& msg) { return l2a_fail(ctx, code, msg); }
+
+// page-locked / device words of a sharded controller (both RNG modes)
+hipError_t alloc_sharded(l2a_controller* c) {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->obs_map_host), sizeof(float) * L2A_MAIL_OBS, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->obs_map_dev), c->obs_map_host, 0);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->keys_dev), sizeof(unsigned long long) * (size_t)c->m);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->payload_dev), sizeof(unsigned long long) * (size_t)(c->m + 3));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->payload_host), sizeof(unsigned long long) * (size_t)(c->m + 3), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->payload_ev, hipEventDisableTiming);
+    return e;
+}
 
 // Producer thread, after the block's draw: one H2D copy on the side stream, completed before the block is marked ready - the
 // consumer neither waits on an event nor launches behind an unfinished copy.
@@ -152,6 +181,7 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
     c->hi = (int)((long long)(rank + 1) * n / world);
     const int n_local = c->hi - c->lo;
     c->act_floats = (size_t)h * m * (n_local > 0 ? n_local : 1) * act_dim;
+    c->glob_floats = (size_t)h * m * n * act_dim;
     l2a_device_guard guard(ctx->device);
     c->device_rng = device_rng; c->seed = seed;
     hipError_t e = hipSuccess;
@@ -164,6 +194,7 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
             for (int k = 0; k < act_dim; ++k) { lr[k] = (float)low[k]; lr[16 + k] = (float)high[k] - (float)low[k]; }
             e = hipMemcpy(c->lowr_dev, lr, sizeof(lr), hipMemcpyHostToDevice);
         }
+        if (e == hipSuccess && sharded) e = alloc_sharded(c);
         if (e != hipSuccess) {
             const std::string msg = std::string("l2a_controller_create_device: ") + hipGetErrorString(e);
             l2a_controller_destroy(c);
@@ -189,14 +220,7 @@ int create(l2a_ctx* ctx, l2a_model* mlp, l2a_lstm* rnn, int obs_dim, int act_dim
                                     c->c64[0], c->c64[1], rng_threads, upload_block, c);
         if (!c->chain) e = hipErrorInvalidValue;
     }
-    if (e == hipSuccess && sharded) {
-        e = hipHostMalloc(reinterpret_cast<void**>(&c->obs_map_host), sizeof(float) * L2A_MAIL_OBS, hipHostMallocMapped);
-        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->obs_map_dev), c->obs_map_host, 0);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->keys_dev), sizeof(unsigned long long) * (size_t)m);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->payload_dev), sizeof(unsigned long long) * (size_t)(m + 3));
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->payload_host), sizeof(unsigned long long) * (size_t)(m + 3), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->payload_ev, hipEventDisableTiming);
-    }
+    if (e == hipSuccess && sharded) e = alloc_sharded(c);
     if (e != hipSuccess) {
         const std::string msg = std::string("l2a_controller_create: ") + hipGetErrorString(e);
         l2a_controller_destroy(c);
@@ -247,12 +271,18 @@ int begin(l2a_controller* c, const double* obs, const float* c0, const float* h0
     bool drew = false;
     if (c->device_rng) {
         // candidates of this step: elements [offset, offset + h m n act_dim) of the stream (seed) - drawn on the launch stream
-        const unsigned long long per_step = (unsigned long long)((c->act_floats + 3) / 4 * 4);
+        const unsigned long long per_step = (unsigned long long)((c->glob_floats + 3) / 4 * 4);
         c->offset = c->calls * per_step;
         l2a_device_guard guard(ctx->device);
-        const long long total = (long long)c->act_floats;
-        hipLaunchKernelGGL(l2a_uniform_fill_k, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           c->seed, c->offset, total, c->act_dim, c->lowr_dev, c->dev[0]);
+        if (!c->sharded || c->world == 1) {
+            const long long total = (long long)c->glob_floats;
+            hipLaunchKernelGGL(l2a_uniform_fill_k, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                               c->seed, c->offset, total, c->act_dim, c->lowr_dev, c->dev[0]);
+        } else if (c->hi > c->lo) {
+            const long long total = (long long)c->h * c->m * (c->hi - c->lo) * c->act_dim;
+            hipLaunchKernelGGL(l2a_uniform_fill_shard_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                               c->seed, c->offset, total, c->n, c->lo, c->hi - c->lo, c->act_dim, c->lowr_dev, c->dev[0]);
+        }
         L2A_HIP(ctx, hipGetLastError());
     } else if ((slot = l2a_ahead_take(c->chain, c->np_addr)) < 0) {
         if (!c->upload_err.empty()) { const std::string msg = c->upload_err; c->upload_err.clear(); return fail(ctx, L2A_EHIP, msg); }
@@ -282,7 +312,8 @@ int begin(l2a_controller* c, const double* obs, const float* c0, const float* h0
     c->result = drew ? L2A_STEP_DREW : L2A_OK;
     if (c->sharded) {
         // what this rank's candidates were drawn from: the generator as this step's draw left it (every rank must agree)
-        c->digest = l2a_mt19937_state_digest(c->np_addr);
+        // (device mode: the stream's seed and position - ranks seeded differently, or out of step, would plan on different candidates)
+        c->digest = c->device_rng ? (c->seed * 0x9E3779B97F4A7C15ull) ^ (c->calls + 1ull) : l2a_mt19937_state_digest(c->np_addr);
         ctx->stamps_us[0] = t0;
         const int rc = launch_sharded(c, true);
         if (rc != L2A_OK) return rc;
@@ -320,8 +351,11 @@ int finish(l2a_controller* c, double* action_out, long long* index_out, float* r
             ctx->stamps_us[4] = l2a_now_us();
             const unsigned long long* v = c->payload_host;
             if (v[c->m + 1] + v[c->m + 2] != L2A_DIGEST_MASK)
-                return fail(ctx, L2A_ESTATE, "candidate sharding needs identical np.random global state on every rank (seed all ranks alike and "
-                                             "keep other consumers of the generator off the planning process; the shards themselves are disjoint)");
+                return fail(ctx, L2A_ESTATE, c->device_rng
+                    ? "candidate sharding needs identical seeds and step counts on every rank (device RNG: build every rank's controller "
+                      "with the same seed at the same step)"
+                    : "candidate sharding needs identical np.random global state on every rank (seed all ranks alike and "
+                      "keep other consumers of the generator off the planning process; the shards themselves are disjoint)");
             if (v[c->m] == 0) break;
             // SOME rank's launch lost its tile-split partner: the reduced flag is the same on every rank, so all of them switch to the
             // unsplit geometry (bit-identical results) and repeat launch + collective together
@@ -423,6 +457,20 @@ int l2a_controller_create_sharded(l2a_model* model, int m, int n, int h, const d
         return fail(ctx, L2A_ESTATE, "l2a_controller_create_sharded: no reduce function and no communicator of this rank / world (l2a_comm_init)");
     return create(ctx, model, nullptr, obs_dim, act_dim, 0, m, n, h, low, high, discount, reward, np_state_addr, rng_threads, out,
                   false, 0, rank, world, reduce, reduce_arg, true);
+}
+
+int l2a_controller_create_sharded_device(l2a_model* model, int m, int n, int h, const double* low, const double* high, double discount,
+                                         const l2a_reward* reward, unsigned long long seed, int rank, int world,
+                                         l2a_reduce_fn reduce, void* reduce_arg, l2a_controller** out) {
+    if (!model) return L2A_EINVAL;
+    l2a_ctx* ctx = nullptr;
+    int obs_dim = 0, act_dim = 0;
+    l2a_model_facts(model, &ctx, &obs_dim, &act_dim);
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, L2A_EINVAL, "l2a_controller_create_sharded_device: bad rank / world");
+    if (!reduce && (!ctx->comm || ctx->comm_world != world || ctx->comm_rank != rank))
+        return fail(ctx, L2A_ESTATE, "l2a_controller_create_sharded_device: no reduce function and no communicator of this rank / world (l2a_comm_init)");
+    return create(ctx, model, nullptr, obs_dim, act_dim, 0, m, n, h, low, high, discount, reward, nullptr, 1, out, true, seed, rank, world,
+                  reduce, reduce_arg, true);
 }
 
 int l2a_lstm_controller_create(l2a_lstm* model, int m, int n, int h, const double* low, const double* high, double discount,

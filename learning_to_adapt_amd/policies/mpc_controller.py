@@ -490,7 +490,9 @@ class MPCController(Policy, Serializable):
             # the sharded step in one C call (parity mode, MLP models): launch, payload, the ONE collective, read-back - the ~80 us
             # of Python glue per step of `_rs_parity_plan` / `_combine_keys` gone.  The collective: torch.distributed behind a
             # callback (default), or the library's own RCCL communicator (L2A_NATIVE_COMM=1).
-            if device or hasattr(native, "units") or not hasattr(native.lib, "l2a_controller_create_sharded"):
+            # (rng="device": every rank fills its slice of the SAME Philox stream - the plan does not depend on the world size -
+            #  and recomputes the winner's action from the stream: no second collective)
+            if hasattr(native, "units") or not hasattr(native.lib, "l2a_controller_create_sharded_device"):
                 return None
             own = os.environ.get("L2A_NATIVE_COMM", "0") == "1" and torch.distributed.get_backend() != "gloo"
             if own:
@@ -526,8 +528,9 @@ class MPCController(Policy, Serializable):
         native = self.dynamics_model.planner_model()
         # (device mode: the library's counter-based stream (seed, steps so far) restarts whenever torch's seed VALUE changes, like
         #  the device CEM's.  Calling torch.manual_seed(s) again with the same s does NOT rewind it - build a new controller, or
-        #  seed with another value in between, to replay a run.  One GPU draws from this Philox stream, a sharded plan from
-        #  torch's generator: the two streams differ, device-mode candidates are not comparable across world sizes - ADVICE r5)
+        #  seed with another value in between, to replay a run.  Since round 6 a sharded MLP plan draws its slices from the SAME
+        #  Philox stream (`l2a_controller_create_sharded_device`): device-mode plans no longer depend on the world size; the
+        #  recurrent planner's sharded device path still uses torch's generator - ADVICE r5)
         # (parity mode: the address of the global generator's state - the C controller caches it; a generator object that was
         #  replaced, np.random.set_bit_generator, must not leave it reading and writing the old, possibly freed one: ADVICE r5)
         key = (os.getpid(), id(native), native.handle.value, world, m, self.n_candidates, self.horizon, float(self.discount),

@@ -44,7 +44,16 @@ class NativeStep(object):
         high = np.ascontiguousarray(high, dtype=np.float64)
         handle = ctypes.c_void_p()
         self.device_rng = device_seed is not None
-        if self.device_rng:
+        self.reduce_error = None
+        if self.device_rng and shard is not None and not self.recurrent:
+            self.addr, self.lock = None, None
+            rank, world, reduce = shard
+            cb = self._make_reduce_cb(lib, native, reduce)
+            rc = lib.l2a_controller_create_sharded_device(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data,
+                                                          float(discount), ctypes.byref(reward),
+                                                          ctypes.c_ulonglong(int(device_seed) & 0xFFFFFFFFFFFFFFFF), int(rank), int(world),
+                                                          cb, None, ctypes.byref(handle))
+        elif self.device_rng:
             self.addr, self.lock = None, None
             create = lib.l2a_lstm_controller_create_device if self.recurrent else lib.l2a_controller_create_device
             rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
@@ -56,34 +65,10 @@ class NativeStep(object):
             self.lock = fast_rng._global_lock()
             if shard is not None and not self.recurrent:
                 rank, world, reduce = shard
-                self._reduce_cb = None
-                if reduce is not None:
-                    self._payload = None
-
-                    def _cb(arg, ptr, words, stream, _reduce=reduce):
-                        # The collective runs on a tensor torch allocated itself (what every backend is used to); the library's
-                        # words are copied in and out on the same stream (two tiny copies) - the alias of the library's buffer
-                        # never reaches the process group.
-                        try:
-                            if self._payload is None or self._payload[0] != (ptr, words):
-                                import torch
-                                alias = _alias_int64(ptr, words, native.device)
-                                self._payload = ((ptr, words), alias, torch.empty_like(alias))
-                            _, alias, own = self._payload
-                            own.copy_(alias)
-                            _reduce(own)
-                            alias.copy_(own)
-                            return 0
-                        except Exception as exc:          # an exception must not unwind through the C frame
-                            self.reduce_error = exc
-                            return -1
-                    self._reduce_cb = lib.REDUCE_FN(_cb)    # (kept alive with the controller)
-                self.reduce_error = None
+                cb = self._make_reduce_cb(lib, native, reduce)
                 rc = lib.l2a_controller_create_sharded(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data,
                                                        float(discount), ctypes.byref(reward), self.addr, fast_rng.threads(),
-                                                       int(rank), int(world),
-                                                       ctypes.cast(self._reduce_cb, ctypes.c_void_p) if self._reduce_cb else None,
-                                                       None, ctypes.byref(handle))
+                                                       int(rank), int(world), cb, None, ctypes.byref(handle))
             else:
                 create = lib.l2a_lstm_controller_create if self.recurrent else lib.l2a_controller_create
                 rc = create(native.handle, self.m, self.n, self.h, low.ctypes.data, high.ctypes.data, float(discount),
@@ -99,6 +84,32 @@ class NativeStep(object):
         self.misses_in_row = 0
         self.cooldown = 0
         self._stats = (ctypes.c_double * 16)()
+
+    def _make_reduce_cb(self, lib, native, reduce):
+        """ctypes callback around ``reduce(tensor)`` (None: the library's own RCCL communicator is used).  The collective runs on
+        a tensor torch allocated itself (what every backend is used to); the library's words are copied in and out on the same
+        stream (two tiny copies) - the alias of the library's buffer never reaches the process group."""
+        self._reduce_cb = None
+        if reduce is None:
+            return None
+        self._payload = None
+
+        def _cb(arg, ptr, words, stream, _reduce=reduce):
+            try:
+                if self._payload is None or self._payload[0] != (ptr, words):
+                    import torch
+                    alias = _alias_int64(ptr, words, native.device)
+                    self._payload = ((ptr, words), alias, torch.empty_like(alias))
+                _, alias, own = self._payload
+                own.copy_(alias)
+                _reduce(own)
+                alias.copy_(own)
+                return 0
+            except Exception as exc:          # an exception must not unwind through the C frame
+                self.reduce_error = exc
+                return -1
+        self._reduce_cb = lib.REDUCE_FN(_cb)    # (kept alive with the controller)
+        return ctypes.cast(self._reduce_cb, ctypes.c_void_p)
 
     def step(self, observations, stream, state=None):
         """One controller step.  Returns True (``self.act`` / ``self.idx`` / ``self.ret`` hold the result; when no valid block of

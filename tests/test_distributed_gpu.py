@@ -154,6 +154,46 @@ def test_a_rank_whose_generator_drifts_is_caught_on_that_step_on_the_gpu(tmp_pat
         assert "identical" in str(o["message"])
 
 
+def _worker_device(rank, world, port, out_dir):
+    _setup(rank, world, port)
+    try:
+        import cases
+        case = dict(cases.CASES["hc_rs_m3_n64_h5"], n=333, h=4)
+        ctrl = cases.product_controller(case, rng="device")
+        torch.manual_seed(1234)
+        obs = np.random.RandomState(3).randn(case["m"], 20)
+        out = {}
+        for k in range(3):
+            a, _ = ctrl.get_actions(obs)
+            out["actions_%d" % k] = a
+            out["best_%d" % k] = np.asarray(ctrl.last_plan["best_index"])
+        out["native"] = np.asarray(int(ctrl._cstep is not None))
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_rng_plan_does_not_depend_on_the_world_size(world, tmp_path):
+    """`rng="device"` at N > 1 (round 6: `l2a_controller_create_sharded_device`): every rank fills its slice of the SAME Philox
+    stream, so the sharded plan picks the candidates - indices and fp32 first actions - that ONE process planning the whole case
+    picks, step after step, and every rank returns them (the winner's action recomputed from the stream, no second collective)."""
+    mp.spawn(_worker_device, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import cases
+    case = dict(cases.CASES["hc_rs_m3_n64_h5"], n=333, h=4)
+    ctrl = cases.product_controller(case, rng="device")
+    torch.manual_seed(1234)
+    obs = np.random.RandomState(3).randn(case["m"], 20)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for k in range(3):
+        want, _ = ctrl.get_actions(obs)
+        for o in outs:
+            assert int(o["native"]) == 1
+            assert np.array_equal(o["best_%d" % k], ctrl.last_plan["best_index"])
+            np.testing.assert_array_equal(o["actions_%d" % k], want)
+
+
 def _worker_rnn(rank, world, port, cid, out_dir):
     _setup(rank, world, port)
     try:
