@@ -34,6 +34,7 @@ candidates sharded over the ranks - strong scaling).  At N > 1 `config.strong_sc
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -512,7 +513,8 @@ def main():
             # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary (same command, another run)
             rocprof_ms, rocprof_src = None, None
             for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-                if name.endswith("_kernel_stats.csv") and name.startswith("r") and "defaults" not in name and "configs" not in name:
+                # (rNN_kernel_stats.csv only: the summaries of other commands - defaults, config-5 shard - hold other instances)
+                if re.match(r"^r\d+_kernel_stats\.csv$", name):
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         for line in f:
                             if "l2a_rollout_mfma_k<1, 8, 2, 2, false" in line:
