@@ -1099,6 +1099,10 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     --spin_left;
                     return false;
                 };
+                // Round 6, measured and dropped (profiles/r06_ab_xord.jsonl): wave 0 reducing the shared set FIRST and publishing its
+                // half at once, wave 1 publishing the group sum after two reduces instead of three - the records leave 1.4k clocks
+                // earlier, the step does not end earlier (1.4165 against 1.4132 ms): the sweep below costs ~3.4k clocks from issue
+                // to return whatever it finds, and it is issued when wave 0 is through its own reduces either way.
                 // Measured and lost (profiles/r03_ab_kernel_variants.jsonl; the code is in the history): two sweeps in flight half a
                 // round trip apart (41 more registers, and loads retire in order: the sweep still in flight stalls the next step's
                 // first operand wait); a learnt delay of the first sweep (every jitter-induced miss of the late workgroup then
