@@ -117,6 +117,15 @@ int l2a_set_xcd_align(l2a_ctx* ctx, int on);
  * = wherever it fits (and l2a_set_split is not 0: a flagged launch degrades to the unsplit geometry as before), 0 = never.
  * Geometry only: results are bit-identical.                                                                     */
 int l2a_set_fan(l2a_ctx* ctx, int on);
+/* Double rounds of the MFMA kernel (hidden width 512, up to 48 observation dims).  A plan of at least two rounds of
+ * 16-candidate tiles (2 x CUs tiles: BASELINE config 3's 625, config 4 on one GPU, run_mb_mpc.py's default 1250) runs its
+ * first 2 x CUs x D tiles as D rounds of DOUBLE tiles - two candidate tiles per workgroup on kernel instances that carry
+ * neither exchange nor half-member code (and so keep their registers at this width): every weight fragment feeds both tiles
+ * and a step's fixed costs are paid once for 32 candidates, ~0.945 of a single round's cost per tile.  The rest of every
+ * env's candidates follows in a second launch on the same stream with the ordinary geometry (whole round, tail split); a rest
+ * of more than a round and a half joins the double tiles.  1 (default) = wherever it applies, 0 = never.
+ * Geometry only: results are bit-identical.                                                                     */
+int l2a_set_double_rounds(l2a_ctx* ctx, int on);
 /* Micro tiles (csrc/l2a_micro.h).  A plan whose 16-candidate tiles would leave CUs idle - e.g. the reference's own default
  * plans, run_grbal.py:84-85 / run_rebal.py:77-78: 5 x 500 candidates = 160 tiles on 256 CUs - can run in candidate tiles of
  * FOUR on v_mfma_f32_4x4x1_16b_f32 instead: workgroups of 4, 8 or 12 candidates, every CU busy, no exchange between
@@ -532,11 +541,12 @@ int l2a_controller_stats(l2a_controller* controller, double* out, int cap);
 /* ---- introspection used by tests (no GPU needed) ------------------------------------------ */
 /* Which launch geometry the library picks for a plan of m envs x n candidates x h steps of an MLP model of this shape (relu /
  * identity, `n_sets` weight sets in `mode`) on a 256-CU device - the launcher's own decision code, stopped before its first HIP
- * call.  policy: NULL or {split, fan, micro, compute units} (negative / 0 = the default: 1, 1, 1, 256).  out[10] =
+ * call.  policy: NULL or {split, fan, micro, compute units, double rounds} (negative / 0 = the default: 1, 1, 1, 256, 1).  out[10] =
  * {kernel (0 generic fp32, 1 matrix core on 16-candidate tiles, 2 micro tiles), candidate tiles per workgroup, split mode
  * (0 none, 1 whole sets, 2 + shared half member, 3 member fan), first shared tile of a tail split or -1, member fan (0 / 1),
  * workgroups launched (incl. the placement's spare ones), LDS bytes per workgroup, sets per batch, micro tiles of the largest
- * workgroup, XCD placement units}.  Results do not depend on the geometry (bit-identical); this is how tests/test_host_logic.py
+ * workgroup (kernel 2) or double-tile workgroups of the launch IN FRONT of this one (kernel 1, l2a_set_double_rounds; 0 = none),
+ * XCD placement units}.  Results do not depend on the geometry (bit-identical); this is how tests/test_host_logic.py
  * pins the routing table without a GPU.                                                                          */
 int l2a_plan_geometry(int obs_dim, int act_dim, int n_hidden, const int* hidden, int n_sets, int mode, int m, int n, int h,
                       const int* policy, int* out);

@@ -27,7 +27,7 @@ KERNEL_CODES = {"auto": 0, "mfma": 1, "valu": 2}
 CELL_CODES = {"lstm": 0, "gru": 1, "rnn": 2}
 
 EXPORTED_SYMBOLS = (
-    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split", "l2a_set_batch", "l2a_set_xcd_align", "l2a_set_fan", "l2a_set_micro",
+    "l2a_init", "l2a_destroy", "l2a_last_error", "l2a_device_info", "l2a_set_kernel", "l2a_set_split", "l2a_set_batch", "l2a_set_xcd_align", "l2a_set_fan", "l2a_set_double_rounds", "l2a_set_micro",
     "l2a_launch_status", "l2a_set_debug_buffer", "l2a_set_spin_limit", "l2a_inject_status",
     "l2a_model_create", "l2a_model_destroy", "l2a_model_set_weights", "l2a_model_set_weights_strided",
     "l2a_model_set_norm", "l2a_model_adapt_sgd", "l2a_model_adapt_sgd_host", "l2a_model_adapt_sgd_raw", "l2a_model_get_weights",
@@ -47,20 +47,22 @@ class L2AError(RuntimeError):
     pass
 
 
-def plan_geometry(obs_dim, act_dim, hidden, n_sets, mode, m, n, h, split=-1, fan=-1, micro=-1, cus=0):
+def plan_geometry(obs_dim, act_dim, hidden, n_sets, mode, m, n, h, split=-1, fan=-1, micro=-1, cus=0, double=-1):
     """The launch geometry the library would pick for this plan (``l2a_plan_geometry``: the launcher's own decision code, no
     GPU needed).  Returns a dict: kernel ('valu' | 'mfma16' | 'micro'), nt, split (0 none, 1 whole sets, 2 shared half member,
-    3 member fan), split_from, fan, workgroups, lds_bytes, sets_per_batch, micro_tiles, placement_units."""
+    3 member fan), split_from, fan, workgroups, lds_bytes, sets_per_batch, micro_tiles, front_workgroups (double-tile workgroups
+    of a launch in front of the described one: ``l2a_set_double_rounds``), placement_units."""
     lib = load()
     hid = (ctypes.c_int * len(hidden))(*[int(x) for x in hidden])
-    pol = (ctypes.c_int * 4)(int(split), int(fan), int(micro), int(cus))
+    pol = (ctypes.c_int * 5)(int(split), int(fan), int(micro), int(cus), int(double))
     out = (ctypes.c_int * 10)()
     rc = lib.l2a_plan_geometry(int(obs_dim), int(act_dim), len(hidden), hid, int(n_sets), MODE_CODES[mode], int(m), int(n), int(h), pol, out)
     if rc != L2A_OK:
         raise L2AError("l2a_plan_geometry failed (%d)" % rc)
     v = list(out)
     return dict(kernel=("valu", "mfma16", "micro")[v[0]], nt=v[1], split=v[2], split_from=v[3], fan=bool(v[4]), workgroups=v[5],
-                lds_bytes=v[6], sets_per_batch=v[7], micro_tiles=v[8], placement_units=v[9])
+                lds_bytes=v[6], sets_per_batch=v[7], micro_tiles=v[8] if v[0] == 2 else 0, front_workgroups=v[8] if v[0] == 1 else 0,
+                placement_units=v[9])
 
 
 _lib = None
@@ -105,6 +107,11 @@ def load():
     else:
         lib.l2a_set_fan.argtypes = [vp, i32]
         lib.l2a_set_fan.restype = i32
+    if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_set_double_rounds"):
+        lib.l2a_set_double_rounds = lambda handle, on: 0
+    else:
+        lib.l2a_set_double_rounds.argtypes = [vp, i32]
+        lib.l2a_set_double_rounds.restype = i32
     if os.environ.get("L2A_LIB_PATH") and not hasattr(lib, "l2a_set_xcd_align"):
         lib.l2a_set_xcd_align = lambda handle, on: 0
     else:
@@ -317,6 +324,10 @@ class Context(object):
     def set_fan(self, on):
         """Member fan: small mean-ensemble plans on one workgroup per (candidate tile, member) - default on; bit-identical."""
         self.check(self.lib.l2a_set_fan(self.handle, int(bool(on))), "l2a_set_fan")
+
+    def set_double_rounds(self, on):
+        """Double rounds: multi-round plans at width 512 run their first rounds on two-tile workgroups - default on; bit-identical."""
+        self.check(self.lib.l2a_set_double_rounds(self.handle, int(bool(on))), "l2a_set_double_rounds")
 
     def launch_status_value(self):
         """Status word of the launches since the last call (stream must be synchronised); reading clears it."""

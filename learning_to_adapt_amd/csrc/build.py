@@ -2,8 +2,8 @@
 
     python learning_to_adapt_amd/csrc/build.py [--force]
 
-The MFMA kernel template is instantiated in eight translation units (one per (NT, TPW) pair, plus the three
-member-fan units), the LSTM kernel in three (one per units / 64); all are compiled in parallel and linked with the two API units.
+The MFMA kernel template is instantiated in ten translation units (one per (NT, TPW) pair, the four
+member-fan units and the whole-tiles unit), the LSTM kernel in three (one per units / 64); all are compiled in parallel and linked with the two API units.
 """
 
 import os
@@ -24,6 +24,9 @@ INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4)]
 # member-fan instances of the same template (-DL2A_INST_FAN=1): NT = 1 at every width, NT = 2 at width 512 (the fan instances
 # carry no half-member code: (2, 8) keeps its registers - 456 VGPRs, no scratch - where the tile-split (2, 8) instances spilled)
 FAN_INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 8)]
+# whole-tiles-only instances (-DL2A_INST_FAN=2: neither exchange nor half-member code): two candidate tiles per workgroup at
+# width 512 - the double rounds launch_rollout puts in front of a multi-round plan
+WHOLE_INSTANCES = [(2, 8)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Rollout kernels: MFMA accumulators in architectural VGPRs where the allocator can afford it - every epilogue reads its
@@ -111,6 +114,9 @@ def unit_table():
     for nt, tpw in FAN_INSTANCES:
         t["l2a_mfma_fan_%d_%d.o" % (nt, tpw)] = ("l2a_mfma_inst.hip", ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw,
                                                                         "-DL2A_INST_FAN=1"] + KERNEL_FLAGS)
+    for nt, tpw in WHOLE_INSTANCES:
+        t["l2a_mfma_whole_%d_%d.o" % (nt, tpw)] = ("l2a_mfma_inst.hip", ["-DL2A_INST_NT=%d" % nt, "-DL2A_INST_TPW=%d" % tpw,
+                                                                          "-DL2A_INST_FAN=2"] + KERNEL_FLAGS)
     return t
 
 
@@ -165,7 +171,7 @@ def build(force=False, verbose=True, only=None):
     for o, (src, flags) in table.items():
         obj = os.path.join(OBJ_DIR, o)
         if only is not None and o.startswith("l2a_mfma_") and os.path.exists(obj) and \
-                tuple(int(x) for x in o[len("l2a_mfma_"):-2].replace("fan_", "").split("_")) not in only:
+                tuple(int(x) for x in o[len("l2a_mfma_"):-2].replace("fan_", "").replace("whole_", "").split("_")) not in only:
             continue
         if not force and only is None and _obj_fresh(obj):
             continue

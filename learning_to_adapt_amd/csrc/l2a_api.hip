@@ -150,6 +150,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     }
     if (p.mode == L2A_MODE_PER_BLOCK && p.m > md->n_sets)
         return fail(ctx, L2A_EINVAL, "per-block mode needs one weight set per env/block");
+    p.c_lo = 0; p.c_hi = p.n; p.done_total = 0;     // one launch covers the plan unless the MFMA branch below cuts it in two
 
     int kind = ctx->kernel_kind;
     if (kind == L2A_KERNEL_AUTO) kind = md->mfma_ok ? L2A_KERNEL_MFMA : L2A_KERNEL_VALU;
@@ -210,14 +211,93 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
     if (kind == L2A_KERNEL_MFMA) {
         const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
         const int cst_bytes = e_loop0 * (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4;
-        int nt = choose_nt(md, p.m, p.n, e_loop0, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16);
+        const int cus0 = ctx->num_cu > 0 ? ctx->num_cu : 256;
+        // LDS plan of a launch whose busiest workgroup runs `nseq` sets in sequence: sets per batch, start of the constants,
+        // bytes (l2a_mfma.h: activation regions | chunk partials of a batch (lb > 1) | constants | exchange staging).
+        // lb = sets per batch: with two hidden layers, layer 0 of up to lb sets runs back to back, then their hidden
+        // GEMMs + output layers, then their reduces - two barriers per batch instead of two per set.  The largest lb
+        // (<= 4, <= the longest set sequence of a workgroup) that fits the CU's LDS; 1 = one set at a time.
+        const int cst_set = 32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H;
+        auto lds_plan = [&](int nt_, int nseq, int x_bytes, int* lb_out, int* cst_off_out) {
+            const int sa = sa_elems_for(md, nt_);
+            const int ps_bytes = L2A_NW * nt_ * md->OT * 64 * 16;       // the waves' output-layer partials of one set
+            const int cst_bytes_all = nseq * cst_set * 4;
+            int lb_ = 1, part_bytes = 0;
+            if (md->n_hidden == 2 && ctx->batch_sets != 1) {
+                const int cap = ctx->batch_sets > 0 ? ctx->batch_sets : 4;
+                for (int lb = (nseq < cap ? nseq : cap); lb >= 2; --lb) {
+                    const int pbytes = lb * ps_bytes;
+                    if (lb * sa * 16 + pbytes + cst_bytes_all + x_bytes <= ctx->lds_per_block) {
+                        lb_ = lb;
+                        part_bytes = pbytes;
+                        break;
+                    }
+                }
+            }
+            *lb_out = lb_;
+            *cst_off_out = ((lb_ > 1 ? lb_ : 2) * sa * 16 + part_bytes) / 16;
+            return *cst_off_out * 16 + cst_bytes_all + x_bytes;
+        };
+        // Double rounds (round 6): a plan of at least two rounds of 16-candidate tiles at hidden width 512 runs its first
+        // 2 x CUs x D tiles as D rounds of DOUBLE tiles on the whole-tiles-only instances (two candidate tiles per workgroup:
+        // every weight fragment feeds both, the step's fixed costs - barriers, phase hand-overs, operand waits - are paid once
+        // for 32 candidates; these instances carry neither exchange nor half-member code, so unlike the general NT = 2 instances
+        // at this width they keep their registers).  The rest of every env's candidates follows in a second launch with the
+        // ordinary geometry (whole round / tail split); a rest of more than a round and a half joins the double tiles.
+        // Per tile a double round costs ~0.945 of a single one (profiles/r06_ab_nh2.jsonl).  Same arithmetic per candidate:
+        // bit-identical results.
+        int front_k = 0;                    // double tiles per env of the front launch
+        {
+            const long long tiles1 = (long long)p.m * ceil_div(p.n, 16);
+            int lb2 = 1, off2 = 0;
+            if (ctx->double_policy != 0 && md->TPW == 8 && md->OT <= 3 && tiles1 >= 2LL * cus0 &&
+                lds_plan(2, e_loop0, 0, &lb2, &off2) <= ctx->lds_per_block) {
+                const long long D = tiles1 / (2LL * cus0);
+                const long long R = tiles1 - 2LL * cus0 * D;
+                if (R == 0 || 2 * R > 3LL * cus0) front_k = ceil_div(p.n, 32);       // everything on double tiles
+                else front_k = (int)((cus0 * D) / p.m);
+                if (32LL * front_k >= p.n) front_k = ceil_div(p.n, 32);
+            }
+        }
+        const int n_front = (32LL * front_k >= p.n) ? (front_k ? p.n : 0) : 32 * front_k;
+        const int n_rest = p.n - n_front;
+        int nt = n_rest > 0 ? choose_nt(md, p.m, n_rest, e_loop0, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16) : 1;
+        if (front_k) {
+            L2AKParams pa = p;
+            pa.c_lo = 0; pa.c_hi = n_front;
+            pa.sa_elems = sa_elems_for(md, 2);
+            pa.tiles_per_env = front_k;
+            pa.cst_set = cst_set;
+            pa.split = 0; pa.split_from = -1; pa.pl_units = 0;
+            pa.n_cst = e_loop0;
+            pa.dbg = ctx->dbg;
+            const int smem_a = lds_plan(2, e_loop0, 0, &pa.lb, &pa.cst_off);
+            const long long wg_a = (long long)p.m * front_k;
+            pa.done_total = (int)(wg_a + (n_rest > 0 ? (long long)p.m * ceil_div(n_rest, 16 * nt) : 0));
+            p.done_total = pa.done_total;
+            if (ctx->dry) {
+                if (n_rest == 0) {
+                    const int g[10] = {1, 2, 0, -1, 0, (int)wg_a, smem_a, pa.lb, 0, 0};
+                    std::memcpy(ctx->dry, g, sizeof(g));
+                    return L2A_OK;
+                }
+            } else {
+                const bool gact_a = !(fast_act(md->hidden_act) && fast_act(md->output_act));
+                const int rc_a = l2a_launch_mfma(2, md->TPW, md->OT, md->KG0, gact_a ? 1 : 0, 2, &pa, (unsigned)wg_a, smem_a, stream);
+                if (rc_a == -100) return fail(ctx, L2A_EINVAL, "no whole-tile MFMA kernel instance for this (obs_dim, act_dim, hidden)");
+                if (rc_a != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch (double rounds): ") + hipGetErrorString((hipError_t)rc_a));
+                L2A_HIP(ctx, hipGetLastError());
+                if (n_rest == 0) return L2A_OK;
+            }
+            p.c_lo = n_front;
+        }
+        const int front_wg = (front_k && n_rest > 0) ? p.m * front_k : 0;
         // Member fan (l2a_mfma.h): E workgroups per tile, one set each - small mean-ensemble plans, e.g. one rank's shard of
         // config 5 (n = 500: 32 tiles -> 160 workgroups of one set instead of 64 of 2.5 sets).  With two candidate tiles per
         // workgroup (width 512, up to 48 observation dims) it reaches twice as far: one of FOUR ranks' shard of config 5
         // (n = 1000: 32 double tiles x 5) - each weight fragment feeds two tiles and the step's fixed costs are paid once for both.
-        const int cus0 = ctx->num_cu > 0 ? ctx->num_cu : 256;
         int fan_nt = 0;
-        if (ctx->split_policy != 0 && ctx->fan_policy != 0 && p.h < 4096 && p.mode == L2A_MODE_MEAN && e_loop0 >= 3 && e_loop0 <= 8) {
+        if (!front_k && ctx->split_policy != 0 && ctx->fan_policy != 0 && p.h < 4096 && p.mode == L2A_MODE_MEAN && e_loop0 >= 3 && e_loop0 <= 8) {
             if ((long long)p.m * ceil_div(p.n, 16) * e_loop0 <= cus0) fan_nt = 1;
             else if (md->TPW == 8 && md->OT <= 3 && (long long)p.m * ceil_div(p.n, 32) * e_loop0 <= cus0 &&
                      2 * sa_elems_for(md, 2) * 16 + (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4 + e_loop0 * 2 * md->OT * 64 * 16 <= ctx->lds_per_block)
@@ -225,9 +305,9 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         }
         if (fan_nt) nt = fan_nt;
         p.sa_elems = sa_elems_for(md, nt);
-        p.tiles_per_env = ceil_div(p.n, 16 * nt);
+        p.tiles_per_env = ceil_div(n_rest, 16 * nt);
         const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
-        p.cst_set = 32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H;
+        p.cst_set = cst_set;
         // Member split: two workgroups per candidate tile (group A | group B of the ensemble) when
         // that still fits one workgroup per CU - e.g. config 2: 125 tiles -> 250 workgroups.
         const long long pairs = (long long)p.m * p.tiles_per_env;
@@ -276,32 +356,12 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             p.spin_limit = ctx->spin_limit;
         }
         p.dbg = ctx->dbg;
-        // LDS layout (l2a_mfma.h): activation regions | chunk partials of a batch (lb > 1) | constants | exchange staging.
-        // lb = sets per batch: with two hidden layers, layer 0 of up to lb sets runs back to back, then their hidden
-        // GEMMs + output layers, then their reduces - two barriers per batch instead of two per set.  The largest lb
-        // (<= 4, <= the longest set sequence of a workgroup) that fits the CU's LDS; 1 = one set at a time.
         const bool uniform_split = p.split && p.split_from < 0;
         const int e_half = (e_loop + 1) / 2;
         const int nseq = fan ? 1 : uniform_split ? e_half : e_loop;  // sets the busiest workgroup runs in sequence
-        const int ps_bytes = L2A_NW * nt * md->OT * 64 * 16;         // the waves' output-layer partials of one set
         const int x_bytes = (fan ? e_loop : 2) * nt * md->OT * 64 * 16;   // exchange staging: the partner's two regions / every member's term
-        const int cst_bytes_all = nseq * p.cst_set * 4;
         p.n_cst = nseq;
-        p.lb = 1;
-        int part_bytes = 0;
-        if (md->n_hidden == 2 && ctx->batch_sets != 1) {
-            const int cap = ctx->batch_sets > 0 ? ctx->batch_sets : 4;
-            for (int lb = (nseq < cap ? nseq : cap); lb >= 2; --lb) {
-                const int pbytes = lb * ps_bytes;
-                if (lb * p.sa_elems * 16 + pbytes + cst_bytes_all + x_bytes <= ctx->lds_per_block) {
-                    p.lb = lb;
-                    part_bytes = pbytes;
-                    break;
-                }
-            }
-        }
-        p.cst_off = ((p.lb > 1 ? p.lb : 2) * p.sa_elems * 16 + part_bytes) / 16;
-        const int smem = p.cst_off * 16 + cst_bytes_all + x_bytes;
+        const int smem = lds_plan(nt, nseq, x_bytes, &p.lb, &p.cst_off);
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded (" + std::to_string(smem) + " B)");
         long long n_wg = fan ? pairs * e_loop : pairs + (p.split ? split_pairs : 0);
@@ -326,11 +386,12 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         const dim3 grid((unsigned)n_wg), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
         if (ctx->dry) {
-            const int g[10] = {1, nt, p.split, p.split_from, fan ? 1 : 0, (int)n_wg, smem, p.lb, 0, p.pl_units};
+            const int g[10] = {1, nt, p.split, p.split_from, fan ? 1 : 0, (int)n_wg, smem, p.lb, front_wg, p.pl_units};
             std::memcpy(ctx->dry, g, sizeof(g));
             return L2A_OK;
         }
         int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, fan ? 1 : 0, &p, grid.x, smem, stream);
+        (void)front_wg;
         if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");
         if (rc != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch: ") + hipGetErrorString((hipError_t)rc));
         rc = L2A_OK;
@@ -445,6 +506,8 @@ int l2a_init(int device, l2a_ctx** out) {
     if (xa && (xa[0] == '0' || xa[0] == '1')) ctx->xcd_align = xa[0] - '0';
     const char* fn = std::getenv("L2A_FAN");
     if (fn && (fn[0] == '0' || fn[0] == '1')) ctx->fan_policy = fn[0] - '0';
+    const char* db = std::getenv("L2A_DOUBLE");
+    if (db && (db[0] == '0' || db[0] == '1')) ctx->double_policy = db[0] - '0';
     const char* bs = std::getenv("L2A_BATCH");
     if (bs && bs[0] >= '0' && bs[0] <= '4') ctx->batch_sets = bs[0] - '0';
     const char* mc = std::getenv("L2A_MICRO");
@@ -475,6 +538,7 @@ int l2a_plan_geometry(int obs_dim, int act_dim, int n_hidden, const int* hidden,
         if (policy[1] >= 0) ctx.fan_policy = policy[1];
         if (policy[2] >= 0) ctx.micro_policy = policy[2];
         if (policy[3] > 0) ctx.num_cu = policy[3];
+        if (policy[4] >= 0) ctx.double_policy = policy[4];
     }
     l2a_model md;
     md.ctx = &ctx;
@@ -504,6 +568,13 @@ int l2a_set_fan(l2a_ctx* ctx, int on) {
     if (!ctx) return L2A_EINVAL;
     if (on != 0 && on != 1) return fail(ctx, L2A_EINVAL, "member fan must be 0 or 1");
     ctx->fan_policy = on;
+    return L2A_OK;
+}
+
+int l2a_set_double_rounds(l2a_ctx* ctx, int on) {
+    if (!ctx) return L2A_EINVAL;
+    if (on != 0 && on != 1) return fail(ctx, L2A_EINVAL, "double rounds must be 0 or 1");
+    ctx->double_policy = on;
     return L2A_OK;
 }
 

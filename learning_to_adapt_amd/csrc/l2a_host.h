@@ -24,6 +24,7 @@ struct l2a_ctx {
     int split_policy = 1;                 // 1 = split members over two workgroups when it fills the chip
     int xcd_align = 1;                    // uniform tile split: pad the grid so that each ensemble group owns four XCDs (L2A_XCD_ALIGN=0: off)
     int fan_policy = 1;                   // member fan (one workgroup per candidate tile and ensemble member): 0 = never, 1 = where E x tiles fit the chip (L2A_FAN=0: off)
+    int double_policy = 1;                // double rounds (two candidate tiles per workgroup on the whole-tiles-only instances in front of a multi-round plan at width 512): 0 = never (L2A_DOUBLE=0: off)
     int batch_sets = 0;                   // MFMA rollout: sets per batch; 0 = as many as fit the LDS, 1 = one at a time
     int micro_policy = 1;                 // micro-tile kernels (l2a_micro.h): 0 = never, 1 = where they fill the chip better, 2 = whenever a plan is eligible
     unsigned int* status_host = nullptr;  // pinned, device-visible launch status word

@@ -73,6 +73,10 @@ struct L2AKParams {
     int obs_per_row;
     int m, n, h;
     int tiles_per_env;
+    int c_lo, c_hi;             // MFMA: this launch covers candidates [c_lo, c_hi) of every env ([0, n) unless a plan is cut in two:
+                                // double rounds on the whole-tile instances in front, the rest behind - l2a_api.hip); rows and
+                                // results stay indexed by the plan's n
+    int done_total;             // MFMA: workgroup-tiles of ALL launches of the plan (0 = this launch's own): the mailbox count
     int cand_offset;
     double discount;            // float64 like the reference's `self.discount ** t` (:126)
     l2a_reward rw;

@@ -340,8 +340,10 @@ __device__ __forceinline__ void l2a_out_phase(const f32x4 (&hreg)[NT][TPW], f32x
             pbuf[((chunk0 * NT + nt) * OT + c) * 64 + lane] = (NCH == 2) ? acc[0][nt][c] + acc[NCH - 1][nt][c] : acc[0][nt][c];
 }
 
-template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = false, bool FAN = false>
+template <int NT, int TPW, int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = false, bool FAN = false, bool WHOLE = false>
 __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKParams p) {
+    static_assert(!(FAN && WHOLE), "an instance is general, member fan or whole-tiles-only");
+    constexpr bool NOHALF = FAN || WHOLE;   // instances without the half-member paths (they cost ~110 VGPRs at width 512)
     constexpr int HT = L2A_NW * TPW;
     constexpr int TH = TPW / 2;         // tiles per wave of a half member
     static_assert(TPW % 2 == 0, "half members split a wave's tiles in two");
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     // plan (e.g. 625 tiles on 256 CUs: 512 whole + 113 shared instead of a third, 44 %-filled round).
     const int tail = p.split_from >= 0;
     const int in_tail = tail && (int)blockIdx.x >= p.split_from;
-    const int split = FAN ? 3 : (tail ? (in_tail ? p.split : 0) : p.split);   // this workgroup's split mode (3 = member fan)
+    const int split = FAN ? 3 : WHOLE ? 0 : (tail ? (in_tail ? p.split : 0) : p.split);   // this workgroup's split mode (3 = member fan)
     const int n_tiles = p.m * p.tiles_per_env;
     const int n_pairs = tail ? n_tiles - p.split_from : n_tiles;       // tiles that are shared by two workgroups
     int bid, grp, lpair, pairid;
@@ -439,9 +441,9 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     bool valid[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        cand[nt] = tb * (16 * NT) + nt * 16 + jc;
-        valid[nt] = cand[nt] < p.n;
-        row[nt] = env * p.n + (valid[nt] ? cand[nt] : p.n - 1);
+        cand[nt] = p.c_lo + tb * (16 * NT) + nt * 16 + jc;     // (a launch covers candidates [c_lo, c_hi) of every env)
+        valid[nt] = cand[nt] < p.c_hi;
+        row[nt] = env * p.n + (valid[nt] ? cand[nt] : p.c_hi - 1);
     }
 
     // Which sets this workgroup runs (split: 0 = all; 1 = group A | group B; 2 = as 1, but the
@@ -453,7 +455,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
     const int e_loop = (p.mode == L2A_MODE_MEAN) ? p.n_sets : 1;
     const int e_half = (e_loop + 1) >> 1;                   // group A = [0, e_half), B = [e_half, e_loop)
     // Member fan (FAN instances, split == 3): workgroup `grp` of a tile runs set `grp` alone, as a full member.
-    const int e_shared = (!FAN && split == 2) ? e_half - 1 : -1;
+    const int e_shared = (!NOHALF && split == 2) ? e_half - 1 : -1;
     const int n_full = FAN ? 1 : (!split ? e_loop : (grp == 0 ? e_half - (split == 2 ? 1 : 0) : e_loop - e_half));
     const int n_seq = FAN ? 1 : n_full + (split == 2 ? 1 : 0);
     const int full0 = FAN ? grp : ((split && grp == 1) ? e_half : 0);       // first full set of this workgroup
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
     float ret[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) ret[nt] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[nt] ? cand[nt] : p.n - 1)] : 0.0f;
+    for (int nt = 0; nt < NT; ++nt) ret[nt] = p.ret_in ? p.ret_in[(long long)env * p.n + (valid[nt] ? cand[nt] : p.c_hi - 1)] : 0.0f;
 
     f32x4* hcur = buf0;
     f32x4* hoth = buf1;
@@ -762,7 +764,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     // the first hidden GEMM of the batch follows (set seq(b0))
                     const int e0 = seq(b0);
                     const __amdgpu_buffer_rsrc_t rs1 = l2a_rsrc(set_base(e0) + p.pk_wmid, wm_bytes);
-                    const bool next_half = !FAN && (e0 == e_shared) && n_hidden == 2;
+                    const bool next_half = !NOHALF && (e0 == e_shared) && n_hidden == 2;
                     if (next_half) {
 #pragma unroll
                         for (int tt = 0; tt < TH; ++tt) {
@@ -805,7 +807,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 constexpr bool last_set = decltype(last_tag)::value;
                 const int i = b0 + j;
                 const int e = seq(i);
-                const bool is_half = !FAN && last_set && (e == e_shared);
+                const bool is_half = !NOHALF && last_set && (e == e_shared);
                 const float* wb = set_base(e);
                 const float* nr = nrm + i * NRM_SET;
                 const __amdgpu_buffer_rsrc_t rs_out = l2a_rsrc(wb + p.pk_wout, wo_bytes);
@@ -871,7 +873,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                 } else {
                     const int en = seq(i + 1);
                     const __amdgpu_buffer_rsrc_t rsn = l2a_rsrc(set_base(en) + p.pk_wmid, wm_bytes);   // nb > 1: two hidden layers
-                    if (!FAN && en == e_shared) {
+                    if (!NOHALF && en == e_shared) {
                         l2a_out_phase<NT, TPW, TPW, OT, 2 * TH, O4>(hreg, pfO, rs_out, c0, [&]() {
 #pragma unroll
                             for (int tt = 0; tt < TH; ++tt) {
@@ -904,7 +906,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             for (int j = 0; j < nb; ++j) {
                 const int i = b0 + j;
                 const int e = seq(i);
-                const bool is_half = !FAN && (e == e_shared);
+                const bool is_half = !NOHALF && (e == e_shared);
                 const float* nr = nrm + i * NRM_SET;
                 const f32x4* pb = (LB > 1) ? pbase + j * PS : hoth;
                 L2A_TS(5)
@@ -1066,7 +1068,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                         }
             }
             // (the staging slots are rewritten after the next step's barriers, which every wave reaches after these reads)
-        } else if (split) {
+        } else if (!WHOLE && split) {
             if (wave == 0) {
                 if (split == 2) xput(1, qsh);
                 else xput(0, dgrp);
@@ -1243,7 +1245,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             }
             if (lane == 0) {
                 if (key != 0ull) atomicMax(p.best_key + env, key);
-                l2a_publish_result(p, n_tiles);
+                l2a_publish_result(p, p.done_total > 0 ? p.done_total : n_tiles);
             }
         }
     }

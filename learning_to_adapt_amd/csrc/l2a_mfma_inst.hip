@@ -1,7 +1,9 @@
 // l2a_mfma_inst.hip - one translation unit per (L2A_INST_NT, L2A_INST_TPW): instantiates the MFMA
 // rollout kernel for every (OT, KG0, GACT) and exports its launcher (see l2a_mfma_launch.h).
 // With -DL2A_INST_FAN=1 the unit holds the member-fan instances instead (one workgroup per candidate tile and
-// ensemble member, l2a_mfma.h "Member fan"; NT = 1 only) and exports l2a_launch_mfma_fan_<NT>_<TPW>.
+// ensemble member, l2a_mfma.h "Member fan") and exports l2a_launch_mfma_fan_<NT>_<TPW>; with -DL2A_INST_FAN=2 the
+// whole-tiles-only instances (no exchange, no half member: the double rounds of multi-round plans at width 512) as
+// l2a_launch_mfma_whole_<NT>_<TPW>.
 #include "l2a_mfma.h"
 
 #ifndef L2A_INST_FAN
@@ -18,7 +20,7 @@ template <int OT, int KG0, bool GACT, int K0L = 4, bool N1 = false, bool O4 = fa
 int launch_one(const L2AKParams* p, unsigned grid, int smem, hipStream_t stream) {
     // one hidden layer: its own instances (no hidden->hidden GEMM in them), generic activation code only
     if (!N1 && p->n_hidden == 1) return launch_one<OT, KG0, true, 4, true>(p, grid, smem, stream);
-    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L, N1, O4, L2A_INST_FAN != 0>;
+    auto kernel = l2a_rollout_mfma_k<L2A_INST_NT, L2A_INST_TPW, OT, KG0, GACT, K0L, N1, O4, L2A_INST_FAN == 1, L2A_INST_FAN == 2>;
     // the dynamic-LDS ceiling of this instance is raised once per device and size, not on every launch (~2 us each)
     static int smem_set[16] = {0};
     int dev = 0;
@@ -61,7 +63,9 @@ int launch_shape(int ot, int kg0, const L2AKParams* p, unsigned grid, int smem, 
 }  // namespace
 
 #define L2A_CAT3(a, b, c) a##b##_##c
-#if L2A_INST_FAN
+#if L2A_INST_FAN == 2
+#define L2A_NAME(nt, tpw) L2A_CAT3(l2a_launch_mfma_whole_, nt, tpw)
+#elif L2A_INST_FAN
 #define L2A_NAME(nt, tpw) L2A_CAT3(l2a_launch_mfma_fan_, nt, tpw)
 #else
 #define L2A_NAME(nt, tpw) L2A_CAT3(l2a_launch_mfma_, nt, tpw)

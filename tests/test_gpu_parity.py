@@ -328,6 +328,76 @@ def test_member_fan_is_bit_identical(name, over):
     assert rel_err(out[(1, 1)][0], want) < RTOL
 
 
+DOUBLE_CASES = [
+    # name, overrides - plans of at least two rounds of 16-candidate tiles at width 512 (csrc/l2a_api.hip "Double rounds"):
+    # BASELINE config 3 (5 x 51 double tiles in front, 5 x 23 tiles shared by pairs behind), config 4's shape on one GPU (all on
+    # double tiles), run_mb_mpc.py's default (two double rounds + a whole round), exactly two rounds (no rest), a ragged last
+    # tile in the rest and in the front launch, three hidden layers, generic activations, the distance reward, a discount
+    ("c3_ant_rs_n2000_h20_pb5", dict(h=3)),
+    ("c4_hc_rs_n16000_h30_e5", dict(h=2)),
+    ("c2_hc_rs_n2000_h30_e5", dict(E=1, mode="single", m=10, n=2000, h=3)),
+    ("c1_hc_rs_n500_h10_e1", dict(n=8192, h=2)),
+    ("c1_hc_rs_n500_h10_e1", dict(n=8999, h=2, discount=0.9)),
+    ("c1_hc_rs_n500_h10_e1", dict(n=16370, h=2)),
+    ("c3b_ant_rs_n500_h10_pb5_3x512", dict(n=2050, h=2)),
+    ("ant_rs_n300_h6_e3", dict(n=9000, m=1, h=2, activation="tanh")),
+    ("arm_rs_n256_h8", dict(n=4100, m=2, h=2)),
+]
+
+
+@pytest.mark.parametrize("name,over", DOUBLE_CASES)
+def test_double_rounds_are_bit_identical(name, over):
+    """A multi-round plan cut in two launches - double tiles on the whole-tiles-only instances in front, the rest of every env's
+    candidates behind - against the one-launch geometries (whole rounds + tail split; no split at all): every return and the
+    arg-max keys bit for bit, with a candidate offset, with and without a returns table, through the blocking mailbox entry;
+    then against the oracle."""
+    case = dict(cases.CASES[name], **over)
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    a = _rs_actions(case, 5, env)
+    obs0 = np.random.RandomState(15).randn(case["m"], env.observation_space.shape[0])
+    ctx = _lib.Context.get(0)
+    dev = native.device
+    geo = _lib.plan_geometry(env.observation_space.shape[0], env.action_space.shape[0], case["hidden"], case.get("E", 1),
+                             case.get("mode", "single"), case["m"], case["n"], case["h"])
+    assert geo["front_workgroups"] > 0 or geo["nt"] == 2, geo         # the case does take the double rounds
+    a_dev = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    out = {}
+    try:
+        for dbl, split in ((1, 1), (0, 1), (0, 0)):
+            ctx.set_double_rounds(dbl)
+            ctx.set_split(split)
+            r, k = _plan_returns(native, case, env, obs0, a, cand_offset=11)
+            keys_only = torch.zeros((case["m"],), dtype=torch.int64, device=dev)
+            native.plan_rs(torch.from_numpy(np.ascontiguousarray(obs0, dtype=np.float32)).to(dev), a_dev,
+                           case["m"], case["n"], case["h"], case.get("discount", 1.0), env.reward_spec,
+                           cand_offset=11, best_key=keys_only)
+            torch.cuda.synchronize()
+            mailed = []
+            for _ in range(3):      # both ring slots of the mailbox, the tile counter re-armed by the last tile of the SECOND launch
+                got = native.plan_rs_sync(obs0, a_dev, case["m"], case["n"], case["h"], case.get("discount", 1.0), env.reward_spec,
+                                          cand_offset=11)
+                assert got is not None
+                mailed.append(got.view(np.int64).copy())
+            ctx.launch_status()
+            assert all(np.array_equal(x, mailed[0]) for x in mailed)
+            out[(dbl, split)] = (r, k, keys_only.cpu().numpy(), mailed[0])
+    finally:
+        ctx.set_split(1)
+        ctx.set_double_rounds(1)
+    ref = out[(0, 0)]
+    assert np.array_equal(ref[1], ref[2]) and np.array_equal(ref[1], ref[3])
+    assert np.isfinite(ref[0]).all()
+    for key in ((1, 1), (0, 1)):
+        for x, y in zip(ref, out[key]):
+            assert np.array_equal(x, y), key
+    from oracle import make_reward
+    from oracle.planner import rollout_returns
+    want = rollout_returns(cases.oracle_dynamics(case), make_reward(case["env"], env.dt), obs0, a, case["n"],
+                           case.get("discount", 1.0)).reshape(case["m"], case["n"])
+    assert rel_err(out[(1, 1)][0], want) < RTOL
+
+
 MICRO_CASES = [
     # name, overrides - the micro-tile kernel (csrc/l2a_micro.h) on every code path it has: per-block sets on the reference's
     # default GrBAL plan, a single model, mean ensembles odd / even (groups A | B), the O4 quarter sums (HalfCheetah, two or

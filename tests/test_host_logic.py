@@ -216,12 +216,26 @@ def test_launch_geometry_routing_table():
     c2 = g(hc, 5, "mean", 1, 2000, 30)
     assert (c2["kernel"], c2["nt"], c2["split"], c2["fan"], c2["placement_units"], c2["sets_per_batch"]) == ("mfma16", 1, 2, False, 2, 3)
     assert c2["workgroups"] == 256 and c2["lds_bytes"] <= 160 * 1024
-    # config 3: 625 tiles = 512 whole + 113 shared by pairs (tail split)
+    # config 3: 625 tiles.  Double rounds (default): 5 x 51 double tiles in front (candidates 0 .. 1631 of every env, two tiles per
+    # workgroup on the whole-tiles-only instances), the other 5 x 23 tiles behind them, shared by pairs; without: 512 whole + 113
+    # shared by pairs in one launch (tail split)
     c3 = g(ant, 5, "per_block", 5, 2000, 20)
-    assert (c3["split"], c3["split_from"], c3["workgroups"]) == (2, 512, 512 + 2 * 113)
-    # config 4's plan on ONE GPU: 1000 tiles, no tail worth splitting; config 5's iteration: 250 whole tiles
-    assert g(hc, 5, "mean", 1, 16000, 30)["split"] == 0 and g(hc, 5, "mean", 1, 16000, 30)["workgroups"] == 1000
-    assert g(hc, 5, "mean", 1, 4000, 30)["workgroups"] == 250
+    assert (c3["front_workgroups"], c3["nt"], c3["split"], c3["split_from"], c3["workgroups"]) == (255, 1, 2, -1, 2 * 115)
+    c3 = g(ant, 5, "per_block", 5, 2000, 20, double=0)
+    assert (c3["front_workgroups"], c3["split"], c3["split_from"], c3["workgroups"]) == (0, 2, 512, 512 + 2 * 113)
+    # config 4's plan on ONE GPU: 1000 tiles = 500 double tiles in one launch (the rest after one double round would be nearly two
+    # rounds); without double rounds 1000 whole tiles, no tail worth splitting; config 5's iteration: 250 whole tiles (under two rounds)
+    c4 = g(hc, 5, "mean", 1, 16000, 30)
+    assert (c4["nt"], c4["split"], c4["workgroups"], c4["front_workgroups"]) == (2, 0, 500, 0) and c4["lds_bytes"] <= 160 * 1024
+    c4 = g(hc, 5, "mean", 1, 16000, 30, double=0)
+    assert (c4["nt"], c4["split"], c4["workgroups"]) == (1, 0, 1000)
+    assert g(hc, 5, "mean", 1, 4000, 30)["workgroups"] == 250 and g(hc, 5, "mean", 1, 4000, 30)["nt"] == 1
+    # run_mb_mpc.py's default (10 envs x 2000 candidates = 1250 tiles): two double rounds in front (10 x 51 double tiles), 230 whole
+    # tiles behind; double rounds need width 512 and at least two rounds of tiles
+    mb = g(hc, 1, "single", 10, 2000, 20)
+    assert (mb["front_workgroups"], mb["nt"], mb["split"], mb["workgroups"]) == (510, 1, 0, 230)
+    assert g(dict(hc, hidden=[256, 256]), 1, "single", 10, 2000, 20)["front_workgroups"] == 0
+    assert g(hc, 1, "single", 1, 8176, 5)["front_workgroups"] == 0 and g(hc, 1, "single", 1, 8192, 5)["nt"] == 2
     # config 5's shards: one rank of 8 -> member fan (32 tiles x 5 members, every member on its own XCDs); one rank of 4 -> the fan
     # with two tiles per workgroup; one rank of 2 -> config 2's tile split
     s8 = g(hc, 5, "mean", 1, 500, 30)
