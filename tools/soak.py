@@ -23,7 +23,9 @@ for name, over in [("c2_hc_rs_n2000_h30_e5", {}), ("c3_ant_rs_n2000_h20_pb5", di
                    ("c2_hc_rs_n2000_h30_e5", dict(h=1)), ("c3b_ant_rs_n500_h10_pb5_3x512", dict(h=4)),
                    ("ant_rs_n300_h6_e3", {}),                                           # (member fan: 2 envs x 19 tiles x 3)
                    ("c5_hc_cem_n4000_h30_e5", dict(n=500, h=8)),                        # member fan: one rank's config-5 shard
-                   ("c5_hc_cem_n4000_h30_e5", dict(n=1000, h=4))]:                      # member fan, two tiles per workgroup
+                   ("c5_hc_cem_n4000_h30_e5", dict(n=1000, h=4)),                       # member fan, two tiles per workgroup
+                   ("c1_hc_rs_n500_h10_e1", dict(n=8192, h=2)),                         # double rounds: all on two-tile workgroups
+                   ("c2_hc_rs_n2000_h30_e5", dict(E=1, mode="single", m=10, h=2))]:     # double rounds + a whole round (run_mb_mpc.py default)
     case = dict(C[name], **over)
     env, model = cases.product_model(case)
     nat = model.planner_model()
