@@ -247,6 +247,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         // Per tile a double round costs ~0.945 of a single one (profiles/r06_ab_nh2.jsonl).  Same arithmetic per candidate:
         // bit-identical results.
         int front_k = 0;                    // double tiles per env of the front launch
+        bool front_has_dbg = false;
         {
             const long long tiles1 = (long long)p.m * ceil_div(p.n, 16);
             int lb2 = 1, off2 = 0;
@@ -270,7 +271,10 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             pa.cst_set = cst_set;
             pa.split = 0; pa.split_from = -1; pa.pl_units = 0;
             pa.n_cst = e_loop0;
-            pa.dbg = ctx->dbg;
+            // (phase stamps, tools/timeline.py: one launch writes them - the rest by default, the double tiles with L2A_DBG_FRONT=1)
+            static const bool dbg_front = [] { const char* e = std::getenv("L2A_DBG_FRONT"); return e && e[0] == '1'; }();
+            pa.dbg = (n_rest == 0 || dbg_front) ? ctx->dbg : nullptr;
+            front_has_dbg = pa.dbg != nullptr;
             const int smem_a = lds_plan(2, e_loop0, 0, &pa.lb, &pa.cst_off);
             const long long wg_a = (long long)p.m * front_k;
             pa.done_total = (int)(wg_a + (n_rest > 0 ? (long long)p.m * ceil_div(n_rest, 16 * nt) : 0));
@@ -355,7 +359,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
             p.status = ctx->status_dev;
             p.spin_limit = ctx->spin_limit;
         }
-        p.dbg = ctx->dbg;
+        p.dbg = front_has_dbg ? nullptr : ctx->dbg;
         const bool uniform_split = p.split && p.split_from < 0;
         const int e_half = (e_loop + 1) / 2;
         const int nseq = fan ? 1 : uniform_split ? e_half : e_loop;  // sets the busiest workgroup runs in sequence

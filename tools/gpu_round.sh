@@ -85,7 +85,9 @@ echo "== N = 2 code path: two gloo ranks sharing this GPU (self-launch; numbers 
 L2A_BENCH_SHARE_GPU=1 L2A_SPLIT=0 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/bench_share2.json 2> $OUT/bench_share2.err; echo "share2 rc=$?"
 echo "== round 6: member fan (config-5 shards), the stationary-cluster probe, two planners on the blocking path"
 timeout 200 python tools/timeline.py c5_hc_cem_n4000_h30_e5 n=500 > $OUT/timeline_c5shard_fan.txt 2>&1; echo "timeline fan rc=$?"
-timeout 200 python tools/timeline.py c3_ant_rs_n2000_h20_pb5 > $OUT/timeline_c3.txt 2>&1; echo "timeline c3 rc=$?"
+timeout 200 python tools/timeline.py c3_ant_rs_n2000_h20_pb5 > $OUT/timeline_c3.txt 2>&1; echo "timeline c3 (rest launch: shared tiles) rc=$?"
+L2A_DBG_FRONT=1 timeout 200 python tools/timeline.py c3_ant_rs_n2000_h20_pb5 > $OUT/timeline_c3_double.txt 2>&1; echo "timeline c3 (front launch: double tiles) rc=$?"
+L2A_DOUBLE=0 timeout 200 python tools/timeline.py c3_ant_rs_n2000_h20_pb5 > $OUT/timeline_c3_single.txt 2>&1; echo "timeline c3 (double rounds off) rc=$?"
 for fan in 1 0; do
   (cd /tmp && L2A_FAN=$fan timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_c5 -o trace -- python $GRAFT_REPO_ROOT/tools/prof_defaults.py c5shard 400 > /dev/null 2>> $GRAFT_REPO_ROOT/$OUT/prof_c5.err)
   f=$(find $OUT/prof_c5 -name "*kernel_stats.csv" | head -1)
