@@ -36,7 +36,7 @@ for f in $SRC/timeline_micro_*.txt; do [ -f "$f" ] && grep -v amdgpu.ids $f > $D
 [ -f $SRC/pmc_micro.txt ] && cp $SRC/pmc_micro.txt $DST/${TAG}_pmc_micro.txt
 [ -f $SRC/ab_rnn_micro.jsonl ] && grep -v amdgpu.ids $SRC/ab_rnn_micro.jsonl > $DST/${TAG}_ab_rnn_micro.jsonl
 [ -f $SRC/defaults_kernel_stats.csv ] && cp $SRC/defaults_kernel_stats.csv $DST/${TAG}_defaults_kernel_stats.csv
-for f in c5shard_kernel_stats.csv probe_c5_shard.jsonl two_planners_sync.jsonl; do [ -f $SRC/$f ] && cp $SRC/$f $DST/${TAG}_$f; done
+for f in c5shard_kernel_stats.csv double_kernel_stats.csv probe_c5_shard.jsonl two_planners_sync.jsonl; do [ -f $SRC/$f ] && cp $SRC/$f $DST/${TAG}_$f; done
 for f in timeline_c5shard_fan.txt timeline_c3.txt timeline_c3_double.txt timeline_c3_single.txt; do [ -f $SRC/$f ] && grep -v amdgpu.ids $SRC/$f | cut -c1-420 > $DST/${TAG}_$f; done
 python tools/pmc_traffic.py $SRC > /dev/null 2>&1 || true
 ls -la $DST | grep ${TAG}_ | awk '{print $5, $9}'

@@ -94,6 +94,13 @@ for fan in 1 0; do
   [ -n "$f" ] && (echo "# config 5 shard (n=500, h=30, E=5 mean; tools/prof_defaults.py c5shard 400), L2A_FAN=$fan"; head -1 "$f"; grep -E '^"(void )?l2a_(rollout|mlp)' "$f") >> $OUT/c5shard_kernel_stats.csv
   rm -rf $OUT/prof_c5
 done; cat $OUT/c5shard_kernel_stats.csv | cut -c1-160
+for shape in c3 c4; do for dbl in 1 0; do
+  (cd /tmp && L2A_DOUBLE=$dbl timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_dbl -o trace -- python $GRAFT_REPO_ROOT/tools/prof_defaults.py $shape 100 > /dev/null 2>> $GRAFT_REPO_ROOT/$OUT/prof_dbl.err)
+  f=$(find $OUT/prof_dbl -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && (echo "# $shape (tools/prof_defaults.py $shape 100), L2A_DOUBLE=$dbl"; head -1 "$f"; grep -E '^"(void )?l2a_(rollout|mlp)' "$f") >> $OUT/double_kernel_stats.csv
+  rm -rf $OUT/prof_dbl
+done; done; cat $OUT/double_kernel_stats.csv | cut -c1-170
+for dbl in 0 1; do for r in 1 2; do L2A_DOUBLE=$dbl timeout 300 python tools/ab_kernel.py 2>/dev/null | sed "s/^{/{\"double\": $dbl, /" >> $OUT/ab_double.jsonl; done; done; echo "ab_double rc=$?"
 timeout 300 python tools/probe_c5_shard.py > $OUT/probe_c5_shard.jsonl 2> $OUT/probe_c5_shard.err; echo "probe_c5_shard rc=$?"
 [ -x tools/probes/stationary ] && (timeout 120 tools/probes/stationary 10 > $OUT/probe_stationary.jsonl 2>&1; echo "stationary rc=$?")
 timeout 300 python tools/two_planners.py sync > $OUT/two_planners_sync.jsonl 2> /dev/null; echo "two_planners sync rc=$?"

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
 
-WHICH = sys.argv[1] if len(sys.argv) > 1 else "all"          # c1 | c3b | c6 | gru | lstm2 | c5shard | all: one shape per rocprof run keeps its row apart
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "all"          # c1 | c3b | c6 | gru | lstm2 | c5shard | c3 | c4 | all: one shape per rocprof run keeps its row apart
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 plans = []
 for name in ("c1_hc_rs_n500_h10_e1", "c3b_ant_rs_n500_h10_pb5_3x512"):
@@ -43,6 +43,20 @@ if WHICH == "c5shard":
     best = torch.zeros((1,), dtype=torch.int64, device=dev)
     rets = torch.zeros((1, 500), dtype=torch.float32, device=dev)
     plans.append((model, lambda: native.plan_rs(obs0, a, 1, 500, 30, 1.0, env.reward_spec, returns_out=rets, best_key=best)))
+if WHICH in ("c3", "c4"):
+    # BASELINE config 3 (5 x 2000 candidates, 5 adapted sets: 625 tiles) / config 4's shape on one GPU (16 000 candidates, E = 5):
+    # the double rounds of csrc/l2a_api.hip - config 3 = a launch of 255 double-tile workgroups + a launch of 115 shared tiles,
+    # config 4 = one launch of 500 double tiles (L2A_DOUBLE=0 in the environment: the one-launch geometries before round 6)
+    case = cases.CASES["c3_ant_rs_n2000_h20_pb5" if WHICH == "c3" else "c4_hc_rs_n16000_h30_e5"]
+    env, model = cases.product_model(case)
+    native = model.planner_model()
+    dev = native.device
+    m, n, h = case["m"], case["n"], case["h"]
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    obs0 = torch.randn((m, od), device=dev)
+    a = (torch.rand((h, m * n, ad), device=dev) * 2 - 1) * float(env.action_space.high[0])
+    best = torch.zeros((m,), dtype=torch.int64, device=dev)
+    plans.append((model, lambda: native.plan_rs(obs0, a, m, n, h, 1.0, env.reward_spec, best_key=best)))
 if WHICH in ("all", "c6"):
     case = cases.CASES["c6_hc_rnn_rs_n500_h10_m5"]
     env, model = cases.product_rnn_model(case)
