@@ -541,13 +541,13 @@ int l2a_controller_stats(l2a_controller* controller, double* out, int cap);
 /* ---- introspection used by tests (no GPU needed) ------------------------------------------ */
 /* Which launch geometry the library picks for a plan of m envs x n candidates x h steps of an MLP model of this shape (relu /
  * identity, `n_sets` weight sets in `mode`) on a 256-CU device - the launcher's own decision code, stopped before its first HIP
- * call.  policy: NULL or {split, fan, micro, compute units, double rounds} (negative / 0 = the default: 1, 1, 1, 256, 1).  out[10] =
+ * call.  policy: NULL or {split, fan, micro, compute units, double rounds} (negative / 0 = the default: 1, 1, 1, 256, 1).  out[12] =
  * {kernel (0 generic fp32, 1 matrix core on 16-candidate tiles, 2 micro tiles), candidate tiles per workgroup, split mode
  * (0 none, 1 whole sets, 2 + shared half member, 3 member fan), first shared tile of a tail split or -1, member fan (0 / 1),
  * workgroups launched (incl. the placement's spare ones), LDS bytes per workgroup, sets per batch, micro tiles of the largest
- * workgroup (kernel 2) or double-tile workgroups of the launch IN FRONT of this one (kernel 1, l2a_set_double_rounds; 0 = none),
- * XCD placement units}.  Results do not depend on the geometry (bit-identical); this is how tests/test_host_logic.py
- * pins the routing table without a GPU.                                                                          */
+ * workgroup, XCD placement units, double-tile workgroups of the launch IN FRONT of the described one (l2a_set_double_rounds:
+ * the described launch then covers the rest of every env's candidates; 0 = the plan is one launch), 0}.  Results do not depend
+ * on the geometry (bit-identical); this is how tests/test_host_logic.py pins the routing table without a GPU.          */
 int l2a_plan_geometry(int obs_dim, int act_dim, int n_hidden, const int* hidden, int n_sets, int mode, int m, int n, int h,
                       const int* policy, int* out);
 /* 1 when (obs_dim, act_dim, hidden[]) is eligible for the MFMA kernel, else 0.

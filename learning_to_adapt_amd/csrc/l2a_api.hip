@@ -158,15 +158,70 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         return fail(ctx, L2A_EINVAL, "model shape is not eligible for the MFMA kernel "
                                      "(needs equal hidden widths of 128/256/512, obs_dim<=64, act_dim<=16)");
 
-    if (kind == L2A_KERNEL_MFMA && md->micro_ok && ctx->micro_policy != 0) {
-        // Micro tiles (l2a_micro.h): every env's ceil(n / 4) candidate tiles of four dealt to W workgroups of at most three -
-        // one workgroup per CU, none idle, no exchange between workgroups.  Plans only (no per-row start states, no state
-        // written out: those launches are one step long or chunk continuations and keep the 16-candidate kernel - same bits).
-        const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-        const int e_loop = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
-        const long long tiles16 = (long long)p.m * ceil_div(p.n, 16);
-        const int quads = ceil_div(p.n, 4);
-        int W = cus / p.m;
+    // ---- matrix-core kernels: where the plan is cut, and which geometry each part takes -----------------------------------
+    const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
+    const int cus0 = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    const int cst_set = 32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H;
+    // LDS plan of a launch whose busiest workgroup runs `nseq` sets in sequence: sets per batch, start of the constants,
+    // bytes (l2a_mfma.h: activation regions | chunk partials of a batch (lb > 1) | constants | exchange staging).
+    // lb = sets per batch: with two hidden layers, layer 0 of up to lb sets runs back to back, then their hidden
+    // GEMMs + output layers, then their reduces - two barriers per batch instead of two per set.  The largest lb
+    // (<= 4, <= the longest set sequence of a workgroup) that fits the CU's LDS; 1 = one set at a time.
+    auto lds_plan = [&](int nt_, int nseq, int x_bytes, int* lb_out, int* cst_off_out) {
+        const int sa = sa_elems_for(md, nt_);
+        const int ps_bytes = L2A_NW * nt_ * md->OT * 64 * 16;       // the waves' output-layer partials of one set
+        const int cst_bytes_all = nseq * cst_set * 4;
+        int lb_ = 1, part_bytes = 0;
+        if (md->n_hidden == 2 && ctx->batch_sets != 1) {
+            const int cap = ctx->batch_sets > 0 ? ctx->batch_sets : 4;
+            for (int lb = (nseq < cap ? nseq : cap); lb >= 2; --lb) {
+                const int pbytes = lb * ps_bytes;
+                if (lb * sa * 16 + pbytes + cst_bytes_all + x_bytes <= ctx->lds_per_block) {
+                    lb_ = lb;
+                    part_bytes = pbytes;
+                    break;
+                }
+            }
+        }
+        *lb_out = lb_;
+        *cst_off_out = ((lb_ > 1 ? lb_ : 2) * sa * 16 + part_bytes) / 16;
+        return *cst_off_out * 16 + cst_bytes_all + x_bytes;
+    };
+    // Double rounds (round 6): a plan of at least two rounds of 16-candidate tiles at hidden width 512 runs its first
+    // 2 x CUs x D tiles as D rounds of DOUBLE tiles on the whole-tiles-only instances (two candidate tiles per workgroup:
+    // every weight fragment feeds both, the step's fixed costs - barriers, phase hand-overs, operand waits - are paid once
+    // for 32 candidates; these instances carry neither exchange nor half-member code, so unlike the general NT = 2 instances
+    // at this width they keep their registers).  The rest of every env's candidates follows in a second launch with whichever
+    // geometry fits it (micro tiles, whole round, tile split); a rest of more than a round and a half joins the double tiles.
+    // Per tile a double round costs ~0.93 of a single one (profiles/r06_ab_double.jsonl).  Same arithmetic per candidate:
+    // bit-identical results.
+    int front_k = 0;                    // double tiles per env of the front launch
+    if (kind == L2A_KERNEL_MFMA) {
+        const long long tiles1 = (long long)p.m * ceil_div(p.n, 16);
+        int lb2 = 1, off2 = 0;
+        if (ctx->double_policy != 0 && md->TPW == 8 && md->OT <= 3 && tiles1 >= 2LL * cus0 &&
+            lds_plan(2, e_loop0, 0, &lb2, &off2) <= ctx->lds_per_block) {
+            const long long D = tiles1 / (2LL * cus0);
+            const long long R = tiles1 - 2LL * cus0 * D;
+            if (R == 0 || 2 * R > 3LL * cus0) front_k = ceil_div(p.n, 32);       // everything on double tiles
+            else front_k = (int)((cus0 * D) / p.m);
+            if (32LL * front_k >= p.n) front_k = ceil_div(p.n, 32);
+        }
+    }
+    const int n_front = (32LL * front_k >= p.n) ? (front_k ? p.n : 0) : 32 * front_k;
+    const int n_rest = p.n - n_front;
+
+    // Micro tiles (l2a_micro.h) for the plan - or for the rest behind a double round: every env's ceil(n / 4) candidate tiles of
+    // four dealt to W workgroups of at most three - one workgroup per CU, none idle, no exchange between workgroups.  Plans only
+    // (no per-row start states, no state written out: those launches are one step long or chunk continuations and keep the
+    // 16-candidate kernel - same bits).
+    bool micro = false;
+    int mc_W = 0, mc_hi = 0, mc_quads = 0, smem_m = 0;
+    long long mc_span = 0;
+    if (kind == L2A_KERNEL_MFMA && n_rest > 0 && md->micro_ok && ctx->micro_policy != 0) {
+        const long long tiles16 = (long long)p.m * ceil_div(n_rest, 16);
+        const int quads = ceil_div(n_rest, 4);
+        int W = cus0 / p.m;
         if (W > quads) W = quads;
         const int hi = W > 0 ? ceil_div(quads, W) : 99;
         // ... and the FEWEST workgroups that keep the largest one at `hi` micro tiles: under this kernel the chip is power limited
@@ -174,128 +229,86 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         // the same weights for less work - 2 500 candidates on 5 x 42 workgroups of 12 instead of 5 x 51 of 12 and 8: c3b 0.325 ->
         // 0.304 ms, the ReBAL default 0.195 -> 0.183 ms (profiles/r04_ab_micro.jsonl)
         if (hi >= 1 && hi <= 3) W = ceil_div(quads, hi);
-        const int smem_need = l2a_mlp_micro_smem(md->H, md->KG0, md->n_hidden, e_loop);
-        const long long span = (long long)((p.mode == L2A_MODE_PER_BLOCK ? p.m : e_loop) - 1) * md->set_stride * 4 +
+        const int smem_need = l2a_mlp_micro_smem(md->H, md->KG0, md->n_hidden, e_loop0);
+        const long long span = (long long)((p.mode == L2A_MODE_PER_BLOCK ? p.m : e_loop0) - 1) * md->set_stride * 4 +
                                l2a_mlp_micro_floats(md->H, md->KG0, md->n_hidden) * 4;
         const bool eligible = !p.obs_per_row && !p.state_out && hi <= 3 && (p.returns_out || p.best_key) &&
                               smem_need <= ctx->lds_per_block && span < (1LL << 31);
         // automatic (profiles/r04_ab_micro.jsonl, hidden width 512): the plans the 16-candidate geometries cannot fill - more
         // than CUs / 2 tiles (no tile split) and fewer than CUs: 0.80 - 0.90 of the 16-candidate launch (per-block 3 x 512 /
         // 2 x 512, mean E = 5, single) - and plans of at most CUs / 2 tiles that run ONE set per candidate (single model,
-        // per-block), whose tile split is bound by its per-step exchange: 0.77 - 0.91.  Small ENSEMBLE plans stay with the tile
+        // per-block), whose tile split is bound by its per-step exchange: 0.77 - 0.91 (config 3's rest behind its double round,
+        // 5 x 23 tiles: 0.312 -> 0.266 ms, profiles/r06_ab_rest.jsonl).  Small ENSEMBLE plans stay with the tile
         // split (every workgroup would stream all E sets: 1.2x), and so does hidden width 256 (one 64-unit tile per wave: 1.12x).
-        const bool unfilled = 2 * tiles16 > cus && tiles16 < cus;
-        const bool small_one_set = e_loop == 1 && 2 * tiles16 <= cus;
+        const bool unfilled = 2 * tiles16 > cus0 && tiles16 < cus0;
+        const bool small_one_set = e_loop0 == 1 && 2 * tiles16 <= cus0;
         const bool wanted = ctx->micro_policy == 2 || (ctx->micro_policy == 1 && md->H == 512 && (unfilled || small_one_set));
         if (eligible && wanted) {
-            p.mc_w = W;
-            p.mc_hi = hi;
-            p.mc_r = quads - W * (hi - 1);          // workgroups that take `hi` micro tiles
-            p.m_bytes = span;
-            p.dbg = ctx->dbg;
-            int smem_m = smem_need;
+            micro = true;
+            mc_W = W; mc_hi = hi; mc_quads = quads; mc_span = span;
+            smem_m = smem_need;
             if (smem_m < 84 * 1024) smem_m = 84 * 1024;     // more than half a CU's LDS: one workgroup per CU
-            const bool gact_m = !(fast_act(md->hidden_act) && fast_act(md->output_act)) || md->n_hidden == 1;
-            if (ctx->dry) {     // [kind, nt, split, split_from, fan, workgroups, lds bytes, sets per batch, micro tiles of the largest workgroup, placement units]
-                const int g[10] = {2, 0, 0, -1, 0, p.m * W, smem_m, 1, hi, 0};
+        }
+    }
+    const int cst_bytes = e_loop0 * cst_set * 4;
+    int nt = (kind == L2A_KERNEL_MFMA && n_rest > 0 && !micro)
+                 ? choose_nt(md, p.m, n_rest, e_loop0, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16) : 1;
+    bool front_has_dbg = false;
+    int front_wg = 0;
+    if (front_k) {
+        L2AKParams pa = p;
+        pa.c_lo = 0; pa.c_hi = n_front;
+        pa.sa_elems = sa_elems_for(md, 2);
+        pa.tiles_per_env = front_k;
+        pa.cst_set = cst_set;
+        pa.split = 0; pa.split_from = -1; pa.pl_units = 0;
+        pa.n_cst = e_loop0;
+        // (phase stamps, tools/timeline.py: one launch writes them - the rest by default, the double tiles with L2A_DBG_FRONT=1)
+        static const bool dbg_front = [] { const char* e = std::getenv("L2A_DBG_FRONT"); return e && e[0] == '1'; }();
+        pa.dbg = (n_rest == 0 || dbg_front) ? ctx->dbg : nullptr;
+        front_has_dbg = pa.dbg != nullptr;
+        const int smem_a = lds_plan(2, e_loop0, 0, &pa.lb, &pa.cst_off);
+        const long long wg_a = (long long)p.m * front_k;
+        // what the mailbox counts: one per workgroup that owns a tile's (or micro-tile group's) key, over both launches
+        const long long rest_units = n_rest == 0 ? 0 : micro ? (long long)p.m * mc_W : (long long)p.m * ceil_div(n_rest, 16 * nt);
+        pa.done_total = (int)(wg_a + rest_units);
+        p.done_total = pa.done_total;
+        if (ctx->dry) {
+            if (n_rest == 0) {
+                const int g[12] = {1, 2, 0, -1, 0, (int)wg_a, smem_a, pa.lb, 0, 0, 0, 0};
                 std::memcpy(ctx->dry, g, sizeof(g));
                 return L2A_OK;
             }
-            const int rc = l2a_launch_mlp_micro(md->H, gact_m ? 1 : 0, &p, (unsigned)(p.m * W), smem_m, stream);
-            if (rc != 0) return fail(ctx, L2A_EHIP, std::string("micro-tile MLP kernel launch: ") +
-                                                        (rc > 0 ? hipGetErrorString((hipError_t)rc) : "no instance"));
+        } else {
+            const bool gact_a = !(fast_act(md->hidden_act) && fast_act(md->output_act));
+            const int rc_a = l2a_launch_mfma(2, md->TPW, md->OT, md->KG0, gact_a ? 1 : 0, 2, &pa, (unsigned)wg_a, smem_a, stream);
+            if (rc_a == -100) return fail(ctx, L2A_EINVAL, "no whole-tile MFMA kernel instance for this (obs_dim, act_dim, hidden)");
+            if (rc_a != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch (double rounds): ") + hipGetErrorString((hipError_t)rc_a));
             L2A_HIP(ctx, hipGetLastError());
+            if (n_rest == 0) return L2A_OK;
+        }
+        p.c_lo = n_front;
+        front_wg = (int)wg_a;
+    }
+    if (micro) {
+        p.mc_w = mc_W;
+        p.mc_hi = mc_hi;
+        p.mc_r = mc_quads - mc_W * (mc_hi - 1);          // workgroups that take `hi` micro tiles
+        p.m_bytes = mc_span;
+        p.dbg = front_has_dbg ? nullptr : ctx->dbg;
+        const bool gact_m = !(fast_act(md->hidden_act) && fast_act(md->output_act)) || md->n_hidden == 1;
+        if (ctx->dry) {     // [kind, nt, split, split_from, fan, workgroups, lds bytes, sets per batch, micro tiles of the largest workgroup, placement units, double-tile workgroups in front, 0]
+            const int g[12] = {2, 0, 0, -1, 0, p.m * mc_W, smem_m, 1, mc_hi, 0, front_wg, 0};
+            std::memcpy(ctx->dry, g, sizeof(g));
             return L2A_OK;
         }
+        const int rc = l2a_launch_mlp_micro(md->H, gact_m ? 1 : 0, &p, (unsigned)(p.m * mc_W), smem_m, stream);
+        if (rc != 0) return fail(ctx, L2A_EHIP, std::string("micro-tile MLP kernel launch: ") +
+                                                    (rc > 0 ? hipGetErrorString((hipError_t)rc) : "no instance"));
+        L2A_HIP(ctx, hipGetLastError());
+        return L2A_OK;
     }
     if (kind == L2A_KERNEL_MFMA) {
-        const int e_loop0 = (p.mode == L2A_MODE_MEAN) ? md->n_sets : 1;
-        const int cst_bytes = e_loop0 * (32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H) * 4;
-        const int cus0 = ctx->num_cu > 0 ? ctx->num_cu : 256;
-        // LDS plan of a launch whose busiest workgroup runs `nseq` sets in sequence: sets per batch, start of the constants,
-        // bytes (l2a_mfma.h: activation regions | chunk partials of a batch (lb > 1) | constants | exchange staging).
-        // lb = sets per batch: with two hidden layers, layer 0 of up to lb sets runs back to back, then their hidden
-        // GEMMs + output layers, then their reduces - two barriers per batch instead of two per set.  The largest lb
-        // (<= 4, <= the longest set sequence of a workgroup) that fits the CU's LDS; 1 = one set at a time.
-        const int cst_set = 32 * md->KG0 + 48 * md->OT + md->n_hidden * md->H;
-        auto lds_plan = [&](int nt_, int nseq, int x_bytes, int* lb_out, int* cst_off_out) {
-            const int sa = sa_elems_for(md, nt_);
-            const int ps_bytes = L2A_NW * nt_ * md->OT * 64 * 16;       // the waves' output-layer partials of one set
-            const int cst_bytes_all = nseq * cst_set * 4;
-            int lb_ = 1, part_bytes = 0;
-            if (md->n_hidden == 2 && ctx->batch_sets != 1) {
-                const int cap = ctx->batch_sets > 0 ? ctx->batch_sets : 4;
-                for (int lb = (nseq < cap ? nseq : cap); lb >= 2; --lb) {
-                    const int pbytes = lb * ps_bytes;
-                    if (lb * sa * 16 + pbytes + cst_bytes_all + x_bytes <= ctx->lds_per_block) {
-                        lb_ = lb;
-                        part_bytes = pbytes;
-                        break;
-                    }
-                }
-            }
-            *lb_out = lb_;
-            *cst_off_out = ((lb_ > 1 ? lb_ : 2) * sa * 16 + part_bytes) / 16;
-            return *cst_off_out * 16 + cst_bytes_all + x_bytes;
-        };
-        // Double rounds (round 6): a plan of at least two rounds of 16-candidate tiles at hidden width 512 runs its first
-        // 2 x CUs x D tiles as D rounds of DOUBLE tiles on the whole-tiles-only instances (two candidate tiles per workgroup:
-        // every weight fragment feeds both, the step's fixed costs - barriers, phase hand-overs, operand waits - are paid once
-        // for 32 candidates; these instances carry neither exchange nor half-member code, so unlike the general NT = 2 instances
-        // at this width they keep their registers).  The rest of every env's candidates follows in a second launch with the
-        // ordinary geometry (whole round / tail split); a rest of more than a round and a half joins the double tiles.
-        // Per tile a double round costs ~0.945 of a single one (profiles/r06_ab_nh2.jsonl).  Same arithmetic per candidate:
-        // bit-identical results.
-        int front_k = 0;                    // double tiles per env of the front launch
-        bool front_has_dbg = false;
-        {
-            const long long tiles1 = (long long)p.m * ceil_div(p.n, 16);
-            int lb2 = 1, off2 = 0;
-            if (ctx->double_policy != 0 && md->TPW == 8 && md->OT <= 3 && tiles1 >= 2LL * cus0 &&
-                lds_plan(2, e_loop0, 0, &lb2, &off2) <= ctx->lds_per_block) {
-                const long long D = tiles1 / (2LL * cus0);
-                const long long R = tiles1 - 2LL * cus0 * D;
-                if (R == 0 || 2 * R > 3LL * cus0) front_k = ceil_div(p.n, 32);       // everything on double tiles
-                else front_k = (int)((cus0 * D) / p.m);
-                if (32LL * front_k >= p.n) front_k = ceil_div(p.n, 32);
-            }
-        }
-        const int n_front = (32LL * front_k >= p.n) ? (front_k ? p.n : 0) : 32 * front_k;
-        const int n_rest = p.n - n_front;
-        int nt = n_rest > 0 ? choose_nt(md, p.m, n_rest, e_loop0, sa_elems_for(md, 2) * 16, cst_bytes + 4 * md->OT * 64 * 16) : 1;
-        if (front_k) {
-            L2AKParams pa = p;
-            pa.c_lo = 0; pa.c_hi = n_front;
-            pa.sa_elems = sa_elems_for(md, 2);
-            pa.tiles_per_env = front_k;
-            pa.cst_set = cst_set;
-            pa.split = 0; pa.split_from = -1; pa.pl_units = 0;
-            pa.n_cst = e_loop0;
-            // (phase stamps, tools/timeline.py: one launch writes them - the rest by default, the double tiles with L2A_DBG_FRONT=1)
-            static const bool dbg_front = [] { const char* e = std::getenv("L2A_DBG_FRONT"); return e && e[0] == '1'; }();
-            pa.dbg = (n_rest == 0 || dbg_front) ? ctx->dbg : nullptr;
-            front_has_dbg = pa.dbg != nullptr;
-            const int smem_a = lds_plan(2, e_loop0, 0, &pa.lb, &pa.cst_off);
-            const long long wg_a = (long long)p.m * front_k;
-            pa.done_total = (int)(wg_a + (n_rest > 0 ? (long long)p.m * ceil_div(n_rest, 16 * nt) : 0));
-            p.done_total = pa.done_total;
-            if (ctx->dry) {
-                if (n_rest == 0) {
-                    const int g[10] = {1, 2, 0, -1, 0, (int)wg_a, smem_a, pa.lb, 0, 0};
-                    std::memcpy(ctx->dry, g, sizeof(g));
-                    return L2A_OK;
-                }
-            } else {
-                const bool gact_a = !(fast_act(md->hidden_act) && fast_act(md->output_act));
-                const int rc_a = l2a_launch_mfma(2, md->TPW, md->OT, md->KG0, gact_a ? 1 : 0, 2, &pa, (unsigned)wg_a, smem_a, stream);
-                if (rc_a == -100) return fail(ctx, L2A_EINVAL, "no whole-tile MFMA kernel instance for this (obs_dim, act_dim, hidden)");
-                if (rc_a != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch (double rounds): ") + hipGetErrorString((hipError_t)rc_a));
-                L2A_HIP(ctx, hipGetLastError());
-                if (n_rest == 0) return L2A_OK;
-            }
-            p.c_lo = n_front;
-        }
-        const int front_wg = (front_k && n_rest > 0) ? p.m * front_k : 0;
         // Member fan (l2a_mfma.h): E workgroups per tile, one set each - small mean-ensemble plans, e.g. one rank's shard of
         // config 5 (n = 500: 32 tiles -> 160 workgroups of one set instead of 64 of 2.5 sets).  With two candidate tiles per
         // workgroup (width 512, up to 48 observation dims) it reaches twice as far: one of FOUR ranks' shard of config 5
@@ -390,12 +403,11 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         const dim3 grid((unsigned)n_wg), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
         if (ctx->dry) {
-            const int g[10] = {1, nt, p.split, p.split_from, fan ? 1 : 0, (int)n_wg, smem, p.lb, front_wg, p.pl_units};
+            const int g[12] = {1, nt, p.split, p.split_from, fan ? 1 : 0, (int)n_wg, smem, p.lb, 0, p.pl_units, front_wg, 0};
             std::memcpy(ctx->dry, g, sizeof(g));
             return L2A_OK;
         }
         int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, fan ? 1 : 0, &p, grid.x, smem, stream);
-        (void)front_wg;
         if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");
         if (rc != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch: ") + hipGetErrorString((hipError_t)rc));
         rc = L2A_OK;
@@ -406,7 +418,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         if (smem > ctx->lds_per_block)
             return fail(ctx, L2A_EINVAL, "LDS budget exceeded by the VALU kernel (" + std::to_string(smem) + " B)");
         if (ctx->dry) {
-            const int g[10] = {0, 0, 0, -1, 0, p.m * p.tiles_per_env, smem, 1, 0, 0};
+            const int g[12] = {0, 0, 0, -1, 0, p.m * p.tiles_per_env, smem, 1, 0, 0, 0, 0};
             std::memcpy(ctx->dry, g, sizeof(g));
             return L2A_OK;
         }
@@ -552,12 +564,12 @@ int l2a_plan_geometry(int obs_dim, int act_dim, int n_hidden, const int* hidden,
     p.m = m; p.n = n; p.h = h; p.discount = 1.0; p.disc0 = 1.0;
     unsigned long long dummy = 0;
     p.best_key = &dummy;                            // "a plan": returns or keys are wanted (never dereferenced here)
-    int g[10] = {0};
+    int g[12] = {0};
     ctx.dry = g;
     const int rc = launch_rollout(&md, p, nullptr);
     ctx.dry = nullptr;
     if (rc != L2A_OK) return rc;
-    for (int i = 0; i < 10; ++i) out[i] = g[i];
+    for (int i = 0; i < 12; ++i) out[i] = g[i];
     return L2A_OK;
 }
 

@@ -603,8 +603,8 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     // this wave's micro tile
     const int ct = wave < MT ? wave : MT - 1;
     const int cand = cand0 + 4 * ct + j;
-    const bool valid = cand < p.n;
-    const int row = env * p.n + (valid ? cand : p.n - 1);
+    const bool valid = cand < p.c_hi;          // (a launch covers candidates [c_lo, c_hi) of every env)
+    const int row = env * p.n + (valid ? cand : p.c_hi - 1);
     // state: dims 4 b .. 4 b + 3 of candidate j
     f32x4 st;
     {
@@ -692,7 +692,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
     load_actions(p.h > 1 ? 1 : 0, av_next);
     write_x();
 
-    float ret = p.ret_in ? p.ret_in[(long long)env * p.n + (valid ? cand : p.n - 1)] : 0.0f;
+    float ret = p.ret_in ? p.ret_in[(long long)env * p.n + (valid ? cand : p.c_hi - 1)] : 0.0f;
     double disc_pow = p.disc0;
     const float e_count = (float)e_loop;
     const float e_inv = 1.0f / e_count;
@@ -929,7 +929,7 @@ __device__ __forceinline__ void l2a_mlp_micro_body(const L2AKParams& p, const in
 #pragma unroll
                 for (int w = 1; w < 4; ++w) key = (kbuf[w] > key) ? kbuf[w] : key;
                 if (key != 0ull) atomicMax(p.best_key + env, key);
-                l2a_publish_result(p, (int)gridDim.x);
+                l2a_publish_result(p, p.done_total > 0 ? p.done_total : (int)gridDim.x);
             }
         }
     }
@@ -949,9 +949,9 @@ __global__ void __launch_bounds__(256) l2a_mlp_micro_k(const L2AKParams p) {
     unsigned long long wg_r0_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_r0_) : : "memory");
 #endif
-    if (mt == 3) l2a_mlp_micro_body<3, UW, GACT>(p, env, 4 * q0, l2a_smem);
-    else if (mt == 2) l2a_mlp_micro_body<2, UW, GACT>(p, env, 4 * q0, l2a_smem);
-    else l2a_mlp_micro_body<1, UW, GACT>(p, env, 4 * q0, l2a_smem);
+    if (mt == 3) l2a_mlp_micro_body<3, UW, GACT>(p, env, p.c_lo + 4 * q0, l2a_smem);
+    else if (mt == 2) l2a_mlp_micro_body<2, UW, GACT>(p, env, p.c_lo + 4 * q0, l2a_smem);
+    else l2a_mlp_micro_body<1, UW, GACT>(p, env, p.c_lo + 4 * q0, l2a_smem);
 #ifdef L2A_TIMELINE
     if (p.dbg && threadIdx.x == 0) {        // per-workgroup record behind the phase stamps: lifetime (100 MHz real time), XCD, size
         unsigned long long wg_r1_;

@@ -349,8 +349,8 @@ DOUBLE_CASES = [
 def test_double_rounds_are_bit_identical(name, over):
     """A multi-round plan cut in two launches - double tiles on the whole-tiles-only instances in front, the rest of every env's
     candidates behind - against the one-launch geometries (whole rounds + tail split; no split at all): every return and the
-    arg-max keys bit for bit, with a candidate offset, with and without a returns table, through the blocking mailbox entry;
-    then against the oracle."""
+    arg-max keys bit for bit, with a candidate offset, with and without a returns table, through the blocking mailbox entry, the
+    rest on micro tiles (where they apply) and on 16-candidate tiles; then against the oracle."""
     case = dict(cases.CASES[name], **over)
     env, model = cases.product_model(case)
     native = model.planner_model()
@@ -364,9 +364,10 @@ def test_double_rounds_are_bit_identical(name, over):
     a_dev = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     out = {}
     try:
-        for dbl, split in ((1, 1), (0, 1), (0, 0)):
+        for dbl, split, micro in ((1, 1, 1), (1, 1, 0), (0, 1, 1), (0, 0, 1)):   # (the rest behind a double round: micro tiles where they apply | 16-candidate tiles)
             ctx.set_double_rounds(dbl)
             ctx.set_split(split)
+            ctx.set_micro(micro)
             r, k = _plan_returns(native, case, env, obs0, a, cand_offset=11)
             keys_only = torch.zeros((case["m"],), dtype=torch.int64, device=dev)
             native.plan_rs(torch.from_numpy(np.ascontiguousarray(obs0, dtype=np.float32)).to(dev), a_dev,
@@ -381,21 +382,22 @@ def test_double_rounds_are_bit_identical(name, over):
                 mailed.append(got.view(np.int64).copy())
             ctx.launch_status()
             assert all(np.array_equal(x, mailed[0]) for x in mailed)
-            out[(dbl, split)] = (r, k, keys_only.cpu().numpy(), mailed[0])
+            out[(dbl, split, micro)] = (r, k, keys_only.cpu().numpy(), mailed[0])
     finally:
         ctx.set_split(1)
         ctx.set_double_rounds(1)
-    ref = out[(0, 0)]
+        ctx.set_micro(1)
+    ref = out[(0, 0, 1)]
     assert np.array_equal(ref[1], ref[2]) and np.array_equal(ref[1], ref[3])
     assert np.isfinite(ref[0]).all()
-    for key in ((1, 1), (0, 1)):
+    for key in ((1, 1, 1), (1, 1, 0), (0, 1, 1)):
         for x, y in zip(ref, out[key]):
             assert np.array_equal(x, y), key
     from oracle import make_reward
     from oracle.planner import rollout_returns
     want = rollout_returns(cases.oracle_dynamics(case), make_reward(case["env"], env.dt), obs0, a, case["n"],
                            case.get("discount", 1.0)).reshape(case["m"], case["n"])
-    assert rel_err(out[(1, 1)][0], want) < RTOL
+    assert rel_err(out[(1, 1, 1)][0], want) < RTOL
 
 
 MICRO_CASES = [

@@ -217,9 +217,12 @@ def test_launch_geometry_routing_table():
     assert (c2["kernel"], c2["nt"], c2["split"], c2["fan"], c2["placement_units"], c2["sets_per_batch"]) == ("mfma16", 1, 2, False, 2, 3)
     assert c2["workgroups"] == 256 and c2["lds_bytes"] <= 160 * 1024
     # config 3: 625 tiles.  Double rounds (default): 5 x 51 double tiles in front (candidates 0 .. 1631 of every env, two tiles per
-    # workgroup on the whole-tiles-only instances), the other 5 x 23 tiles behind them, shared by pairs; without: 512 whole + 113
-    # shared by pairs in one launch (tail split)
+    # workgroup on the whole-tiles-only instances), the other 5 x 368 candidates behind them on micro tiles (5 x 46 workgroups of
+    # eight candidates; micro tiles off: 5 x 23 tiles shared by pairs); without double rounds: 512 whole + 113 shared by pairs in
+    # one launch (tail split)
     c3 = g(ant, 5, "per_block", 5, 2000, 20)
+    assert (c3["front_workgroups"], c3["kernel"], c3["workgroups"], c3["micro_tiles"]) == (255, "micro", 5 * 46, 2)
+    c3 = g(ant, 5, "per_block", 5, 2000, 20, micro=0)
     assert (c3["front_workgroups"], c3["nt"], c3["split"], c3["split_from"], c3["workgroups"]) == (255, 1, 2, -1, 2 * 115)
     c3 = g(ant, 5, "per_block", 5, 2000, 20, double=0)
     assert (c3["front_workgroups"], c3["split"], c3["split_from"], c3["workgroups"]) == (0, 2, 512, 512 + 2 * 113)

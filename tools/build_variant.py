@@ -16,7 +16,7 @@ from learning_to_adapt_amd.csrc import build as b  # noqa: E402
 
 def main():
     name = sys.argv[1]
-    units = ["l2a_mfma_1_8.o", "l2a_mfma_fan_1_8.o", "l2a_mfma_whole_2_8.o", "l2a_lstm_4.o", "l2a_micro.o", "l2a_rnn_micro.o"]
+    units = ["l2a_api.o", "l2a_mfma_1_8.o", "l2a_mfma_fan_1_8.o", "l2a_mfma_whole_2_8.o", "l2a_lstm_4.o", "l2a_micro.o", "l2a_rnn_micro.o"]
     defs = []
     for a in sys.argv[2:]:
         if a.startswith("--units="):
