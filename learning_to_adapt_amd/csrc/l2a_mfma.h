@@ -69,6 +69,11 @@
 
 #include "l2a_kernels.h"
 
+// Early exchange of the tile split (phase C of the kernel): -DL2A_XEARLY=0 builds the instances without it (A/B, tools/build_variant.py).
+#ifndef L2A_XEARLY
+#define L2A_XEARLY 1
+#endif
+
 // Waves per workgroup.  4 = one wave per SIMD: a lone wave issues its MFMAs back to back (32
 // cycles each) with loads / LDS reads / address math slotted in between, whereas two waves on
 // one SIMD were measured (tools/timeline.py) to leave the matrix pipe ~25 % idle - the older
@@ -638,6 +643,17 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             return ok;
         };
 
+        // Early exchange (round 6; tile split with a shared set whose last batch holds two or more sets - config 2: all three):
+        // the records leave as early as the canonical order allows and the partner's are requested BEFORE this workgroup is
+        // through its own epilogue.  Wave 0 reduces the shared set FIRST and publishes this half of it at once; wave 1 (natural
+        // order) publishes the group sum of the full sets right after the last of them; wave 3 requests the partner's two
+        // records straight after its own last reduce and looks at them only after the next step's actions are taken over - the
+        // ~3.4k clocks a sweep takes from issue to return (whatever it finds) now run under the other waves' reduces and the
+        // hand-over instead of behind them.  The shared set adds nothing to `dgrp` in phase C (its term is formed in the
+        // combine), so its place in wave 0's order changes no bit.  Config 2: 1.4153 -> 1.3997 ms (profiles/r06_ab_xsweep.jsonl;
+        // the records leaving early WITHOUT the early request gained nothing: r06_ab_xord.jsonl).
+        bool xearly = false;        // this step's records left in phase C, wave 3 holds the requested partner records in `sw`
+        u32x4 sw[2][NT][OT][2];
         for (int b0 = 0; b0 < n_seq; b0 += LB) {
             const int nb = (n_seq - b0 < LB) ? n_seq - b0 : LB;
             f32x4 hreg[NT][TPW];    // activations of the LAST hidden layer (stay in registers)
@@ -903,7 +919,13 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
 
             // ======== phase C: canonical reduce of every set of the batch ===========================
             __syncthreads();
-            for (int j = 0; j < nb; ++j) {
+            // (the batch that ends with the shared set, if it holds another set too)
+            // (instances of up to 32 input features: the requested records are 16 VGPRs per obs tile, and the Ant's instance -
+            //  496 VGPRs without them - would spill)
+            constexpr bool XE_OK = L2A_XEARLY && !NOHALF && NT == 1 && OT <= 2 && KG0 <= 2;
+            const bool xe = XE_OK && split == 2 && nb >= 2 && b0 + nb == n_seq;
+            for (int jj = 0; jj < nb; ++jj) {
+                const int j = (xe && wave == 0) ? (jj == 0 ? nb - 1 : jj - 1) : jj;     // wave 0: the shared set first
                 const int i = b0 + j;
                 const int e = seq(i);
                 const bool is_half = !NOHALF && (e == e_shared);
@@ -959,9 +981,25 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     }
                 }
                 // the group sum of the full sets leaves as soon as it exists (LB == 1: it travels under the half set)
-                if (split == 2 && i == n_full - 1 && wave == 0) xput(0, dgrp);
+                if (!NOHALF && split == 2 && i == n_full - 1 && wave == (XE_OK ? 1 : 0)) xput(0, dgrp);
+                if (xe && wave == 0 && jj == 0) xput(1, qsh);
+                if (xe && wave == 3 && jj == nb - 1) {
+                    // single model (E == 1): there are no full sets, region 0 is never written - not requested
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+#pragma unroll
+                                for (int hh = 0; hh < 2; ++hh)
+                                    sw[r][nt][c][hh] = (r == 1 || e_loop > 1)
+                                        ? __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase(grp ^ 1, r) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_SC1)
+                                        : (u32x4){xtag, 0u, xtag, 0u};
+                }
                 L2A_TS(6)
             }
+            if (xe) xearly = true;
             // LDS hazards.  LB == 1: the partial sums live in `hoth`; `hcur` was last read by the final
             // hidden layer, before the barrier above.  n_hidden >= 2: the next writes are layer 0
             // -> `hcur` (free) and, only after the layer-0 barrier, `hoth` again (every wave has
@@ -1069,7 +1107,7 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             }
             // (the staging slots are rewritten after the next step's barriers, which every wave reaches after these reads)
         } else if (!WHOLE && split) {
-            if (wave == 0) {
+            if (wave == 0 && !xearly) {
                 if (split == 2) xput(1, qsh);
                 else xput(0, dgrp);
             }
@@ -1077,7 +1115,52 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
             // while the records travel (a write-through store + an sc1 load across two XCDs' L2s: ~4k clocks),
             // take over the next step's actions and request the ones after them
             take_actions(t + 2);
-            if (wave == 0) {
+            if (xearly && wave == 3) {
+                // the records requested in phase C: usually valid; a miss costs a further round trip, as before
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+#pragma unroll
+                                for (int hh = 0; hh < 2; ++hh)
+                                    ok = ok && (sw[r][nt][c][hh].x == xtag) && (sw[r][nt][c][hh].z == xtag);
+                    if (__all(ok)) break;
+                    if (spin_left == 0) {               // partner never arrived: flag the launch, do not hang
+                        if (lane == 0) __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    --spin_left;
+                    __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int c = 0; c < OT; ++c)
+#pragma unroll
+                                for (int hh = 0; hh < 2; ++hh)
+                                    if (r == 1 || e_loop > 1)
+                                        sw[r][nt][c][hh] = __builtin_amdgcn_raw_buffer_load_b128(
+                                            xrs, xbase(grp ^ 1, r) + ((nt * OT + c) * 2 + hh) * 1024, 0, L2A_SC1);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < OT; ++c) {
+                            f32x4 v;
+                            v[0] = __uint_as_float(sw[r][nt][c][0].y); v[1] = __uint_as_float(sw[r][nt][c][0].w);
+                            v[2] = __uint_as_float(sw[r][nt][c][1].y); v[3] = __uint_as_float(sw[r][nt][c][1].w);
+                            xlds[((r * NT + nt) * OT + c) * 64 + lane] = v;
+                        }
+                { const int e = 7; L2A_TS(12) }
+            }
+            if (wave == 0 && !xearly) {
                 f32x4 oth[2][NT][OT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -1101,10 +1184,6 @@ __global__ void __launch_bounds__(64 * L2A_NW) l2a_rollout_mfma_k(const L2AKPara
                     --spin_left;
                     return false;
                 };
-                // Round 6, measured and dropped (profiles/r06_ab_xord.jsonl): wave 0 reducing the shared set FIRST and publishing its
-                // half at once, wave 1 publishing the group sum after two reduces instead of three - the records leave 1.4k clocks
-                // earlier, the step does not end earlier (1.4165 against 1.4132 ms): the sweep below costs ~3.4k clocks from issue
-                // to return whatever it finds, and it is issued when wave 0 is through its own reduces either way.
                 // Measured and lost (profiles/r03_ab_kernel_variants.jsonl; the code is in the history): two sweeps in flight half a
                 // round trip apart (41 more registers, and loads retire in order: the sweep still in flight stalls the next step's
                 // first operand wait); a learnt delay of the first sweep (every jitter-induced miss of the late workgroup then
