@@ -129,6 +129,10 @@ for grp, members in GROUPS:
             line.append("s%d.%s %6.0f" % (e, nm, np.median(d[grp, 2:, e, 0, slot] - t_end_prev)))
     x = d[grp, 2:, 7, 0, :]
     for slot, nm in ((9, "sets.done"), (11, "published"), (12, "swept"), (10, "at.barrier"), (13, "past.barrier"), (7, "step.end")):
+        if slot == 12 and x[:, 12].max() == 0 and d[grp, 2:, 7, 3, 12].max() != 0:
+            # early exchange (round 6): wave 3 requests the partner's records in phase C and holds them after the hand-over
+            line.append("swept(wave 3) %6.0f" % np.median(d[grp, 2:, 7, 3, 12] - t_end_prev))
+            continue
         line.append("%s %6.0f" % (nm, np.median(x[:, slot] - t_end_prev)))
     print("  group %d: " % grp + "  ".join(line))
     print("           sweeps: median %d max %d; waves reach the post-exchange barrier at %s"
