@@ -123,8 +123,9 @@ int l2a_set_fan(l2a_ctx* ctx, int on);
  * neither exchange nor half-member code (and so keep their registers at this width): every weight fragment feeds both tiles
  * and a step's fixed costs are paid once for 32 candidates, ~0.945 of a single round's cost per tile.  The rest of every
  * env's candidates follows in a second launch on the same stream with the ordinary geometry (whole round, tail split); a rest
- * of more than a round and a half joins the double tiles.  1 (default) = wherever it applies, 0 = never.
- * Geometry only: results are bit-identical.                                                                     */
+ * of more than a round and a half joins the double tiles.  The same instances also run WHOLE single tiles of plans with one
+ * weight set per candidate (single model, per-block sets), 3 - 4 % faster per round than the general instances.
+ * 1 (default) = wherever they apply, 0 = never (general instances only).  Geometry only: results are bit-identical.   */
 int l2a_set_double_rounds(l2a_ctx* ctx, int on);
 /* Micro tiles (csrc/l2a_micro.h).  A plan whose 16-candidate tiles would leave CUs idle - e.g. the reference's own default
  * plans, run_grbal.py:84-85 / run_rebal.py:77-78: 5 x 500 candidates = 160 tiles on 256 CUs - can run in candidate tiles of
@@ -546,7 +547,8 @@ int l2a_controller_stats(l2a_controller* controller, double* out, int cap);
  * (0 none, 1 whole sets, 2 + shared half member, 3 member fan), first shared tile of a tail split or -1, member fan (0 / 1),
  * workgroups launched (incl. the placement's spare ones), LDS bytes per workgroup, sets per batch, micro tiles of the largest
  * workgroup, XCD placement units, double-tile workgroups of the launch IN FRONT of the described one (l2a_set_double_rounds:
- * the described launch then covers the rest of every env's candidates; 0 = the plan is one launch), 0}.  Results do not depend
+ * the described launch then covers the rest of every env's candidates; 0 = the plan is one launch), 1 when the described launch
+ * runs on a whole-tiles-only kernel instance (double tiles; whole single tiles of one set per candidate)}.  Results do not depend
  * on the geometry (bit-identical); this is how tests/test_host_logic.py pins the routing table without a GPU.          */
 int l2a_plan_geometry(int obs_dim, int act_dim, int n_hidden, const int* hidden, int n_sets, int mode, int m, int n, int h,
                       const int* policy, int* out);

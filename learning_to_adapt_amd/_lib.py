@@ -51,7 +51,8 @@ def plan_geometry(obs_dim, act_dim, hidden, n_sets, mode, m, n, h, split=-1, fan
     """The launch geometry the library would pick for this plan (``l2a_plan_geometry``: the launcher's own decision code, no
     GPU needed).  Returns a dict: kernel ('valu' | 'mfma16' | 'micro'), nt, split (0 none, 1 whole sets, 2 shared half member,
     3 member fan), split_from, fan, workgroups, lds_bytes, sets_per_batch, micro_tiles, placement_units, front_workgroups
-    (double-tile workgroups of a launch IN FRONT of the described one: ``l2a_set_double_rounds``)."""
+    (double-tile workgroups of a launch IN FRONT of the described one: ``l2a_set_double_rounds``), whole_instance (the
+    described launch runs on a whole-tiles-only kernel instance)."""
     lib = load()
     hid = (ctypes.c_int * len(hidden))(*[int(x) for x in hidden])
     pol = (ctypes.c_int * 5)(int(split), int(fan), int(micro), int(cus), int(double))
@@ -61,7 +62,8 @@ def plan_geometry(obs_dim, act_dim, hidden, n_sets, mode, m, n, h, split=-1, fan
         raise L2AError("l2a_plan_geometry failed (%d)" % rc)
     v = list(out)
     return dict(kernel=("valu", "mfma16", "micro")[v[0]], nt=v[1], split=v[2], split_from=v[3], fan=bool(v[4]), workgroups=v[5],
-                lds_bytes=v[6], sets_per_batch=v[7], micro_tiles=v[8], placement_units=v[9], front_workgroups=v[10])
+                lds_bytes=v[6], sets_per_batch=v[7], micro_tiles=v[8], placement_units=v[9], front_workgroups=v[10],
+                whole_instance=bool(v[11]))
 
 
 _lib = None

@@ -26,7 +26,7 @@ INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 2), (2, 4)]
 FAN_INSTANCES = [(1, 2), (1, 4), (1, 8), (2, 8)]
 # whole-tiles-only instances (-DL2A_INST_FAN=2: neither exchange nor half-member code): two candidate tiles per workgroup at
 # width 512 - the double rounds launch_rollout puts in front of a multi-round plan
-WHOLE_INSTANCES = [(2, 8)]
+WHOLE_INSTANCES = [(2, 8), (1, 8)]
 LSTM_INSTANCES = [2, 4, 8]          # UTW = units / 64
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Rollout kernels: MFMA accumulators in architectural VGPRs where the allocator can afford it - every epilogue reads its

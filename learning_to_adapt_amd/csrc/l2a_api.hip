@@ -275,7 +275,7 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         p.done_total = pa.done_total;
         if (ctx->dry) {
             if (n_rest == 0) {
-                const int g[12] = {1, 2, 0, -1, 0, (int)wg_a, smem_a, pa.lb, 0, 0, 0, 0};
+                const int g[12] = {1, 2, 0, -1, 0, (int)wg_a, smem_a, pa.lb, 0, 0, 0, 1};
                 std::memcpy(ctx->dry, g, sizeof(g));
                 return L2A_OK;
             }
@@ -403,11 +403,19 @@ int launch_rollout(l2a_model* md, L2AKParams& p, void* stream_v) {
         const dim3 grid((unsigned)n_wg), block(64 * L2A_NW);
         const bool gact = !(fast_act(md->hidden_act) && fast_act(md->output_act));
         if (ctx->dry) {
-            const int g[12] = {1, nt, p.split, p.split_from, fan ? 1 : 0, (int)n_wg, smem, p.lb, 0, p.pl_units, front_wg, 0};
+            const bool whole1_dry = !fan && ctx->double_policy != 0 && e_loop == 1 && nt == 1 && md->TPW == 8 && md->OT <= 3 &&
+                                    p.split == 0 && p.split_from < 0;
+            const int g[12] = {1, nt, p.split, p.split_from, fan ? 1 : 0, (int)n_wg, smem, p.lb, 0, p.pl_units, front_wg, whole1_dry ? 1 : 0};
             std::memcpy(ctx->dry, g, sizeof(g));
             return L2A_OK;
         }
-        int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, fan ? 1 : 0, &p, grid.x, smem, stream);
+        // Whole tiles of ONE set per candidate (single model, per-block sets) at width 512 also run on the whole-tiles-only
+        // instances (332 - 368 VGPRs instead of 442 - 496: -3 .. -4 % per round, profiles/r06_ab_whole1.jsonl); ensembles keep the
+        // general instances (config 5's iteration, five sets in batches of three: +3.4 % on the whole-tiles-only one)
+        const bool whole1 = !fan && ctx->double_policy != 0 && e_loop == 1 && nt == 1 && md->TPW == 8 && md->OT <= 3 &&
+                            p.split == 0 && p.split_from < 0;
+        const int geo = fan ? 1 : whole1 ? 2 : 0;
+        int rc = l2a_launch_mfma(nt, md->TPW, md->OT, md->KG0, gact ? 1 : 0, geo, &p, grid.x, smem, stream);
         if (rc == -100) return fail(ctx, L2A_EINVAL, "no MFMA kernel instance for this (obs_dim, act_dim, hidden)");
         if (rc != 0) return fail(ctx, L2A_EHIP, std::string("MFMA kernel launch: ") + hipGetErrorString((hipError_t)rc));
         rc = L2A_OK;

@@ -23,7 +23,7 @@ L2A_DECL_LAUNCH(2, 2) L2A_DECL_LAUNCH(2, 4)
 // member-fan instances (p->split == 3: one workgroup per candidate tile and ensemble member), NT = 1
 L2A_DECL_LAUNCH(fan_1, 2) L2A_DECL_LAUNCH(fan_1, 4) L2A_DECL_LAUNCH(fan_1, 8) L2A_DECL_LAUNCH(fan_2, 8)
 // whole-tiles-only instances (no exchange, no half member), two tiles per workgroup at width 512: double rounds
-L2A_DECL_LAUNCH(whole_2, 8)
+L2A_DECL_LAUNCH(whole_2, 8) L2A_DECL_LAUNCH(whole_1, 8)
 #undef L2A_DECL_LAUNCH
 
 // geo: 0 = general instances (whole tiles, tile split, tail split), 1 = member fan, 2 = whole tiles only
@@ -32,6 +32,7 @@ inline int l2a_launch_mfma(int nt, int tpw, int ot, int kg0, int gact, int geo, 
     static_assert(L2A_NW == 4, "instances are generated for 4-wave workgroups (TPW = H / 64)");
     if (geo == 2) {
         if (nt == 2 && tpw == 8) return l2a_launch_mfma_whole_2_8(ot, kg0, gact, p, grid, smem, stream);
+        if (nt == 1 && tpw == 8) return l2a_launch_mfma_whole_1_8(ot, kg0, gact, p, grid, smem, stream);
         return -100;
     }
     if (geo == 1) {

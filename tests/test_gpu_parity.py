@@ -342,6 +342,10 @@ DOUBLE_CASES = [
     ("c3b_ant_rs_n500_h10_pb5_3x512", dict(n=2050, h=2)),
     ("ant_rs_n300_h6_e3", dict(n=9000, m=1, h=2, activation="tanh")),
     ("arm_rs_n256_h8", dict(n=4100, m=2, h=2)),
+    # whole SINGLE tiles of one set per candidate on the whole-tiles-only instances: a full round of a single model, per-block
+    # sets whose plan is too large for micro tiles
+    ("c1_hc_rs_n500_h10_e1", dict(n=4096, h=3)),
+    ("c3_ant_rs_n2000_h20_pb5", dict(n=800, h=3)),
 ]
 
 
@@ -360,7 +364,7 @@ def test_double_rounds_are_bit_identical(name, over):
     dev = native.device
     geo = _lib.plan_geometry(env.observation_space.shape[0], env.action_space.shape[0], case["hidden"], case.get("E", 1),
                              case.get("mode", "single"), case["m"], case["n"], case["h"])
-    assert geo["front_workgroups"] > 0 or geo["nt"] == 2, geo         # the case does take the double rounds
+    assert geo["front_workgroups"] > 0 or geo["nt"] == 2 or geo["whole_instance"], geo     # the case does take the whole-tiles-only instances
     a_dev = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     out = {}
     try:

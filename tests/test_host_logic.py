@@ -236,7 +236,11 @@ def test_launch_geometry_routing_table():
     # run_mb_mpc.py's default (10 envs x 2000 candidates = 1250 tiles): two double rounds in front (10 x 51 double tiles), 230 whole
     # tiles behind; double rounds need width 512 and at least two rounds of tiles
     mb = g(hc, 1, "single", 10, 2000, 20)
-    assert (mb["front_workgroups"], mb["nt"], mb["split"], mb["workgroups"]) == (510, 1, 0, 230)
+    assert (mb["front_workgroups"], mb["nt"], mb["split"], mb["workgroups"], mb["whole_instance"]) == (510, 1, 0, 230, True)
+    # whole single tiles of ONE set per candidate run on the whole-tiles-only instances too (a full round of a single model; not
+    # ensembles: config 5's iteration keeps the general instance), off with the double rounds
+    assert g(hc, 1, "single", 1, 4096, 10)["whole_instance"] and not g(hc, 1, "single", 1, 4096, 10, double=0)["whole_instance"]
+    assert not g(hc, 5, "mean", 1, 4000, 30)["whole_instance"] and g(hc, 5, "mean", 1, 16000, 30)["whole_instance"]
     assert g(dict(hc, hidden=[256, 256]), 1, "single", 10, 2000, 20)["front_workgroups"] == 0
     assert g(hc, 1, "single", 1, 8176, 5)["front_workgroups"] == 0 and g(hc, 1, "single", 1, 8192, 5)["nt"] == 2
     # config 5's shards: one rank of 8 -> member fan (32 tiles x 5 members, every member on its own XCDs); one rank of 4 -> the fan
